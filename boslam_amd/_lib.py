@@ -1,0 +1,136 @@
+"""ctypes binding of libboslam_hip.so (include/boslam_hip.h).  No CPU fallback: if the library or a HIP device is
+missing every entry point raises."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libboslam_hip.so")
+
+BH_OK, BH_ERR_INVALID, BH_ERR_HIP, BH_ERR_CAPACITY, BH_ERR_NOMEM, BH_ERR_NUMERIC = 0, -1, -2, -3, -4, -5
+BH_MEM_HOST, BH_MEM_DEVICE = 0, 1
+
+
+class BhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"boslam_hip error {code}: {msg}")
+        self.code = code
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scaleFactor", C.c_float), ("nlevels", C.c_int),
+                ("edgeThreshold", C.c_int), ("firstLevel", C.c_int), ("patchSize", C.c_int),
+                ("fastThreshold", C.c_int)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4")])
+
+_vp, _i, _d = C.c_void_p, C.c_int, C.c_double
+_SIGS = {
+    "bh_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "bh_ctx_destroy": (None, [_vp]),
+    "bh_last_error": (C.c_char_p, [_vp]),
+    "bh_ctx_set_stream": (_i, [_vp, _vp]),
+    "bh_ctx_synchronize": (_i, [_vp]),
+    "bh_ctx_status": (_i, [_vp]),
+    "bh_version": (C.c_char_p, []),
+    "bh_orb_detect_describe": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, C.POINTER(OrbParams), _i, _vp, _vp, _vp, _i]),
+    "bh_orb_geometry": (_i, [_i, _i, C.POINTER(OrbParams), _vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
+    "bh_orb_debug_fetch": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "bh_kp_backproject": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _vp, _i]),
+    "bh_match_hamming_crosscheck": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i]),
+    "bh_pose_only_ba": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i]),
+    "bh_ba_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "bh_ba_destroy": (None, [_vp]),
+    "bh_ba_set_problem": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i]),
+    "bh_ba_optimize": (_i, [_vp, _i, _d, _i, C.POINTER(_i)]),
+    "bh_ba_get_poses": (_i, [_vp, _vp, _vp, _i]),
+    "bh_ba_get_points": (_i, [_vp, _vp, _i]),
+    "bh_ba_get_chi2": (_i, [_vp, _vp, _i]),
+    "bh_ba_get_log": (_i, [_vp, _vp, _i]),
+}
+
+_LIB = None
+MISSING = []
+
+
+def exported_symbols():
+    """Names include/boslam_hip.h declares (kept in sync by tests/test_abi.py)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise BhError(BH_ERR_HIP, f"{LIB_PATH} is not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name, None)
+            if fn is None:                     # tests/test_abi.py asserts this never happens
+                MISSING.append(name)
+                continue
+            fn.restype, fn.argtypes = res, args
+        _LIB = L
+    return _LIB
+
+
+def ptr(a):
+    """Pointer of a numpy array / int device address / None."""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.c_void_p(int(a))
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, "data_ptr"):             # torch tensor (device memory plumbing only)
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(type(a))
+
+
+class Context:
+    """One bh_ctx (own HIP stream + device workspace).  Use one per calling thread."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        rc = lib().bh_ctx_create(device, C.byref(h))
+        if rc != BH_OK:
+            raise BhError(rc, "bh_ctx_create failed: no usable HIP device (the HIP path is mandatory, no fallback)")
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != BH_OK:
+            raise BhError(rc, lib().bh_last_error(self.h).decode())
+
+    def set_stream(self, stream_handle):
+        self.check(lib().bh_ctx_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def synchronize(self):
+        self.check(lib().bh_ctx_synchronize(self.h))
+
+    def status(self):
+        self.check(lib().bh_ctx_status(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().bh_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DEFAULT = {}
+
+
+def default_context(device=0):
+    import threading
+    key = (threading.get_ident(), device)
+    if key not in _DEFAULT:
+        _DEFAULT[key] = Context(device)
+    return _DEFAULT[key]

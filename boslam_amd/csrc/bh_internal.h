@@ -1,0 +1,72 @@
+// Internal declarations shared by the translation units of libboslam_hip.so (gfx950 only).
+#ifndef BH_INTERNAL_H
+#define BH_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include "../../include/boslam_hip.h"
+
+#define BH_MAX_LEVELS 16
+
+struct bh_buf {                      // grow-only device allocation
+    void*  p = nullptr;
+    size_t cap = 0;
+};
+
+struct bh_level_geom {
+    int   w, h, pitch;               // pitch: bytes per row, multiple of 64
+    int   off;                       // byte offset of the level inside one frame's pyramid (multiple of 64)
+    float scale;                     // (float)pow(scaleFactor, l)
+    int   nfeat;                     // n_l
+    int   tiles_x, tiles_y, tile_base;   // 64x32 tiles
+    int   tabx_off, taby_off;        // offsets (in u32) into the resize coefficient table
+};
+
+struct bh_orb_geom {
+    int nlevels, W, H;
+    int pyr_stride;                  // bytes per frame
+    int ntiles;                      // over all levels
+    int fast_thr, edge_thr;
+    int tab_len;
+    bh_level_geom lv[BH_MAX_LEVELS];
+};
+
+struct bh_ctx {
+    int         device = 0;
+    hipStream_t stream = nullptr;    // stream in use
+    hipStream_t own_stream = nullptr;
+    char        err[512] = {0};
+    // ---- ORB workspace ----
+    bh_orb_geom geom = {};
+    bh_orb_params geom_params = {};
+    int         geom_valid = 0;
+    int         ws_frames = 0;       // frames the pyramid workspace holds
+    bh_buf      pyr, mpyr, nms, blur, hist, tab, kpmeta, status;
+    bh_buf      st_img, st_mask, st_depth, st_kps, st_desc, st_nkp;     // host-mode staging
+    bh_buf      st_a, st_b, st_c, st_d, st_e, st_f, st_g, st_h;         // generic staging (match / BA)
+    int         last_B = 0;
+    int         last_has_mask = 0;
+};
+
+int  bh_set_err(bh_ctx* ctx, int code, const char* fmt, ...);
+int  bh_reserve(bh_ctx* ctx, bh_buf* b, size_t bytes);
+
+#define BH_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return bh_set_err((ctx), BH_ERR_HIP, "%s failed: %s (%s:%d)", #call,                   \
+                              hipGetErrorString(e_), __FILE__, __LINE__);                          \
+    } while (0)
+
+#define BH_TRY(expr)                                                                               \
+    do { int rc_ = (expr); if (rc_ != BH_OK) return rc_; } while (0)
+
+// device status word bits (bh_ctx::status[0])
+#define BH_ST_KP_OVERFLOW    1u   // more keypoints than max_kp
+#define BH_ST_CAND_OVERFLOW  2u   // more FAST candidates above the retainBest threshold than the LDS list holds
+
+#endif

@@ -1,0 +1,86 @@
+// ctx.hip — context, error reporting and workspace management of libboslam_hip.so.
+#include "bh_internal.h"
+#include <stdarg.h>
+
+int bh_set_err(bh_ctx* ctx, int code, const char* fmt, ...)
+{
+    if (ctx) {
+        va_list ap; va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+int bh_reserve(bh_ctx* ctx, bh_buf* b, size_t bytes)
+{
+    if (bytes <= b->cap) return BH_OK;
+    // a grow frees the old block: make sure nothing enqueued still uses it
+    if (b->p) { BH_HIP(ctx, hipStreamSynchronize(ctx->stream)); BH_HIP(ctx, hipFree(b->p)); b->p = nullptr; b->cap = 0; }
+    size_t want = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b->p, want);
+    if (e != hipSuccess) { b->p = nullptr; return bh_set_err(ctx, BH_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+    b->cap = want;
+    return BH_OK;
+}
+
+static void release(bh_buf* b) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+
+extern "C" const char* bh_version(void) { return "boslam_hip 0.1 (gfx950)"; }
+
+extern "C" int bh_ctx_create(int device, bh_ctx** out)
+{
+    if (!out) return BH_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return BH_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return BH_ERR_HIP;
+    bh_ctx* ctx = new bh_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BH_ERR_HIP; }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return BH_OK;
+}
+
+extern "C" void bh_ctx_destroy(bh_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    bh_buf* all[] = { &ctx->pyr, &ctx->mpyr, &ctx->nms, &ctx->blur, &ctx->hist, &ctx->tab, &ctx->kpmeta, &ctx->status,
+                      &ctx->st_img, &ctx->st_mask, &ctx->st_depth, &ctx->st_kps, &ctx->st_desc, &ctx->st_nkp,
+                      &ctx->st_a, &ctx->st_b, &ctx->st_c, &ctx->st_d, &ctx->st_e, &ctx->st_f, &ctx->st_g, &ctx->st_h };
+    for (bh_buf* b : all) release(b);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" const char* bh_last_error(const bh_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int bh_ctx_set_stream(bh_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return BH_OK;
+}
+
+extern "C" int bh_ctx_synchronize(bh_ctx* ctx)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BH_OK;
+}
+
+extern "C" int bh_ctx_status(bh_ctx* ctx)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (!ctx->status.p) return BH_OK;
+    uint32_t st = 0;
+    BH_HIP(ctx, hipMemcpyAsync(&st, ctx->status.p, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (st & BH_ST_KP_OVERFLOW) return bh_set_err(ctx, BH_ERR_CAPACITY, "more keypoints than max_kp (ties at the retainBest cut); output truncated");
+    if (st & BH_ST_CAND_OVERFLOW) return bh_set_err(ctx, BH_ERR_CAPACITY, "FAST candidate list overflow in k_select; output truncated");
+    return BH_OK;
+}

@@ -1,0 +1,150 @@
+// match.hip — brute-force Hamming matcher with OpenCV's cross-check rule, batched over independent pairs (gfx950).
+//
+// Replaces cv2.BFMatcher_create(cv2.NORM_HAMMING, crossCheck=True).match(q, t) — reference slam/tracking.py:45,56,121,
+// slam/local_mapping.py:21, slam/covisibility_graph.py:34, experiments/pnp_two_way_tracking.py:11,42.
+//
+// One 1024-lane workgroup per (query, train) pair.  The query descriptors sit in LDS (32 B each, read as two
+// broadcast ds_read_b128 per query: every lane of a wave reads the same address, so there is no bank conflict);
+// each lane owns one train descriptor in 8 VGPRs and walks the queries with xor + v_bcnt (popcount-accumulate),
+// keeping the first minimum (strict '<').  The per-query reduction "closest among the trains that chose me, first
+// train wins a tie" is one LDS atomicMin on the packed key (distance << 20 | train index).  Integer work, exact.
+#include "bh_internal.h"
+
+#define MT       1024          // lanes per workgroup
+#define QCHUNK   1024          // queries staged in LDS at a time
+#define NQ_MAX   8192          // per-query result slots in LDS
+#define NT_MAX   (1 << 20)
+
+__device__ __forceinline__ int mt_wave_excl_scan(int v, int lane)
+{
+    int s = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(s, d, 64); if (lane >= d) s += o; }
+    return s - v;
+}
+
+__global__ __launch_bounds__(MT) void k_match(const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int q_stride,
+                                              const uint8_t* __restrict__ t, const int* __restrict__ nt_arr, int t_stride,
+                                              int* __restrict__ qidx, int* __restrict__ tidx, int* __restrict__ dist,
+                                              int* __restrict__ n_match, int out_stride, uint32_t* __restrict__ status)
+{
+    __shared__ uint4    s_q[QCHUNK * 2];
+    __shared__ uint32_t s_best[NQ_MAX];
+    __shared__ int      s_wcnt[MT / 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t b = blockIdx.x;
+    int nq = nq_arr[b], nt = nt_arr[b];
+    if (nq > NQ_MAX || nt > NT_MAX) { if (tid == 0) { atomicOr(status, 4u); n_match[b] = 0; } return; }
+    if (nq <= 0 || nt <= 0) { if (tid == 0) n_match[b] = 0; return; }
+    const uint4* qb = reinterpret_cast<const uint4*>(q + b * (size_t)q_stride * 32);
+    const uint4* tb = reinterpret_cast<const uint4*>(t + b * (size_t)t_stride * 32);
+
+    for (int i = tid; i < nq; i += MT) s_best[i] = 0xffffffffu;
+    const int nchunks = (nq + QCHUNK - 1) / QCHUNK;
+    const int rounds = (nt + MT - 1) / MT;
+    for (int r = 0; r < rounds; r++) {
+        const int j = r * MT + tid;
+        uint4 ta = make_uint4(0, 0, 0, 0), tc = ta;
+        if (j < nt) { ta = tb[2 * j]; tc = tb[2 * j + 1]; }
+        int best_d = 0x7fffffff, best_i = 0;
+        for (int c = 0; c < nchunks; c++) {
+            const int q0 = c * QCHUNK, qn = min(QCHUNK, nq - q0);
+            if (nchunks > 1 || r == 0) {
+                __syncthreads();
+                for (int i = tid; i < qn * 2; i += MT) s_q[i] = qb[2 * q0 + i];
+                __syncthreads();
+            }
+            if (j < nt) {
+                for (int i = 0; i < qn; i++) {
+                    const uint4 a = s_q[2 * i], c4 = s_q[2 * i + 1];
+                    int d = __popc(a.x ^ ta.x);
+                    d += __popc(a.y ^ ta.y); d += __popc(a.z ^ ta.z); d += __popc(a.w ^ ta.w);
+                    d += __popc(c4.x ^ tc.x); d += __popc(c4.y ^ tc.y); d += __popc(c4.z ^ tc.z); d += __popc(c4.w ^ tc.w);
+                    if (d < best_d) { best_d = d; best_i = q0 + i; }
+                }
+            }
+        }
+        if (j < nt) atomicMin(&s_best[best_i], ((uint32_t)best_d << 20) | (uint32_t)j);
+    }
+    __syncthreads();
+    // ascending-queryIdx compaction
+    const int per = (nq + MT - 1) / MT;
+    const int i0 = tid * per;
+    int cnt = 0;
+    for (int e = 0; e < per; e++) { const int i = i0 + e; if (i < nq && s_best[i] != 0xffffffffu) cnt++; }
+    const int wpre = mt_wave_excl_scan(cnt, lane);
+    if (lane == 63) s_wcnt[wv] = wpre + cnt;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int i = 0; i < MT / 64; i++) { const int c = s_wcnt[i]; if (i < wv) base += c; total += c; }
+    int pos = base + wpre;
+    const size_t ob = b * (size_t)out_stride;
+    for (int e = 0; e < per; e++) {
+        const int i = i0 + e;
+        if (i < nq) {
+            const uint32_t k = s_best[i];
+            if (k != 0xffffffffu) {
+                if (pos < out_stride) { qidx[ob + pos] = i; tidx[ob + pos] = (int)(k & 0xfffffu); dist[ob + pos] = (int)(k >> 20); }
+                pos++;
+            }
+        }
+    }
+    if (tid == 0) { if (total > out_stride) { atomicOr(status, 8u); total = out_stride; } n_match[b] = total; }
+}
+
+extern "C" int bh_match_hamming_crosscheck(bh_ctx* ctx, const uint8_t* q, const int* nq, int q_stride,
+                                           const uint8_t* t, const int* nt, int t_stride, int B,
+                                           int* qidx, int* tidx, int* dist, int* n_match, int out_stride, int mem)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (!q || !t || !nq || !nt || !qidx || !tidx || !dist || !n_match || B < 0 || q_stride < 0 || t_stride < 0 ||
+        out_stride < 1 || (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_match_hamming_crosscheck: bad argument");
+    if (B == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    BH_TRY(bh_reserve(ctx, &ctx->status, 256));
+    const uint8_t* d_q = q; const uint8_t* d_t = t; const int* d_nq = nq; const int* d_nt = nt;
+    int *d_qi = qidx, *d_ti = tidx, *d_d = dist, *d_nm = n_match;
+    if (mem == BH_MEM_HOST) {
+        // host mode: rows actually used per pair may be fewer than the stride; copy the strided blocks whole
+        size_t qbytes = 0, tbytes = 0;
+        int maxq = 0, maxt = 0;
+        for (int b = 0; b < B; b++) {
+            if (nq[b] < 0 || nt[b] < 0) return bh_set_err(ctx, BH_ERR_INVALID, "negative descriptor count");
+            if (nq[b] > NQ_MAX || nt[b] > NT_MAX) return bh_set_err(ctx, BH_ERR_INVALID, "descriptor count above the supported maximum (nq <= 8192, nt <= 2^20)");
+            maxq = nq[b] > maxq ? nq[b] : maxq; maxt = nt[b] > maxt ? nt[b] : maxt;
+        }
+        if ((B > 1 && (q_stride < maxq || t_stride < maxt))) return bh_set_err(ctx, BH_ERR_INVALID, "stride smaller than a pair's row count");
+        qbytes = ((size_t)(B - 1) * q_stride + maxq) * 32; tbytes = ((size_t)(B - 1) * t_stride + maxt) * 32;
+        const size_t ob = sizeof(int) * (size_t)B * out_stride;
+        BH_TRY(bh_reserve(ctx, &ctx->st_a, qbytes + 32)); BH_TRY(bh_reserve(ctx, &ctx->st_b, tbytes + 32));
+        BH_TRY(bh_reserve(ctx, &ctx->st_c, sizeof(int) * 2 * B));
+        BH_TRY(bh_reserve(ctx, &ctx->st_d, ob * 3 + sizeof(int) * B));
+        if (qbytes) BH_HIP(ctx, hipMemcpyAsync(ctx->st_a.p, q, qbytes, hipMemcpyHostToDevice, st));
+        if (tbytes) BH_HIP(ctx, hipMemcpyAsync(ctx->st_b.p, t, tbytes, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_c.p, nq, sizeof(int) * B, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync((int*)ctx->st_c.p + B, nt, sizeof(int) * B, hipMemcpyHostToDevice, st));
+        d_q = (const uint8_t*)ctx->st_a.p; d_t = (const uint8_t*)ctx->st_b.p;
+        d_nq = (const int*)ctx->st_c.p; d_nt = d_nq + B;
+        d_qi = (int*)ctx->st_d.p; d_ti = d_qi + (size_t)B * out_stride; d_d = d_ti + (size_t)B * out_stride;
+        d_nm = d_d + (size_t)B * out_stride;
+        BH_HIP(ctx, hipMemsetAsync(ctx->status.p, 0, 256, st));
+    }
+    hipLaunchKernelGGL(k_match, dim3(B), dim3(MT), 0, st, d_q, d_nq, q_stride, d_t, d_nt, t_stride, d_qi, d_ti, d_d, d_nm,
+                       out_stride, (uint32_t*)ctx->status.p);
+    BH_HIP(ctx, hipGetLastError());
+    if (mem == BH_MEM_HOST) {
+        const size_t ob = sizeof(int) * (size_t)B * out_stride;
+        BH_HIP(ctx, hipMemcpyAsync(qidx, d_qi, ob, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(tidx, d_ti, ob, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(dist, d_d, ob, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(n_match, d_nm, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        uint32_t stw = 0;
+        BH_HIP(ctx, hipMemcpyAsync(&stw, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipStreamSynchronize(st));
+        if (stw & 8u) return bh_set_err(ctx, BH_ERR_CAPACITY, "more matches than out_stride");
+    }
+    return BH_OK;
+}

@@ -1,0 +1,851 @@
+// orb.hip — batched ORB detect + describe for gfx950 (MI355X).
+//
+// Replaces cv2.ORB_create(**orb_params).detectAndCompute(frame, mask) — reference camera.py:49-62,141 — for a batch of
+// frames resident in HBM.  Stages (one kernel each, all frames and all pyramid levels per launch where the data
+// dependence allows):
+//   k_gray_mask   BGR -> gray (level 0) and depth/mask -> level-0 mask           streaming, 4 px / lane
+//   k_pyr_down    level l from level l-1 (bit-exact fixed-point bilinear), image and mask   (nlevels-1 launches)
+//   k_fast        FAST-9/16 corner test + score + 3x3 NMS + mask/border filter on 64x32 LDS tiles;
+//                 writes a dense u8 score map and a 256-bin score histogram per (frame, level)
+//   k_blur        7x7 sigma-2 fixed-point Gaussian on 64x32 LDS tiles
+//   k_select      one workgroup per frame: retainBest(2 n_l) threshold from the histogram, raster compaction of the
+//                 score map, Harris response, retainBest(n_l) by rank counting in LDS, intensity-centroid angle
+//   k_brief       one wave per keypoint: 256 rotated pixel-pair tests, 4 ballots -> 32 bytes
+// Every integer stage is exact; the float formulas (Harris response, fastAtan2, cos/sin of the angle) are written
+// one IEEE operation at a time and the file is compiled with -ffp-contract=off.
+#include "bh_internal.h"
+#include <math.h>
+#include <float.h>
+
+#define TILE_W 64
+#define TILE_H 32
+
+// ------------------------------------------------------------------------------------------------ geometry (host)
+static int round_even_f(float v) { return (int)lrintf(v); }
+static int round_even_d(double v) { return (int)lrint(v); }
+static int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+static int build_geom(const bh_orb_params* p, int H, int W, bh_orb_geom* g)
+{
+    if (!p || p->nlevels < 1 || p->nlevels > BH_MAX_LEVELS || p->firstLevel != 0 || p->patchSize != 31 ||
+        p->nfeatures < 0 || p->scaleFactor <= 1.0f || H < 1 || W < 1 || W > 16383 || H > 16383 ||
+        p->edgeThreshold < 19)   // Harris(4) / IC(15) / BRIEF(<=19) windows must stay inside the level image
+        return BH_ERR_INVALID;
+    memset(g, 0, sizeof(*g));
+    g->nlevels = p->nlevels; g->W = W; g->H = H;
+    g->fast_thr = p->fastThreshold < 0 ? 0 : (p->fastThreshold > 255 ? 255 : p->fastThreshold);
+    g->edge_thr = p->edgeThreshold;
+    // features per level
+    float factor = (float)(1.0 / p->scaleFactor);
+    float nd = p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)p->nlevels));
+    int sum = 0;
+    int off = 0, tiles = 0, tab = 0;
+    for (int l = 0; l < p->nlevels; l++) {
+        bh_level_geom& L = g->lv[l];
+        L.scale = (float)pow((double)p->scaleFactor, (double)l);
+        L.w = round_even_f((float)W / L.scale);
+        L.h = round_even_f((float)H / L.scale);
+        if (L.w < 1 || L.h < 1) return BH_ERR_INVALID;
+        L.pitch = align_up(L.w, 64);
+        L.off = off; off += L.pitch * L.h;
+        L.tiles_x = (L.w + TILE_W - 1) / TILE_W;
+        L.tiles_y = (L.h + TILE_H - 1) / TILE_H;
+        L.tile_base = tiles; tiles += L.tiles_x * L.tiles_y;
+        L.tabx_off = tab; tab += L.w;
+        L.taby_off = tab; tab += L.h;
+        if (l < p->nlevels - 1) { L.nfeat = round_even_f(nd); sum += L.nfeat; nd *= factor; }
+        else L.nfeat = p->nfeatures - sum > 0 ? p->nfeatures - sum : 0;
+    }
+    g->pyr_stride = off; g->ntiles = tiles; g->tab_len = tab;
+    return BH_OK;
+}
+
+// Fixed-point bilinear coefficients per axis: entry = (source offset << 16) | c1, c0 = 256 - c1.
+static void lin_coeffs(int src, int dst, uint32_t* out)
+{
+    double inv_scale = (double)dst / (double)src;
+    double scale = 1.0 / inv_scale;
+    for (int d = 0; d < dst; d++) {
+        double fval = scale * ((double)d + 0.5) - 0.5;
+        int ival = (int)floor(fval);
+        uint32_t ofs, c1;
+        if (ival >= 0 && src > 1) {
+            if (ival < src - 1) { ofs = (uint32_t)ival; c1 = (uint32_t)round_even_d((fval - (double)ival) * 256.0); }
+            else { ofs = (uint32_t)(src - 1); c1 = 0; }
+        } else { ofs = 0; c1 = 0; }
+        out[d] = (ofs << 16) | c1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gray + mask, level 0
+__global__ __launch_bounds__(256) void k_gray_mask(const uint8_t* __restrict__ img, int channels,
+                                                   const uint8_t* __restrict__ mask,
+                                                   const uint16_t* __restrict__ depth,
+                                                   uint8_t* __restrict__ pyr, uint8_t* __restrict__ mpyr,
+                                                   int W, int H, int pitch, int pyr_stride)
+{
+    const int groups = pitch >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int y = idx / groups, x = (idx - y * groups) << 2;
+    if (y >= H) return;
+    const size_t f = blockIdx.y;
+    const size_t px = (size_t)f * H * W + (size_t)y * W + x;
+    uint32_t g4 = 0, m4 = 0;
+    if (x + 3 < W && (W & 3) == 0) {
+        if (channels == 3) {
+            const uint32_t* s = reinterpret_cast<const uint32_t*>(img + px * 3);
+            uint32_t a = s[0], b = s[1], c = s[2];          // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+            uint32_t bb[4] = { a & 255u, (a >> 24) & 255u, (b >> 16) & 255u, (c >> 8) & 255u };
+            uint32_t gg[4] = { (a >> 8) & 255u, b & 255u, (b >> 24) & 255u, (c >> 16) & 255u };
+            uint32_t rr[4] = { (a >> 16) & 255u, (b >> 8) & 255u, c & 255u, (c >> 24) & 255u };
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                g4 |= ((bb[i] * 1868u + gg[i] * 9617u + rr[i] * 4899u + 8192u) >> 14) << (8 * i);
+        } else {
+            g4 = *reinterpret_cast<const uint32_t*>(img + px);
+        }
+        if (mask) m4 = *reinterpret_cast<const uint32_t*>(mask + px);
+        else if (depth) {
+            uint2 d = *reinterpret_cast<const uint2*>(depth + px);
+            m4 = ((d.x & 0xffffu) ? 0xffu : 0u) | ((d.x >> 16) ? 0xff00u : 0u) |
+                 ((d.y & 0xffffu) ? 0xff0000u : 0u) | ((d.y >> 16) ? 0xff000000u : 0u);
+        }
+    } else {
+        for (int i = 0; i < 4; i++) {
+            if (x + i >= W) break;
+            uint32_t gv;
+            if (channels == 3) {
+                const uint8_t* s = img + (px + i) * 3;
+                gv = ((uint32_t)s[0] * 1868u + (uint32_t)s[1] * 9617u + (uint32_t)s[2] * 4899u + 8192u) >> 14;
+            } else gv = img[px + i];
+            g4 |= gv << (8 * i);
+            uint32_t mv = mask ? mask[px + i] : (depth ? (depth[px + i] ? 255u : 0u) : 0u);
+            m4 |= mv << (8 * i);
+        }
+    }
+    const size_t o = f * pyr_stride + (size_t)y * pitch + x;
+    *reinterpret_cast<uint32_t*>(pyr + o) = g4;
+    if (mpyr) *reinterpret_cast<uint32_t*>(mpyr + o) = m4;
+}
+
+// ------------------------------------------------------------------------------------------------ pyramid level l from l-1
+// INTER_LINEAR_EXACT arithmetic: horizontal 8.8 fixed point, vertical 16.16, round to nearest.
+__global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, uint8_t* __restrict__ mpyr,
+                                                  bh_orb_geom g, int level, const uint32_t* __restrict__ tab)
+{
+    const bh_level_geom S = g.lv[level - 1], D = g.lv[level];
+    const int groups = D.pitch >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int y = idx / groups, x = (idx - y * groups) << 2;
+    if (y >= D.h) return;
+    const size_t fb = (size_t)blockIdx.y * g.pyr_stride;
+    const uint32_t ty = tab[D.taby_off + y];
+    const int r0 = ty >> 16, r1 = min(r0 + 1, S.h - 1);
+    const uint32_t yc1 = ty & 0xffffu, yc0 = 256u - yc1;
+    const uint8_t* s0 = pyr + fb + S.off + (size_t)r0 * S.pitch;
+    const uint8_t* s1 = pyr + fb + S.off + (size_t)r1 * S.pitch;
+    const uint8_t* m0 = mpyr ? mpyr + fb + S.off + (size_t)r0 * S.pitch : nullptr;
+    const uint8_t* m1 = mpyr ? mpyr + fb + S.off + (size_t)r1 * S.pitch : nullptr;
+    uint32_t o4 = 0, mo4 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (x + i < D.w) {
+            const uint32_t tx = tab[D.tabx_off + x + i];
+            const int a = tx >> 16, b = min(a + 1, S.w - 1);
+            const uint32_t c1 = tx & 0xffffu, c0 = 256u - c1;
+            uint32_t h0 = c0 * s0[a] + c1 * s0[b];
+            uint32_t h1 = c0 * s1[a] + c1 * s1[b];
+            uint32_t v = (yc0 * h0 + yc1 * h1 + 32768u) >> 16;
+            o4 |= v << (8 * i);
+            if (mpyr) {
+                h0 = c0 * m0[a] + c1 * m0[b];
+                h1 = c0 * m1[a] + c1 * m1[b];
+                v = (yc0 * h0 + yc1 * h1 + 32768u) >> 16;
+                mo4 |= (v > 254u ? v : 0u) << (8 * i);                 // THRESH_TOZERO at 254
+            }
+        }
+    }
+    const size_t o = fb + D.off + (size_t)y * D.pitch + x;
+    *reinterpret_cast<uint32_t*>(pyr + o) = o4;
+    if (mpyr) *reinterpret_cast<uint32_t*>(mpyr + o) = mo4;
+}
+
+// ------------------------------------------------------------------------------------------------ tile decode
+__device__ __forceinline__ int tile_level(const bh_orb_geom& g, int tile)
+{
+    int l = 0;
+    for (int i = 1; i < g.nlevels; i++) if (tile >= g.lv[i].tile_base) l = i;
+    return l;
+}
+
+// ------------------------------------------------------------------------------------------------ FAST-9/16 + NMS
+#define FPX_W (TILE_W + 8)      // pixel tile: x0-4 .. x0+67  (18 words)
+#define FPX_H (TILE_H + 8)      //             y0-4 .. y0+35
+#define FSC_W (TILE_W + 2)      // score tile: x0-1 .. x0+64
+#define FSC_H (TILE_H + 2)
+#define FSC_P (FSC_W + 2)       // padded row
+
+__device__ __forceinline__ uint32_t contig9(uint32_t m)
+{
+    m |= m << 16;
+    uint32_t a = m & (m >> 1);
+    a &= a >> 2;
+    a &= a >> 4;
+    a &= m >> 8;
+    return a & 0xffffu;
+}
+
+__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ mpyr,
+                                              uint8_t* __restrict__ nms, uint32_t* __restrict__ hist, bh_orb_geom g)
+{
+    __shared__ uint32_t s_px[FPX_H * (FPX_W / 4)];
+    __shared__ uint8_t  s_sc[FSC_H * FSC_P];
+    __shared__ uint16_t s_list[FSC_H * FSC_W];
+    __shared__ uint32_t s_hist[256];
+    __shared__ int s_n;
+
+    const int tid = threadIdx.x;
+    const int level = tile_level(g, blockIdx.x);
+    const bh_level_geom L = g.lv[level];
+    const int t = blockIdx.x - L.tile_base;
+    const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
+    const size_t fbase = (size_t)blockIdx.y * g.pyr_stride + L.off;
+    const uint8_t* img = pyr + fbase;
+
+    s_hist[tid] = 0;
+    if (tid == 0) s_n = 0;
+    // load the pixel tile as aligned words; outside the image -> 0 (never used by a valid pixel)
+    for (int i = tid; i < FPX_H * (FPX_W / 4); i += 256) {
+        const int r = i / (FPX_W / 4), c = i - r * (FPX_W / 4);
+        const int y = y0 - 4 + r, x = x0 - 4 + c * 4;
+        uint32_t v = 0;
+        if (y >= 0 && y < L.h && x >= 0 && x < L.pitch) v = *reinterpret_cast<const uint32_t*>(img + (size_t)y * L.pitch + x);
+        s_px[i] = v;
+    }
+    for (int i = tid; i < FSC_H * FSC_P; i += 256) s_sc[i] = 0;
+    __syncthreads();
+
+    const uint8_t* px = reinterpret_cast<const uint8_t*>(s_px);
+    const int thr = g.fast_thr;
+    // phase 1: corner test for every pixel of the score tile
+    for (int i = tid; i < FSC_H * FSC_W; i += 256) {
+        const int sy = i / FSC_W, sx = i - sy * FSC_W;
+        const int x = x0 - 1 + sx, y = y0 - 1 + sy;
+        if (x < 3 || x > L.w - 4 || y < 3 || y > L.h - 4) continue;
+        const uint8_t* c = px + (sy + 3) * FPX_W + (sx + 3);
+        const int v = c[0], lo = v - thr, hi = v + thr;
+        uint32_t dm = 0, bm = 0;
+#define FAST_T(k, dx, dy) { const int p = c[(dy) * FPX_W + (dx)]; dm |= (uint32_t)(p < lo) << k; bm |= (uint32_t)(p > hi) << k; }
+        FAST_T(0, 0, 3)  FAST_T(1, 1, 3)  FAST_T(2, 2, 2)  FAST_T(3, 3, 1)
+        FAST_T(4, 3, 0)  FAST_T(5, 3, -1) FAST_T(6, 2, -2) FAST_T(7, 1, -3)
+        FAST_T(8, 0, -3) FAST_T(9, -1, -3) FAST_T(10, -2, -2) FAST_T(11, -3, -1)
+        FAST_T(12, -3, 0) FAST_T(13, -3, 1) FAST_T(14, -2, 2) FAST_T(15, -1, 3)
+#undef FAST_T
+        if (contig9(dm) | contig9(bm)) s_list[atomicAdd(&s_n, 1)] = (uint16_t)i;
+    }
+    __syncthreads();
+    // phase 2: corner score (largest threshold at which the pixel is still a corner), corners only
+    const int n = s_n;
+    for (int j = tid; j < n; j += 256) {
+        const int i = s_list[j];
+        const int sy = i / FSC_W, sx = i - sy * FSC_W;
+        const uint8_t* c = px + (sy + 3) * FPX_W + (sx + 3);
+        const int v = c[0];
+        int d[16];
+        d[0] = v - c[3 * FPX_W];       d[1] = v - c[3 * FPX_W + 1];   d[2] = v - c[2 * FPX_W + 2];   d[3] = v - c[FPX_W + 3];
+        d[4] = v - c[3];               d[5] = v - c[-FPX_W + 3];      d[6] = v - c[-2 * FPX_W + 2];  d[7] = v - c[-3 * FPX_W + 1];
+        d[8] = v - c[-3 * FPX_W];      d[9] = v - c[-3 * FPX_W - 1];  d[10] = v - c[-2 * FPX_W - 2]; d[11] = v - c[-FPX_W - 3];
+        d[12] = v - c[-3];             d[13] = v - c[FPX_W - 3];      d[14] = v - c[2 * FPX_W - 2];  d[15] = v - c[3 * FPX_W - 1];
+        int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+        int a0 = thr, b0 = INT_MAX;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+            const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+            a0 = max(a0, mn9);
+            b0 = min(b0, mx9);
+        }
+        b0 = min(b0, -a0);
+        s_sc[sy * FSC_P + sx] = (uint8_t)(-b0 - 1);
+    }
+    __syncthreads();
+    // phase 3: strict 3x3 NMS, mask and border filter, dense score-map store (4 px per lane) + histogram
+    const uint8_t* msk = mpyr ? mpyr + fbase : nullptr;
+    const int et = g.edge_thr;
+    for (int wd = tid; wd < TILE_H * (TILE_W / 4); wd += 256) {
+        const int oy = wd / (TILE_W / 4), ox = (wd - oy * (TILE_W / 4)) * 4;
+        const int y = y0 + oy;
+        if (y >= L.h) continue;
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = x0 + ox + i;
+            const uint8_t* s = s_sc + (oy + 1) * FSC_P + (ox + i + 1);
+            const int sc = s[0];
+            if (sc == 0) continue;
+            const bool keep = sc > s[-1] && sc > s[1] && sc > s[-FSC_P - 1] && sc > s[-FSC_P] && sc > s[-FSC_P + 1] &&
+                              sc > s[FSC_P - 1] && sc > s[FSC_P] && sc > s[FSC_P + 1];
+            if (!keep) continue;
+            if (!(x >= et && x < L.w - et && y >= et && y < L.h - et)) continue;
+            if (msk && msk[(size_t)y * L.pitch + x] == 0) continue;
+            out |= (uint32_t)sc << (8 * i);
+            atomicAdd(&s_hist[sc], 1u);
+        }
+        *reinterpret_cast<uint32_t*>(nms + fbase + (size_t)y * L.pitch + x0 + ox) = out;
+    }
+    __syncthreads();
+    if (s_hist[tid]) atomicAdd(&hist[((size_t)blockIdx.y * g.nlevels + level) * 256 + tid], s_hist[tid]);
+}
+
+// ------------------------------------------------------------------------------------------------ 7x7 Gaussian blur
+struct bh_gauss7 { int k[7]; };
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (i < 0) i = -i; else if (i >= n) i = 2 * (n - 1) - i;
+    return min(max(i, 0), n - 1);
+}
+
+#define BPX_W (TILE_W + 8)      // x0-4 .. x0+67
+#define BPX_H (TILE_H + 6)      // y0-3 .. y0+34
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                              bh_orb_geom g, bh_gauss7 G)
+{
+    __shared__ uint32_t s_px[BPX_H * (BPX_W / 4)];
+    __shared__ uint16_t s_h[BPX_H * TILE_W];
+
+    const int tid = threadIdx.x;
+    const int level = tile_level(g, blockIdx.x);
+    const bh_level_geom L = g.lv[level];
+    const int t = blockIdx.x - L.tile_base;
+    const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
+    const size_t fbase = (size_t)blockIdx.y * g.pyr_stride + L.off;
+    const uint8_t* img = pyr + fbase;
+
+    const bool interior = x0 >= 4 && x0 + TILE_W + 4 <= L.w && y0 >= 3 && y0 + TILE_H + 3 <= L.h;
+    if (interior) {
+        for (int i = tid; i < BPX_H * (BPX_W / 4); i += 256) {
+            const int r = i / (BPX_W / 4), c = i - r * (BPX_W / 4);
+            s_px[i] = *reinterpret_cast<const uint32_t*>(img + (size_t)(y0 - 3 + r) * L.pitch + x0 - 4 + c * 4);
+        }
+    } else {
+        uint8_t* p8 = reinterpret_cast<uint8_t*>(s_px);
+        for (int i = tid; i < BPX_H * BPX_W; i += 256) {
+            const int r = i / BPX_W, c = i - r * BPX_W;
+            p8[i] = img[(size_t)reflect101(y0 - 3 + r, L.h) * L.pitch + reflect101(x0 - 4 + c, L.w)];
+        }
+    }
+    __syncthreads();
+    const uint8_t* px = reinterpret_cast<const uint8_t*>(s_px);
+    // horizontal pass: sum <= 257*255 fits u16
+    for (int i = tid; i < BPX_H * TILE_W; i += 256) {
+        const int r = i / TILE_W, c = i - r * TILE_W;
+        const uint8_t* p = px + r * BPX_W + c + 1;            // x0 + c - 3
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s += G.k[k] * p[k];
+        s_h[i] = (uint16_t)s;
+    }
+    __syncthreads();
+    for (int wd = tid; wd < TILE_H * (TILE_W / 4); wd += 256) {
+        const int oy = wd / (TILE_W / 4), ox = (wd - oy * (TILE_W / 4)) * 4;
+        const int y = y0 + oy;
+        if (y >= L.h) continue;
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) s += G.k[k] * s_h[(oy + k) * TILE_W + ox + i];
+            s = (s + 32768) >> 16;
+            out |= (uint32_t)min(s, 255) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t*>(blur + fbase + (size_t)y * L.pitch + x0 + ox) = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ select (per frame)
+#define SEL_T    1024
+#define SEL_W    16            // waves
+#define CAND_CAP 4096
+
+__device__ __forceinline__ int wave_excl_scan(int v, int lane)
+{
+    int s = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(s, d, 64); if (lane >= d) s += o; }
+    return s - v;
+}
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ int count_ge(uint32_t w, uint32_t thr)
+{
+    return (int)(((w & 255u) >= thr) + (((w >> 8) & 255u) >= thr) + (((w >> 16) & 255u) >= thr) + ((w >> 24) >= thr));
+}
+
+struct bh_umax { int u[16]; };
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = __fdiv_rn(ax, ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ nms,
+                                                  const uint32_t* __restrict__ hist, bh_orb_geom g, bh_umax UM,
+                                                  float patch_size, int max_kp, bh_kp* __restrict__ kps,
+                                                  uint32_t* __restrict__ kpmeta, int* __restrict__ n_kp,
+                                                  uint32_t* __restrict__ status)
+{
+    __shared__ uint32_t s_xy[CAND_CAP];
+    __shared__ float    s_resp[CAND_CAP];
+    __shared__ uint32_t s_hs[256];
+    __shared__ int s_wcnt[SEL_W];
+    __shared__ int s_thr, s_nout;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t f = blockIdx.x;
+    const size_t fb = f * g.pyr_stride;
+    bh_kp* okp = kps + f * max_kp;
+    uint32_t* ometa = kpmeta + f * max_kp;
+    if (tid == 0) s_nout = 0;
+
+    for (int level = 0; level < g.nlevels; level++) {
+        const bh_level_geom L = g.lv[level];
+        const int n2 = 2 * L.nfeat;
+        // (a) retainBest(2 n_l) threshold on the u8 FAST score: largest s with #(score >= s) >= 2 n_l
+        if (tid < 256) s_hs[tid] = hist[(f * g.nlevels + level) * 256 + tid];
+        if (tid == 0) s_thr = 1;
+        __syncthreads();
+        if (tid >= 1 && tid < 256) {
+            uint32_t suf = 0;
+            for (int b = tid; b < 256; b++) suf += s_hs[b];
+            const uint32_t suf1 = suf - s_hs[tid];                 // #(score >= tid+1)
+            if (suf >= (uint32_t)n2 && suf1 < (uint32_t)n2) s_thr = tid;
+        }
+        __syncthreads();
+        const uint32_t thr = n2 > 0 ? (uint32_t)s_thr : 256u;
+        // (b) pass A: per-wave count of kept candidates over its contiguous slice of the score map
+        const uint4* map = reinterpret_cast<const uint4*>(nms + fb + L.off);
+        const int nvec = (L.pitch * L.h) >> 4;
+        const int seg = (nvec + SEL_W - 1) / SEL_W;
+        const int v0 = wv * seg, v1 = min(v0 + seg, nvec);
+        int cnt = 0;
+        for (int v = v0 + lane; v < v1; v += 64) {
+            const uint4 q = map[v];
+            if (q.x | q.y | q.z | q.w) cnt += count_ge(q.x, thr) + count_ge(q.y, thr) + count_ge(q.z, thr) + count_ge(q.w, thr);
+        }
+        cnt = wave_sum(cnt);
+        if (lane == 0) s_wcnt[wv] = cnt;
+        __syncthreads();
+        int base = 0, total = 0;
+        for (int i = 0; i < SEL_W; i++) { const int c = s_wcnt[i]; if (i < wv) base += c; total += c; }
+        // (c) pass B: emit (x,y) in raster order
+        for (int vb = v0; vb < v1; vb += 64) {
+            const int v = vb + lane;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (v < v1) q = map[v];
+            const uint32_t wds[4] = { q.x, q.y, q.z, q.w };
+            int c = 0;
+            if (q.x | q.y | q.z | q.w) c = count_ge(q.x, thr) + count_ge(q.y, thr) + count_ge(q.z, thr) + count_ge(q.w, thr);
+            if (__ballot(c != 0) == 0ull) continue;
+            int pos = base + wave_excl_scan(c, lane);
+            base += wave_sum(c);
+            if (c) {
+                const int byte0 = v << 4;
+                const int y = byte0 / L.pitch, xb = byte0 - y * L.pitch;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t s = (wds[k >> 2] >> (8 * (k & 3))) & 255u;
+                    if (s >= thr) { if (pos < CAND_CAP) s_xy[pos] = ((uint32_t)y << 16) | (uint32_t)(xb + k); pos++; }
+                }
+            }
+        }
+        if (total > CAND_CAP) { if (tid == 0) atomicOr(status, BH_ST_CAND_OVERFLOW); total = CAND_CAP; }
+        __syncthreads();
+        const int m = total;
+        // (d) Harris response, 7x7 block of 3x3 Sobel products
+        const uint8_t* img = pyr + fb + L.off;
+        for (int i = tid; i < m; i += SEL_T) {
+            const uint32_t xy = s_xy[i];
+            const int cx = xy & 0xffffu, cy = xy >> 16;
+            int a = 0, b = 0, c = 0;
+            int r0[9], r1[9], r2[9];
+            const uint8_t* p = img + (size_t)(cy - 4) * L.pitch + cx - 4;
+#pragma unroll
+            for (int k = 0; k < 9; k++) { r0[k] = p[k]; r1[k] = p[L.pitch + k]; }
+            for (int row = 2; row < 9; row++) {
+                const uint8_t* q = p + (size_t)row * L.pitch;
+#pragma unroll
+                for (int k = 0; k < 9; k++) r2[k] = q[k];
+#pragma unroll
+                for (int k = 1; k < 8; k++) {
+                    const int Ix = (r1[k + 1] - r1[k - 1]) * 2 + (r0[k + 1] - r0[k - 1]) + (r2[k + 1] - r2[k - 1]);
+                    const int Iy = (r2[k] - r0[k]) * 2 + (r2[k - 1] - r0[k - 1]) + (r2[k + 1] - r0[k + 1]);
+                    a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
+            }
+            const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+            const float scale_sq_sq = scale * scale * scale * scale;
+            const float fa = (float)a, fbb = (float)b, fc = (float)c;
+            const float t1 = fa * fbb, t2 = fc * fc, s = fa + fbb;
+            const float t3 = (0.04f * s) * s;
+            s_resp[i] = ((t1 - t2) - t3) * scale_sq_sq;
+        }
+        __syncthreads();
+        // (e) retainBest(n_l): keep i iff fewer than n_l responses are strictly greater (ties at the cut all kept)
+        const int per = (m + SEL_T - 1) / SEL_T;          // consecutive entries per thread (<= 4)
+        const int i0 = tid * per;
+        int keep_mask = 0, kcnt = 0;
+        for (int e = 0; e < per; e++) {
+            const int i = i0 + e;
+            if (i >= m) break;
+            bool keep = true;
+            if (m > L.nfeat) {
+                const float r = s_resp[i];
+                int rank = 0;
+                for (int j = 0; j < m; j++) rank += (s_resp[j] > r);
+                keep = rank < L.nfeat;
+            }
+            if (keep) { keep_mask |= 1 << e; kcnt++; }
+        }
+        // block exclusive scan of kcnt
+        const int wpre = wave_excl_scan(kcnt, lane);
+        const int wtot = wave_sum(kcnt);
+        __syncthreads();                                   // s_wcnt reuse
+        if (lane == 0) s_wcnt[wv] = wtot;
+        __syncthreads();
+        int kbase = s_nout, ktotal = 0;
+        for (int i = 0; i < SEL_W; i++) { const int c = s_wcnt[i]; if (i < wv) kbase += c; ktotal += c; }
+        int pos = kbase + wpre;
+        for (int e = 0; e < per; e++) {
+            if (!(keep_mask & (1 << e))) continue;
+            if (pos < max_kp) {
+                const uint32_t xy = s_xy[i0 + e];
+                const int cx = xy & 0xffffu, cy = xy >> 16;
+                bh_kp k;
+                k.x = (float)cx * L.scale; k.y = (float)cy * L.scale;
+                k.size = patch_size * L.scale; k.angle = -1.f; k.response = s_resp[i0 + e]; k.octave = level;
+                okp[pos] = k;
+                ometa[pos] = ((uint32_t)level << 28) | ((uint32_t)cy << 14) | (uint32_t)cx;
+            }
+            pos++;
+        }
+        __syncthreads();
+        if (tid == 0) s_nout += ktotal;
+        __syncthreads();
+    }
+    int nout = s_nout;
+    if (nout > max_kp) { if (tid == 0) atomicOr(status, BH_ST_KP_OVERFLOW); nout = max_kp; }
+    if (tid == 0) n_kp[f] = nout;
+    // (f) intensity-centroid angle, one wave per keypoint: lanes cover 2 rows x 32 columns per step
+    for (int k = wv; k < nout; k += SEL_W) {
+        const uint32_t meta = ometa[k];
+        const int level = meta >> 28, cy = (meta >> 14) & 0x3fff, cx = meta & 0x3fff;
+        const bh_level_geom L = g.lv[level];
+        const uint8_t* c = pyr + fb + L.off + (size_t)cy * L.pitch + cx;
+        const int u = (lane & 31) - 15;
+        int m10 = 0, m01 = 0;
+        for (int it = 0; it < 16; it++) {
+            const int v = it * 2 + (lane >> 5) - 15;
+            if (v <= 15 && (lane & 31) < 31) {
+                const int av = v < 0 ? -v : v;
+                if (u >= -UM.u[av] && u <= UM.u[av]) {
+                    const int I = c[v * L.pitch + u];
+                    m10 += u * I; m01 += v * I;
+                }
+            }
+        }
+        m10 = wave_sum(m10); m01 = wave_sum(m01);
+        if (lane == 0) okp[k].angle = fast_atan2_deg((float)m01, (float)m10);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ steered BRIEF
+__constant__ signed char c_pattern[1024] = {
+#include "brief_pattern.h"
+};
+
+__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blur, bh_orb_geom g, int max_kp,
+                                               const bh_kp* __restrict__ kps, const int* __restrict__ n_kp,
+                                               uint8_t* __restrict__ desc)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t f = blockIdx.y;
+    if (k >= n_kp[f]) return;
+    const bh_kp kp = kps[f * max_kp + k];
+    const bh_level_geom L = g.lv[kp.octave];
+    const float inv = 1.f / L.scale;
+    const int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
+    float angle = kp.angle;
+    angle *= (float)(3.1415926535897932384626433832795 / 180.f);
+    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const uint8_t* center = blur + f * g.pyr_stride + L.off + (size_t)cy * L.pitch + cx;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const signed char* q = c_pattern + (t * 64 + lane) * 4;
+        const float qx0 = (float)q[0], qy0 = (float)q[1], qx1 = (float)q[2], qy1 = (float)q[3];
+        const float x0 = qx0 * a - qy0 * b, y0 = qx0 * b + qy0 * a;
+        const float x1 = qx1 * a - qy1 * b, y1 = qx1 * b + qy1 * a;
+        const int t0 = center[__float2int_rn(y0) * L.pitch + __float2int_rn(x0)];
+        const int t1 = center[__float2int_rn(y1) * L.pitch + __float2int_rn(x1)];
+        bits[t] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        reinterpret_cast<unsigned long long*>(desc + (f * max_kp + k) * 32)[lane] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ kp -> int coords + 3-D
+__global__ __launch_bounds__(256) void k_kp_backproject(const bh_kp* __restrict__ kps, const int* __restrict__ n_kp,
+                                                        const uint16_t* __restrict__ depth, int H, int W, int max_kp,
+                                                        double fx, double fy, double ppx, double ppy,
+                                                        long long* __restrict__ kp_xy, double* __restrict__ cloud)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const size_t f = blockIdx.y;
+    if (k >= n_kp[f]) return;
+    const bh_kp kp = kps[f * max_kp + k];
+    const long long u = (long long)kp.x, v = (long long)kp.y;            // int() truncation, camera.py:142
+    kp_xy[(f * max_kp + k) * 2] = u; kp_xy[(f * max_kp + k) * 2 + 1] = v;
+    if (cloud && depth) {
+        const double z = (double)depth[f * H * W + (size_t)v * W + u] / 1000;
+        const double xn = ((double)u - ppx) / fx, yn = ((double)v - ppy) / fy;
+        double* o = cloud + (f * max_kp + k) * 3;
+        o[0] = xn * z; o[1] = yn * z; o[2] = z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static void umax_table(int* umax /*[17]*/)
+{
+    const int hp = 15;
+    int v, v0, vmax = (int)floor(hp * sqrtf(2.f) / 2 + 1);
+    int vmin = (int)ceil(hp * sqrtf(2.f) / 2);
+    for (v = 0; v <= vmax; ++v) umax[v] = round_even_d(sqrt((double)hp * hp - v * v));
+    for (v = hp, v0 = 0; v >= vmin; --v) {
+        while (umax[v0] == umax[v0 + 1]) ++v0;
+        umax[v] = v0;
+        ++v0;
+    }
+}
+
+static void gauss7_coeffs(int* k)
+{
+    float cf[7]; double sum = 0, sigma = 2.0, s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(s2 * x * x); sum += cf[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i] * sum); k[i] = round_even_f(cf[i] * 256.f); }
+}
+
+static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
+{
+    if (ctx->geom_valid && memcmp(&ctx->geom_params, p, sizeof(*p)) == 0 && ctx->geom.H == H && ctx->geom.W == W)
+        return BH_OK;
+    bh_orb_geom g;
+    if (build_geom(p, H, W, &g) != BH_OK) return bh_set_err(ctx, BH_ERR_INVALID, "unsupported ORB parameters / image size");
+    uint32_t* tab = (uint32_t*)malloc(sizeof(uint32_t) * (g.tab_len + 1));
+    for (int l = 1; l < g.nlevels; l++) {
+        lin_coeffs(g.lv[l - 1].w, g.lv[l].w, tab + g.lv[l].tabx_off);
+        lin_coeffs(g.lv[l - 1].h, g.lv[l].h, tab + g.lv[l].taby_off);
+    }
+    int rc = bh_reserve(ctx, &ctx->tab, sizeof(uint32_t) * (g.tab_len + 1));
+    if (rc == BH_OK) {
+        hipError_t e = hipMemcpyAsync(ctx->tab.p, tab, sizeof(uint32_t) * g.tab_len, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = bh_set_err(ctx, BH_ERR_HIP, "coefficient table upload failed: %s", hipGetErrorString(e));
+    }
+    free(tab);
+    if (rc != BH_OK) return rc;
+    ctx->geom = g; ctx->geom_params = *p; ctx->geom_valid = 1; ctx->ws_frames = 0;
+    return BH_OK;
+}
+
+extern "C" int bh_orb_geometry(int H, int W, const bh_orb_params* params, int* w, int* h, int* pitch, int* off,
+                               int* nfeat, int* total_bytes)
+{
+    bh_orb_geom g;
+    if (build_geom(params, H, W, &g) != BH_OK) return BH_ERR_INVALID;
+    for (int l = 0; l < g.nlevels; l++) {
+        if (w) w[l] = g.lv[l].w;
+        if (h) h[l] = g.lv[l].h;
+        if (pitch) pitch[l] = g.lv[l].pitch;
+        if (off) off[l] = g.lv[l].off;
+        if (nfeat) nfeat[l] = g.lv[l].nfeat;
+    }
+    if (total_bytes) *total_bytes = g.pyr_stride;
+    return BH_OK;
+}
+
+#define ORB_CHUNK 256
+
+extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int channels, const uint8_t* mask,
+                                      const uint16_t* depth, int B, int H, int W, const bh_orb_params* params,
+                                      int max_kp, bh_kp* kps, uint8_t* desc, int* n_kp, int mem)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (!img || !params || !kps || !desc || !n_kp || B < 0 || max_kp < 1 || (channels != 1 && channels != 3) ||
+        (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_orb_detect_describe: bad argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    BH_TRY(ensure_geom(ctx, params, H, W));
+    if (B == 0) return BH_OK;
+    const bh_orb_geom& g = ctx->geom;
+    hipStream_t st = ctx->stream;
+    const int chunk = B < ORB_CHUNK ? B : ORB_CHUNK;
+    const bool has_mask = mask != nullptr || depth != nullptr;
+
+    const size_t ws = (size_t)g.pyr_stride * chunk;
+    BH_TRY(bh_reserve(ctx, &ctx->pyr, ws));
+    if (has_mask) BH_TRY(bh_reserve(ctx, &ctx->mpyr, ws));
+    BH_TRY(bh_reserve(ctx, &ctx->nms, ws));
+    BH_TRY(bh_reserve(ctx, &ctx->blur, ws));
+    BH_TRY(bh_reserve(ctx, &ctx->hist, sizeof(uint32_t) * 256 * g.nlevels * chunk));
+    BH_TRY(bh_reserve(ctx, &ctx->kpmeta, sizeof(uint32_t) * (size_t)max_kp * chunk));
+    BH_TRY(bh_reserve(ctx, &ctx->status, 256));
+    ctx->ws_frames = chunk;
+
+    const size_t fpx = (size_t)H * W;
+    if (mem == BH_MEM_HOST) {
+        BH_TRY(bh_reserve(ctx, &ctx->st_img, fpx * channels * chunk));
+        if (mask) BH_TRY(bh_reserve(ctx, &ctx->st_mask, fpx * chunk));
+        else if (depth) BH_TRY(bh_reserve(ctx, &ctx->st_depth, fpx * 2 * chunk));
+        BH_TRY(bh_reserve(ctx, &ctx->st_kps, sizeof(bh_kp) * (size_t)max_kp * chunk));
+        BH_TRY(bh_reserve(ctx, &ctx->st_desc, (size_t)32 * max_kp * chunk));
+        BH_TRY(bh_reserve(ctx, &ctx->st_nkp, sizeof(int) * chunk));
+    }
+    BH_HIP(ctx, hipMemsetAsync(ctx->status.p, 0, 256, st));
+
+    bh_umax UM; { int um[17]; umax_table(um); for (int i = 0; i < 16; i++) UM.u[i] = um[i]; }
+    bh_gauss7 G; gauss7_coeffs(G.k);
+
+    for (int f0 = 0; f0 < B; f0 += chunk) {
+        const int nb = (B - f0) < chunk ? (B - f0) : chunk;
+        const uint8_t* d_img; const uint8_t* d_mask = nullptr; const uint16_t* d_depth = nullptr;
+        bh_kp* d_kps; uint8_t* d_desc; int* d_nkp;
+        if (mem == BH_MEM_HOST) {
+            BH_HIP(ctx, hipMemcpyAsync(ctx->st_img.p, img + (size_t)f0 * fpx * channels, fpx * channels * nb, hipMemcpyHostToDevice, st));
+            d_img = (const uint8_t*)ctx->st_img.p;
+            if (mask) { BH_HIP(ctx, hipMemcpyAsync(ctx->st_mask.p, mask + (size_t)f0 * fpx, fpx * nb, hipMemcpyHostToDevice, st)); d_mask = (const uint8_t*)ctx->st_mask.p; }
+            else if (depth) { BH_HIP(ctx, hipMemcpyAsync(ctx->st_depth.p, depth + (size_t)f0 * fpx, fpx * 2 * nb, hipMemcpyHostToDevice, st)); d_depth = (const uint16_t*)ctx->st_depth.p; }
+            d_kps = (bh_kp*)ctx->st_kps.p; d_desc = (uint8_t*)ctx->st_desc.p; d_nkp = (int*)ctx->st_nkp.p;
+        } else {
+            d_img = img + (size_t)f0 * fpx * channels;
+            if (mask) d_mask = mask + (size_t)f0 * fpx; else if (depth) d_depth = depth + (size_t)f0 * fpx;
+            d_kps = kps + (size_t)f0 * max_kp; d_desc = desc + (size_t)f0 * max_kp * 32; d_nkp = n_kp + f0;
+        }
+        uint8_t* pyr = (uint8_t*)ctx->pyr.p; uint8_t* mpyr = has_mask ? (uint8_t*)ctx->mpyr.p : nullptr;
+        uint8_t* nms = (uint8_t*)ctx->nms.p; uint8_t* blur = (uint8_t*)ctx->blur.p;
+        uint32_t* hist = (uint32_t*)ctx->hist.p;
+
+        BH_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * g.nlevels * nb, st));
+        {
+            const int n = (g.lv[0].pitch >> 2) * g.lv[0].h;
+            hipLaunchKernelGGL(k_gray_mask, dim3((n + 255) / 256, nb), dim3(256), 0, st, d_img, channels, d_mask, d_depth,
+                               pyr, mpyr, W, H, g.lv[0].pitch, g.pyr_stride);
+        }
+        for (int l = 1; l < g.nlevels; l++) {
+            const int n = (g.lv[l].pitch >> 2) * g.lv[l].h;
+            hipLaunchKernelGGL(k_pyr_down, dim3((n + 255) / 256, nb), dim3(256), 0, st, pyr, mpyr, g, l, (const uint32_t*)ctx->tab.p);
+        }
+        hipLaunchKernelGGL(k_fast, dim3(g.ntiles, nb), dim3(256), 0, st, pyr, mpyr, nms, hist, g);
+        hipLaunchKernelGGL(k_blur, dim3(g.ntiles, nb), dim3(256), 0, st, pyr, blur, g, G);
+        hipLaunchKernelGGL(k_select, dim3(nb), dim3(SEL_T), 0, st, pyr, nms, hist, g, UM, (float)params->patchSize, max_kp,
+                           d_kps, (uint32_t*)ctx->kpmeta.p, d_nkp, (uint32_t*)ctx->status.p);
+        hipLaunchKernelGGL(k_brief, dim3((max_kp + 3) / 4, nb), dim3(256), 0, st, blur, g, max_kp, d_kps, d_nkp, d_desc);
+        BH_HIP(ctx, hipGetLastError());
+        if (mem == BH_MEM_HOST) {
+            BH_HIP(ctx, hipMemcpyAsync(kps + (size_t)f0 * max_kp, d_kps, sizeof(bh_kp) * (size_t)max_kp * nb, hipMemcpyDeviceToHost, st));
+            BH_HIP(ctx, hipMemcpyAsync(desc + (size_t)f0 * max_kp * 32, d_desc, (size_t)32 * max_kp * nb, hipMemcpyDeviceToHost, st));
+            BH_HIP(ctx, hipMemcpyAsync(n_kp + f0, d_nkp, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+            BH_HIP(ctx, hipStreamSynchronize(st));
+        }
+        ctx->last_B = nb; ctx->last_has_mask = has_mask;
+    }
+    if (mem == BH_MEM_HOST) return bh_ctx_status(ctx);
+    return BH_OK;
+}
+
+extern "C" int bh_orb_debug_fetch(bh_ctx* ctx, int frame, uint8_t* pyr, uint8_t* mask_pyr, uint8_t* nms, uint8_t* blur)
+{
+    if (!ctx || !ctx->geom_valid || frame < 0 || frame >= ctx->last_B)
+        return ctx ? bh_set_err(ctx, BH_ERR_INVALID, "bh_orb_debug_fetch: no such frame in the last chunk") : BH_ERR_INVALID;
+    const size_t n = ctx->geom.pyr_stride, o = (size_t)frame * n;
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (pyr)  BH_HIP(ctx, hipMemcpy(pyr, (uint8_t*)ctx->pyr.p + o, n, hipMemcpyDeviceToHost));
+    if (mask_pyr && ctx->last_has_mask) BH_HIP(ctx, hipMemcpy(mask_pyr, (uint8_t*)ctx->mpyr.p + o, n, hipMemcpyDeviceToHost));
+    if (nms)  BH_HIP(ctx, hipMemcpy(nms, (uint8_t*)ctx->nms.p + o, n, hipMemcpyDeviceToHost));
+    if (blur) BH_HIP(ctx, hipMemcpy(blur, (uint8_t*)ctx->blur.p + o, n, hipMemcpyDeviceToHost));
+    return BH_OK;
+}
+
+extern "C" int bh_kp_backproject(bh_ctx* ctx, const bh_kp* kps, const int* n_kp, const uint16_t* depth, int B, int H,
+                                 int W, int max_kp, double fx, double fy, double ppx, double ppy,
+                                 int64_t* kp_xy, double* cloud_kp, int mem)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (!kps || !n_kp || !kp_xy || B < 0 || max_kp < 1 || (cloud_kp && !depth))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_kp_backproject: bad argument");
+    if (B == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const bh_kp* d_kps = kps; const int* d_n = n_kp; const uint16_t* d_depth = depth;
+    long long* d_xy = (long long*)kp_xy; double* d_cl = cloud_kp;
+    const size_t nk = (size_t)B * max_kp;
+    if (mem == BH_MEM_HOST) {
+        BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(bh_kp) * nk));
+        BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(int) * B));
+        BH_TRY(bh_reserve(ctx, &ctx->st_c, sizeof(long long) * 2 * nk));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_a.p, kps, sizeof(bh_kp) * nk, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_b.p, n_kp, sizeof(int) * B, hipMemcpyHostToDevice, st));
+        d_kps = (const bh_kp*)ctx->st_a.p; d_n = (const int*)ctx->st_b.p; d_xy = (long long*)ctx->st_c.p;
+        if (cloud_kp) {
+            BH_TRY(bh_reserve(ctx, &ctx->st_d, (size_t)B * H * W * 2));
+            BH_TRY(bh_reserve(ctx, &ctx->st_e, sizeof(double) * 3 * nk));
+            BH_HIP(ctx, hipMemcpyAsync(ctx->st_d.p, depth, (size_t)B * H * W * 2, hipMemcpyHostToDevice, st));
+            d_depth = (const uint16_t*)ctx->st_d.p; d_cl = (double*)ctx->st_e.p;
+        }
+    }
+    hipLaunchKernelGGL(k_kp_backproject, dim3((max_kp + 255) / 256, B), dim3(256), 0, st, d_kps, d_n, d_depth, H, W, max_kp,
+                       fx, fy, ppx, ppy, d_xy, d_cl);
+    BH_HIP(ctx, hipGetLastError());
+    if (mem == BH_MEM_HOST) {
+        BH_HIP(ctx, hipMemcpyAsync(kp_xy, d_xy, sizeof(long long) * 2 * nk, hipMemcpyDeviceToHost, st));
+        if (cloud_kp) BH_HIP(ctx, hipMemcpyAsync(cloud_kp, d_cl, sizeof(double) * 3 * nk, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipStreamSynchronize(st));
+    }
+    return BH_OK;
+}

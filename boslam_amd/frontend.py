@@ -1,0 +1,130 @@
+"""Batched front-end over the C ABI: ORB detect+describe, keypoint back-projection, Hamming cross-check matching.
+
+Host-side mirror of what the reference does one frame at a time in RsCamera.get (camera.py:131-168) and
+Tracker._track_wrt_refkf (slam/tracking.py:54-62), batched over frames.  All arithmetic happens in
+libboslam_hip.so; this module only shapes arrays."""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import OrbParams, KP_DTYPE, BH_MEM_HOST, BH_MEM_DEVICE
+
+# camera.py:49-56
+REFERENCE_ORB_PARAMS = dict(nfeatures=600, scaleFactor=1.2, nlevels=8, edgeThreshold=31, firstLevel=0,
+                            patchSize=31, fastThreshold=20)
+
+
+def make_params(**kw):
+    p = dict(REFERENCE_ORB_PARAMS)
+    p.update(kw)
+    return OrbParams(int(p["nfeatures"]), float(p["scaleFactor"]), int(p["nlevels"]), int(p["edgeThreshold"]),
+                     int(p["firstLevel"]), int(p["patchSize"]), int(p["fastThreshold"]))
+
+
+def default_max_kp(params):
+    return int(params.nfeatures) + 64 + int(params.nfeatures) // 8
+
+
+def orb_geometry(H, W, params):
+    n = params.nlevels
+    w, h, pitch, off, nf = (np.zeros(n, np.int32) for _ in range(5))
+    total = C.c_int(0)
+    rc = _lib.lib().bh_orb_geometry(H, W, C.byref(params), _lib.ptr(w), _lib.ptr(h), _lib.ptr(pitch), _lib.ptr(off),
+                                    _lib.ptr(nf), C.byref(total))
+    if rc != 0:
+        raise _lib.BhError(rc, "unsupported ORB parameters")
+    return dict(w=w, h=h, pitch=pitch, off=off, nfeat=nf, total=total.value)
+
+
+def orb_detect_describe(ctx, imgs, mask=None, depth=None, params=None, max_kp=None):
+    """Host arrays in, host arrays out.  imgs u8[B][H][W][3] or u8[B][H][W]; returns (kps[B][max_kp], desc, n_kp)."""
+    params = params or make_params()
+    imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+    B, H, W = imgs.shape[:3]
+    ch = 1 if imgs.ndim == 3 else imgs.shape[3]
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert mask.shape == (B, H, W)
+    if depth is not None:
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        assert depth.shape == (B, H, W)
+    max_kp = max_kp or default_max_kp(params)
+    kps = np.zeros((B, max_kp), KP_DTYPE)
+    desc = np.zeros((B, max_kp, 32), np.uint8)
+    n = np.zeros(B, np.int32)
+    ctx.check(_lib.lib().bh_orb_detect_describe(ctx.h, _lib.ptr(imgs), ch, _lib.ptr(mask), _lib.ptr(depth), B, H, W,
+                                                C.byref(params), max_kp, _lib.ptr(kps), _lib.ptr(desc), _lib.ptr(n),
+                                                BH_MEM_HOST))
+    return kps, desc, n
+
+
+def orb_debug_fetch(ctx, frame, H, W, params):
+    g = orb_geometry(H, W, params)
+    out = {k: np.zeros(g["total"], np.uint8) for k in ("pyr", "mask", "nms", "blur")}
+    ctx.check(_lib.lib().bh_orb_debug_fetch(ctx.h, frame, _lib.ptr(out["pyr"]), _lib.ptr(out["mask"]),
+                                            _lib.ptr(out["nms"]), _lib.ptr(out["blur"])))
+    out.update(g)
+    return out
+
+
+def kp_backproject(ctx, kps, n_kp, depth, fx, fy, ppx, ppy):
+    """camera.py:142 + camera.py:90-118 for a batch: returns (kp_arr i64[B][max_kp][2], cloud_kp f64[B][max_kp][3])."""
+    kps = np.ascontiguousarray(kps)
+    B, max_kp = kps.shape
+    n_kp = np.ascontiguousarray(n_kp, dtype=np.int32)
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    H, W = depth.shape[1:]
+    xy = np.zeros((B, max_kp, 2), np.int64)
+    cloud = np.zeros((B, max_kp, 3), np.float64)
+    ctx.check(_lib.lib().bh_kp_backproject(ctx.h, _lib.ptr(kps), _lib.ptr(n_kp), _lib.ptr(depth), B, H, W, max_kp,
+                                           fx, fy, ppx, ppy, _lib.ptr(xy), _lib.ptr(cloud), BH_MEM_HOST))
+    return xy, cloud
+
+
+def match_pairs(ctx, q, nq, t, nt, out_stride=None):
+    """B independent pairs.  q u8[B][Sq][32], t u8[B][St][32] -> (qidx, tidx, dist)[B][out_stride], n_match[B]."""
+    q = np.ascontiguousarray(q, dtype=np.uint8); t = np.ascontiguousarray(t, dtype=np.uint8)
+    B, Sq = q.shape[:2]; St = t.shape[1]
+    nq = np.ascontiguousarray(nq, dtype=np.int32); nt = np.ascontiguousarray(nt, dtype=np.int32)
+    out_stride = out_stride or max(1, min(Sq, St))
+    qi = np.zeros((B, out_stride), np.int32); ti = np.zeros_like(qi); d = np.zeros_like(qi)
+    nm = np.zeros(B, np.int32)
+    ctx.check(_lib.lib().bh_match_hamming_crosscheck(ctx.h, _lib.ptr(q), _lib.ptr(nq), Sq, _lib.ptr(t), _lib.ptr(nt), St,
+                                                     B, _lib.ptr(qi), _lib.ptr(ti), _lib.ptr(d), _lib.ptr(nm),
+                                                     out_stride, BH_MEM_HOST))
+    return qi, ti, d, nm
+
+
+class DeviceFrontEnd:
+    """HBM-resident batch pipeline used by bench.py: inputs and outputs are device buffers (torch tensors are used
+    only as the allocator); ORB on B frames then consecutive-frame matching (query = frame i, train = frame i-1,
+    the direction of slam/tracking.py:56)."""
+
+    def __init__(self, ctx, B, H, W, params, max_kp=None, torch_device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.ctx, self.B, self.H, self.W, self.params = ctx, B, H, W, params
+        self.max_kp = max_kp or default_max_kp(params)
+        dev = torch_device
+        self.kps = torch.zeros((B, self.max_kp, 6), dtype=torch.float32, device=dev)      # bh_kp = 6 x 4 bytes
+        self.desc = torch.zeros((B, self.max_kp, 32), dtype=torch.uint8, device=dev)
+        self.n_kp = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.qidx = torch.zeros((B, self.max_kp), dtype=torch.int32, device=dev)
+        self.tidx = torch.zeros_like(self.qidx)
+        self.dist = torch.zeros_like(self.qidx)
+        self.n_match = torch.zeros((B,), dtype=torch.int32, device=dev)
+
+    def run(self, bgr, depth):
+        """bgr u8[B][H][W][3], depth u16-as-int16 [B][H][W] device tensors.  Enqueues; does not synchronise."""
+        L = _lib.lib()
+        c = self.ctx
+        ch = 1 if bgr.dim() == 3 else bgr.shape[3]
+        c.check(L.bh_orb_detect_describe(c.h, _lib.ptr(bgr), ch, None, _lib.ptr(depth), self.B, self.H, self.W,
+                                         C.byref(self.params), self.max_kp, _lib.ptr(self.kps), _lib.ptr(self.desc),
+                                         _lib.ptr(self.n_kp), BH_MEM_DEVICE))
+        if self.B > 1:
+            row = self.max_kp * 32
+            c.check(L.bh_match_hamming_crosscheck(
+                c.h, self.desc.data_ptr() + row, self.n_kp.data_ptr() + 4, self.max_kp,
+                self.desc.data_ptr(), self.n_kp.data_ptr(), self.max_kp, self.B - 1,
+                self.qidx.data_ptr() + 4 * self.max_kp, self.tidx.data_ptr() + 4 * self.max_kp,
+                self.dist.data_ptr() + 4 * self.max_kp, self.n_match.data_ptr() + 4, self.max_kp, BH_MEM_DEVICE))

@@ -1,0 +1,148 @@
+/*
+ * boslam_hip.h — C ABI of libboslam_hip.so: the MI355X (gfx950) implementation of boslam's data-parallel hot path.
+ *
+ * The reference (BOpermanis/boslam) has no plugin/operator API: its hot path is a set of third-party Python call
+ * sites (cv2 / g2o / pyDBoW3).  Every entry point below names the reference call site it replaces (file:line in
+ * the reference tree).  INTEGRATION.md shows the ctypes stubs a maintainer adds at those sites.
+ *
+ * Conventions
+ *   - plain pointers and sizes; the caller owns every buffer; the library never keeps a caller pointer past a call.
+ *   - `mem` says where the bulk arrays of THAT call live: BH_MEM_HOST (the library stages them through its own
+ *     device workspace and synchronises before returning) or BH_MEM_DEVICE (pointers are device pointers; the work
+ *     is enqueued on the context's stream and the call returns without synchronising; small count arrays such as
+ *     n_kp are device arrays too).
+ *   - every function returns BH_OK (0) or a negative error; bh_last_error(ctx) gives the text.  No exceptions, no
+ *     CPU fallback: without a usable HIP device bh_ctx_create fails.
+ *   - one bh_ctx per calling thread (the reference runs the tracker on the main thread and local mapping on a
+ *     daemon thread, slam/main.py:37-47): a context owns its stream and workspace, there is no global mutable state.
+ */
+#ifndef BOSLAM_HIP_H
+#define BOSLAM_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BH_OK             0
+#define BH_ERR_INVALID   -1   /* bad argument */
+#define BH_ERR_HIP       -2   /* HIP runtime error (no device, launch failure, ...) */
+#define BH_ERR_CAPACITY  -3   /* an output or internal list overflowed; results truncated in canonical order */
+#define BH_ERR_NOMEM     -4
+#define BH_ERR_NUMERIC   -5   /* linear solve failed / non-finite state (the shims map this to the reference's
+                                 (False, None, None, None), slam/optimizer.py:140-142) */
+
+#define BH_MEM_HOST       0
+#define BH_MEM_DEVICE     1
+
+typedef struct bh_ctx bh_ctx;
+
+/* cv2.ORB_create(**orb_params) — camera.py:49-62.  WTA_K = 2 and scoreType = HARRIS_SCORE are the implicit
+ * defaults the reference relies on; firstLevel must be 0 and patchSize 31 (the only values the reference uses). */
+typedef struct {
+    int   nfeatures;
+    float scaleFactor;
+    int   nlevels;
+    int   edgeThreshold;
+    int   firstLevel;
+    int   patchSize;
+    int   fastThreshold;
+} bh_orb_params;
+
+/* cv2.KeyPoint fields the reference reads (k.pt at camera.py:142) plus the rest of the detector output. */
+typedef struct {
+    float x, y;        /* pt, level-0 coordinates */
+    float size;        /* patchSize * scale(level) */
+    float angle;       /* degrees, [0,360) */
+    float response;    /* Harris response */
+    int   octave;      /* pyramid level */
+} bh_kp;
+
+/* ---- context ------------------------------------------------------------------------------------------------- */
+int         bh_ctx_create(int device, bh_ctx** out);
+void        bh_ctx_destroy(bh_ctx* ctx);
+const char* bh_last_error(const bh_ctx* ctx);
+/* Adopt an existing hipStream_t (e.g. the caller's torch stream); NULL restores the context's own stream. */
+int         bh_ctx_set_stream(bh_ctx* ctx, void* hip_stream);
+int         bh_ctx_synchronize(bh_ctx* ctx);
+/* Deferred status of BH_MEM_DEVICE work (capacity flags raised on the device); synchronises the stream. */
+int         bh_ctx_status(bh_ctx* ctx);
+const char* bh_version(void);
+
+/* ---- ORB detect + describe ------------------------------------------------------------------------------------
+ * Replaces feature_extractor.detectAndCompute(frame, mask=(depth_image > 0) * 255) — camera.py:141 — for a batch
+ * of B frames.
+ *   img      u8[B][H][W][channels], channels 3 (BGR, camera.py:70 bgr8) or 1 (gray)
+ *   mask     u8[B][H][W] or NULL      (cv2 semantics: keypoints on mask==0 pixels are dropped)
+ *   depth    u16[B][H][W] or NULL     (when given and mask is NULL the mask is (depth>0)*255, fused on device)
+ *   kps      bh_kp[B][max_kp], desc u8[B][max_kp][32], n_kp int[B]
+ * Keypoint order is canonical: level-major, raster (y, x) inside a level (DESIGN.md "canonical order").
+ * max_kp must allow for ties at the retainBest threshold (nfeatures + slack); overflow raises BH_ERR_CAPACITY. */
+int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int channels, const uint8_t* mask,
+                           const uint16_t* depth, int B, int H, int W, const bh_orb_params* params,
+                           int max_kp, bh_kp* kps, uint8_t* desc, int* n_kp, int mem);
+
+/* Debug/inspection: copy the per-frame intermediates of the LAST bh_orb_detect_describe call for frame `frame`
+ * to host buffers (each may be NULL).  Layout: level l at off[l] with row pitch pitch[l] (bh_orb_geometry). */
+int bh_orb_geometry(int H, int W, const bh_orb_params* params, int* w, int* h, int* pitch, int* off,
+                    int* nfeat, int* total_bytes);
+int bh_orb_debug_fetch(bh_ctx* ctx, int frame, uint8_t* pyr, uint8_t* mask_pyr, uint8_t* nms, uint8_t* blur);
+
+/* kp_arr = [(int(x), int(y)) for k in kp] — camera.py:142 — and the keypoint gather of
+ * convert_depth_frame_to_pointcloud — camera.py:90-118: xyz = ((u-ppx)/fx*z, (v-ppy)/fy*z, z), z = depth/1000.
+ *   kp_xy i64[B][max_kp][2] (x,y) out ; cloud_kp f64[B][max_kp][3] out (may be NULL) */
+int bh_kp_backproject(bh_ctx* ctx, const bh_kp* kps, const int* n_kp, const uint16_t* depth, int B, int H, int W,
+                      int max_kp, double fx, double fy, double ppx, double ppy,
+                      int64_t* kp_xy, double* cloud_kp, int mem);
+
+/* ---- brute-force Hamming matcher with cross-check ------------------------------------------------------------------
+ * Replaces cv2.BFMatcher_create(cv2.NORM_HAMMING, crossCheck=True).match(q, t) — slam/tracking.py:45,56,121,
+ * slam/local_mapping.py:21, slam/covisibility_graph.py:34, experiments/pnp_two_way_tracking.py:11,42 — for B
+ * independent (query, train) pairs.  Pair b: q + b*q_stride*32 with nq[b] rows, t + b*t_stride*32 with nt[b] rows.
+ * Output pair b at out_stride*b: qidx/tidx/dist (ascending queryIdx, OpenCV's crosscheck rule), n_match[b]. */
+int bh_match_hamming_crosscheck(bh_ctx* ctx, const uint8_t* q, const int* nq, int q_stride,
+                                const uint8_t* t, const int* nt, int t_stride, int B,
+                                int* qidx, int* tidx, int* dist, int* n_match, int out_stride, int mem);
+
+/* ---- pose-only bundle adjustment ----------------------------------------------------------------------------------
+ * Replaces CamOnlyBA(pixels, points, cam, ...) — slam/optimizer.py:82-142, called at slam/tracking.py:73,128 —
+ * for B independent problems (one free VertexCam initialised to identity, n fixed points, EdgeProjectP2MC,
+ * information I2, Huber(delta), Levenberg with g2o's lambda schedule, `iters` outer iterations).
+ *   pix f64[B][stride][2], pts f64[B][stride][3], n int[B]; K = {fx, fy, cx, cy, baseline}
+ *   R f64[B][9] row-major, t f64[B][3]  (SBACam = camera-in-world, as optimizer.py:137-139 returns it)
+ *   chi2 f64[B][stride] (per-edge e'e at the state g2o leaves them in), inlier u8[B][stride] (chi2 <= chi2_thr)
+ *   status int[B]: BH_OK or BH_ERR_NUMERIC per problem */
+int bh_pose_only_ba(bh_ctx* ctx, const double* pix, const double* pts, const int* n, int B, int stride,
+                    const double K[5], int iters, double huber_delta, double chi2_thr,
+                    double* R, double* t, double* chi2, uint8_t* inlier, int* status, int mem);
+
+/* ---- local bundle adjustment --------------------------------------------------------------------------------------
+ * Replaces the g2o graph of BundleAdjustment — slam/optimizer.py:8-79 — as driven by
+ * CovisibilityGraph.optimize_local — slam/covisibility_graph.py:186-235.
+ *   poses: R f64[C][9] row-major + t f64[C][3] (camera-in-world, as add_pose passes them, optimizer.py:21-38),
+ *          fixed u8[C]
+ *   points f64[P][3] (all free + marginalised, optimizer.py:40-47)
+ *   edges  pose index i32[E], point index i32[E], measurement f64[E][2] (optimizer.py:49-62; the 640x480
+ *          admission gate of optimizer.py:52-54 is applied by the caller-side shim or by bh_ba_edge_gate)
+ * bh_ba_optimize runs `iters` Levenberg iterations (Schur complement on the points, dense Cholesky of the reduced
+ * camera system); `verbose_errors` != 0 reproduces SparseOptimizer::optimize's verbose branch, which recomputes
+ * the active errors after every iteration (BundleAdjustment.optimize passes flag_verbose=True, optimizer.py:16-19). */
+typedef struct bh_ba bh_ba;
+int  bh_ba_create(bh_ctx* ctx, const double K[5], bh_ba** out);
+void bh_ba_destroy(bh_ba* ba);
+int  bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double* t, const uint8_t* fixed,
+                       int P, const double* points, int E, const int* edge_pose, const int* edge_point,
+                       const double* meas, int mem);
+int  bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verbose_errors, int* iters_done);
+int  bh_ba_get_poses(bh_ba* ba, double* R, double* t, int mem);
+int  bh_ba_get_points(bh_ba* ba, double* points, int mem);
+int  bh_ba_get_chi2(bh_ba* ba, double* chi2, int mem);
+/* per-iteration log of the last optimize: f64[iters_done][4] = {robust chi2 after, lambda, trials, accepted} */
+int  bh_ba_get_log(bh_ba* ba, double* log, int max_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOSLAM_HIP_H */

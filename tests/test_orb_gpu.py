@@ -1,0 +1,94 @@
+"""GPU parity: the HIP ORB pipeline vs the CPU oracle (bit-exact), stage by stage and end to end."""
+import numpy as np
+import pytest
+
+import oracle
+from boslam_amd import frontend, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_frame(bgr, depth, nfeatures, debug=False):
+    P = oracle.orb_params(nfeatures=nfeatures)
+    mask = None if depth is None else (depth > 0).astype(np.uint8) * 255
+    return oracle.orb_detect_describe(bgr, mask, P, max_kp=4 * nfeatures + 256, debug=debug)
+
+
+def _unpitch(buf, g, key_off="off"):
+    """pitched device pyramid -> tight per-level arrays"""
+    out = []
+    for l in range(len(g["w"])):
+        w, h, p, o = int(g["w"][l]), int(g["h"][l]), int(g["pitch"][l]), int(g["off"][l])
+        out.append(buf[o:o + p * h].reshape(h, p)[:, :w])
+    return out
+
+
+@pytest.mark.parametrize("nfeatures", [600, 1000])
+def test_orb_intermediates_and_output_match_oracle(ctx, nfeatures):
+    B = 3
+    bgr, depth = synth.render_batch(B)
+    params = frontend.make_params(nfeatures=nfeatures)
+    kps, desc, n = frontend.orb_detect_describe(ctx, bgr, depth=depth, params=params)
+    for f in range(B):
+        ok, od, rc, dbg = _oracle_frame(bgr[f], depth[f], nfeatures, debug=True)
+        assert rc == 0
+        dev = frontend.orb_debug_fetch(ctx, f, 480, 640, params)
+        for name in ("pyr", "mask", "nms", "blur"):
+            lv = _unpitch(dev[name], dev)
+            for l in range(params.nlevels):
+                w, h, o = int(dbg["w"][l]), int(dbg["h"][l]), int(dbg["off"][l])
+                ref = dbg[name][o:o + w * h].reshape(h, w)
+                assert lv[l].shape == ref.shape
+                bad = np.argwhere(lv[l] != ref)
+                assert len(bad) == 0, f"{name} level {l} frame {f}: {len(bad)} px differ, first {bad[:3]}"
+        assert n[f] == len(ok), (n[f], len(ok))
+        k = kps[f, :n[f]]
+        for fld in ("x", "y", "size", "response", "angle"):
+            assert np.array_equal(k[fld].view(np.uint32), ok[fld].view(np.uint32)), fld
+        assert np.array_equal(k["octave"], ok["octave"])
+        assert np.array_equal(desc[f, :n[f]], od)
+
+
+def test_orb_gray_input_no_mask(ctx):
+    bgr, _ = synth.render_batch(2)
+    gray = np.ascontiguousarray(bgr[..., 1])
+    params = frontend.make_params(nfeatures=500)
+    kps, desc, n = frontend.orb_detect_describe(ctx, gray, params=params)
+    for f in range(2):
+        ok, od, rc = oracle.orb_detect_describe(gray[f], None, oracle.orb_params(nfeatures=500), max_kp=2000)
+        assert n[f] == len(ok)
+        assert np.array_equal(desc[f, :n[f]], od)
+        assert np.array_equal(kps[f, :n[f]]["angle"].view(np.uint32), ok["angle"].view(np.uint32))
+
+
+def test_match_crosscheck_matches_oracle(ctx):
+    rng = np.random.default_rng(5)
+    cases = [(1000, 1000), (600, 600), (600, 2500), (1, 1), (37, 5), (5, 37), (0, 10), (10, 0), (1500, 700)]
+    Sq = max(c[0] for c in cases); St = max(c[1] for c in cases)
+    q = rng.integers(0, 256, size=(len(cases), Sq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, size=(len(cases), St, 32), dtype=np.uint8)
+    # plant near-duplicates and exact ties so the first-minimum rules are exercised
+    for b, (nq, nt) in enumerate(cases):
+        for k in range(min(nq, nt) // 2):
+            t[b, (k * 7) % nt] = q[b, (k * 3) % nq] ^ np.uint8(1 << (k % 8))
+        if nt > 3 and nq > 3:
+            t[b, 1] = t[b, 0]; q[b, 2] = q[b, 1]
+    nq = np.array([c[0] for c in cases], np.int32); nt = np.array([c[1] for c in cases], np.int32)
+    qi, ti, d, nm = frontend.match_pairs(ctx, q, nq, t, nt)
+    for b, (a, c) in enumerate(cases):
+        oq, ot, od = oracle.match_crosscheck(q[b, :a], t[b, :c])
+        assert nm[b] == len(oq), (b, nm[b], len(oq))
+        assert np.array_equal(qi[b, :nm[b]], oq) and np.array_equal(ti[b, :nm[b]], ot) and np.array_equal(d[b, :nm[b]], od)
+
+
+def test_backproject_matches_oracle(ctx):
+    bgr, depth = synth.render_batch(2)
+    params = frontend.make_params(nfeatures=600)
+    kps, desc, n = frontend.orb_detect_describe(ctx, bgr, depth=depth, params=params)
+    xy, cloud = frontend.kp_backproject(ctx, kps, n, depth, synth.FX, synth.FY, synth.CX, synth.CY)
+    for f in range(2):
+        oxy = oracle.kp_to_int(kps[f, :n[f]])
+        assert np.array_equal(xy[f, :n[f]], oxy)
+        oc = oracle.backproject(depth[f], oxy, synth.FX, synth.FY, synth.CX, synth.CY)
+        assert np.array_equal(cloud[f, :n[f]], oc)
+        assert (oc[:, 2] > 0).all()            # the ORB mask keeps keypoints off depth holes
