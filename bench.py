@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — RGB-D frames/s of ORB detect+describe + BF-Hamming cross-check match (BASELINE.json configs[1]).
+
+A step = one pass of the front-end hot path over one HBM-resident batch: B synthetic 640x480 RGB-D frames ->
+ORB (nfeatures=1000, the reference's other parameters, camera.py:49-56) -> match frame i against frame i-1
+(direction of slam/tracking.py:56).  N>1: one process per GPU, each with its own B frames (frames are independent:
+weak scaling, no data-path collective); rank 0 prints ONE JSON line.
+
+The JSON line also carries
+  roofline      the dominant kernel's algorithmic bytes / its hipEvent-measured duration vs the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (OpenMP over frames) timed on the host cores on a bounded sample of the same frames
+  local_ba      secondary metric of BASELINE.json: LM iterations/s of the local BA on config 3 (when built)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_FRAME = 921600 + 614400 + 32 * 1000 + 24 * 1000        # 1 592 000 B/frame at N=1000
+HBM_PEAK_GBS = 8000.0                                                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def gen_frames_device(torch, B, dev, start=0, chunk=50):
+    """Synthetic frames rendered on the GPU (data generation, not timed): same scene as boslam_amd.synth."""
+    from boslam_amd import synth
+    tex = torch.from_numpy(synth._texture()).to(dev)
+    bgr = torch.empty((B, synth.HEIGHT, synth.WIDTH, 3), dtype=torch.uint8, device=dev)
+    depth = torch.empty((B, synth.HEIGHT, synth.WIDTH), dtype=torch.int16, device=dev)
+    u = torch.arange(synth.WIDTH, dtype=torch.float64, device=dev)
+    v = torch.arange(synth.HEIGHT, dtype=torch.float64, device=dev)
+    gains = torch.tensor([1.0, 0.9, 0.8], dtype=torch.float32, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(2025 + start)
+    rng = np.random.default_rng(2026 + start)
+    for c0 in range(0, B, chunk):
+        n = min(chunk, B - c0)
+        k = torch.arange(start + c0, start + c0 + n, dtype=torch.float64, device=dev)
+        sx = (2.0 * (u[None, :] - synth.CX) / synth.FX + 0.002 * k[:, None]) * 370.0 + 640.0      # [n][W]
+        sy = (2.0 * (v[None, :] - synth.CY) / synth.FY + 0.001 * k[:, None]) * 370.0 + 480.0      # [n][H]
+        x0 = sx.floor().clamp(0, 2046).long(); fx = (sx - sx.floor()).float()
+        y0 = sy.floor().clamp(0, 2046).long(); fy = (sy - sy.floor()).float()
+        yy = y0[:, :, None]; xx = x0[:, None, :]
+        t00 = tex[yy, xx]; t01 = tex[yy, xx + 1]; t10 = tex[yy + 1, xx]; t11 = tex[yy + 1, xx + 1]
+        top = t00 * (1 - fx)[:, None, :] + t01 * fx[:, None, :]
+        bot = t10 * (1 - fx)[:, None, :] + t11 * fx[:, None, :]
+        img = top * (1 - fy)[:, :, None] + bot * fy[:, :, None]
+        img = img + 4.0 * torch.randn(img.shape, generator=g, device=dev, dtype=torch.float32)
+        bgr[c0:c0 + n] = (img[..., None] * gains).round().clamp(0, 255).to(torch.uint8)
+        d = torch.full((n, synth.HEIGHT, synth.WIDTH), 2000, dtype=torch.int16, device=dev)
+        X = torch.arange(synth.WIDTH, device=dev)[None, None, :]; Y = torch.arange(synth.HEIGHT, device=dev)[None, :, None]
+        for _ in range(12):
+            w = torch.from_numpy(rng.integers(20, 60, size=n)).to(dev)[:, None, None]
+            h = torch.from_numpy(rng.integers(15, 45, size=n)).to(dev)[:, None, None]
+            xh = torch.from_numpy(rng.integers(0, synth.WIDTH - 60, size=n)).to(dev)[:, None, None]
+            yh = torch.from_numpy(rng.integers(0, synth.HEIGHT - 45, size=n)).to(dev)[:, None, None]
+            d[(X >= xh) & (X < xh + w) & (Y >= yh) & (Y < yh + h)] = 0
+        depth[c0:c0 + n] = d
+    return bgr, depth
+
+
+def cpu_baseline(bgr_host, depth_host, nfeatures, max_kp):
+    """Oracle (OpenMP over frames) on the host cores, bounded sample; returns dict for the JSON line."""
+    import oracle
+    P = oracle.orb_params(nfeatures=nfeatures)
+    cores = min(len(os.sched_getaffinity(0)), 16)      # the box's CPU share for one GPU is 16 cores
+    oracle.set_num_threads(cores)
+    n = len(bgr_host)
+    t0 = time.perf_counter()
+    kps, desc, nk, rc = oracle.orb_batch(bgr_host, depth_host, P, max_kp)
+    oracle.match_consecutive(desc, nk, max_kp)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"{n} of the benchmark's own frames: ORB(nfeatures={nfeatures}) + {n - 1} consecutive-frame "
+                      f"cross-check matches, CPU oracle (C, -O3, OpenMP over frames), {dt:.1f} s wall"}, (kps, desc, nk)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (BASELINE config 2: 1000)")
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--cpu-sample", type=int, default=1000, help="frames in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-ba", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+
+    from boslam_amd import Context, frontend
+    ctx = Context(local)
+    params = frontend.make_params(nfeatures=args.nfeatures)
+    B = args.frames
+    bgr, depth = gen_frames_device(torch, B, dev, start=rank * B)
+    fe = frontend.DeviceFrontEnd(ctx, B, 480, 640, params, torch_device=dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(); ctx.synchronize()
+
+    for _ in range(args.warmup):
+        fe.run(bgr, depth)
+    barrier()
+    ctx.status()
+    ctx.timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fe.run(bgr, depth)
+    barrier()
+    dt = time.perf_counter() - t0
+    ktimes = ctx.timing_read()
+    ctx.timing(False)
+    ctx.status()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        n_kp = fe.n_kp.cpu().numpy(); n_match = fe.n_match.cpu().numpy()
+        fps = world * B * args.steps / dt
+        # dominant kernel by summed hipEvent time; its own compulsory traffic per frame
+        per_frame_bytes = {"k_gray_mask": 921600 + 614400 + 2 * 307200, "k_pyr_down": 2 * (926546 + 643332),
+                           "k_fast": 2 * 950532, "k_blur": 2 * 950532, "k_select": 950532 + 56 * args.nfeatures,
+                           "k_brief": 56 * args.nfeatures, "k_match": 2 * 32 * args.nfeatures + 12 * args.nfeatures}
+        dom = max(ktimes, key=lambda k: ktimes[k][0])
+        dom_ms, dom_n = ktimes[dom]
+        launches_per_step = dom_n / args.steps
+        frames_per_launch = B / launches_per_step if dom != "k_pyr_down" else B / (launches_per_step / (params.nlevels - 1))
+        if dom == "k_pyr_down":
+            alg_bytes = per_frame_bytes[dom] * frames_per_launch / (params.nlevels - 1)
+        else:
+            alg_bytes = per_frame_bytes[dom] * frames_per_launch
+        avg_s = dom_ms / dom_n / 1e3
+        achieved = alg_bytes / avg_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "avg_launch_ms": round(dom_ms / dom_n, 4), "alg_bytes_per_launch": int(alg_bytes),
+                    "path_achieved": round(fps / world * ALG_BYTES_PER_FRAME / 1e9, 2),
+                    "path_frac": round(fps / world * ALG_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 5),
+                    "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(ktimes.items())}}
+        out = {"metric": "rgbd_frames_per_sec_orb_match_640x480", "value": round(fps, 1), "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+               "data": "synthetic",
+               "config": {"workload": "configs[1]: batched ORB detect+describe + BF-Hamming cross-check match, "
+                                      f"{B} frames 640x480 RGB-D per GPU per step, nfeatures={args.nfeatures}",
+                          "frames_per_gpu": B, "mean_kp_per_frame": float(n_kp.mean()),
+                          "mean_matches_per_pair": float(n_match[1:].mean()) if B > 1 else 0.0,
+                          "parallelism": f"frames sharded x{world}, no collective"},
+               "roofline": roofline}
+        if args.cpu_sample > 0:
+            ns = min(args.cpu_sample, B)
+            bh = bgr[:ns].cpu().numpy(); dh = depth[:ns].cpu().numpy().view(np.uint16)
+            cb, (okps, odesc, onk) = cpu_baseline(bh, dh, args.nfeatures, fe.max_kp)
+            out["cpu_baseline"] = cb
+            # the same sample doubles as a parity spot check of the timed outputs
+            ddesc = fe.desc[:ns].cpu().numpy()
+            same = bool(np.array_equal(onk, n_kp[:ns])) and all(
+                np.array_equal(ddesc[f, :onk[f]], odesc[f, :onk[f]]) for f in range(ns))
+            out["parity_sample_ok"] = same
+        if not args.no_ba:
+            try:
+                from boslam_amd import ba_bench
+                out["local_ba"] = ba_bench.run(ctx, dev)
+            except ImportError:
+                pass
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,8 @@ _SIGS = {
     "bh_ctx_synchronize": (_i, [_vp]),
     "bh_ctx_status": (_i, [_vp]),
     "bh_version": (C.c_char_p, []),
+    "bh_ctx_timing": (_i, [_vp, _i]),
+    "bh_ctx_timing_read": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_i)]),
     "bh_orb_detect_describe": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, C.POINTER(OrbParams), _i, _vp, _vp, _vp, _i]),
     "bh_orb_geometry": (_i, [_i, _i, C.POINTER(OrbParams), _vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "bh_orb_debug_fetch": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
@@ -112,6 +114,15 @@ class Context:
 
     def status(self):
         self.check(lib().bh_ctx_status(self.h))
+
+    def timing(self, enable):
+        self.check(lib().bh_ctx_timing(self.h, 1 if enable else 0))
+
+    def timing_read(self):
+        """{kernel name: (total ms, launches)} since timing was enabled."""
+        ms = (C.c_double * 32)(); cnt = (C.c_longlong * 32)(); names = (C.c_char_p * 32)(); n = C.c_int(0)
+        self.check(lib().bh_ctx_timing_read(self.h, 32, ms, cnt, names, C.byref(n)))
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value) if cnt[i]}
 
     def close(self):
         if getattr(self, "h", None):

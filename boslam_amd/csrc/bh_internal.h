@@ -34,6 +34,12 @@ struct bh_orb_geom {
     bh_level_geom lv[BH_MAX_LEVELS];
 };
 
+// kernel ids for the optional per-kernel hipEvent timing (bh_ctx_timing / bh_ctx_timing_read)
+enum bh_kid { BH_K_GRAY = 0, BH_K_PYR, BH_K_FAST, BH_K_BLUR, BH_K_SELECT, BH_K_BRIEF, BH_K_MATCH, BH_K_BACKPROJ,
+              BH_K_POSE_BA, BH_K_BA_LINEARIZE, BH_K_BA_SCHUR, BH_K_BA_SOLVE, BH_K_BA_UPDATE, BH_K_BA_OTHER, BH_K_COUNT };
+
+struct bh_time_rec { int kid; hipEvent_t e0, e1; };
+
 struct bh_ctx {
     int         device = 0;
     hipStream_t stream = nullptr;    // stream in use
@@ -49,7 +55,25 @@ struct bh_ctx {
     bh_buf      st_a, st_b, st_c, st_d, st_e, st_f, st_g, st_h;         // generic staging (match / BA)
     int         last_B = 0;
     int         last_has_mask = 0;
+    // ---- per-kernel timing ----
+    int         timing_on = 0;
+    bh_time_rec* trecs = nullptr;
+    int         n_trecs = 0, cap_trecs = 0;
+    hipEvent_t* epool = nullptr;
+    int         n_epool = 0, cap_epool = 0;
+    double      t_ms[BH_K_COUNT] = {0};
+    long long   t_cnt[BH_K_COUNT] = {0};
 };
+
+// Bracket one kernel launch with events when timing is on.
+void bh_time_begin(bh_ctx* ctx, int kid);
+void bh_time_end(bh_ctx* ctx);
+#define BH_LAUNCH(ctx, kid, kernel, grid, block, st, ...)                                          \
+    do {                                                                                           \
+        bh_time_begin((ctx), (kid));                                                               \
+        hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                               \
+        bh_time_end(ctx);                                                                          \
+    } while (0)
 
 int  bh_set_err(bh_ctx* ctx, int code, const char* fmt, ...);
 int  bh_reserve(bh_ctx* ctx, bh_buf* b, size_t bytes);

@@ -24,6 +24,7 @@ int bh_reserve(bh_ctx* ctx, bh_buf* b, size_t bytes)
     return BH_OK;
 }
 
+static int drain_timing(bh_ctx* ctx);
 static void release(bh_buf* b) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
 
 extern "C" const char* bh_version(void) { return "boslam_hip 0.1 (gfx950)"; }
@@ -52,6 +53,9 @@ extern "C" void bh_ctx_destroy(bh_ctx* ctx)
                       &ctx->st_img, &ctx->st_mask, &ctx->st_depth, &ctx->st_kps, &ctx->st_desc, &ctx->st_nkp,
                       &ctx->st_a, &ctx->st_b, &ctx->st_c, &ctx->st_d, &ctx->st_e, &ctx->st_f, &ctx->st_g, &ctx->st_h };
     for (bh_buf* b : all) release(b);
+    (void)drain_timing(ctx);
+    for (int i = 0; i < ctx->n_epool; i++) (void)hipEventDestroy(ctx->epool[i]);
+    free(ctx->epool); free(ctx->trecs);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -81,6 +85,80 @@ extern "C" int bh_ctx_status(bh_ctx* ctx)
     BH_HIP(ctx, hipMemcpyAsync(&st, ctx->status.p, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (st & BH_ST_KP_OVERFLOW) return bh_set_err(ctx, BH_ERR_CAPACITY, "more keypoints than max_kp (ties at the retainBest cut); output truncated");
+    if (st & 4u) return bh_set_err(ctx, BH_ERR_INVALID, "matcher: descriptor count above the supported maximum (nq <= 8192, nt <= 2^20)");
+    if (st & 8u) return bh_set_err(ctx, BH_ERR_CAPACITY, "matcher: more matches than out_stride");
     if (st & BH_ST_CAND_OVERFLOW) return bh_set_err(ctx, BH_ERR_CAPACITY, "FAST candidate list overflow in k_select; output truncated");
+    return BH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ per-kernel timing
+static const char* k_names[BH_K_COUNT] = { "k_gray_mask", "k_pyr_down", "k_fast", "k_blur", "k_select", "k_brief",
+                                           "k_match", "k_kp_backproject", "k_pose_ba", "k_ba_linearize", "k_ba_schur",
+                                           "k_ba_solve", "k_ba_update", "k_ba_other" };
+
+static hipEvent_t take_event(bh_ctx* ctx)
+{
+    if (ctx->n_epool > 0) return ctx->epool[--ctx->n_epool];
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+static void give_event(bh_ctx* ctx, hipEvent_t e)
+{
+    if (ctx->n_epool == ctx->cap_epool) {
+        ctx->cap_epool = ctx->cap_epool ? ctx->cap_epool * 2 : 256;
+        ctx->epool = (hipEvent_t*)realloc(ctx->epool, sizeof(hipEvent_t) * ctx->cap_epool);
+    }
+    ctx->epool[ctx->n_epool++] = e;
+}
+
+void bh_time_begin(bh_ctx* ctx, int kid)
+{
+    if (!ctx->timing_on) return;
+    if (ctx->n_trecs == ctx->cap_trecs) {
+        ctx->cap_trecs = ctx->cap_trecs ? ctx->cap_trecs * 2 : 256;
+        ctx->trecs = (bh_time_rec*)realloc(ctx->trecs, sizeof(bh_time_rec) * ctx->cap_trecs);
+    }
+    bh_time_rec& r = ctx->trecs[ctx->n_trecs++];
+    r.kid = kid; r.e0 = take_event(ctx); r.e1 = take_event(ctx);
+    (void)hipEventRecord(r.e0, ctx->stream);
+}
+void bh_time_end(bh_ctx* ctx)
+{
+    if (!ctx->timing_on) return;
+    (void)hipEventRecord(ctx->trecs[ctx->n_trecs - 1].e1, ctx->stream);
+}
+
+static int drain_timing(bh_ctx* ctx)
+{
+    if (ctx->n_trecs == 0) return BH_OK;
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < ctx->n_trecs; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->trecs[i].e0, ctx->trecs[i].e1) == hipSuccess) {
+            ctx->t_ms[ctx->trecs[i].kid] += ms; ctx->t_cnt[ctx->trecs[i].kid]++;
+        }
+        give_event(ctx, ctx->trecs[i].e0); give_event(ctx, ctx->trecs[i].e1);
+    }
+    ctx->n_trecs = 0;
+    return BH_OK;
+}
+
+extern "C" int bh_ctx_timing(bh_ctx* ctx, int enable)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    BH_TRY(drain_timing(ctx));
+    for (int i = 0; i < BH_K_COUNT; i++) { ctx->t_ms[i] = 0; ctx->t_cnt[i] = 0; }
+    ctx->timing_on = enable ? 1 : 0;
+    return BH_OK;
+}
+
+extern "C" int bh_ctx_timing_read(bh_ctx* ctx, int max_k, double* total_ms, long long* launches, const char** names, int* n_k)
+{
+    if (!ctx || !total_ms || !launches || !n_k) return BH_ERR_INVALID;
+    BH_TRY(drain_timing(ctx));
+    int n = BH_K_COUNT < max_k ? BH_K_COUNT : max_k;
+    for (int i = 0; i < n; i++) { total_ms[i] = ctx->t_ms[i]; launches[i] = ctx->t_cnt[i]; if (names) names[i] = k_names[i]; }
+    *n_k = n;
     return BH_OK;
 }

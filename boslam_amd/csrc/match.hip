@@ -132,7 +132,7 @@ extern "C" int bh_match_hamming_crosscheck(bh_ctx* ctx, const uint8_t* q, const 
         d_nm = d_d + (size_t)B * out_stride;
         BH_HIP(ctx, hipMemsetAsync(ctx->status.p, 0, 256, st));
     }
-    hipLaunchKernelGGL(k_match, dim3(B), dim3(MT), 0, st, d_q, d_nq, q_stride, d_t, d_nt, t_stride, d_qi, d_ti, d_d, d_nm,
+    BH_LAUNCH(ctx, BH_K_MATCH, k_match, dim3(B), dim3(MT), st, d_q, d_nq, q_stride, d_t, d_nt, t_stride, d_qi, d_ti, d_d, d_nm,
                        out_stride, (uint32_t*)ctx->status.p);
     BH_HIP(ctx, hipGetLastError());
     if (mem == BH_MEM_HOST) {

@@ -774,18 +774,18 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         BH_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * g.nlevels * nb, st));
         {
             const int n = (g.lv[0].pitch >> 2) * g.lv[0].h;
-            hipLaunchKernelGGL(k_gray_mask, dim3((n + 255) / 256, nb), dim3(256), 0, st, d_img, channels, d_mask, d_depth,
+            BH_LAUNCH(ctx, BH_K_GRAY, k_gray_mask, dim3((n + 255) / 256, nb), dim3(256), st, d_img, channels, d_mask, d_depth,
                                pyr, mpyr, W, H, g.lv[0].pitch, g.pyr_stride);
         }
         for (int l = 1; l < g.nlevels; l++) {
             const int n = (g.lv[l].pitch >> 2) * g.lv[l].h;
-            hipLaunchKernelGGL(k_pyr_down, dim3((n + 255) / 256, nb), dim3(256), 0, st, pyr, mpyr, g, l, (const uint32_t*)ctx->tab.p);
+            BH_LAUNCH(ctx, BH_K_PYR, k_pyr_down, dim3((n + 255) / 256, nb), dim3(256), st, pyr, mpyr, g, l, (const uint32_t*)ctx->tab.p);
         }
-        hipLaunchKernelGGL(k_fast, dim3(g.ntiles, nb), dim3(256), 0, st, pyr, mpyr, nms, hist, g);
-        hipLaunchKernelGGL(k_blur, dim3(g.ntiles, nb), dim3(256), 0, st, pyr, blur, g, G);
-        hipLaunchKernelGGL(k_select, dim3(nb), dim3(SEL_T), 0, st, pyr, nms, hist, g, UM, (float)params->patchSize, max_kp,
+        BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, nms, hist, g);
+        BH_LAUNCH(ctx, BH_K_BLUR, k_blur, dim3(g.ntiles, nb), dim3(256), st, pyr, blur, g, G);
+        BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(nb), dim3(SEL_T), st, pyr, nms, hist, g, UM, (float)params->patchSize, max_kp,
                            d_kps, (uint32_t*)ctx->kpmeta.p, d_nkp, (uint32_t*)ctx->status.p);
-        hipLaunchKernelGGL(k_brief, dim3((max_kp + 3) / 4, nb), dim3(256), 0, st, blur, g, max_kp, d_kps, d_nkp, d_desc);
+        BH_LAUNCH(ctx, BH_K_BRIEF, k_brief, dim3((max_kp + 3) / 4, nb), dim3(256), st, blur, g, max_kp, d_kps, d_nkp, d_desc);
         BH_HIP(ctx, hipGetLastError());
         if (mem == BH_MEM_HOST) {
             BH_HIP(ctx, hipMemcpyAsync(kps + (size_t)f0 * max_kp, d_kps, sizeof(bh_kp) * (size_t)max_kp * nb, hipMemcpyDeviceToHost, st));
@@ -839,7 +839,7 @@ extern "C" int bh_kp_backproject(bh_ctx* ctx, const bh_kp* kps, const int* n_kp,
             d_depth = (const uint16_t*)ctx->st_d.p; d_cl = (double*)ctx->st_e.p;
         }
     }
-    hipLaunchKernelGGL(k_kp_backproject, dim3((max_kp + 255) / 256, B), dim3(256), 0, st, d_kps, d_n, d_depth, H, W, max_kp,
+    BH_LAUNCH(ctx, BH_K_BACKPROJ, k_kp_backproject, dim3((max_kp + 255) / 256, B), dim3(256), st, d_kps, d_n, d_depth, H, W, max_kp,
                        fx, fy, ppx, ppy, d_xy, d_cl);
     BH_HIP(ctx, hipGetLastError());
     if (mem == BH_MEM_HOST) {

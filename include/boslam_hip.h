@@ -70,6 +70,12 @@ int         bh_ctx_synchronize(bh_ctx* ctx);
 /* Deferred status of BH_MEM_DEVICE work (capacity flags raised on the device); synchronises the stream. */
 int         bh_ctx_status(bh_ctx* ctx);
 const char* bh_version(void);
+/* Optional per-kernel timing with hipEvents recorded on the context's stream around every kernel launch
+ * (bench.py uses it for the roofline figure).  bh_ctx_timing(ctx, 1) resets and enables, (ctx, 0) disables;
+ * bh_ctx_timing_read synchronises and returns, per kernel, the summed duration (ms) and the launch count. */
+int         bh_ctx_timing(bh_ctx* ctx, int enable);
+int         bh_ctx_timing_read(bh_ctx* ctx, int max_k, double* total_ms, long long* launches,
+                               const char** names, int* n_k);
 
 /* ---- ORB detect + describe ------------------------------------------------------------------------------------
  * Replaces feature_extractor.detectAndCompute(frame, mask=(depth_image > 0) * 255) — camera.py:141 — for a batch

@@ -131,3 +131,11 @@ def backproject(depth, xy, fx, fy, ppx, ppy):
     lib().orc_backproject(_p(depth), depth.shape[1], _p(xy), len(xy), C.c_double(fx), C.c_double(fy),
                           C.c_double(ppx), C.c_double(ppy), _p(out))
     return out
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))

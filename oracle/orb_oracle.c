@@ -540,3 +540,13 @@ void orc_backproject(const uint16_t* depth, int W, const int64_t* xy, int n,
         xyz[3*i] = xn * z; xyz[3*i+1] = yn * z; xyz[3*i+2] = z;
     }
 }
+
+/* number of OpenMP threads the batched entry points use (1 when built without -fopenmp) */
+#ifdef _OPENMP
+#include <omp.h>
+int orc_num_threads(void) { return omp_get_max_threads(); }
+void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+int orc_num_threads(void) { return 1; }
+void orc_set_num_threads(int n) { (void)n; }
+#endif
