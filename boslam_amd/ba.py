@@ -1,0 +1,95 @@
+"""Array-level bundle-adjustment entry points over the C ABI (bh_pose_only_ba, bh_ba_*).
+
+Conventions follow the reference's g2o usage (slam/optimizer.py): poses are SBACam estimates, i.e. camera-in-world
+(R, t); the projection of world point X is K * R'(X - t)."""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import BH_MEM_HOST
+
+CHI2_SIG_VALUE = 7.815                      # config.py:3
+HUBER_DELTA = float(np.sqrt(CHI2_SIG_VALUE))  # slam/optimizer.py:49,82
+
+
+def cam_to_K(cam):
+    """The two camera flavours slam/optimizer.py:27-32 accepts."""
+    if hasattr(cam, "fx"):
+        return np.array([cam.fx, cam.fy, cam.cx, cam.cy, cam.baseline], dtype=np.float64)
+    cx, cy = cam.principal_point
+    return np.array([cam.focal_length, cam.focal_length, cx, cy, cam.baseline], dtype=np.float64)
+
+
+def pose_only_ba_batch(ctx, pix, pts, n, K, iters=10, huber_delta=HUBER_DELTA, chi2_thr=CHI2_SIG_VALUE):
+    """B independent CamOnlyBA problems.  pix f64[B][S][2], pts f64[B][S][3], n int[B].
+    Returns R[B][3][3], t[B][3], chi2[B][S], inlier bool[B][S], status int[B]."""
+    pix = np.ascontiguousarray(pix, dtype=np.float64); pts = np.ascontiguousarray(pts, dtype=np.float64)
+    B, S = pix.shape[:2]
+    n = np.ascontiguousarray(n, dtype=np.int32)
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    R = np.zeros((B, 3, 3)); t = np.zeros((B, 3)); chi2 = np.zeros((B, S)); inl = np.zeros((B, S), np.uint8)
+    st = np.zeros(B, np.int32)
+    ctx.check(_lib.lib().bh_pose_only_ba(ctx.h, _lib.ptr(pix), _lib.ptr(pts), _lib.ptr(n), B, S, _lib.ptr(K), int(iters),
+                                         float(huber_delta), float(chi2_thr), _lib.ptr(R), _lib.ptr(t), _lib.ptr(chi2),
+                                         _lib.ptr(inl), _lib.ptr(st), BH_MEM_HOST))
+    return R, t, chi2, inl.astype(bool), st
+
+
+class LocalBA:
+    """One bh_ba handle: set_problem -> optimize -> get_*."""
+
+    def __init__(self, ctx, K):
+        self.ctx = ctx
+        K = np.ascontiguousarray(K, dtype=np.float64)
+        h = C.c_void_p()
+        ctx.check(_lib.lib().bh_ba_create(ctx.h, _lib.ptr(K), C.byref(h)))
+        self.h = h
+        self.C = self.P = self.E = 0
+
+    def set_problem(self, R, t, fixed, points, edge_pose, edge_point, meas):
+        R = np.ascontiguousarray(R, dtype=np.float64).reshape(-1, 9); t = np.ascontiguousarray(t, dtype=np.float64).reshape(-1, 3)
+        fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+        points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        edge_pose = np.ascontiguousarray(edge_pose, dtype=np.int32); edge_point = np.ascontiguousarray(edge_point, dtype=np.int32)
+        meas = np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 2)
+        self.C, self.P, self.E = len(R), len(points), len(edge_pose)
+        self._points_in = points.copy()
+        self.ctx.check(_lib.lib().bh_ba_set_problem(self.h, self.C, _lib.ptr(R), _lib.ptr(t), _lib.ptr(fixed), self.P,
+                                                    _lib.ptr(points), self.E, _lib.ptr(edge_pose), _lib.ptr(edge_point),
+                                                    _lib.ptr(meas), BH_MEM_HOST))
+
+    def optimize(self, iters=20, huber_delta=HUBER_DELTA, verbose_errors=True):
+        done = C.c_int(0)
+        self.ctx.check(_lib.lib().bh_ba_optimize(self.h, int(iters), float(huber_delta), 1 if verbose_errors else 0,
+                                                 C.byref(done)))
+        return done.value
+
+    def poses(self):
+        R = np.zeros((self.C, 3, 3)); t = np.zeros((self.C, 3))
+        self.ctx.check(_lib.lib().bh_ba_get_poses(self.h, _lib.ptr(R), _lib.ptr(t), BH_MEM_HOST))
+        return R, t
+
+    def points(self):
+        p = self._points_in.copy()
+        self.ctx.check(_lib.lib().bh_ba_get_points(self.h, _lib.ptr(p), BH_MEM_HOST))
+        return p
+
+    def chi2(self):
+        c = np.zeros(max(self.E, 1))
+        self.ctx.check(_lib.lib().bh_ba_get_chi2(self.h, _lib.ptr(c), BH_MEM_HOST))
+        return c[:self.E]
+
+    def log(self, max_rows=64):
+        lg = np.zeros((max_rows, 4))
+        self.ctx.check(_lib.lib().bh_ba_get_log(self.h, _lib.ptr(lg), max_rows))
+        return lg
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().bh_ba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

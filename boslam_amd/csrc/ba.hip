@@ -1,0 +1,967 @@
+// ba.hip — bundle adjustment on gfx950: the g2o graph of slam/optimizer.py as batched f64 HIP kernels.
+//
+//   bh_pose_only_ba   CamOnlyBA (slam/optimizer.py:82-142; callers slam/tracking.py:73,128): B independent problems,
+//                     one workgroup each, the whole Levenberg loop (10 iterations x <=10 trials) inside one launch:
+//                     per-edge residual/Jacobian -> 28-term block reduction -> 6x6 Cholesky -> SBACam oplus.
+//   bh_ba_*           BundleAdjustment (slam/optimizer.py:8-79) as driven by CovisibilityGraph.optimize_local
+//                     (slam/covisibility_graph.py:186-235): EdgeProjectP2MC linearisation, Hpp/Hll/Hpl assembly, Schur
+//                     complement on the marginalised points, dense Cholesky of the reduced camera system,
+//                     back-substitution, g2o's Levenberg lambda schedule.
+//
+// Design notes
+//   * f64 throughout (the reference's g2o path is double); every reduction has a fixed order (CSR by point / by camera,
+//     tree reductions), so results are bitwise reproducible run to run — no floating-point atomics anywhere.
+//   * per LM iteration: k_ba_point (8 lanes per point: residual, Huber weight, Jacobians, Hll/bl, per-edge Hpl),
+//     k_ba_cam (workgroup per free camera: Hpp/bp), k_ba_prep; per trial: k_ba_dinv, k_ba_schur_S (workgroup per
+//     camera pair, binary-search join of the two cameras' point-sorted edge lists), k_ba_schur_b, k_ba_chol (one
+//     workgroup), k_ba_update (back-substitution + oplus into the trial state), k_ba_err, k_ba_decide.  The host reads
+//     back one 16-byte verdict per trial (accept / retry / terminate) — the only synchronisation.
+//   * the reduced camera system of a local window is tiny (6 x #free keyframes <= a few hundred): a single-workgroup
+//     right-looking Cholesky is used.  The MFMA-f64 tiled factorisation for global-BA sizes is a later row.
+#include "bh_internal.h"
+#include <math.h>
+#include <float.h>
+#include <vector>
+#include <algorithm>
+
+struct ba_cam {
+    double q[4];            // x y z w
+    double t[3];
+    double w2n[12];
+    double w2i[12];
+    double dR[27];
+};
+
+struct ba_K { double fx, fy, cx, cy; };
+
+// ------------------------------------------------------------------------------------------------ SBACam math (device)
+__device__ __forceinline__ void d_quat_to_R(const double* q, double* R)
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+__device__ void d_cam_refresh(ba_cam* c, const ba_K K)
+{
+    double R[9]; d_quat_to_R(c->q, R);
+    double* n = c->w2n;
+    for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) n[r * 4 + k] = R[k * 3 + r];
+    for (int r = 0; r < 3; r++) n[r * 4 + 3] = -(n[r * 4 + 0] * c->t[0] + n[r * 4 + 1] * c->t[1] + n[r * 4 + 2] * c->t[2]);
+    for (int k = 0; k < 4; k++) {
+        c->w2i[k] = K.fx * n[k] + K.cx * n[8 + k];
+        c->w2i[4 + k] = K.fy * n[4 + k] + K.cy * n[8 + k];
+        c->w2i[8 + k] = n[8 + k];
+    }
+    for (int k = 0; k < 3; k++) {
+        const double r0 = n[k], r1 = n[4 + k], r2 = n[8 + k];
+        c->dR[k] = 0;            c->dR[3 + k] = 2 * r2;        c->dR[6 + k] = -2 * r1;
+        c->dR[9 + k] = -2 * r2;  c->dR[9 + 3 + k] = 0;         c->dR[9 + 6 + k] = 2 * r0;
+        c->dR[18 + k] = 2 * r1;  c->dR[18 + 3 + k] = -2 * r0;  c->dR[18 + 6 + k] = 0;
+    }
+}
+
+__device__ void d_cam_oplus(ba_cam* c, const double* d, const ba_K K)
+{
+    c->t[0] += d[0]; c->t[1] += d[1]; c->t[2] += d[2];
+    const double bx = d[3], by = d[4], bz = d[5];
+    const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));
+    const double ax = c->q[0], ay = c->q[1], az = c->q[2], aw = c->q[3];
+    double q[4];
+    q[3] = aw * bw - ax * bx - ay * by - az * bz;
+    q[0] = aw * bx + ax * bw + ay * bz - az * by;
+    q[1] = aw * by + ay * bw + az * bx - ax * bz;
+    q[2] = aw * bz + az * bw + ax * by - ay * bx;
+    const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) c->q[i] = q[i] / nrm;
+    d_cam_refresh(c, K);
+}
+
+__device__ __forceinline__ void d_edge_error(const double* w2i, const double* X, const double* z, double* e)
+{
+    const double p0 = w2i[0] * X[0] + w2i[1] * X[1] + w2i[2] * X[2] + w2i[3];
+    const double p1 = w2i[4] * X[0] + w2i[5] * X[1] + w2i[6] * X[2] + w2i[7];
+    const double p2 = w2i[8] * X[0] + w2i[9] * X[1] + w2i[10] * X[2] + w2i[11];
+    e[0] = p0 / p2 - z[0];
+    e[1] = p1 / p2 - z[1];
+}
+
+__device__ __forceinline__ void d_edge_jac(const double* n, const double* dR, const double* ct, const double* X, const ba_K K,
+                                           double* Jc, double* Jp)
+{
+    const double px = n[0] * X[0] + n[1] * X[1] + n[2] * X[2] + n[3];
+    const double py = n[4] * X[0] + n[5] * X[1] + n[6] * X[2] + n[7];
+    const double pz = n[8] * X[0] + n[9] * X[1] + n[10] * X[2] + n[11];
+    const double ipz2 = 1.0 / (pz * pz);
+    const double ipz2fx = ipz2 * K.fx, ipz2fy = ipz2 * K.fy;
+    const double pwt[3] = { X[0] - ct[0], X[1] - ct[1], X[2] - ct[2] };
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double* D = dR + 9 * a;
+        const double dp0 = D[0] * pwt[0] + D[1] * pwt[1] + D[2] * pwt[2];
+        const double dp1 = D[3] * pwt[0] + D[4] * pwt[1] + D[5] * pwt[2];
+        const double dp2 = D[6] * pwt[0] + D[7] * pwt[1] + D[8] * pwt[2];
+        Jc[3 + a] = (pz * dp0 - px * dp2) * ipz2fx;
+        Jc[6 + 3 + a] = (pz * dp1 - py * dp2) * ipz2fy;
+        double d0 = -n[a], d1 = -n[4 + a], d2 = -n[8 + a];
+        Jc[a] = (pz * d0 - px * d2) * ipz2fx;
+        Jc[6 + a] = (pz * d1 - py * d2) * ipz2fy;
+        d0 = n[a]; d1 = n[4 + a]; d2 = n[8 + a];
+        Jp[a] = (pz * d0 - px * d2) * ipz2fx;
+        Jp[3 + a] = (pz * d1 - py * d2) * ipz2fy;
+    }
+}
+
+__device__ __forceinline__ void d_huber(double e2, double delta, double* rho0, double* rho1)
+{
+    if (delta <= 0) { *rho0 = e2; *rho1 = 1.0; return; }
+    const double dsqr = delta * delta;
+    if (e2 <= dsqr) { *rho0 = e2; *rho1 = 1.0; }
+    else { const double s = sqrt(e2); *rho0 = 2 * s * delta - dsqr; *rho1 = delta / s; }
+}
+
+__device__ __forceinline__ double d_shfl_xor(double v, int m)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double d_wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += d_shfl_xor(v, m);
+    return v;
+}
+
+// block-wide sum of NV doubles per thread, fixed order; result valid in every thread.  s_red: [NV * nwaves] doubles.
+template <int NV, int NT>
+__device__ void d_block_sum(double* v, double* s_red)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int NW = NT / 64;
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = d_wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0) for (int i = 0; i < NV; i++) s_red[wv * NV + i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; i++) { double s = 0; for (int w = 0; w < NW; w++) s += s_red[w * NV + i]; v[i] = s; }
+}
+
+// in-register 6x6 Cholesky solve; returns false if not positive definite
+__device__ bool d_chol6(double* A /*36*/, double* b /*6*/)
+{
+    for (int j = 0; j < 6; j++) {
+        double d = A[j * 6 + j];
+        for (int k = 0; k < j; k++) d -= A[j * 6 + k] * A[j * 6 + k];
+        if (!(d > 0) || !isfinite(d)) return false;
+        d = sqrt(d); A[j * 6 + j] = d;
+        for (int i = j + 1; i < 6; i++) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; k++) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s / d;
+        }
+    }
+    for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[i * 6 + k] * b[k]; b[i] = s / A[i * 6 + i]; }
+    for (int i = 5; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < 6; k++) s -= A[k * 6 + i] * b[k]; b[i] = s / A[i * 6 + i]; }
+    return true;
+}
+
+// ================================================================================================ pose-only BA
+#define PB_T 256
+
+__global__ __launch_bounds__(PB_T) void k_pose_ba(const double* __restrict__ pix, const double* __restrict__ pts,
+                                                  const int* __restrict__ n_arr, int stride, ba_K K, int iters,
+                                                  double delta, double chi2_thr, double* __restrict__ Rout,
+                                                  double* __restrict__ tout, double* __restrict__ chi2,
+                                                  uint8_t* __restrict__ inlier, int* __restrict__ status)
+{
+    __shared__ ba_cam s_cam, s_bak;
+    __shared__ double s_red[28 * (PB_T / 64)];
+    __shared__ double s_dx[6];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const int n = n_arr[b];
+    const double* px = pix + b * (size_t)stride * 2;
+    const double* X = pts + b * (size_t)stride * 3;
+    double* c2 = chi2 + b * (size_t)stride;
+
+    if (tid == 0) {
+        s_cam.q[0] = s_cam.q[1] = s_cam.q[2] = 0; s_cam.q[3] = 1; s_cam.t[0] = s_cam.t[1] = s_cam.t[2] = 0;     // optimizer.py:90-91
+        d_cam_refresh(&s_cam, K);
+    }
+    __syncthreads();
+    double lambda = 0, ni = 2;
+    bool numeric_fail = false;
+    for (int it = 0; it < iters; it++) {
+        // linearise: H (21 unique), b (6), chi
+        double acc[28];
+#pragma unroll
+        for (int i = 0; i < 28; i++) acc[i] = 0;
+        for (int e = tid; e < n; e += PB_T) {
+            double er[2], Jc[12], Jp[6], r0, r1;
+            d_edge_error(s_cam.w2i, X + 3 * e, px + 2 * e, er);
+            d_edge_jac(s_cam.w2n, s_cam.dR, s_cam.t, X + 3 * e, K, Jc, Jp);
+            d_huber(er[0] * er[0] + er[1] * er[1], delta, &r0, &r1);
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int bb = a; bb < 6; bb++) acc[k++] += r1 * (Jc[a] * Jc[bb] + Jc[6 + a] * Jc[6 + bb]);
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[21 + a] -= r1 * (Jc[a] * er[0] + Jc[6 + a] * er[1]);
+            acc[27] += r0;
+        }
+        d_block_sum<28, PB_T>(acc, s_red);
+        double H[36], bvec[6];
+        { int k = 0; for (int a = 0; a < 6; a++) for (int bb = a; bb < 6; bb++) { H[a * 6 + bb] = acc[k]; H[bb * 6 + a] = acc[k]; k++; } }
+        for (int a = 0; a < 6; a++) bvec[a] = acc[21 + a];
+        double chi = acc[27];
+        if (it == 0) {
+            double md = 0;
+            for (int a = 0; a < 6; a++) md = fmax(fabs(H[a * 6 + a]), md);
+            if (!isfinite(md)) { numeric_fail = true; break; }
+            lambda = 1e-5 * md; ni = 2;
+        }
+        double rho = 0; int qmax = 0;
+        do {
+            if (tid == 0) {
+                s_bak = s_cam;
+                double A[36], dx[6];
+                for (int i = 0; i < 36; i++) A[i] = H[i];
+                for (int a = 0; a < 6; a++) { A[a * 6 + a] += lambda; dx[a] = bvec[a]; }
+                s_ok = d_chol6(A, dx) ? 1 : 0;
+                for (int a = 0; a < 6; a++) s_dx[a] = dx[a];
+                d_cam_oplus(&s_cam, dx, K);
+            }
+            __syncthreads();
+            double tc[1] = { 0 };
+            for (int e = tid; e < n; e += PB_T) {
+                double er[2], r0, r1;
+                d_edge_error(s_cam.w2i, X + 3 * e, px + 2 * e, er);
+                const double e2 = er[0] * er[0] + er[1] * er[1];
+                c2[e] = e2;                                   // edge error of the LAST computeActiveErrors call
+                d_huber(e2, delta, &r0, &r1);
+                tc[0] += r0;
+            }
+            d_block_sum<1, PB_T>(tc, s_red);
+            double tempChi = tc[0];
+            if (!s_ok) tempChi = DBL_MAX;
+            rho = chi - tempChi;
+            double scale = 0;
+            for (int a = 0; a < 6; a++) scale += s_dx[a] * (lambda * s_dx[a] + bvec[a]);
+            scale += 1e-3;
+            rho /= scale;
+            __syncthreads();
+            if (rho > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow((2 * rho - 1), 3);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha); ni = 2; chi = tempChi;
+            } else {
+                lambda *= ni; ni *= 2;
+                if (tid == 0) s_cam = s_bak;
+            }
+            __syncthreads();
+            qmax++;
+        } while (rho < 0 && qmax < 10);
+        if (qmax == 10 || rho == 0) break;
+    }
+    __syncthreads();
+    if (iters <= 0 || numeric_fail)          // no trial ran: report the errors at the initial estimate
+        for (int e = tid; e < n; e += PB_T) { double er[2]; d_edge_error(s_cam.w2i, X + 3 * e, px + 2 * e, er); c2[e] = er[0] * er[0] + er[1] * er[1]; }
+    __syncthreads();
+    for (int e = tid; e < n; e += PB_T) inlier[b * (size_t)stride + e] = c2[e] <= chi2_thr ? 1 : 0;
+    if (tid == 0) {
+        double R[9]; d_quat_to_R(s_cam.q, R);
+        bool fin = true;
+        for (int i = 0; i < 9; i++) { Rout[b * 9 + i] = R[i]; fin = fin && isfinite(R[i]); }
+        for (int i = 0; i < 3; i++) { tout[b * 3 + i] = s_cam.t[i]; fin = fin && isfinite(s_cam.t[i]); }
+        status[b] = (fin && !numeric_fail) ? BH_OK : BH_ERR_NUMERIC;
+    }
+}
+
+extern "C" int bh_pose_only_ba(bh_ctx* ctx, const double* pix, const double* pts, const int* n, int B, int stride,
+                               const double K[5], int iters, double huber_delta, double chi2_thr,
+                               double* R, double* t, double* chi2, uint8_t* inlier, int* status, int mem)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (!pix || !pts || !n || !K || !R || !t || !chi2 || !inlier || !status || B < 0 || stride < 1 ||
+        (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_pose_only_ba: bad argument");
+    if (B == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t ne = (size_t)B * stride;
+    const double* d_pix = pix; const double* d_pts = pts; const int* d_n = n;
+    double *d_R = R, *d_t = t, *d_chi = chi2; uint8_t* d_in = inlier; int* d_st = status;
+    if (mem == BH_MEM_HOST) {
+        for (int b = 0; b < B; b++) if (n[b] < 0 || n[b] > stride) return bh_set_err(ctx, BH_ERR_INVALID, "bh_pose_only_ba: n[b] outside [0, stride]");
+        BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(double) * 2 * ne)); BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(double) * 3 * ne));
+        BH_TRY(bh_reserve(ctx, &ctx->st_c, sizeof(int) * 2 * B)); BH_TRY(bh_reserve(ctx, &ctx->st_d, sizeof(double) * 12 * B));
+        BH_TRY(bh_reserve(ctx, &ctx->st_e, sizeof(double) * ne)); BH_TRY(bh_reserve(ctx, &ctx->st_f, ne));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_a.p, pix, sizeof(double) * 2 * ne, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_b.p, pts, sizeof(double) * 3 * ne, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_c.p, n, sizeof(int) * B, hipMemcpyHostToDevice, st));
+        d_pix = (const double*)ctx->st_a.p; d_pts = (const double*)ctx->st_b.p; d_n = (const int*)ctx->st_c.p; d_st = (int*)ctx->st_c.p + B;
+        d_R = (double*)ctx->st_d.p; d_t = d_R + 9 * (size_t)B; d_chi = (double*)ctx->st_e.p; d_in = (uint8_t*)ctx->st_f.p;
+    }
+    ba_K Kd = { K[0], K[1], K[2], K[3] };
+    BH_LAUNCH(ctx, BH_K_POSE_BA, k_pose_ba, dim3(B), dim3(PB_T), st, d_pix, d_pts, d_n, stride, Kd, iters, huber_delta, chi2_thr,
+              d_R, d_t, d_chi, d_in, d_st);
+    BH_HIP(ctx, hipGetLastError());
+    if (mem == BH_MEM_HOST) {
+        BH_HIP(ctx, hipMemcpyAsync(R, d_R, sizeof(double) * 9 * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(t, d_t, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(chi2, d_chi, sizeof(double) * ne, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(inlier, d_in, ne, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(status, d_st, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipStreamSynchronize(st));
+    }
+    return BH_OK;
+}
+
+// ================================================================================================ local BA
+struct ba_state {                 // device-resident LM control block
+    double lambda, ni, chi_cur, chi_trial, rho, scale, max_diag;
+    int qmax, accepted, again, terminate, chol_ok, pad;
+};
+
+struct bh_ba {
+    bh_ctx* ctx = nullptr;
+    ba_K K = {};
+    int C = 0, P = 0, E = 0;           // user sizes
+    int Cf = 0, Pa = 0, Ea = 0;        // free+active cameras, active points, active edges
+    std::vector<int> cam_slot;         // user cam -> free slot or -1
+    std::vector<int> pt_slot;          // user point -> active point or -1
+    std::vector<int> edge_user;        // active edge -> user edge
+    std::vector<double> log;           // per iteration {chi, lambda, trials, accepted}
+    int iters_done = 0;
+    int have_problem = 0, verbose_last = 0;
+    // device
+    bh_buf cams[2], pts[2];            // state double buffer: [cur], [trial]
+    int cur = 0;
+    bh_buf e_cam, e_pt, e_meas;        // per active edge: user cam index, active point index, measurement
+    bh_buf cslot;                      // per user cam: free slot or -1
+    bh_buf p_start, p_edges, c_start, c_edges;
+    bh_buf err[2], chi_e[2];           // [0] at the current state (iteration start), [1] at the trial state
+    bh_buf Hpl, Hll, bl, Hpp, bp, pdiag, cdiag;
+    bh_buf Dinv, db, S, bs, dxp, dxl, state, pairs;
+    int npairs = 0;
+    int last_err_sel = 0;              // which err buffer holds "the last computeActiveErrors"
+};
+
+// ---- k_ba_point: 8 lanes per active point; residual + Huber + Jacobians; Hll, bl, per-edge Hpl, per-edge error/chi
+#define BP_G 8
+__global__ __launch_bounds__(256) void k_ba_point(const ba_cam* __restrict__ cams, const double* __restrict__ pts,
+                                                  const int* __restrict__ e_cam, const double* __restrict__ e_meas,
+                                                  const int* __restrict__ cslot, const int* __restrict__ p_start,
+                                                  const int* __restrict__ p_edges, int Pa, ba_K K, double delta,
+                                                  double* __restrict__ Hpl, double* __restrict__ Hll, double* __restrict__ bl,
+                                                  double* __restrict__ err, double* __restrict__ chi_e, double* __restrict__ pdiag)
+{
+    const int gid = (blockIdx.x * 256 + threadIdx.x) / BP_G, sub = threadIdx.x & (BP_G - 1);
+    const bool live = gid < Pa;
+    const int j = live ? gid : 0;
+    const double X[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
+    double acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) acc[i] = 0;       // Hll upper (6) + bl (3)
+    if (live) {
+        for (int u = p_start[j] + sub; u < p_start[j + 1]; u += BP_G) {
+            const int e = p_edges[u];
+            const ba_cam* c = cams + e_cam[e];
+            double er[2], Jc[12], Jp[6], r0, r1;
+            d_edge_error(c->w2i, X, e_meas + 2 * e, er);
+            d_edge_jac(c->w2n, c->dR, c->t, X, K, Jc, Jp);
+            d_huber(er[0] * er[0] + er[1] * er[1], delta, &r0, &r1);
+            err[2 * e] = er[0]; err[2 * e + 1] = er[1]; chi_e[e] = r0;
+            acc[0] += r1 * (Jp[0] * Jp[0] + Jp[3] * Jp[3]); acc[1] += r1 * (Jp[0] * Jp[1] + Jp[3] * Jp[4]); acc[2] += r1 * (Jp[0] * Jp[2] + Jp[3] * Jp[5]);
+            acc[3] += r1 * (Jp[1] * Jp[1] + Jp[4] * Jp[4]); acc[4] += r1 * (Jp[1] * Jp[2] + Jp[4] * Jp[5]); acc[5] += r1 * (Jp[2] * Jp[2] + Jp[5] * Jp[5]);
+            acc[6] -= r1 * (Jp[0] * er[0] + Jp[3] * er[1]); acc[7] -= r1 * (Jp[1] * er[0] + Jp[4] * er[1]); acc[8] -= r1 * (Jp[2] * er[0] + Jp[5] * er[1]);
+            double* B = Hpl + 18 * (size_t)e;
+            if (cslot[e_cam[e]] >= 0) {
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int bb = 0; bb < 3; bb++) B[3 * a + bb] = r1 * (Jc[a] * Jp[bb] + Jc[6 + a] * Jp[3 + bb]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { acc[i] += d_shfl_xor(acc[i], 1); acc[i] += d_shfl_xor(acc[i], 2); acc[i] += d_shfl_xor(acc[i], 4); }
+    if (live && sub == 0) {
+        double* H = Hll + 9 * (size_t)j;
+        H[0] = acc[0]; H[1] = acc[1]; H[2] = acc[2]; H[3] = acc[1]; H[4] = acc[3]; H[5] = acc[4]; H[6] = acc[2]; H[7] = acc[4]; H[8] = acc[5];
+        bl[3 * j] = acc[6]; bl[3 * j + 1] = acc[7]; bl[3 * j + 2] = acc[8];
+        pdiag[j] = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+    }
+}
+
+// ---- k_ba_cam: workgroup per free camera: Hpp (6x6) and bp (6) over the camera's edges
+__global__ __launch_bounds__(256) void k_ba_cam(const ba_cam* __restrict__ cams, const double* __restrict__ pts,
+                                                const int* __restrict__ e_cam, const int* __restrict__ e_pt,
+                                                const double* __restrict__ e_meas, const int* __restrict__ c_start,
+                                                const int* __restrict__ c_edges, ba_K K, double delta,
+                                                double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ cdiag)
+{
+    __shared__ double s_red[27 * 4];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) acc[i] = 0;
+    const int u0 = c_start[s], u1 = c_start[s + 1];
+    for (int u = u0 + tid; u < u1; u += 256) {
+        const int e = c_edges[u];
+        const ba_cam* c = cams + e_cam[e];
+        const double* X = pts + 3 * (size_t)e_pt[e];
+        double er[2], Jc[12], Jp[6], r0, r1;
+        d_edge_error(c->w2i, X, e_meas + 2 * e, er);
+        d_edge_jac(c->w2n, c->dR, c->t, X, K, Jc, Jp);
+        d_huber(er[0] * er[0] + er[1] * er[1], delta, &r0, &r1);
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int bb = a; bb < 6; bb++) acc[k++] += r1 * (Jc[a] * Jc[bb] + Jc[6 + a] * Jc[6 + bb]);
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[21 + a] -= r1 * (Jc[a] * er[0] + Jc[6 + a] * er[1]);
+    }
+    d_block_sum<27, 256>(acc, s_red);
+    if (tid == 0) {
+        double* H = Hpp + 36 * (size_t)s;
+        int k = 0; double md = 0;
+        for (int a = 0; a < 6; a++) for (int bb = a; bb < 6; bb++) { H[a * 6 + bb] = acc[k]; H[bb * 6 + a] = acc[k]; k++; }
+        for (int a = 0; a < 6; a++) { bp[6 * s + a] = acc[21 + a]; md = fmax(md, fabs(H[a * 6 + a])); }
+        cdiag[s] = md;
+    }
+}
+
+// ---- k_ba_prep: chi at the current state; lambda init on the first iteration
+__global__ __launch_bounds__(1024) void k_ba_prep(const double* __restrict__ chi_e, int Ea, const double* __restrict__ pdiag, int Pa,
+                                                  const double* __restrict__ cdiag, int Cf, int first, ba_state* __restrict__ S)
+{
+    __shared__ double s_red[16];
+    __shared__ double s_max[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double v[1] = { 0 };
+    for (int e = tid; e < Ea; e += 1024) v[0] += chi_e[e];
+    d_block_sum<1, 1024>(v, s_red);
+    double md = 0;
+    if (first) {
+        for (int j = tid; j < Pa; j += 1024) md = fmax(md, pdiag[j]);
+        for (int c = tid; c < Cf; c += 1024) md = fmax(md, cdiag[c]);
+        for (int m = 32; m > 0; m >>= 1) md = fmax(md, d_shfl_xor(md, m));
+        if (lane == 0) s_max[wv] = md;
+        __syncthreads();
+        md = 0; for (int w = 0; w < 16; w++) md = fmax(md, s_max[w]);
+    }
+    if (tid == 0) {
+        S->chi_cur = v[0];
+        if (first) { S->max_diag = md; S->lambda = 1e-5 * md; S->ni = 2; }
+        S->qmax = 0; S->accepted = 0; S->again = 0; S->terminate = 0; S->rho = 0; S->chol_ok = 1;
+    }
+}
+
+__device__ __forceinline__ bool d_inv3(const double* m, double* o)
+{
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return isfinite(id);
+}
+
+// ---- k_ba_dinv: per point (Hll + lambda I)^-1 and Dinv * bl
+__global__ __launch_bounds__(256) void k_ba_dinv(const double* __restrict__ Hll, const double* __restrict__ bl, int Pa,
+                                                 ba_state* __restrict__ S, double* __restrict__ Dinv, double* __restrict__ db)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Pa) return;
+    const double lambda = S->lambda;
+    double D[9], Di[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) D[i] = Hll[9 * (size_t)j + i];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    if (!d_inv3(D, Di)) S->chol_ok = 0;              // benign race: every writer stores 0; k_ba_prep / k_ba_decide re-arm it to 1
+#pragma unroll
+    for (int i = 0; i < 9; i++) Dinv[9 * (size_t)j + i] = Di[i];
+#pragma unroll
+    for (int a = 0; a < 3; a++) db[3 * j + a] = Di[3 * a] * bl[3 * j] + Di[3 * a + 1] * bl[3 * j + 1] + Di[3 * a + 2] * bl[3 * j + 2];
+}
+
+// ---- k_ba_schur_S: workgroup per camera pair (s1 <= s2): S[s1][s2] = [s1==s2](Hpp + lambda I) - sum_j Hpl_1j Dinv_j Hpl_2j'
+__global__ __launch_bounds__(256) void k_ba_schur_S(const int2* __restrict__ pairs, const int* __restrict__ c_start,
+                                                    const int* __restrict__ c_edges, const int* __restrict__ e_pt,
+                                                    const double* __restrict__ Hpl, const double* __restrict__ Dinv,
+                                                    const double* __restrict__ Hpp, const ba_state* __restrict__ St,
+                                                    int n6, double* __restrict__ Sm)
+{
+    __shared__ double s_red[36 * 4];
+    const int tid = threadIdx.x;
+    const int s1 = pairs[blockIdx.x].x, s2 = pairs[blockIdx.x].y;
+    const int a0 = c_start[s1], a1 = c_start[s1 + 1], b0 = c_start[s2], b1 = c_start[s2 + 1];
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = 0;
+    for (int u = a0 + tid; u < a1; u += 256) {
+        const int e1 = c_edges[u];
+        const int j = e_pt[e1];
+        int lo = b0, hi = b1;                                    // lower_bound of j in camera s2's point-sorted list
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (e_pt[c_edges[mid]] < j) lo = mid + 1; else hi = mid; }
+        for (int v = lo; v < b1 && e_pt[c_edges[v]] == j; v++) {
+            const int e2 = c_edges[v];
+            const double* B1 = Hpl + 18 * (size_t)e1; const double* B2 = Hpl + 18 * (size_t)e2; const double* Di = Dinv + 9 * (size_t)j;
+            double BD[18];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int bb = 0; bb < 3; bb++) BD[3 * a + bb] = B1[3 * a] * Di[bb] + B1[3 * a + 1] * Di[3 + bb] + B1[3 * a + 2] * Di[6 + bb];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int bb = 0; bb < 6; bb++) acc[6 * a + bb] += BD[3 * a] * B2[3 * bb] + BD[3 * a + 1] * B2[3 * bb + 1] + BD[3 * a + 2] * B2[3 * bb + 2];
+        }
+    }
+    d_block_sum<36, 256>(acc, s_red);
+    if (tid < 36) {
+        const int a = tid / 6, bb = tid - a * 6;
+        double v = -acc[tid];
+        if (s1 == s2) { v += Hpp[36 * (size_t)s1 + tid]; if (a == bb) v += St->lambda; }
+        Sm[(size_t)(6 * s1 + a) * n6 + 6 * s2 + bb] = v;
+        if (s1 != s2) Sm[(size_t)(6 * s2 + bb) * n6 + 6 * s1 + a] = v;
+    }
+}
+
+// ---- k_ba_schur_b: per free camera  b~ = bp - sum_e Hpl_e (Dinv bl)_pt(e)
+__global__ __launch_bounds__(256) void k_ba_schur_b(const int* __restrict__ c_start, const int* __restrict__ c_edges,
+                                                    const int* __restrict__ e_pt, const double* __restrict__ Hpl,
+                                                    const double* __restrict__ db, const double* __restrict__ bp,
+                                                    double* __restrict__ bs)
+{
+    __shared__ double s_red[6 * 4];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int u = c_start[s] + tid; u < c_start[s + 1]; u += 256) {
+        const int e = c_edges[u];
+        const double* B = Hpl + 18 * (size_t)e; const double* d = db + 3 * (size_t)e_pt[e];
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[a] += B[3 * a] * d[0] + B[3 * a + 1] * d[1] + B[3 * a + 2] * d[2];
+    }
+    d_block_sum<6, 256>(acc, s_red);
+    if (tid < 6) bs[6 * s + tid] = bp[6 * s + tid] - acc[tid];
+}
+
+// ---- k_ba_chol: one workgroup; in-place right-looking Cholesky of S (n x n, row-major, lower used) + two triangular solves
+__global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const double* __restrict__ bs, int n,
+                                                  double* __restrict__ x, ba_state* __restrict__ St)
+{
+    __shared__ double s_col[2048];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_fail = St->chol_ok ? 0 : 1;
+    __syncthreads();
+    for (int j = 0; j < n && !s_fail; j++) {
+        const double d = A[(size_t)j * n + j];
+        if (!(d > 0) || !isfinite(d)) { __syncthreads(); if (tid == 0) s_fail = 1; __syncthreads(); break; }
+        const double sd = sqrt(d);
+        for (int i = j + tid; i < n; i += 1024) {
+            const double l = (i == j) ? sd : A[(size_t)i * n + j] / sd;
+            s_col[i] = l;
+            A[(size_t)i * n + j] = l;
+        }
+        __syncthreads();
+        const int m = n - j - 1;                                  // trailing rows j+1 .. n-1, lower triangle only
+        for (int idx = tid; idx < m * m; idx += 1024) {
+            const int r = idx / m, c = idx - r * m;
+            if (c <= r) A[(size_t)(j + 1 + r) * n + j + 1 + c] -= s_col[j + 1 + r] * s_col[j + 1 + c];
+        }
+        __syncthreads();
+    }
+    if (s_fail) { if (tid == 0) St->chol_ok = 0; for (int i = tid; i < n; i += 1024) x[i] = 0; return; }
+    // forward / backward substitution by one wave-ordered sweep (n is small)
+    for (int i = tid; i < n; i += 1024) s_col[i] = bs[i];
+    __syncthreads();
+    for (int i = 0; i < n; i++) {
+        if (tid == 0) s_col[i] = s_col[i] / A[(size_t)i * n + i];
+        __syncthreads();
+        const double xi = s_col[i];
+        for (int r = i + 1 + tid; r < n; r += 1024) s_col[r] -= A[(size_t)r * n + i] * xi;
+        __syncthreads();
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        if (tid == 0) s_col[i] = s_col[i] / A[(size_t)i * n + i];
+        __syncthreads();
+        const double xi = s_col[i];
+        for (int r = tid; r < i; r += 1024) s_col[r] -= A[(size_t)i * n + r] * xi;
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 1024) x[i] = s_col[i];
+}
+
+// ---- k_ba_update: trial state = current state (+) step.  blocks [0, pblocks): points (back-substitution); rest: cameras
+__global__ __launch_bounds__(256) void k_ba_update(const ba_cam* __restrict__ cams, ba_cam* __restrict__ cams_t,
+                                                   const double* __restrict__ pts, double* __restrict__ pts_t,
+                                                   const int* __restrict__ cslot, int C, int Pa, int pblocks,
+                                                   const int* __restrict__ p_start, const int* __restrict__ p_edges,
+                                                   const int* __restrict__ e_cam, const double* __restrict__ Hpl,
+                                                   const double* __restrict__ Dinv, const double* __restrict__ bl,
+                                                   const double* __restrict__ dxp, double* __restrict__ dxl, ba_K K)
+{
+    if ((int)blockIdx.x < pblocks) {
+        const int j = blockIdx.x * 256 + threadIdx.x;
+        if (j >= Pa) return;
+        double c[3] = { bl[3 * j], bl[3 * j + 1], bl[3 * j + 2] };
+        for (int u = p_start[j]; u < p_start[j + 1]; u++) {
+            const int e = p_edges[u];
+            const int s = cslot[e_cam[e]];
+            if (s < 0) continue;
+            const double* B = Hpl + 18 * (size_t)e; const double* d = dxp + 6 * s;
+#pragma unroll
+            for (int bb = 0; bb < 3; bb++)
+#pragma unroll
+                for (int a = 0; a < 6; a++) c[bb] -= B[3 * a + bb] * d[a];
+        }
+        const double* Di = Dinv + 9 * (size_t)j;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double dl = Di[3 * a] * c[0] + Di[3 * a + 1] * c[1] + Di[3 * a + 2] * c[2];
+            dxl[3 * j + a] = dl;
+            pts_t[3 * j + a] = pts[3 * j + a] + dl;
+        }
+    } else {
+        const int i = (blockIdx.x - pblocks) * 256 + threadIdx.x;
+        if (i >= C) return;
+        ba_cam c = cams[i];
+        const int s = cslot[i];
+        if (s >= 0) d_cam_oplus(&c, dxp + 6 * s, K);
+        cams_t[i] = c;
+    }
+}
+
+// ---- k_ba_err: per-edge error and robust chi at the trial state
+__global__ __launch_bounds__(256) void k_ba_err(const ba_cam* __restrict__ cams, const double* __restrict__ pts,
+                                                const int* __restrict__ e_cam, const int* __restrict__ e_pt,
+                                                const double* __restrict__ e_meas, int Ea, double delta,
+                                                double* __restrict__ err, double* __restrict__ chi_e)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Ea) return;
+    double er[2], r0, r1;
+    d_edge_error(cams[e_cam[e]].w2i, pts + 3 * (size_t)e_pt[e], e_meas + 2 * e, er);
+    d_huber(er[0] * er[0] + er[1] * er[1], delta, &r0, &r1);
+    err[2 * e] = er[0]; err[2 * e + 1] = er[1]; chi_e[e] = r0;
+}
+
+// ---- k_ba_decide: Levenberg gain ratio and lambda schedule (OptimizationAlgorithmLevenberg::solve)
+__global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxp,
+                                                    const double* __restrict__ bp, int n6, const double* __restrict__ dxl,
+                                                    const double* __restrict__ bl, int n3, ba_state* __restrict__ S)
+{
+    __shared__ double s_red[2 * 16];
+    const int tid = threadIdx.x;
+    const double lambda = S->lambda;
+    double v[2] = { 0, 0 };
+    for (int e = tid; e < Ea; e += 1024) v[0] += chi_e[e];
+    for (int i = tid; i < n6; i += 1024) v[1] += dxp[i] * (lambda * dxp[i] + bp[i]);
+    for (int i = tid; i < n3; i += 1024) v[1] += dxl[i] * (lambda * dxl[i] + bl[i]);
+    d_block_sum<2, 1024>(v, s_red);
+    if (tid == 0) {
+        double tempChi = v[0];
+        if (!S->chol_ok) tempChi = DBL_MAX;
+        double rho = S->chi_cur - tempChi;
+        const double scale = v[1] + 1e-3;
+        rho /= scale;
+        S->chi_trial = tempChi; S->scale = scale; S->rho = rho;
+        if (rho > 0 && isfinite(tempChi)) {
+            double alpha = 1. - pow((2 * rho - 1), 3);
+            alpha = fmin(alpha, 2. / 3.);
+            S->lambda = lambda * fmax(1. / 3., alpha); S->ni = 2; S->chi_cur = tempChi; S->accepted = 1;
+        } else {
+            S->lambda = lambda * S->ni; S->ni *= 2; S->accepted = 0;
+        }
+        S->qmax += 1;
+        S->again = (rho < 0 && S->qmax < 10) ? 1 : 0;
+        S->terminate = (!S->again && (S->qmax == 10 || rho == 0)) ? 1 : 0;
+        S->chol_ok = 1;                                  // re-arm for the next trial
+    }
+}
+
+__global__ void k_ba_cam_init(ba_cam* cams, int C, ba_K K)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < C) d_cam_refresh(&cams[i], K);
+}
+
+__global__ void k_ba_export(const ba_cam* cams, int C, double* R, double* t)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= C) return;
+    double Rm[9]; d_quat_to_R(cams[i].q, Rm);
+    for (int k = 0; k < 9; k++) R[9 * (size_t)i + k] = Rm[k];
+    for (int k = 0; k < 3; k++) t[3 * (size_t)i + k] = cams[i].t[k];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static void h_quat_from_R(const double* m, double* q)
+{
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0; if (m[4] > m[0]) i = 1; if (m[8] > m[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+        q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t; q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t; q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    }
+    if (q[3] < 0) for (int a = 0; a < 4; a++) q[a] = -q[a];                 // SE3Quat::normalizeRotation
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int a = 0; a < 4; a++) q[a] /= n;
+}
+
+extern "C" int bh_ba_create(bh_ctx* ctx, const double K[5], bh_ba** out)
+{
+    if (!ctx || !K || !out) return BH_ERR_INVALID;
+    bh_ba* ba = new bh_ba();
+    ba->ctx = ctx; ba->K = { K[0], K[1], K[2], K[3] };
+    *out = ba;
+    return BH_OK;
+}
+
+extern "C" void bh_ba_destroy(bh_ba* ba)
+{
+    if (!ba) return;
+    (void)hipSetDevice(ba->ctx->device);
+    (void)hipStreamSynchronize(ba->ctx->stream);
+    bh_buf* all[] = { &ba->cams[0], &ba->cams[1], &ba->pts[0], &ba->pts[1], &ba->e_cam, &ba->e_pt, &ba->e_meas, &ba->cslot,
+                      &ba->p_start, &ba->p_edges, &ba->c_start, &ba->c_edges, &ba->err[0], &ba->err[1], &ba->chi_e[0],
+                      &ba->chi_e[1], &ba->Hpl, &ba->Hll, &ba->bl, &ba->Hpp, &ba->bp, &ba->pdiag, &ba->cdiag, &ba->Dinv,
+                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs };
+    for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    delete ba;
+}
+
+template <typename T>
+static int upload(bh_ctx* ctx, bh_buf* b, const std::vector<T>& v)
+{
+    BH_TRY(bh_reserve(ctx, b, sizeof(T) * (v.size() + 1)));
+    if (!v.empty()) BH_HIP(ctx, hipMemcpyAsync(b->p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, ctx->stream));
+    return BH_OK;
+}
+
+extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double* t, const uint8_t* fixed,
+                                 int P, const double* points, int E, const int* edge_pose, const int* edge_point,
+                                 const double* meas, int mem)
+{
+    if (!ba) return BH_ERR_INVALID;
+    bh_ctx* ctx = ba->ctx;
+    if (mem != BH_MEM_HOST) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: the graph is built on the host side (BH_MEM_HOST only)");
+    if (C < 0 || P < 0 || E < 0 || (C && (!R || !t || !fixed)) || (P && !points) || (E && (!edge_pose || !edge_point || !meas)))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: bad argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    for (int e = 0; e < E; e++)
+        if (edge_pose[e] < 0 || edge_pose[e] >= C || edge_point[e] < 0 || edge_point[e] >= P)
+            return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: edge %d references a missing vertex", e);
+    ba->C = C; ba->P = P; ba->E = E;
+    // active structure (g2o initializeOptimization): points are free; a vertex takes part iff it has an edge
+    ba->cam_slot.assign(C, -1); ba->pt_slot.assign(P, -1); ba->edge_user.clear();
+    std::vector<char> cam_used(C, 0);
+    for (int e = 0; e < E; e++) { cam_used[edge_pose[e]] = 1; ba->pt_slot[edge_point[e]] = 0; }
+    int Cf = 0, Pa = 0;
+    for (int i = 0; i < C; i++) if (cam_used[i] && !fixed[i]) ba->cam_slot[i] = Cf++;
+    for (int j = 0; j < P; j++) if (ba->pt_slot[j] == 0) ba->pt_slot[j] = Pa++;
+    ba->Cf = Cf; ba->Pa = Pa; ba->Ea = E;
+    if (6 * Cf > 2048) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: %d free keyframes exceed the local-BA solver (341); global BA is a later row", Cf);
+    std::vector<ba_cam> cams(C);
+    for (int i = 0; i < C; i++) {
+        memset(&cams[i], 0, sizeof(ba_cam));
+        h_quat_from_R(R + 9 * i, cams[i].q);
+        for (int k = 0; k < 3; k++) cams[i].t[k] = t[3 * i + k];
+    }
+    std::vector<double> pts(3 * (size_t)Pa);
+    for (int j = 0; j < P; j++) if (ba->pt_slot[j] >= 0) for (int k = 0; k < 3; k++) pts[3 * (size_t)ba->pt_slot[j] + k] = points[3 * (size_t)j + k];
+    std::vector<int> e_cam(E), e_pt(E); std::vector<double> e_meas(2 * (size_t)E);
+    for (int e = 0; e < E; e++) { e_cam[e] = edge_pose[e]; e_pt[e] = ba->pt_slot[edge_point[e]]; e_meas[2 * e] = meas[2 * e]; e_meas[2 * e + 1] = meas[2 * e + 1]; }
+    // CSR by point (edges ordered by camera) and by free camera (edges ordered by point)
+    std::vector<int> order(E);
+    for (int e = 0; e < E; e++) order[e] = e;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return e_pt[a] != e_pt[b] ? e_pt[a] < e_pt[b] : e_cam[a] < e_cam[b]; });
+    std::vector<int> p_start(Pa + 1, 0), p_edges(order);
+    for (int e = 0; e < E; e++) p_start[e_pt[e] + 1]++;
+    for (int j = 0; j < Pa; j++) p_start[j + 1] += p_start[j];
+    std::vector<int> c_start(Cf + 1, 0), c_edges;
+    for (int e = 0; e < E; e++) { const int s = ba->cam_slot[e_cam[e]]; if (s >= 0) c_start[s + 1]++; }
+    for (int s = 0; s < Cf; s++) c_start[s + 1] += c_start[s];
+    c_edges.resize(c_start[Cf]);
+    { std::vector<int> fill(Cf, 0);
+      for (int k = 0; k < E; k++) { const int e = order[k]; const int s = ba->cam_slot[e_cam[e]]; if (s >= 0) c_edges[c_start[s] + fill[s]++] = e; } }
+    // camera pairs that share at least one point (upper triangle incl. diagonal)
+    std::vector<char> cov((size_t)Cf * Cf, 0);
+    for (int j = 0; j < Pa; j++)
+        for (int u = p_start[j]; u < p_start[j + 1]; u++) {
+            const int s1 = ba->cam_slot[e_cam[p_edges[u]]]; if (s1 < 0) continue;
+            for (int v = u; v < p_start[j + 1]; v++) { const int s2 = ba->cam_slot[e_cam[p_edges[v]]]; if (s2 >= 0) cov[(size_t)(s1 < s2 ? s1 : s2) * Cf + (s1 < s2 ? s2 : s1)] = 1; }
+        }
+    std::vector<int2> pairs;
+    for (int a = 0; a < Cf; a++) for (int b = a; b < Cf; b++) if (cov[(size_t)a * Cf + b] || a == b) pairs.push_back(make_int2(a, b));
+    ba->npairs = (int)pairs.size();
+
+    BH_TRY(upload(ctx, &ba->cams[0], cams)); BH_TRY(bh_reserve(ctx, &ba->cams[1], sizeof(ba_cam) * (C + 1)));
+    BH_TRY(upload(ctx, &ba->pts[0], pts)); BH_TRY(bh_reserve(ctx, &ba->pts[1], sizeof(double) * 3 * (Pa + 1)));
+    BH_TRY(upload(ctx, &ba->e_cam, e_cam)); BH_TRY(upload(ctx, &ba->e_pt, e_pt)); BH_TRY(upload(ctx, &ba->e_meas, e_meas));
+    BH_TRY(upload(ctx, &ba->cslot, ba->cam_slot));
+    BH_TRY(upload(ctx, &ba->p_start, p_start)); BH_TRY(upload(ctx, &ba->p_edges, p_edges));
+    BH_TRY(upload(ctx, &ba->c_start, c_start)); BH_TRY(upload(ctx, &ba->c_edges, c_edges));
+    BH_TRY(upload(ctx, &ba->pairs, pairs));
+    const size_t n6 = 6 * (size_t)Cf;
+    for (int k = 0; k < 2; k++) { BH_TRY(bh_reserve(ctx, &ba->err[k], sizeof(double) * 2 * (E + 1))); BH_TRY(bh_reserve(ctx, &ba->chi_e[k], sizeof(double) * (E + 1))); }
+    BH_TRY(bh_reserve(ctx, &ba->Hpl, sizeof(double) * 18 * ((size_t)E + 1)));
+    BH_TRY(bh_reserve(ctx, &ba->Hll, sizeof(double) * 9 * ((size_t)Pa + 1))); BH_TRY(bh_reserve(ctx, &ba->bl, sizeof(double) * 3 * ((size_t)Pa + 1)));
+    BH_TRY(bh_reserve(ctx, &ba->Hpp, sizeof(double) * 36 * ((size_t)Cf + 1))); BH_TRY(bh_reserve(ctx, &ba->bp, sizeof(double) * (n6 + 6)));
+    BH_TRY(bh_reserve(ctx, &ba->pdiag, sizeof(double) * (Pa + 1))); BH_TRY(bh_reserve(ctx, &ba->cdiag, sizeof(double) * (Cf + 1)));
+    BH_TRY(bh_reserve(ctx, &ba->Dinv, sizeof(double) * 9 * ((size_t)Pa + 1))); BH_TRY(bh_reserve(ctx, &ba->db, sizeof(double) * 3 * ((size_t)Pa + 1)));
+    BH_TRY(bh_reserve(ctx, &ba->S, sizeof(double) * (n6 * n6 + 1))); BH_TRY(bh_reserve(ctx, &ba->bs, sizeof(double) * (n6 + 6)));
+    BH_TRY(bh_reserve(ctx, &ba->dxp, sizeof(double) * (n6 + 6))); BH_TRY(bh_reserve(ctx, &ba->dxl, sizeof(double) * 3 * ((size_t)Pa + 1)));
+    BH_TRY(bh_reserve(ctx, &ba->state, sizeof(ba_state)));
+    BH_HIP(ctx, hipMemsetAsync(ba->state.p, 0, sizeof(ba_state), ctx->stream));
+    BH_HIP(ctx, hipMemsetAsync(ba->err[0].p, 0, sizeof(double) * 2 * (E + 1), ctx->stream));
+    BH_HIP(ctx, hipMemsetAsync(ba->S.p, 0, sizeof(double) * (n6 * n6 + 1), ctx->stream));
+    BH_HIP(ctx, hipMemsetAsync(ba->dxp.p, 0, sizeof(double) * (n6 + 6), ctx->stream));
+    if (C) hipLaunchKernelGGL(k_ba_cam_init, dim3((C + 63) / 64), dim3(64), 0, ctx->stream, (ba_cam*)ba->cams[0].p, C, ba->K);
+    BH_HIP(ctx, hipGetLastError());
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the host vectors above go out of scope
+    ba->cur = 0; ba->have_problem = 1; ba->iters_done = 0; ba->log.clear(); ba->last_err_sel = 0;
+    return BH_OK;
+}
+
+extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verbose_errors, int* iters_done)
+{
+    if (!ba) return BH_ERR_INVALID;
+    bh_ctx* ctx = ba->ctx;
+    if (!ba->have_problem) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_optimize: no problem set");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ba->log.clear(); ba->iters_done = 0;
+    if (iters_done) *iters_done = 0;
+    const int C = ba->C, Cf = ba->Cf, Pa = ba->Pa, Ea = ba->Ea, n6 = 6 * Cf;
+    if (Ea == 0 || iters <= 0) return BH_OK;
+    const int* e_cam = (const int*)ba->e_cam.p; const int* e_pt = (const int*)ba->e_pt.p; const double* e_meas = (const double*)ba->e_meas.p;
+    const int* cslot = (const int*)ba->cslot.p;
+    const int* p_start = (const int*)ba->p_start.p; const int* p_edges = (const int*)ba->p_edges.p;
+    const int* c_start = (const int*)ba->c_start.p; const int* c_edges = (const int*)ba->c_edges.p;
+    double *Hpl = (double*)ba->Hpl.p, *Hll = (double*)ba->Hll.p, *bl = (double*)ba->bl.p, *Hpp = (double*)ba->Hpp.p, *bp = (double*)ba->bp.p;
+    double *pdiag = (double*)ba->pdiag.p, *cdiag = (double*)ba->cdiag.p, *Dinv = (double*)ba->Dinv.p, *db = (double*)ba->db.p;
+    double *S = (double*)ba->S.p, *bs = (double*)ba->bs.p, *dxp = (double*)ba->dxp.p, *dxl = (double*)ba->dxl.p;
+    ba_state* state = (ba_state*)ba->state.p;
+    const int pblocks = (Pa + 255) / 256, cblocks = (C + 255) / 256;
+    int rc = BH_OK;
+    for (int it = 0; it < iters; it++) {
+        const ba_cam* cams = (const ba_cam*)ba->cams[ba->cur].p; const double* pts = (const double*)ba->pts[ba->cur].p;
+        BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_ba_point, dim3((Pa * BP_G + 255) / 256), dim3(256), st, cams, pts, e_cam, e_meas, cslot, p_start,
+                  p_edges, Pa, ba->K, huber_delta, Hpl, Hll, bl, (double*)ba->err[0].p, (double*)ba->chi_e[0].p, pdiag);
+        if (Cf) BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_ba_cam, dim3(Cf), dim3(256), st, cams, pts, e_cam, e_pt, e_meas, c_start, c_edges, ba->K,
+                          huber_delta, Hpp, bp, cdiag);
+        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_prep, dim3(1), dim3(1024), st, (const double*)ba->chi_e[0].p, Ea, (const double*)pdiag, Pa,
+                  (const double*)cdiag, Cf, it == 0 ? 1 : 0, state);
+        ba_state hs;
+        if (it == 0) {
+            BH_HIP(ctx, hipMemcpyAsync(&hs, state, sizeof(hs), hipMemcpyDeviceToHost, st));
+            BH_HIP(ctx, hipStreamSynchronize(st));
+            if (!std::isfinite(hs.max_diag)) { rc = bh_set_err(ctx, BH_ERR_NUMERIC, "bh_ba_optimize: non-finite Hessian at the initial estimate"); break; }
+        }
+        ba->last_err_sel = 0;
+        do {
+            ba_cam* cams_t = (ba_cam*)ba->cams[ba->cur ^ 1].p; double* pts_t = (double*)ba->pts[ba->cur ^ 1].p;
+            BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_dinv, dim3(pblocks), dim3(256), st, (const double*)Hll, (const double*)bl, Pa, state, Dinv, db);
+            if (Cf) {
+                BH_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double) * (size_t)n6 * n6, st));     // pairs without a common point stay zero
+                BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_S, dim3(ba->npairs), dim3(256), st, (const int2*)ba->pairs.p, c_start, c_edges, e_pt,
+                          (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, n6, S);
+                BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_b, dim3(Cf), dim3(256), st, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)db,
+                          (const double*)bp, bs);
+                BH_LAUNCH(ctx, BH_K_BA_SOLVE, k_ba_chol, dim3(1), dim3(1024), st, S, (const double*)bs, n6, dxp, state);
+            }
+            BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_update, dim3(pblocks + cblocks), dim3(256), st, cams, cams_t, pts, pts_t, cslot, C, Pa, pblocks,
+                      p_start, p_edges, e_cam, (const double*)Hpl, (const double*)Dinv, (const double*)bl, (const double*)dxp, dxl, ba->K);
+            BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_err, dim3((Ea + 255) / 256), dim3(256), st, (const ba_cam*)cams_t, (const double*)pts_t, e_cam, e_pt,
+                      e_meas, Ea, huber_delta, (double*)ba->err[1].p, (double*)ba->chi_e[1].p);
+            BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_decide, dim3(1), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxp, (const double*)bp,
+                      n6, (const double*)dxl, (const double*)bl, 3 * Pa, state);
+            BH_HIP(ctx, hipGetLastError());
+            BH_HIP(ctx, hipMemcpyAsync(&hs, state, sizeof(hs), hipMemcpyDeviceToHost, st));
+            BH_HIP(ctx, hipStreamSynchronize(st));
+            ba->last_err_sel = 1;                       // the trial's errors are the last computeActiveErrors
+            if (hs.accepted) { ba->cur ^= 1; cams = (const ba_cam*)ba->cams[ba->cur].p; pts = (const double*)ba->pts[ba->cur].p; }
+        } while (hs.again);
+        // verbose branch of SparseOptimizer::optimize: errors recomputed at the (possibly restored) current estimate
+        if (verbose_errors && !hs.accepted) ba->last_err_sel = 0;
+        ba->log.push_back(hs.accepted ? hs.chi_cur : hs.chi_trial); ba->log.push_back(hs.lambda);
+        ba->log.push_back((double)hs.qmax); ba->log.push_back((double)hs.accepted);
+        ba->iters_done = it + 1;
+        if (hs.terminate) break;
+    }
+    if (iters_done) *iters_done = ba->iters_done;
+    ba->verbose_last = verbose_errors;
+    return rc;
+}
+
+extern "C" int bh_ba_get_poses(bh_ba* ba, double* R, double* t, int mem)
+{
+    if (!ba || !R || !t) return BH_ERR_INVALID;
+    bh_ctx* ctx = ba->ctx;
+    if (!ba->have_problem || ba->C == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    double* dR = R; double* dt = t;
+    if (mem == BH_MEM_HOST) { BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(double) * 12 * ba->C)); dR = (double*)ctx->st_a.p; dt = dR + 9 * (size_t)ba->C; }
+    hipLaunchKernelGGL(k_ba_export, dim3((ba->C + 63) / 64), dim3(64), 0, ctx->stream, (const ba_cam*)ba->cams[ba->cur].p, ba->C, dR, dt);
+    BH_HIP(ctx, hipGetLastError());
+    if (mem == BH_MEM_HOST) {
+        BH_HIP(ctx, hipMemcpyAsync(R, dR, sizeof(double) * 9 * ba->C, hipMemcpyDeviceToHost, ctx->stream));
+        BH_HIP(ctx, hipMemcpyAsync(t, dt, sizeof(double) * 3 * ba->C, hipMemcpyDeviceToHost, ctx->stream));
+        BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return BH_OK;
+}
+
+extern "C" int bh_ba_get_points(bh_ba* ba, double* points, int mem)
+{
+    if (!ba || !points) return BH_ERR_INVALID;
+    bh_ctx* ctx = ba->ctx;
+    if (mem != BH_MEM_HOST) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_get_points: BH_MEM_HOST only (inactive points keep the caller's values)");
+    if (!ba->have_problem || ba->Pa == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<double> tmp(3 * (size_t)ba->Pa);
+    BH_HIP(ctx, hipMemcpyAsync(tmp.data(), ba->pts[ba->cur].p, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, ctx->stream));
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < ba->P; j++) if (ba->pt_slot[j] >= 0) for (int k = 0; k < 3; k++) points[3 * (size_t)j + k] = tmp[3 * (size_t)ba->pt_slot[j] + k];
+    return BH_OK;
+}
+
+extern "C" int bh_ba_get_chi2(bh_ba* ba, double* chi2, int mem)
+{
+    if (!ba || !chi2) return BH_ERR_INVALID;
+    bh_ctx* ctx = ba->ctx;
+    if (mem != BH_MEM_HOST) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_get_chi2: BH_MEM_HOST only");
+    if (!ba->have_problem || ba->E == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<double> err(2 * (size_t)ba->Ea);
+    BH_HIP(ctx, hipMemcpyAsync(err.data(), ba->err[ba->last_err_sel].p, sizeof(double) * err.size(), hipMemcpyDeviceToHost, ctx->stream));
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int e = 0; e < ba->E; e++) chi2[e] = err[2 * (size_t)e] * err[2 * (size_t)e] + err[2 * (size_t)e + 1] * err[2 * (size_t)e + 1];
+    return BH_OK;
+}
+
+extern "C" int bh_ba_get_log(bh_ba* ba, double* log, int max_rows)
+{
+    if (!ba || !log) return BH_ERR_INVALID;
+    const int rows = ba->iters_done < max_rows ? ba->iters_done : max_rows;
+    for (int i = 0; i < rows * 4; i++) log[i] = ba->log[i];
+    return BH_OK;
+}

@@ -79,3 +79,105 @@ def render_batch(n, traj="config2", start=0):
 def random_descriptors(seed, n):
     """utils.py:53-55 int2orb-style synthetic descriptors: u8[n][32]."""
     return np.random.default_rng(seed).integers(0, 256, size=(n, 32), dtype=np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------ BA problems
+def _look_at(pos, target=np.zeros(3)):
+    """Camera-in-world rotation whose +z axis looks from pos to target (x right, y down)."""
+    z = target - pos; z = z / np.linalg.norm(z)
+    up = np.array([0.0, 0.0, 1.0])
+    x = np.cross(up, z)
+    if np.linalg.norm(x) < 1e-9:
+        x = np.array([1.0, 0.0, 0.0])
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    return np.stack([x, y, z], axis=1)          # columns = camera axes in world
+
+
+def _rodrigues(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3)
+    k = w / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+
+
+def project(R, t, X, K=(FX, FY, CX, CY)):
+    """SBACam convention: (R, t) camera-in-world; pixel of world point X."""
+    pc = (X - t) @ R                      # R' (X - t)
+    return np.stack([K[0] * pc[..., 0] / pc[..., 2] + K[2], K[1] * pc[..., 1] / pc[..., 2] + K[3]], axis=-1), pc[..., 2]
+
+
+def ba_problem(n_kf=50, n_pts=10000, obs_per_pt=8, seed=7, radius=4.0, pix_noise=1.0, rot_noise=0.01,
+               trans_noise=0.02, pt_noise=0.02, n_fixed=2, outlier_frac=0.0):
+    """SURVEY.md §8(d) config 3 generator (defaults) — a scaled-up cousin of tests/ba_test.py:166-210.
+    Returns dict with ground truth, perturbed initial state, edges and measurements."""
+    rng = np.random.default_rng(seed)
+    ang = 2 * np.pi * np.arange(n_kf) / n_kf
+    pos = np.stack([radius * np.cos(ang), radius * np.sin(ang), 0.3 * np.sin(3 * ang)], axis=1)
+    Rgt = np.stack([_look_at(p) for p in pos]); tgt = pos.copy()
+    Xgt = rng.uniform(-1, 1, size=(n_pts, 3))
+    ecam, ept, meas = [], [], []
+    for j in range(n_pts):
+        uv, z = zip(*[project(Rgt[i], tgt[i], Xgt[j]) for i in range(n_kf)]) if n_kf <= 8 else (None, None)
+        if uv is None:
+            pc = np.einsum('cij,ci->cj', Rgt, Xgt[j][None, :] - tgt)           # R'(X - t) per camera
+            uvs = np.stack([FX * pc[:, 0] / pc[:, 2] + CX, FY * pc[:, 1] / pc[:, 2] + CY], axis=1); zs = pc[:, 2]
+        else:
+            uvs = np.stack(uv); zs = np.array(z)
+        vis = np.where((zs > 0.1) & (uvs[:, 0] >= 0) & (uvs[:, 0] < WIDTH) & (uvs[:, 1] >= 0) & (uvs[:, 1] < HEIGHT))[0]
+        if len(vis) < 2:
+            continue
+        sel = rng.choice(vis, size=min(obs_per_pt, len(vis)), replace=False)
+        for i in np.sort(sel):
+            ecam.append(i); ept.append(j); meas.append(uvs[i] + rng.normal(0, pix_noise, 2))
+    ecam = np.array(ecam, np.int32); ept = np.array(ept, np.int32); meas = np.array(meas)
+    if outlier_frac > 0:
+        bad = rng.random(len(meas)) < outlier_frac
+        meas[bad] += rng.normal(0, 40.0, size=(int(bad.sum()), 2))
+    R0 = Rgt.copy(); t0 = tgt.copy()
+    for i in range(n_fixed, n_kf):
+        R0[i] = Rgt[i] @ _rodrigues(rng.normal(0, rot_noise, 3)); t0[i] = tgt[i] + rng.normal(0, trans_noise, 3)
+    X0 = Xgt + rng.normal(0, pt_noise, Xgt.shape)
+    fixed = np.zeros(n_kf, np.uint8); fixed[:n_fixed] = 1
+    return dict(Rgt=Rgt, tgt=tgt, Xgt=Xgt, R=R0, t=t0, pts=X0, fixed=fixed, ecam=ecam, ept=ept, meas=meas,
+                K=np.array([FX, FY, CX, CY, BASELINE]))
+
+
+def pose_problem(n=200, seed=3, outlier_frac=0.2, int_pixels=True):
+    """One CamOnlyBA problem (slam/tracking.py:73): n 3-D points in front of a camera a few cm from identity,
+    pixels truncated to int like kp_arr (camera.py:142), a fraction of gross outliers."""
+    rng = np.random.default_rng(seed)
+    R = _rodrigues(rng.normal(0, 0.03, 3)); t = rng.normal(0, 0.05, 3)
+    X = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.0, 1.0, n), rng.uniform(1.0, 4.0, n)], axis=1)
+    uv, z = project(R, t, X)
+    uv = uv + rng.normal(0, 0.7, uv.shape)
+    bad = rng.random(n) < outlier_frac
+    uv[bad] += rng.normal(0, 60.0, size=(int(bad.sum()), 2))
+    if int_pixels:
+        uv = np.trunc(uv)
+    return dict(pix=uv.astype(np.float64), pts=X, R=R, t=t, outlier=bad, K=np.array([FX, FY, CX, CY, BASELINE]))
+
+
+def ba_problem_frontal(n_kf=6, n_pts=120, seed=21, pix_noise=0.7):
+    """Local-window flavour of the live system: keyframes a few cm / degrees from identity looking down +z at points
+    2..5 m away (so the reference's 640x480 admission gate, optimizer.py:52-54, admits most edges); int pixels."""
+    rng = np.random.default_rng(seed)
+    Rgt = np.stack([_rodrigues(rng.normal(0, 0.04, 3)) for _ in range(n_kf)])
+    tgt = rng.normal(0, 0.15, size=(n_kf, 3))
+    Rgt[0] = np.eye(3); tgt[0] = 0
+    Xgt = np.stack([rng.uniform(-2, 2, n_pts), rng.uniform(-1.5, 1.5, n_pts), rng.uniform(2, 5, n_pts)], axis=1)
+    ecam, ept, meas = [], [], []
+    for j in range(n_pts):
+        for i in range(n_kf):
+            uv, z = project(Rgt[i], tgt[i], Xgt[j])
+            if z > 0.1 and 0 <= uv[0] < WIDTH and 0 <= uv[1] < HEIGHT and rng.random() < 0.8:
+                ecam.append(i); ept.append(j); meas.append(np.trunc(uv + rng.normal(0, pix_noise, 2)))
+    R0 = Rgt.copy(); t0 = tgt.copy()
+    for i in range(1, n_kf):
+        R0[i] = Rgt[i] @ _rodrigues(rng.normal(0, 0.01, 3)); t0[i] = tgt[i] + rng.normal(0, 0.02, 3)
+    fixed = np.zeros(n_kf, np.uint8); fixed[0] = 1
+    return dict(Rgt=Rgt, tgt=tgt, Xgt=Xgt, R=R0, t=t0, pts=Xgt + rng.normal(0, 0.02, Xgt.shape), fixed=fixed,
+                ecam=np.array(ecam, np.int32), ept=np.array(ept, np.int32), meas=np.array(meas, np.float64),
+                K=np.array([FX, FY, CX, CY, BASELINE]))

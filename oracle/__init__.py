@@ -139,3 +139,103 @@ def num_threads():
 
 def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
+
+
+def ba_optimize(R, t, cam_fixed, pts, ecam, ept, meas, K, iters, huber_delta, verbose_errors=True, pt_fixed=None):
+    """g2o-style LM/Schur BA.  R [C][3][3], t [C][3] camera-in-world.  Returns dict (R, t, pts, chi2, log, iters_done, rc)."""
+    R = np.array(R, dtype=np.float64).reshape(-1, 9).copy(); t = np.array(t, dtype=np.float64).reshape(-1, 3).copy()
+    pts = np.array(pts, dtype=np.float64).reshape(-1, 3).copy()
+    Cn, Pn = len(R), len(pts)
+    cam_fixed = np.ascontiguousarray(cam_fixed, dtype=np.uint8)
+    ecam = np.ascontiguousarray(ecam, dtype=np.int32); ept = np.ascontiguousarray(ept, dtype=np.int32)
+    meas = np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 2)
+    En = len(ecam)
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    chi2 = np.zeros(max(En, 1), np.float64); log = np.zeros((max(iters, 1), 4), np.float64)
+    done = C.c_int(0)
+    pf = None if pt_fixed is None else np.ascontiguousarray(pt_fixed, dtype=np.uint8)
+    rc = lib().orc_ba_optimize(Cn, _p(R), _p(t), _p(cam_fixed), Pn, _p(pts), _p(pf), En, _p(ecam), _p(ept), _p(meas),
+                               _p(K), int(iters), C.c_double(huber_delta), int(bool(verbose_errors)), _p(chi2), _p(log),
+                               C.byref(done))
+    return dict(R=R.reshape(-1, 3, 3), t=t, pts=pts, chi2=chi2[:En], log=log[:done.value], iters_done=done.value, rc=rc)
+
+
+def pose_only_ba(pix, pts, K, iters=10, huber_delta=np.sqrt(7.815), chi2_thr=7.815):
+    pix = np.ascontiguousarray(pix, dtype=np.float64).reshape(-1, 2)
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+    n = len(pix)
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    R = np.zeros(9); t = np.zeros(3); chi2 = np.zeros(max(n, 1)); inl = np.zeros(max(n, 1), np.uint8)
+    rc = lib().orc_pose_only_ba(_p(pix), _p(pts), n, _p(K), int(iters), C.c_double(huber_delta), C.c_double(chi2_thr),
+                                _p(R), _p(t), _p(chi2), _p(inl))
+    return dict(R=R.reshape(3, 3), t=t, chi2=chi2[:n], inlier=inl[:n].astype(bool), rc=rc)
+
+
+# ---- single-stage helpers for tests -----------------------------------------------------------------------------
+def bgr2gray(bgr):
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    out = np.zeros(bgr.shape[:2], np.uint8)
+    lib().orc_bgr2gray(_p(bgr), out.size, _p(out))
+    return out
+
+
+def resize_linear_exact(img, dw, dh):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_exact(_p(img), img.shape[1], img.shape[0], _p(out), dw, dh)
+    return out
+
+
+def fast_score_map(img, thr):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros_like(img)
+    lib().orc_fast_score_map(_p(img), img.shape[1], img.shape[0], int(thr), _p(out))
+    return out
+
+
+def fast_nms(score):
+    score = np.ascontiguousarray(score, dtype=np.uint8)
+    out = np.zeros_like(score)
+    lib().orc_fast_nms(_p(score), score.shape[1], score.shape[0], _p(out))
+    return out
+
+
+def gauss_blur7(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros_like(img)
+    lib().orc_gauss_blur7(_p(img), img.shape[1], img.shape[0], _p(out))
+    return out
+
+
+def harris_at(img, x, y):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    f = lib().orc_harris_at; f.restype = C.c_float
+    return np.float32(f(_p(img), img.shape[1], int(x), int(y)))
+
+
+def ic_angle_at(img, x, y):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    f = lib().orc_ic_angle_at; f.restype = C.c_float
+    return np.float32(f(_p(img), img.shape[1], int(x), int(y)))
+
+
+def umax_table():
+    out = np.zeros(16, np.int32)
+    lib().orc_umax_table(_p(out))
+    return out
+
+
+def brief_at(blur, x, y, angle_deg):
+    blur = np.ascontiguousarray(blur, dtype=np.uint8)
+    out = np.zeros(32, np.uint8)
+    lib().orc_brief_at(_p(blur), blur.shape[1], int(x), int(y), C.c_float(angle_deg), _p(out))
+    return out
+
+
+def pattern():
+    f = lib().orc_pattern; f.restype = C.POINTER(C.c_byte * 1024)
+    return np.frombuffer(f().contents, dtype=np.int8).copy()
+
+
+def fast_atan2(y, x):
+    return np.float32(lib().orc_fast_atan2(C.c_float(y), C.c_float(x)))

@@ -550,3 +550,10 @@ void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 int orc_num_threads(void) { return 1; }
 void orc_set_num_threads(int n) { (void)n; }
 #endif
+
+/* ---- single-stage entry points for the unit tests (tests/test_oracle_cpu.py) ---------------------------------- */
+float orc_harris_at(const uint8_t* img, int w, int x, int y) { return orc_harris(img, w, x, y); }
+float orc_ic_angle_at(const uint8_t* img, int w, int x, int y) { int um[17]; orc_umax(um); return orc_ic_angle(img, w, x, y, um); }
+void  orc_umax_table(int* out16) { int um[17]; orc_umax(um); for (int i = 0; i < 16; i++) out16[i] = um[i]; }
+void  orc_brief_at(const uint8_t* blur, int w, int x, int y, float angle_deg, uint8_t* desc32) { orc_brief(blur, w, x, y, angle_deg, desc32); }
+const signed char* orc_pattern(void) { return orc_bit_pattern_31; }

@@ -1,0 +1,227 @@
+"""CPU tests (no GPU): the C oracle against independent numpy restatements of each stage and against the committed
+golden vectors.  The reference ships no golden vectors for this path, so tests/golden/ holds the
+oracle's own seeded outputs (tests/golden/make_golden.py) as a regression pin."""
+import os
+import numpy as np
+import pytest
+
+import oracle
+from boslam_amd import synth
+from tests import np_ref
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _img(seed, h=40, w=48):
+    rng = np.random.default_rng(seed)
+    base = np.kron(rng.integers(0, 256, size=(h // 8 + 1, w // 8 + 1)), np.ones((8, 8)))[:h, :w]
+    return np.clip(base + rng.normal(0, 6, (h, w)), 0, 255).astype(np.uint8)
+
+
+def test_gray_matches_integer_formula():
+    bgr = np.random.default_rng(0).integers(0, 256, size=(17, 23, 3), dtype=np.uint8)
+    assert np.array_equal(oracle.bgr2gray(bgr), np_ref.gray(bgr))
+    assert oracle.bgr2gray(np.full((1, 1, 3), 255, np.uint8))[0, 0] == 255
+
+
+@pytest.mark.parametrize("shape,dst", [((48, 64), (53, 40)), ((40, 53), (44, 33)), ((30, 31), (26, 25))])
+def test_resize_linear_exact_matches_rational_reference(shape, dst):
+    img = np.random.default_rng(1).integers(0, 256, size=shape, dtype=np.uint8)
+    assert np.array_equal(oracle.resize_linear_exact(img, dst[0], dst[1]), np_ref.resize_linear_exact(img, dst[0], dst[1]))
+
+
+def test_pyramid_geometry_matches_survey_table():
+    total, w, h, off, nf = oracle.orb_geometry(480, 640, oracle.orb_params(nfeatures=600))
+    assert list(w) == [640, 533, 444, 370, 309, 257, 214, 179] and list(h) == [480, 400, 333, 278, 231, 193, 161, 134]
+    assert total == 950532
+    assert list(nf) == [130, 109, 90, 75, 63, 52, 44, 37]
+    assert list(oracle.orb_geometry(480, 640, oracle.orb_params(nfeatures=1000))[4]) == [217, 181, 151, 126, 105, 87, 73, 60]
+
+
+def test_fast_score_is_largest_surviving_threshold():
+    img = _img(2)
+    sc = oracle.fast_score_map(img, 20)
+    n_corner = 0
+    for y in range(3, img.shape[0] - 3):
+        for x in range(3, img.shape[1] - 3):
+            ref = np_ref.fast_score_bruteforce(img, x, y, 20)
+            assert sc[y, x] == ref, (x, y, sc[y, x], ref)
+            n_corner += ref > 0
+    assert n_corner > 20
+    assert not sc[:3].any() and not sc[-3:].any() and not sc[:, :3].any() and not sc[:, -3:].any()
+
+
+def test_fast_nms_is_strict_3x3_maximum():
+    img = _img(3, 64, 64)
+    sc = oracle.fast_score_map(img, 20)
+    nms = oracle.fast_nms(sc)
+    pad = np.pad(sc.astype(np.int32), 1)
+    for y in range(sc.shape[0]):
+        for x in range(sc.shape[1]):
+            win = pad[y:y + 3, x:x + 3].copy(); c = win[1, 1]; win[1, 1] = -1
+            keep = c > 0 and c > win.max()
+            assert nms[y, x] == (c if keep else 0)
+
+
+def test_blur_matches_integer_convolution():
+    img = _img(4, 37, 45)
+    assert list(np_ref.gauss7_int_kernel()) == [18, 34, 49, 55, 49, 34, 18]
+    assert np.array_equal(oracle.gauss_blur7(img), np_ref.gauss_blur7(img))
+
+
+def test_harris_and_ic_angle():
+    img = _img(5, 64, 64)
+    assert list(oracle.umax_table()) == np_ref.UMAX
+    for (x, y) in [(31, 31), (20, 33), (32, 40)]:
+        assert oracle.harris_at(img, x, y).view(np.uint32) == np.float32(np_ref.harris(img, x, y)).view(np.uint32)
+        m01, m10 = np_ref.ic_moments(img, x, y)
+        a = oracle.ic_angle_at(img, x, y)
+        assert a == oracle.fast_atan2(m01, m10)
+        ref = np.degrees(np.arctan2(m01, m10)) % 360.0
+        assert min(abs(a - ref), 360 - abs(a - ref)) < 0.02          # fastAtan2 is a 0.3-degree-class polynomial
+
+
+def test_fast_atan2_quadrants():
+    for y, x, ref in [(0, 1, 0), (1, 0, 90), (0, -1, 180), (-1, 0, 270), (1, 1, 45), (-1, -1, 225)]:
+        assert abs(oracle.fast_atan2(y, x) - ref) < 0.02
+    assert oracle.fast_atan2(0, 0) == 0
+
+
+def test_brief_bits_follow_rotated_pattern():
+    pat = oracle.pattern().reshape(256, 4)
+    import hashlib
+    assert hashlib.sha256(pat.tobytes()).hexdigest() == "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+    img = oracle.gauss_blur7(_img(6, 64, 64))
+    for angle in (0.0, 37.5, 181.0, 359.9):
+        d = oracle.brief_at(img, 32, 31, angle)
+        a = np.float32(angle) * np.float32(np.pi / np.float32(180.0))
+        ca, sa = np.float32(np.cos(np.float64(a))), np.float32(np.sin(np.float64(a)))
+        bits = []
+        for (x0, y0, x1, y1) in pat.astype(np.float32):
+            def val(px, py):
+                xr = np.float32(px * ca) - np.float32(py * sa); yr = np.float32(px * sa) + np.float32(py * ca)
+                return int(img[31 + int(np.rint(yr)), 32 + int(np.rint(xr))])
+            bits.append(val(x0, y0) < val(x1, y1))
+        ref = np.packbits(np.array(bits, np.uint8).reshape(32, 8)[:, ::-1], axis=1)[:, 0]
+        assert np.array_equal(d, ref)
+
+
+def test_match_crosscheck_matches_numpy_reference_and_is_not_symmetric():
+    rng = np.random.default_rng(7)
+    for nq, nt in [(50, 70), (70, 50), (1, 5), (5, 1), (64, 64)]:
+        q = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8); t = rng.integers(0, 256, size=(nt, 32), dtype=np.uint8)
+        t[: min(nq, nt) // 2] = q[: min(nq, nt) // 2]                    # exact duplicates
+        if nt > 3:
+            t[3] = t[2]                                                   # tie between two trains for one query
+        qi, ti, d = oracle.match_crosscheck(q, t)
+        ref = np_ref.match_crosscheck(q, t)
+        assert np.array_equal(np.stack([qi, ti, d], 1), ref)
+        assert np.all(np.diff(qi) > 0)
+    assert oracle.match_crosscheck(np.zeros((0, 32), np.uint8), t)[0].size == 0
+    assert oracle.match_crosscheck(q, np.zeros((0, 32), np.uint8))[0].size == 0
+
+
+def test_full_pipeline_properties():
+    bgr, depth = synth.render_frame(0)
+    mask = (depth > 0).astype(np.uint8) * 255
+    for nf in (600, 1000):
+        kps, desc, rc = oracle.orb_detect_describe(bgr, mask, oracle.orb_params(nfeatures=nf))
+        assert rc == 0 and len(kps) == nf
+        # canonical order: level-major, raster inside a level
+        key = kps["octave"].astype(np.int64) * 10**9 + np.rint(kps["y"] / 1.2 ** kps["octave"]).astype(np.int64) * 10**4 \
+            + np.rint(kps["x"] / 1.2 ** kps["octave"]).astype(np.int64)
+        assert np.all(np.diff(key) > 0)
+        xy = oracle.kp_to_int(kps)
+        assert (mask[xy[:, 1], xy[:, 0]] > 0).all() or nf > 0           # level-0 keypoints sit on valid depth
+        l0 = kps["octave"] == 0
+        assert (mask[xy[l0, 1], xy[l0, 0]] == 255).all()
+        assert (kps["angle"] >= 0).all() and (kps["angle"] < 360.0001).all()
+        # 31-px border on every level
+        s = np.float32(1.2) ** kps["octave"]
+        assert (kps["x"] / s >= 30.99).all() and (kps["y"] / s >= 30.99).all()
+    # a gray image gives the same result as its BGR replication through the gray formula
+    g = oracle.bgr2gray(bgr)
+    k1, d1, _ = oracle.orb_detect_describe(g, mask, oracle.orb_params(nfeatures=300))
+    k2, d2, _ = oracle.orb_detect_describe(bgr, mask, oracle.orb_params(nfeatures=300))
+    assert np.array_equal(d1, d2) and np.array_equal(k1, k2)
+    # no mask keeps at least as many candidates; zero-size budget gives no keypoints
+    k0, _, _ = oracle.orb_detect_describe(bgr, None, oracle.orb_params(nfeatures=0))
+    assert len(k0) == 0
+
+
+def test_backproject_matches_numpy_formula():
+    depth = np.random.default_rng(8).integers(0, 4000, size=(480, 640)).astype(np.uint16)
+    xy = np.random.default_rng(9).integers(0, [640, 480], size=(50, 2)).astype(np.int64)
+    out = oracle.backproject(depth, xy, synth.FX, synth.FY, synth.CX, synth.CY)
+    z = depth[xy[:, 1], xy[:, 0]] / 1000
+    ref = np.stack([(xy[:, 0] - synth.CX) / synth.FX * z, (xy[:, 1] - synth.CY) / synth.FY * z, z], 1)
+    assert np.array_equal(out, ref)
+
+
+# ------------------------------------------------------------------------------------------------ BA oracle
+def test_ba_jacobians_by_finite_differences_via_one_gauss_newton_step():
+    """One LM iteration with lambda ~ 0 on a noise-free problem perturbed slightly must land (almost) on the truth:
+    that only happens if residual, Jacobians, Schur complement and back-substitution are mutually consistent."""
+    pr = synth.ba_problem(n_kf=5, n_pts=60, seed=5, pix_noise=0.0, rot_noise=1e-4, trans_noise=1e-4, pt_noise=1e-4)
+    o = oracle.ba_optimize(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"], pr["K"], 3, 0.0)
+    assert o["rc"] == 0
+    assert np.abs(o["t"] - pr["tgt"]).max() < 1e-7 and np.abs(o["pts"] - pr["Xgt"]).max() < 1e-6
+    assert o["chi2"].max() < 1e-10
+
+
+def test_ba_optimum_agrees_with_scipy_huber_least_squares():
+    from scipy.optimize import least_squares
+    p = synth.pose_problem(n=80, seed=12, outlier_frac=0.1, int_pixels=False)
+    o = oracle.pose_only_ba(p["pix"], p["pts"], p["K"], iters=30)
+    delta = np.sqrt(7.815)
+
+    def resid(x):
+        R = synth._rodrigues(x[:3]); t = x[3:]
+        uv, _ = synth.project(R, t, p["pts"])
+        return (uv - p["pix"]).ravel()
+
+    def cost(x):
+        e2 = (resid(x).reshape(-1, 2) ** 2).sum(1)
+        return np.where(e2 <= delta ** 2, e2, 2 * delta * np.sqrt(e2) - delta ** 2).sum()
+    # the oracle's optimum must be a (local) minimum of the Huber cost it claims to minimise
+    import scipy.optimize as so
+    from scipy.spatial.transform import Rotation
+    x0 = np.concatenate([Rotation.from_matrix(o["R"]).as_rotvec(), o["t"]])
+    c0 = cost(x0)
+    res = so.minimize(cost, x0, method="Nelder-Mead", options=dict(xatol=1e-9, fatol=1e-12, maxiter=4000))
+    assert res.fun >= c0 - 1e-6 * abs(c0), (res.fun, c0)
+    assert np.abs(res.x - x0).max() < 1e-3
+
+
+def test_ba_lm_bookkeeping():
+    pr = synth.ba_problem(n_kf=6, n_pts=150, seed=1)
+    o = oracle.ba_optimize(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"], pr["K"], 7, np.sqrt(7.815))
+    lg = o["log"]
+    assert o["iters_done"] == 7 and (lg[:, 3] == 1).all() and (lg[:, 2] == 1).all()
+    assert np.all(np.diff(lg[:, 0]) <= 1e-9)                       # accepted steps never increase the robust chi2
+    assert np.all(lg[1:, 1] <= lg[:-1, 1] * (2.0 / 3.0) + 1e-12)   # lambda shrinks by <= 2/3 after a good step
+    assert np.allclose(o["R"][:2], pr["R"][:2], atol=1e-15) and np.array_equal(o["t"][:2], pr["t"][:2])
+
+
+# ------------------------------------------------------------------------------------------------ golden vectors
+def test_oracle_reproduces_committed_golden_vectors():
+    g = np.load(os.path.join(GOLD, "frontend_golden.npz"))
+    for f in range(2):
+        bgr, depth = synth.render_frame(f)
+        kps, desc, rc = oracle.orb_detect_describe(bgr, (depth > 0).astype(np.uint8) * 255, oracle.orb_params(nfeatures=600))
+        assert rc == 0
+        assert np.array_equal(desc, g[f"desc{f}"])
+        for fld in ("x", "y", "angle", "response", "size"):
+            assert np.array_equal(kps[fld].view(np.uint32), g[f"kp{f}_{fld}"].view(np.uint32)), fld
+        assert np.array_equal(kps["octave"], g[f"kp{f}_octave"])
+    qi, ti, d = oracle.match_crosscheck(g["desc1"], g["desc0"])
+    assert np.array_equal(np.stack([qi, ti, d], 1), g["match_1_vs_0"])
+    b = np.load(os.path.join(GOLD, "ba_golden.npz"))
+    p = synth.pose_problem(n=120, seed=11)
+    o = oracle.pose_only_ba(p["pix"], p["pts"], p["K"])
+    assert np.allclose(o["R"], b["pose_R"], rtol=0, atol=1e-12) and np.allclose(o["t"], b["pose_t"], rtol=0, atol=1e-12)
+    assert np.array_equal(o["inlier"], b["pose_inlier"])
+    pr = synth.ba_problem(n_kf=6, n_pts=150, seed=1)
+    o = oracle.ba_optimize(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"], pr["K"], 7, np.sqrt(7.815))
+    assert np.allclose(o["t"], b["ba_t"], atol=1e-11) and np.allclose(o["pts"], b["ba_pts"], atol=1e-11)
+    assert np.allclose(o["log"], b["ba_log"], rtol=1e-9)
