@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--cpu-sample", type=int, default=1000, help="frames in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--bow", action="store_true", help="also time the config-4 BoW L1 query (adds ~20 s of data generation)")
     args = ap.parse_args()
 
     import torch
@@ -186,11 +187,11 @@ def main():
                 np.array_equal(ddesc[f, :onk[f]], odesc[f, :onk[f]]) for f in range(ns))
             out["parity_sample_ok"] = same
         if not args.no_ba:
-            try:
-                from boslam_amd import ba_bench
-                out["local_ba"] = ba_bench.run(ctx, dev)
-            except ImportError:
-                pass
+            from boslam_amd import ba_bench
+            out["local_ba"] = ba_bench.run(ctx, dev)
+        if args.bow:
+            from boslam_amd import bow_bench
+            out["bow_query"] = bow_bench.run(ctx)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

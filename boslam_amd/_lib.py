@@ -51,6 +51,11 @@ _SIGS = {
     "bh_ba_get_points": (_i, [_vp, _vp, _i]),
     "bh_ba_get_chi2": (_i, [_vp, _vp, _i]),
     "bh_ba_get_log": (_i, [_vp, _vp, _i]),
+    "bh_visibility_gate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _d, _d, _d, _i, _i, _d, _vp, _vp, _i]),
+    "bh_bow_create": (_i, [_vp, C.POINTER(_vp)]),
+    "bh_bow_destroy": (None, [_vp]),
+    "bh_bow_set_db": (_i, [_vp, C.c_longlong, _vp, _vp, _vp, _i]),
+    "bh_bow_query_l1": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i]),
 }
 
 _LIB = None

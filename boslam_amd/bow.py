@@ -1,0 +1,93 @@
+"""Local-map visibility gate and DBoW3-style L1 database query over the C ABI, plus the keyframe-sharded multi-GPU
+query (per-rank top-k + all-gather + merge).
+
+Mirrors
+  Tracker._track_local_map's per-point gate           slam/tracking.py:97-111
+  Dbow.query -> pyDBoW3 Database.query(des, [], 1, -1) slam/bow_db.py:37-42, docker/pydbow3/src/dbow3.cpp:147-152
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import BH_MEM_HOST
+
+COS60 = float(np.cos(np.pi / 3))            # slam/tracking.py:19
+
+
+def visibility_gate(ctx, pts, normals, R, t, see_vector, f, cx, cy, width=640, height=480, cos_thr=COS60):
+    """One frame: returns the indices (input order) of the map points that project inside the image and face the camera."""
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(1, -1, 3)
+    normals = np.ascontiguousarray(normals, dtype=np.float64).reshape(1, -1, 3)
+    M = pts.shape[1]
+    if M == 0:
+        return np.zeros(0, np.int32)
+    R = np.ascontiguousarray(R, dtype=np.float64).reshape(1, 9); t = np.ascontiguousarray(t, dtype=np.float64).reshape(1, 3)
+    see = np.ascontiguousarray(see_vector, dtype=np.float64).reshape(1, 3)
+    idx = np.zeros((1, M), np.int32); n = np.zeros(1, np.int32); Ms = np.array([M], np.int32)
+    ctx.check(_lib.lib().bh_visibility_gate(ctx.h, _lib.ptr(pts), _lib.ptr(normals), _lib.ptr(Ms), 1, M, _lib.ptr(R), _lib.ptr(t),
+                                            _lib.ptr(see), float(f), float(cx), float(cy), int(width), int(height),
+                                            float(cos_thr), _lib.ptr(idx), _lib.ptr(n), BH_MEM_HOST))
+    return idx[0, :n[0]].copy()
+
+
+class BowDatabase:
+    """Device-resident BoW database (CSR over entries) with L1 top-k query."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(_lib.lib().bh_bow_create(ctx.h, C.byref(h)))
+        self.h = h
+        self.n_entries = 0
+
+    def set_db(self, start, words, vals):
+        start = np.ascontiguousarray(start, dtype=np.int64); words = np.ascontiguousarray(words, dtype=np.uint32)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        self.n_entries = len(start) - 1
+        self.ctx.check(_lib.lib().bh_bow_set_db(self.h, self.n_entries, _lib.ptr(start), _lib.ptr(words), _lib.ptr(vals), BH_MEM_HOST))
+
+    def query(self, q_words, q_vals, max_results=1):
+        q_words = np.ascontiguousarray(q_words, dtype=np.uint32); q_vals = np.ascontiguousarray(q_vals, dtype=np.float64)
+        ids = np.zeros(max_results, np.int32); sc = np.zeros(max_results, np.float64); n = C.c_int(0)
+        self.ctx.check(_lib.lib().bh_bow_query_l1(self.h, _lib.ptr(q_words), _lib.ptr(q_vals), len(q_words), int(max_results),
+                                                  _lib.ptr(ids), _lib.ptr(sc), C.byref(n), BH_MEM_HOST))
+        return ids[:n.value].copy(), sc[:n.value].copy()
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().bh_bow_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_topk(id_lists, score_lists, k):
+    """Merge per-shard (global id, score) lists: best score first, ties by ascending id."""
+    ids = np.concatenate([np.asarray(i, dtype=np.int64) for i in id_lists]) if id_lists else np.zeros(0, np.int64)
+    sc = np.concatenate([np.asarray(s, dtype=np.float64) for s in score_lists]) if score_lists else np.zeros(0)
+    order = np.lexsort((ids, -sc))
+    return ids[order][:k], sc[order][:k]
+
+
+def sharded_query(local_query, entry_base, k, dist=None, device="cpu"):
+    """Keyframe-sharded query: `local_query()` -> (local ids, scores) on this rank's shard whose first entry has global
+    id `entry_base`; every rank returns the global top-k.  The only collective is an all-gather of k (id, score) pairs
+    per rank (8*k*16 B on an 8-GPU node)."""
+    ids, sc = local_query()
+    ids = np.asarray(ids, dtype=np.int64) + int(entry_base)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return merge_topk([ids], [sc], k)
+    import torch
+    pad_i = torch.full((k,), -1, dtype=torch.int64, device=device); pad_s = torch.full((k,), -1.0, dtype=torch.float64, device=device)
+    pad_i[:len(ids)] = torch.from_numpy(ids).to(device); pad_s[:len(sc)] = torch.from_numpy(np.asarray(sc, dtype=np.float64)).to(device)
+    world = dist.get_world_size()
+    gi = [torch.empty_like(pad_i) for _ in range(world)]; gs = [torch.empty_like(pad_s) for _ in range(world)]
+    dist.all_gather(gi, pad_i); dist.all_gather(gs, pad_s)
+    li, ls = [], []
+    for a, b in zip(gi, gs):
+        a = a.cpu().numpy(); b = b.cpu().numpy()
+        li.append(a[a >= 0]); ls.append(b[a >= 0])
+    return merge_topk(li, ls, k)

@@ -1,0 +1,321 @@
+// bow.hip — (1) local-map visibility gate, (2) DBoW3 L1 database query, for gfx950.
+//
+// (1) bh_visibility_gate replaces the per-point Python loop of slam/tracking.py:97-111
+//     (pixel = cam.cam_map(SE3Quat(frame.R, frame.t) * mp.pt3d); in-image test; dot(see_vector, n) < cos60):
+//     one workgroup per frame, f64, ordered compaction of the surviving indices (ballot + prefix sums).
+// (2) bh_bow_* replaces Database::query(des, [], max_results, -1) — slam/bow_db.py:37-42 ->
+//     docker/pydbow3/src/dbow3.cpp:147-152 — the L1 score of one query BoW vector against every database entry.
+//     HBM-streaming design: the database is a padded SoA CSR (u32 word ids / f64 weights, rows padded to 4 entries so
+//     that every lane issues aligned 16-B loads); a persistent grid of 1024-lane workgroups keeps a bitmap of the query's
+//     words in LDS (vocabulary 10^6 words -> 125 KB) and walks whole entries one wave at a time; a bitmap hit is confirmed
+//     by binary search in the query (also in LDS), and hits are accumulated in ascending word order (lane order via
+//     ballot, then in-lane order), i.e. the exact summation order of DBoW3's queryL1 — scores are bit-identical to the
+//     CPU restatement.  Only the word-id stream is read for non-matching entries (weights are touched on hits only).
+#include "bh_internal.h"
+#include <math.h>
+#include <vector>
+
+// ================================================================================================ visibility gate
+__global__ __launch_bounds__(1024) void k_gate(const double* __restrict__ pts, const double* __restrict__ nrm,
+                                               const int* __restrict__ M_arr, int stride, const double* __restrict__ Rm,
+                                               const double* __restrict__ tv, const double* __restrict__ seev,
+                                               double f, double cx, double cy, int width, int height, double cos_thr,
+                                               int* __restrict__ idx, int* __restrict__ n_out)
+{
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t b = blockIdx.x;
+    const int M = M_arr[b];
+    const double* R = Rm + 9 * b; const double* t = tv + 3 * b; const double* see = seev + 3 * b;
+    const double* P = pts + b * (size_t)stride * 3; const double* N = nrm + b * (size_t)stride * 3;
+    int* out = idx + b * (size_t)stride;
+    int base = 0;
+    for (int c0 = 0; c0 < M; c0 += 1024) {
+        const int i = c0 + tid;
+        bool keep = false;
+        if (i < M) {
+            const double px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
+            const double qx = R[0] * px + R[1] * py + R[2] * pz + t[0];
+            const double qy = R[3] * px + R[4] * py + R[5] * pz + t[1];
+            const double qz = R[6] * px + R[7] * py + R[8] * pz + t[2];
+            const double u = qx / qz * f + cx, v = qy / qz * f + cy;
+            if (0 <= u && u < width && 0 <= v && v < height) {
+                const double d = see[0] * N[3 * i] + see[1] * N[3 * i + 1] + see[2] * N[3 * i + 2];
+                keep = d < cos_thr;
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pre = __popcll(m & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) s_w[wv] = __popcll(m);
+        __syncthreads();
+        int wbase = 0, tot = 0;
+        for (int w = 0; w < 16; w++) { const int c = s_w[w]; if (w < wv) wbase += c; tot += c; }
+        if (keep) out[base + wbase + pre] = i;
+        base += tot;
+    }
+    if (tid == 0) n_out[b] = base;
+}
+
+extern "C" int bh_visibility_gate(bh_ctx* ctx, const double* pts, const double* normals, const int* M, int B, int stride,
+                                  const double* R, const double* t, const double* see, double f, double cx, double cy,
+                                  int width, int height, double cos_thr, int* idx, int* n_out, int mem)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (!pts || !normals || !M || !R || !t || !see || !idx || !n_out || B < 0 || stride < 1 ||
+        (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_visibility_gate: bad argument");
+    if (B == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t np = (size_t)B * stride;
+    const double *d_p = pts, *d_n = normals, *d_R = R, *d_t = t, *d_s = see; const int* d_M = M; int *d_i = idx, *d_o = n_out;
+    if (mem == BH_MEM_HOST) {
+        for (int b = 0; b < B; b++) if (M[b] < 0 || M[b] > stride) return bh_set_err(ctx, BH_ERR_INVALID, "bh_visibility_gate: M[b] outside [0, stride]");
+        BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(double) * 3 * np)); BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(double) * 3 * np));
+        BH_TRY(bh_reserve(ctx, &ctx->st_c, sizeof(double) * 15 * B)); BH_TRY(bh_reserve(ctx, &ctx->st_d, sizeof(int) * (np + 2 * (size_t)B)));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_a.p, pts, sizeof(double) * 3 * np, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_b.p, normals, sizeof(double) * 3 * np, hipMemcpyHostToDevice, st));
+        double* c = (double*)ctx->st_c.p;
+        BH_HIP(ctx, hipMemcpyAsync(c, R, sizeof(double) * 9 * B, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(c + 9 * (size_t)B, t, sizeof(double) * 3 * B, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(c + 12 * (size_t)B, see, sizeof(double) * 3 * B, hipMemcpyHostToDevice, st));
+        int* di = (int*)ctx->st_d.p;
+        BH_HIP(ctx, hipMemcpyAsync(di + np + B, M, sizeof(int) * B, hipMemcpyHostToDevice, st));
+        d_p = (const double*)ctx->st_a.p; d_n = (const double*)ctx->st_b.p; d_R = c; d_t = c + 9 * (size_t)B; d_s = c + 12 * (size_t)B;
+        d_i = di; d_o = di + np; d_M = di + np + B;
+    }
+    BH_LAUNCH(ctx, BH_K_GATE, k_gate, dim3(B), dim3(1024), st, d_p, d_n, d_M, stride, d_R, d_t, d_s, f, cx, cy, width, height, cos_thr, d_i, d_o);
+    BH_HIP(ctx, hipGetLastError());
+    if (mem == BH_MEM_HOST) {
+        BH_HIP(ctx, hipMemcpyAsync(idx, d_i, sizeof(int) * np, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(n_out, d_o, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipStreamSynchronize(st));
+    }
+    return BH_OK;
+}
+
+// ================================================================================================ BoW L1 query
+#define BOW_T        1024
+#define BOW_BITS     (1u << 20)                    // LDS bitmap: 2^20 bits = 128 KiB (vocabulary 10^6 words: exact)
+#define BOW_QMAX     1536                          // query words kept in LDS beside the bitmap (12 B each)
+#define BOW_PAD_WORD 0xffffffffu
+
+struct bh_bow {
+    bh_ctx* ctx = nullptr;
+    long long n_entries = 0, n_elems = 0;          // padded element count
+    bh_buf pstart, words, vals, acc, qw, qv, res;
+};
+
+__global__ __launch_bounds__(256) void k_bow_pack(const long long* __restrict__ start, const uint32_t* __restrict__ w,
+                                                  const double* __restrict__ v, const long long* __restrict__ pstart,
+                                                  long long n_entries, uint32_t* __restrict__ pw, double* __restrict__ pv)
+{
+    const long long e = blockIdx.x;
+    if (e >= n_entries) return;
+    const long long a = start[e], n = start[e + 1] - a, pa = pstart[e], pn = pstart[e + 1] - pa;
+    for (long long i = threadIdx.x; i < pn; i += 256) {
+        pw[pa + i] = i < n ? w[a + i] : BOW_PAD_WORD;
+        pv[pa + i] = i < n ? v[a + i] : 0.0;
+    }
+}
+
+__device__ __forceinline__ double bow_shfl(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl(lo, src, 64); hi = __shfl(hi, src, 64);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(BOW_T) void k_bow_scan(const long long* __restrict__ pstart, const uint32_t* __restrict__ pw,
+                                                    const double* __restrict__ pv, long long n_entries,
+                                                    const uint32_t* __restrict__ qw, const double* __restrict__ qv, int nq,
+                                                    double* __restrict__ acc_out)
+{
+    extern __shared__ uint32_t smem[];
+    uint32_t* s_bits = smem;                                   // BOW_BITS / 32 words
+    uint32_t* s_qw = smem + BOW_BITS / 32;                     // BOW_QMAX
+    double*   s_qv = reinterpret_cast<double*>(s_qw + BOW_QMAX);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < (int)(BOW_BITS / 32); i += BOW_T) s_bits[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nq; i += BOW_T) {
+        const uint32_t w = qw[i];
+        atomicOr(&s_bits[(w & (BOW_BITS - 1)) >> 5], 1u << (w & 31));
+        s_qw[i] = w; s_qv[i] = qv[i];
+    }
+    __syncthreads();
+    const long long wstride = (long long)gridDim.x * (BOW_T / 64);
+    for (long long e = (long long)blockIdx.x * (BOW_T / 64) + wv; e < n_entries; e += wstride) {
+        const long long a = pstart[e], b = pstart[e + 1];
+        double acc = 0.0; bool any = false;
+        for (long long c0 = a; c0 < b; c0 += 256) {
+            const long long i = c0 + 4 * lane;
+            uint4 w4 = make_uint4(BOW_PAD_WORD, BOW_PAD_WORD, BOW_PAD_WORD, BOW_PAD_WORD);
+            if (i < b) w4 = *reinterpret_cast<const uint4*>(pw + i);
+            const uint32_t ws[4] = { w4.x, w4.y, w4.z, w4.w };
+            double val[4] = { 0, 0, 0, 0 };
+            int hitm = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t w = ws[k];
+                if (w != BOW_PAD_WORD && (s_bits[(w & (BOW_BITS - 1)) >> 5] >> (w & 31)) & 1u) {
+                    int lo = 0, hi = nq;                       // confirm + locate in the sorted query
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_qw[mid] < w) lo = mid + 1; else hi = mid; }
+                    if (lo < nq && s_qw[lo] == w) {
+                        const double q = s_qv[lo], d = pv[i + k];
+                        val[k] = fabs(q - d) - fabs(q) - fabs(d);
+                        hitm |= 1 << k;
+                    }
+                }
+            }
+            unsigned long long m = __ballot(hitm != 0);
+            while (m) {                                        // ascending word order: lanes in order, then in-lane order
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int hm = __shfl(hitm, src, 64);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const double v = bow_shfl(val[k], src); if (hm & (1 << k)) acc += v; }
+                any = true;
+            }
+        }
+        if (lane == 0) acc_out[e] = any ? acc : INFINITY;        // +inf: no common word, entry absent from the results
+    }
+}
+
+// single workgroup: k rounds of argmin (ties -> smaller id), results best first
+__global__ __launch_bounds__(1024) void k_bow_topk(double* __restrict__ acc, long long n_entries, int k,
+                                                   int* __restrict__ ids, double* __restrict__ scores, int* __restrict__ n_res)
+{
+    __shared__ double s_v[16];
+    __shared__ long long s_i[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int found = 0;
+    for (int r = 0; r < k; r++) {
+        double bv = INFINITY; long long bi = -1;
+        for (long long e = tid; e < n_entries; e += 1024) { const double v = acc[e]; if (v < bv) { bv = v; bi = e; } }
+        for (int m = 32; m > 0; m >>= 1) {
+            int lo = __double2loint(bv), hi = __double2hiint(bv);
+            const double ov = __hiloint2double(__shfl_xor(hi, m, 64), __shfl_xor(lo, m, 64));
+            const long long oi = ((long long)__shfl_xor((int)(bi >> 32), m, 64) << 32) | (unsigned)__shfl_xor((int)(bi & 0xffffffff), m, 64);
+            if (oi >= 0 && (ov < bv || (ov == bv && (bi < 0 || oi < bi)))) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { s_v[wv] = bv; s_i[wv] = bi; }
+        __syncthreads();
+        bv = INFINITY; bi = -1;
+        for (int w = 0; w < 16; w++) { const double ov = s_v[w]; const long long oi = s_i[w]; if (oi >= 0 && (ov < bv || (ov == bv && (bi < 0 || oi < bi)))) { bv = ov; bi = oi; } }
+        if (bi < 0) break;
+        if (tid == 0) { ids[r] = (int)bi; scores[r] = -bv / 2.0; acc[bi] = INFINITY; }
+        found = r + 1;
+        __syncthreads();
+    }
+    if (tid == 0) *n_res = found;
+}
+
+extern "C" int bh_bow_create(bh_ctx* ctx, bh_bow** out)
+{
+    if (!ctx || !out) return BH_ERR_INVALID;
+    bh_bow* b = new bh_bow(); b->ctx = ctx; *out = b;
+    return BH_OK;
+}
+
+extern "C" void bh_bow_destroy(bh_bow* bow)
+{
+    if (!bow) return;
+    (void)hipSetDevice(bow->ctx->device);
+    (void)hipStreamSynchronize(bow->ctx->stream);
+    bh_buf* all[] = { &bow->pstart, &bow->words, &bow->vals, &bow->acc, &bow->qw, &bow->qv, &bow->res };
+    for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    delete bow;
+}
+
+extern "C" int bh_bow_set_db(bh_bow* bow, long long n_entries, const int64_t* start, const uint32_t* words,
+                             const double* vals, int mem)
+{
+    if (!bow) return BH_ERR_INVALID;
+    bh_ctx* ctx = bow->ctx;
+    if (n_entries < 0 || (n_entries && (!start || !words || !vals)) || (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_set_db: bad argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<long long> hstart(n_entries + 1, 0);
+    if (n_entries) {
+        if (mem == BH_MEM_HOST) for (long long e = 0; e <= n_entries; e++) hstart[e] = start[e];
+        else { BH_HIP(ctx, hipMemcpyAsync(hstart.data(), start, sizeof(long long) * (n_entries + 1), hipMemcpyDeviceToHost, st)); BH_HIP(ctx, hipStreamSynchronize(st)); }
+    }
+    std::vector<long long> pst(n_entries + 1, 0);
+    for (long long e = 0; e < n_entries; e++) {
+        const long long n = hstart[e + 1] - hstart[e];
+        if (n < 0) return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_set_db: start[] not ascending");
+        pst[e + 1] = pst[e] + ((n + 3) & ~3ll);
+    }
+    const long long nel = hstart[n_entries] - hstart[0], npad = pst[n_entries];
+    bow->n_entries = n_entries; bow->n_elems = npad;
+    BH_TRY(bh_reserve(ctx, &bow->pstart, sizeof(long long) * (n_entries + 1)));
+    BH_TRY(bh_reserve(ctx, &bow->words, sizeof(uint32_t) * (npad + 4))); BH_TRY(bh_reserve(ctx, &bow->vals, sizeof(double) * (npad + 4)));
+    BH_TRY(bh_reserve(ctx, &bow->acc, sizeof(double) * (n_entries + 1)));
+    BH_HIP(ctx, hipMemcpyAsync(bow->pstart.p, pst.data(), sizeof(long long) * (n_entries + 1), hipMemcpyHostToDevice, st));
+    if (n_entries == 0) { BH_HIP(ctx, hipStreamSynchronize(st)); return BH_OK; }
+    const long long* d_start; const uint32_t* d_w = words; const double* d_v = vals;
+    BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(long long) * (n_entries + 1)));
+    BH_HIP(ctx, hipMemcpyAsync(ctx->st_a.p, hstart.data(), sizeof(long long) * (n_entries + 1), hipMemcpyHostToDevice, st));
+    d_start = (const long long*)ctx->st_a.p;
+    if (mem == BH_MEM_HOST) {
+        BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(uint32_t) * (nel + 1))); BH_TRY(bh_reserve(ctx, &ctx->st_c, sizeof(double) * (nel + 1)));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_b.p, words + hstart[0], sizeof(uint32_t) * nel, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_c.p, vals + hstart[0], sizeof(double) * nel, hipMemcpyHostToDevice, st));
+        d_w = (const uint32_t*)ctx->st_b.p - hstart[0]; d_v = (const double*)ctx->st_c.p - hstart[0];
+    }
+    hipLaunchKernelGGL(k_bow_pack, dim3((unsigned)n_entries), dim3(256), 0, st, d_start, d_w, d_v, (const long long*)bow->pstart.p,
+                       n_entries, (uint32_t*)bow->words.p, (double*)bow->vals.p);
+    BH_HIP(ctx, hipGetLastError());
+    BH_HIP(ctx, hipStreamSynchronize(st));
+    return BH_OK;
+}
+
+extern "C" int bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, int max_results,
+                               int* ids, double* scores, int* n_results, int mem)
+{
+    if (!bow) return BH_ERR_INVALID;
+    bh_ctx* ctx = bow->ctx;
+    if (!q_words || !q_vals || !ids || !scores || !n_results || nq < 0 || max_results < 1 || max_results > 1024 ||
+        (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_query_l1: bad argument");
+    if (nq > BOW_QMAX) return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_query_l1: more than %d query words", BOW_QMAX);
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (bow->n_entries == 0 || nq == 0) {
+        if (mem == BH_MEM_HOST) *n_results = 0; else BH_HIP(ctx, hipMemsetAsync(n_results, 0, sizeof(int), st));
+        return BH_OK;
+    }
+    const uint32_t* d_qw = q_words; const double* d_qv = q_vals; int* d_ids = ids; double* d_sc = scores; int* d_n = n_results;
+    if (mem == BH_MEM_HOST) {
+        for (int i = 1; i < nq; i++) if (q_words[i] <= q_words[i - 1]) return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_query_l1: query words must be strictly ascending");
+        BH_TRY(bh_reserve(ctx, &bow->qw, sizeof(uint32_t) * (nq + 1))); BH_TRY(bh_reserve(ctx, &bow->qv, sizeof(double) * (nq + 1)));
+        BH_TRY(bh_reserve(ctx, &bow->res, (sizeof(double) + sizeof(int)) * max_results + 64));
+        BH_HIP(ctx, hipMemcpyAsync(bow->qw.p, q_words, sizeof(uint32_t) * nq, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(bow->qv.p, q_vals, sizeof(double) * nq, hipMemcpyHostToDevice, st));
+        d_qw = (const uint32_t*)bow->qw.p; d_qv = (const double*)bow->qv.p;
+        d_sc = (double*)bow->res.p; d_ids = (int*)(d_sc + max_results); d_n = d_ids + max_results;
+    }
+    const size_t lds = BOW_BITS / 8 + BOW_QMAX * (sizeof(uint32_t) + sizeof(double));
+    static bool attr_set = false;
+    if (!attr_set) { BH_HIP(ctx, hipFuncSetAttribute((const void*)k_bow_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    int grid = 256;                                            // one persistent workgroup per CU (LDS-limited to 1/CU anyway)
+    const long long need = (bow->n_entries + BOW_T / 64 - 1) / (BOW_T / 64);
+    if (need < grid) grid = (int)need;
+    bh_time_begin(ctx, BH_K_BOW_SCAN);
+    hipLaunchKernelGGL(k_bow_scan, dim3(grid), dim3(BOW_T), lds, st, (const long long*)bow->pstart.p, (const uint32_t*)bow->words.p,
+                       (const double*)bow->vals.p, bow->n_entries, d_qw, d_qv, nq, (double*)bow->acc.p);
+    bh_time_end(ctx);
+    hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, st, (double*)bow->acc.p, bow->n_entries, max_results, d_ids, d_sc, d_n);
+    BH_HIP(ctx, hipGetLastError());
+    if (mem == BH_MEM_HOST) {
+        BH_HIP(ctx, hipMemcpyAsync(scores, d_sc, sizeof(double) * max_results, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(ids, d_ids, sizeof(int) * max_results, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(n_results, d_n, sizeof(int), hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipStreamSynchronize(st));
+    }
+    return BH_OK;
+}

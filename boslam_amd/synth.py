@@ -181,3 +181,32 @@ def ba_problem_frontal(n_kf=6, n_pts=120, seed=21, pix_noise=0.7):
     return dict(Rgt=Rgt, tgt=tgt, Xgt=Xgt, R=R0, t=t0, pts=Xgt + rng.normal(0, 0.02, Xgt.shape), fixed=fixed,
                 ecam=np.array(ecam, np.int32), ept=np.array(ept, np.int32), meas=np.array(meas, np.float64),
                 K=np.array([FX, FY, CX, CY, BASELINE]))
+
+
+# ------------------------------------------------------------------------------------------------ BoW database
+def bow_database(n_entries=100000, words_per_entry=1000, vocab=10**6, seed=11, query_entry=12345, redraw=0.2):
+    """entries with `words_per_entry` distinct random words out of a 10^6-word vocabulary
+    (k=10, L=6), TF-IDF-like weights U(0,1) L1-normalised per entry; query = entry `query_entry` with 20 % of its words
+    re-drawn.  Returns CSR (start i64, words u32 ascending per entry, vals f64) and the query (words, vals)."""
+    rng = np.random.default_rng(seed)
+    words = rng.integers(0, vocab, size=(n_entries, words_per_entry), dtype=np.int64)
+    words.sort(axis=1)
+    # make the words of an entry distinct: bump duplicates (rare) by re-sorting unique-ified rows lazily
+    dup = (np.diff(words, axis=1) == 0).any(axis=1)
+    for e in np.nonzero(dup)[0]:
+        w = np.unique(words[e])
+        while len(w) < words_per_entry:
+            w = np.unique(np.concatenate([w, rng.integers(0, vocab, size=words_per_entry - len(w))]))
+        words[e] = w
+    vals = rng.random((n_entries, words_per_entry))
+    vals /= vals.sum(axis=1, keepdims=True)
+    start = np.arange(n_entries + 1, dtype=np.int64) * words_per_entry
+    qe = min(query_entry, n_entries - 1)
+    qw = words[qe].copy(); qv = vals[qe].copy()
+    nre = int(redraw * words_per_entry)
+    pos = rng.choice(words_per_entry, size=nre, replace=False)
+    qw[pos] = rng.integers(0, vocab, size=nre)
+    qw, ui = np.unique(qw, return_index=True)
+    qv = qv[ui] / qv[ui].sum()
+    return dict(start=start, words=words.reshape(-1).astype(np.uint32), vals=vals.reshape(-1), q_words=qw.astype(np.uint32),
+                q_vals=qv, query_entry=qe)

@@ -148,6 +148,32 @@ int  bh_ba_get_chi2(bh_ba* ba, double* chi2, int mem);
 /* per-iteration log of the last optimize: f64[iters_done][4] = {robust chi2 after, lambda, trials, accepted} */
 int  bh_ba_get_log(bh_ba* ba, double* log, int max_rows);
 
+/* ---- local-map visibility gate ------------------------------------------------------------------------------------
+ * Replaces the per-map-point loop of Tracker._track_local_map — slam/tracking.py:97-111 — for B frames:
+ *   q = R p + t ; pixel = (q.x/q.z*f + cx, q.y/q.z*f + cy)   [cam.cam_map(g2o.SE3Quat(frame.R, frame.t) * mp.pt3d)]
+ *   keep iff 0 <= u < width and 0 <= v < height and dot(see_vector, n) < cos_thr (cos60, tracking.py:19,104)
+ *   pts / normals f64[B][stride][3], M int[B]; R f64[B][9] row-major, t f64[B][3], see f64[B][3]
+ *   idx int[B][stride]: surviving indices in input order, n_out int[B] */
+int bh_visibility_gate(bh_ctx* ctx, const double* pts, const double* normals, const int* M, int B, int stride,
+                       const double* R, const double* t, const double* see, double f, double cx, double cy,
+                       int width, int height, double cos_thr, int* idx, int* n_out, int mem);
+
+/* ---- DBoW3 L1 database query -----------------------------------------------------------------------------------------
+ * Replaces Database::query(features, [], max_results, -1) — slam/bow_db.py:37-42 -> docker/pydbow3/src/dbow3.cpp:147-152
+ * — at the BoW-vector level (vocabulary-tree quantisation of descriptors is SURVEY §8(f) rank 1):
+ *   database: CSR over entries (keyframes): words u32 ascending per entry, weights f64 (TF-IDF, L1-normalised)
+ *   query   : strictly ascending word ids + weights
+ *   result  : up to max_results (id, Score = -sum(|q-d|-|q|-|d|)/2) best first; entries sharing no word are absent;
+ *             equal scores are ordered by ascending entry id.
+ * Multi-GPU: entries shard across ranks; each rank queries its shard and the per-rank top-k lists are all-gathered
+ * (boslam_amd/bow.py). */
+typedef struct bh_bow bh_bow;
+int  bh_bow_create(bh_ctx* ctx, bh_bow** out);
+void bh_bow_destroy(bh_bow* bow);
+int  bh_bow_set_db(bh_bow* bow, long long n_entries, const int64_t* start, const uint32_t* words, const double* vals, int mem);
+int  bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, int max_results,
+                     int* ids, double* scores, int* n_results, int mem);
+
 #ifdef __cplusplus
 }
 #endif

@@ -239,3 +239,23 @@ def pattern():
 
 def fast_atan2(y, x):
     return np.float32(lib().orc_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def visibility_gate(pts, normals, R, t, f, cx, cy, width, height, see, cos_thr=np.cos(np.pi / 3)):
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3); normals = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
+    R = np.ascontiguousarray(R, dtype=np.float64); t = np.ascontiguousarray(t, dtype=np.float64).reshape(3)
+    see = np.ascontiguousarray(see, dtype=np.float64).reshape(3)
+    idx = np.zeros(max(len(pts), 1), np.int32)
+    n = lib().orc_visibility_gate(_p(pts), _p(normals), len(pts), _p(R), _p(t), C.c_double(f), C.c_double(cx), C.c_double(cy),
+                                  int(width), int(height), _p(see), C.c_double(cos_thr), _p(idx))
+    return idx[:n].copy()
+
+
+def bow_query_l1(q_words, q_vals, start, words, vals, max_results=1):
+    q_words = np.ascontiguousarray(q_words, dtype=np.uint32); q_vals = np.ascontiguousarray(q_vals, dtype=np.float64)
+    start = np.ascontiguousarray(start, dtype=np.int64); words = np.ascontiguousarray(words, dtype=np.uint32)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    ids = np.zeros(max(max_results, 1), np.int32); sc = np.zeros(max(max_results, 1), np.float64)
+    n = lib().orc_bow_query_l1(_p(q_words), _p(q_vals), len(q_words), _p(start), _p(words), _p(vals), len(start) - 1,
+                               int(max_results), _p(ids), _p(sc))
+    return ids[:n].copy(), sc[:n].copy()

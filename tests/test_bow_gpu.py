@@ -1,0 +1,69 @@
+"""GPU parity: local-map visibility gate and DBoW3-style L1 query vs the CPU oracle (indices exact, scores bit-exact)."""
+import numpy as np
+import pytest
+
+import oracle
+from boslam_amd import bow, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_visibility_gate_matches_oracle(ctx):
+    rng = np.random.default_rng(2)
+    for M in (1, 77, 1024, 5000):
+        pts = np.stack([rng.uniform(-3, 3, M), rng.uniform(-2, 2, M), rng.uniform(-1, 6, M)], 1)
+        nrm = rng.normal(size=(M, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        R = synth._rodrigues(rng.normal(0, 0.1, 3)); t = rng.normal(0, 0.2, 3)
+        see = R @ np.array([0.0, 0.0, 1.0]); see /= np.linalg.norm(see)            # camera.py:26-29
+        pts[0] = [0.0, 0.0, 0.0]                                                     # z may be ~0: inf/nan pixel -> rejected
+        got = bow.visibility_gate(ctx, pts, nrm, R, t, see, synth.FX, synth.CX, synth.CY)
+        ref = oracle.visibility_gate(pts, nrm, R, t, synth.FX, synth.CX, synth.CY, 640, 480, see)
+        assert np.array_equal(got, ref)
+        assert 0 < len(ref) < M or M == 1
+    assert len(bow.visibility_gate(ctx, np.zeros((0, 3)), np.zeros((0, 3)), np.eye(3), np.zeros(3), [0, 0, 1], 1, 0, 0)) == 0
+
+
+@pytest.mark.parametrize("n_entries,wpe,k", [(300, 40, 5), (5000, 333, 10), (20000, 1000, 10)])
+def test_bow_query_matches_oracle(ctx, n_entries, wpe, k):
+    db = synth.bow_database(n_entries=n_entries, words_per_entry=wpe, query_entry=n_entries // 3, seed=n_entries)
+    d = bow.BowDatabase(ctx)
+    d.set_db(db["start"], db["words"], db["vals"])
+    ids, sc = d.query(db["q_words"], db["q_vals"], k)
+    oi, os_ = oracle.bow_query_l1(db["q_words"], db["q_vals"], db["start"], db["words"], db["vals"], k)
+    assert np.array_equal(ids, oi)
+    assert np.array_equal(sc.view(np.uint64), os_.view(np.uint64)), "scores must be bit-identical (same summation order)"
+    assert ids[0] == db["query_entry"] and sc[0] > 0.5                        # relocalisation finds the perturbed entry
+    i1, s1 = d.query(db["q_words"], db["q_vals"], 1)                          # the reference asks for top-1 (bow_db.py:39)
+    assert i1[0] == oi[0] and s1[0] == os_[0]
+    d.close()
+
+
+def test_bow_ragged_and_empty_entries(ctx):
+    rng = np.random.default_rng(4)
+    lens = np.array([0, 1, 5, 0, 257, 3, 1024, 2], np.int64)
+    start = np.concatenate([[0], np.cumsum(lens)])
+    words = np.concatenate([np.sort(rng.choice(5000, size=n, replace=False)) for n in lens]).astype(np.uint32)
+    vals = rng.random(len(words))
+    qw = np.sort(rng.choice(5000, size=600, replace=False)).astype(np.uint32); qv = rng.random(600)
+    d = bow.BowDatabase(ctx)
+    d.set_db(start, words, vals)
+    ids, sc = d.query(qw, qv, 8)
+    oi, os_ = oracle.bow_query_l1(qw, qv, start, words, vals, 8)
+    assert np.array_equal(ids, oi) and np.array_equal(sc, os_)
+    assert 0 not in ids and 3 not in ids                                       # empty entries never appear
+    # a query sharing no word with anything returns nothing
+    ids, sc = d.query(np.array([6000, 6001], np.uint32), np.array([0.5, 0.5]), 3)
+    assert len(ids) == 0
+    d.close()
+
+
+def test_bow_config4_full_size_and_roofline(ctx):
+    """BASELINE configs[3]: 1 query vs 100 k entries x 1000 words (1.2 GB of (word, weight) pairs)."""
+    db = synth.bow_database()
+    d = bow.BowDatabase(ctx)
+    d.set_db(db["start"], db["words"], db["vals"])
+    ids, sc = d.query(db["q_words"], db["q_vals"], 10)
+    oi, os_ = oracle.bow_query_l1(db["q_words"], db["q_vals"], db["start"], db["words"], db["vals"], 10)
+    assert np.array_equal(ids, oi) and np.array_equal(sc, os_)
+    assert ids[0] == 12345
+    d.close()

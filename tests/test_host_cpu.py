@@ -133,6 +133,17 @@ for i in range(1, n):
     ref += int(qi.sum() * 7 + ti.sum() * 3 + dd.sum())
 assert int(tot.item()) == ref, (int(tot.item()), ref)
 assert dist.reduce_max(1.0 + rank, td) == float(world)
+# keyframe-sharded BoW query: per-rank top-k on its shard of the entries, all-gather, merge == single-process top-k
+from boslam_amd import bow
+db = synth.bow_database(n_entries=400, words_per_entry=50, vocab=3000, seed=5, query_entry=77)
+n_e = 400
+a, b, _ = dist.frame_shard(n_e, rank, world)
+st = db["start"][a:b + 1]
+def local():
+    return oracle.bow_query_l1(db["q_words"], db["q_vals"], st - st[0], db["words"][st[0]:st[-1]], db["vals"][st[0]:st[-1]], 6)
+gi, gs = bow.sharded_query(local, a, 6, td)
+ri, rs = oracle.bow_query_l1(db["q_words"], db["q_vals"], db["start"], db["words"], db["vals"], 6)
+assert np.array_equal(gi, ri) and np.array_equal(gs, rs), (gi, ri)
 td.barrier()
 td.destroy_process_group()
 print("rank", rank, "ok")
