@@ -23,6 +23,8 @@ struct bh_level_geom {
     int   nfeat;                     // n_l
     int   tiles_x, tiles_y, tile_base;   // 64x32 tiles
     int   tabx_off, taby_off;        // offsets (in u32) into the resize coefficient table
+    int   nsx_in, n_edge, nrb;       // blur: interior / edge 4-px strips per row, 16-row blocks
+    int   bblk_base, eblk_base;      // blur: first workgroup of the level in the interior / edge launch
 };
 
 struct bh_orb_geom {
@@ -31,6 +33,7 @@ struct bh_orb_geom {
     int ntiles;                      // over all levels
     int fast_thr, edge_thr;
     int tab_len;
+    int bblk_total, eblk_total;
     bh_level_geom lv[BH_MAX_LEVELS];
 };
 
@@ -50,7 +53,7 @@ struct bh_ctx {
     bh_orb_params geom_params = {};
     int         geom_valid = 0;
     int         ws_frames = 0;       // frames the pyramid workspace holds
-    bh_buf      pyr, mpyr, nms, blur, hist, tab, kpmeta, status;
+    bh_buf      pyr, mpyr, nms, blur, hist, tab, sel_xy, sel_resp, sel_cnt, status;
     bh_buf      st_img, st_mask, st_depth, st_kps, st_desc, st_nkp;     // host-mode staging
     bh_buf      st_a, st_b, st_c, st_d, st_e, st_f, st_g, st_h;         // generic staging (match / BA)
     int         last_B = 0;

@@ -49,7 +49,7 @@ extern "C" void bh_ctx_destroy(bh_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    bh_buf* all[] = { &ctx->pyr, &ctx->mpyr, &ctx->nms, &ctx->blur, &ctx->hist, &ctx->tab, &ctx->kpmeta, &ctx->status,
+    bh_buf* all[] = { &ctx->pyr, &ctx->mpyr, &ctx->nms, &ctx->blur, &ctx->hist, &ctx->tab, &ctx->sel_xy, &ctx->sel_resp, &ctx->sel_cnt, &ctx->status,
                       &ctx->st_img, &ctx->st_mask, &ctx->st_depth, &ctx->st_kps, &ctx->st_desc, &ctx->st_nkp,
                       &ctx->st_a, &ctx->st_b, &ctx->st_c, &ctx->st_d, &ctx->st_e, &ctx->st_f, &ctx->st_g, &ctx->st_h };
     for (bh_buf* b : all) release(b);

@@ -7,10 +7,10 @@
 //   k_pyr_down    level l from level l-1 (bit-exact fixed-point bilinear), image and mask   (nlevels-1 launches)
 //   k_fast        FAST-9/16 corner test + score + 3x3 NMS + mask/border filter on 64x32 LDS tiles;
 //                 writes a dense u8 score map and a 256-bin score histogram per (frame, level)
-//   k_blur        7x7 sigma-2 fixed-point Gaussian on 64x32 LDS tiles
-//   k_select      one workgroup per frame: retainBest(2 n_l) threshold from the histogram, raster compaction of the
-//                 score map, Harris response, retainBest(n_l) by rank counting in LDS, intensity-centroid angle
-//   k_brief       one wave per keypoint: 256 rotated pixel-pair tests, 4 ballots -> 32 bytes
+//   k_blur        7x7 sigma-2 fixed-point Gaussian: register-sliding 4-px column strips, v_dot4_u32_u8 row sums, no LDS
+//   k_select      one workgroup per (level, frame): retainBest(2 n_l) threshold from the histogram, raster compaction of
+//                 the score map, Harris response, retainBest(n_l) by rank counting in LDS -> per-level staging slots
+//   k_describe    one wave per keypoint: intensity-centroid angle, then 256 rotated pixel-pair tests, 4 ballots -> 32 B
 // Every integer stage is exact; the float formulas (Harris response, fastAtan2, cos/sin of the angle) are written
 // one IEEE operation at a time and the file is compiled with -ffp-contract=off.
 #include "bh_internal.h"
@@ -39,7 +39,7 @@ static int build_geom(const bh_orb_params* p, int H, int W, bh_orb_geom* g)
     float factor = (float)(1.0 / p->scaleFactor);
     float nd = p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)p->nlevels));
     int sum = 0;
-    int off = 0, tiles = 0, tab = 0;
+    int off = 0, tiles = 0, tab = 0, bblk = 0, eblk = 0;
     for (int l = 0; l < p->nlevels; l++) {
         bh_level_geom& L = g->lv[l];
         L.scale = (float)pow((double)p->scaleFactor, (double)l);
@@ -51,12 +51,18 @@ static int build_geom(const bh_orb_params* p, int H, int W, bh_orb_geom* g)
         L.tiles_x = (L.w + TILE_W - 1) / TILE_W;
         L.tiles_y = (L.h + TILE_H - 1) / TILE_H;
         L.tile_base = tiles; tiles += L.tiles_x * L.tiles_y;
+        // blur strips: interior strips sx = 1 .. nsx_in (x0-4 >= 0 and x0+8 <= w), the rest are edge strips
+        L.nsx_in = (L.w - 8) / 4 > 0 ? (L.w - 8) / 4 : 0;
+        L.n_edge = (L.w + 3) / 4 - L.nsx_in;
+        L.nrb = (L.h + 15) / 16;
+        L.bblk_base = bblk; bblk += (L.nsx_in * L.nrb + 255) / 256;
+        L.eblk_base = eblk; eblk += (L.n_edge * L.nrb + 255) / 256;
         L.tabx_off = tab; tab += L.w;
         L.taby_off = tab; tab += L.h;
         if (l < p->nlevels - 1) { L.nfeat = round_even_f(nd); sum += L.nfeat; nd *= factor; }
         else L.nfeat = p->nfeatures - sum > 0 ? p->nfeatures - sum : 0;
     }
-    g->pyr_stride = off; g->ntiles = tiles; g->tab_len = tab;
+    g->pyr_stride = off; g->ntiles = tiles; g->tab_len = tab; g->bblk_total = bblk; g->eblk_total = eblk;
     return BH_OK;
 }
 
@@ -228,24 +234,26 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
 
     const uint8_t* px = reinterpret_cast<const uint8_t*>(s_px);
     const int thr = g.fast_thr;
-    // phase 1: corner test for every pixel of the score tile
+    // phase 1: cheap necessary test on every pixel of the score tile (the opposite-pair rule of the reference detector:
+    // a 9-arc contains ring pixel k or k+8, so each opposite pair must hold a darker -- or a brighter -- pixel);
+    // pairs (0,8) and (4,12) reject ~97 % of the pixels; survivors go to an LDS list so that phase 2 runs dense.
     for (int i = tid; i < FSC_H * FSC_W; i += 256) {
         const int sy = i / FSC_W, sx = i - sy * FSC_W;
         const int x = x0 - 1 + sx, y = y0 - 1 + sy;
         if (x < 3 || x > L.w - 4 || y < 3 || y > L.h - 4) continue;
         const uint8_t* c = px + (sy + 3) * FPX_W + (sx + 3);
         const int v = c[0], lo = v - thr, hi = v + thr;
-        uint32_t dm = 0, bm = 0;
-#define FAST_T(k, dx, dy) { const int p = c[(dy) * FPX_W + (dx)]; dm |= (uint32_t)(p < lo) << k; bm |= (uint32_t)(p > hi) << k; }
-        FAST_T(0, 0, 3)  FAST_T(1, 1, 3)  FAST_T(2, 2, 2)  FAST_T(3, 3, 1)
-        FAST_T(4, 3, 0)  FAST_T(5, 3, -1) FAST_T(6, 2, -2) FAST_T(7, 1, -3)
-        FAST_T(8, 0, -3) FAST_T(9, -1, -3) FAST_T(10, -2, -2) FAST_T(11, -3, -1)
-        FAST_T(12, -3, 0) FAST_T(13, -3, 1) FAST_T(14, -2, 2) FAST_T(15, -1, 3)
-#undef FAST_T
-        if (contig9(dm) | contig9(bm)) s_list[atomicAdd(&s_n, 1)] = (uint16_t)i;
+        const int p0 = c[3 * FPX_W], p8 = c[-3 * FPX_W];
+        bool dk = (p0 < lo) | (p8 < lo), br = (p0 > hi) | (p8 > hi);
+        if (!(dk | br)) continue;
+        const int p4 = c[3], p12 = c[-3];
+        dk &= (p4 < lo) | (p12 < lo); br &= (p4 > hi) | (p12 > hi);
+        if (!(dk | br)) continue;
+        s_list[atomicAdd(&s_n, 1)] = (uint16_t)i;
     }
     __syncthreads();
-    // phase 2: corner score (largest threshold at which the pixel is still a corner), corners only
+    // phase 2: full 16-pixel ring test on the survivors; corners get their score (largest threshold at which the pixel
+    // is still a corner) by a doubling min/max tree over the 16 arcs
     const int n = s_n;
     for (int j = tid; j < n; j += 256) {
         const int i = s_list[j];
@@ -257,6 +265,10 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
         d[4] = v - c[3];               d[5] = v - c[-FPX_W + 3];      d[6] = v - c[-2 * FPX_W + 2];  d[7] = v - c[-3 * FPX_W + 1];
         d[8] = v - c[-3 * FPX_W];      d[9] = v - c[-3 * FPX_W - 1];  d[10] = v - c[-2 * FPX_W - 2]; d[11] = v - c[-FPX_W - 3];
         d[12] = v - c[-3];             d[13] = v - c[FPX_W - 3];      d[14] = v - c[2 * FPX_W - 2];  d[15] = v - c[3 * FPX_W - 1];
+        uint32_t dm = 0, bm = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { dm |= (uint32_t)(d[k] > thr) << k; bm |= (uint32_t)(d[k] < -thr) << k; }
+        if (!(contig9(dm) | contig9(bm))) continue;
         int mn2[16], mx2[16], mn4[16], mx4[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
@@ -311,69 +323,73 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return min(max(i, 0), n - 1);
 }
 
-#define BPX_W (TILE_W + 8)      // x0-4 .. x0+67
-#define BPX_H (TILE_H + 6)      // y0-3 .. y0+34
+// Register-sliding strip kernel, no LDS: one lane owns a 4-px wide column strip and BL_R output rows.  Per input row it
+// loads the three aligned words covering x0-4 .. x0+7, forms the 4 horizontal sums with v_alignbyte + v_dot4_u32_u8
+// (taps {k0..k3} and {k4,k5,k6,0}), keeps the last 7 rows of sums in registers and emits one packed u32 per output row.
+// Interior strips (all 12 px inside the level) take aligned word loads; the 2-3 strips per row that touch the left/right
+// border run the same body with reflect-101 byte gathers in a separate small launch (EDGE) so that no wave diverges.
+#define BL_R 16
 
+template <bool EDGE>
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                               bh_orb_geom g, bh_gauss7 G)
 {
-    __shared__ uint32_t s_px[BPX_H * (BPX_W / 4)];
-    __shared__ uint16_t s_h[BPX_H * TILE_W];
-
-    const int tid = threadIdx.x;
-    const int level = tile_level(g, blockIdx.x);
+    int level = 0;
+    for (int i = 1; i < g.nlevels; i++) if ((int)blockIdx.x >= (EDGE ? g.lv[i].eblk_base : g.lv[i].bblk_base)) level = i;
     const bh_level_geom L = g.lv[level];
-    const int t = blockIdx.x - L.tile_base;
-    const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
-    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
+    const int nsx = EDGE ? L.n_edge : L.nsx_in;
+    const int idx = ((int)blockIdx.x - (EDGE ? L.eblk_base : L.bblk_base)) * 256 + threadIdx.x;
+    const int rb = idx / nsx, si = idx - rb * nsx;
+    if (rb >= L.nrb) return;
+    // interior strips are 1 .. nsx_in; edge strips are 0 and nsx_in+1 .. nsx_in+n_edge-1
+    const int sx = EDGE ? (si == 0 ? 0 : L.nsx_in + si) : si + 1;
+    const int x0 = sx * 4, y0 = rb * BL_R;
     const size_t fbase = (size_t)blockIdx.y * g.pyr_stride + L.off;
     const uint8_t* img = pyr + fbase;
-
-    const bool interior = x0 >= 4 && x0 + TILE_W + 4 <= L.w && y0 >= 3 && y0 + TILE_H + 3 <= L.h;
-    if (interior) {
-        for (int i = tid; i < BPX_H * (BPX_W / 4); i += 256) {
-            const int r = i / (BPX_W / 4), c = i - r * (BPX_W / 4);
-            s_px[i] = *reinterpret_cast<const uint32_t*>(img + (size_t)(y0 - 3 + r) * L.pitch + x0 - 4 + c * 4);
-        }
-    } else {
-        uint8_t* p8 = reinterpret_cast<uint8_t*>(s_px);
-        for (int i = tid; i < BPX_H * BPX_W; i += 256) {
-            const int r = i / BPX_W, c = i - r * BPX_W;
-            p8[i] = img[(size_t)reflect101(y0 - 3 + r, L.h) * L.pitch + reflect101(x0 - 4 + c, L.w)];
-        }
-    }
-    __syncthreads();
-    const uint8_t* px = reinterpret_cast<const uint8_t*>(s_px);
-    // horizontal pass: sum <= 257*255 fits u16
-    for (int i = tid; i < BPX_H * TILE_W; i += 256) {
-        const int r = i / TILE_W, c = i - r * TILE_W;
-        const uint8_t* p = px + r * BPX_W + c + 1;            // x0 + c - 3
-        int s = 0;
+    const uint32_t K03 = (uint32_t)G.k[0] | ((uint32_t)G.k[1] << 8) | ((uint32_t)G.k[2] << 16) | ((uint32_t)G.k[3] << 24);
+    const uint32_t K46 = (uint32_t)G.k[4] | ((uint32_t)G.k[5] << 8) | ((uint32_t)G.k[6] << 16);
+    uint32_t hs[7][4];
 #pragma unroll
-        for (int k = 0; k < 7; k++) s += G.k[k] * p[k];
-        s_h[i] = (uint16_t)s;
-    }
-    __syncthreads();
-    for (int wd = tid; wd < TILE_H * (TILE_W / 4); wd += 256) {
-        const int oy = wd / (TILE_W / 4), ox = (wd - oy * (TILE_W / 4)) * 4;
-        const int y = y0 + oy;
-        if (y >= L.h) continue;
-        uint32_t out = 0;
+    for (int r = 0; r < BL_R + 6; r++) {
+        const int yr = reflect101(y0 - 3 + r, L.h);
+        const uint8_t* row = img + (size_t)yr * L.pitch;
+        uint32_t W0, W1, W2;
+        if (!EDGE) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(row + x0 - 4);
+            W0 = p[0]; W1 = p[1]; W2 = p[2];
+        } else {
+            W0 = W1 = W2 = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int s = 0;
-#pragma unroll
-            for (int k = 0; k < 7; k++) s += G.k[k] * s_h[(oy + k) * TILE_W + ox + i];
-            s = (s + 32768) >> 16;
-            out |= (uint32_t)min(s, 255) << (8 * i);
+            for (int k = 0; k < 4; k++) {
+                W0 |= (uint32_t)row[reflect101(x0 - 4 + k, L.w)] << (8 * k);
+                W1 |= (uint32_t)row[reflect101(x0 + k, L.w)] << (8 * k);
+                W2 |= (uint32_t)row[reflect101(x0 + 4 + k, L.w)] << (8 * k);
+            }
         }
-        *reinterpret_cast<uint32_t*>(blur + fbase + (size_t)y * L.pitch + x0 + ox) = out;
+        uint32_t* h = hs[r % 7];
+        h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 1), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 1), K46, 0u, false), false);
+        h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 2), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 2), K46, 0u, false), false);
+        h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 3), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 3), K46, 0u, false), false);
+        h[3] = __builtin_amdgcn_udot4(W1, K03, __builtin_amdgcn_udot4(W2, K46, 0u, false), false);
+        if (r >= 6) {
+            const int y = y0 + r - 6;
+            uint32_t out = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t s = 32768u;
+#pragma unroll
+                for (int k = 0; k < 7; k++) s += __umul24(hs[(r - 6 + k) % 7][i], (uint32_t)G.k[k]);
+                s >>= 16;
+                out |= min(s, 255u) << (8 * i);
+            }
+            if (y < L.h) *reinterpret_cast<uint32_t*>(blur + fbase + (size_t)y * L.pitch + x0) = out;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ select (per frame)
-#define SEL_T    1024
-#define SEL_W    16            // waves
+#define SEL_T    512
+#define SEL_W    8             // waves
 #define CAND_CAP 4096
 
 __device__ __forceinline__ int wave_excl_scan(int v, int lane)
@@ -419,199 +435,202 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
+// One workgroup per (level, frame).  Output: the level's kept candidates in raster order in a staging slot
+// sel_xy/sel_resp[frame][level][sel_cap] + sel_cnt[frame][level]; k_describe turns slots into final keypoints.
 __global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ nms,
-                                                  const uint32_t* __restrict__ hist, bh_orb_geom g, bh_umax UM,
-                                                  float patch_size, int max_kp, bh_kp* __restrict__ kps,
-                                                  uint32_t* __restrict__ kpmeta, int* __restrict__ n_kp,
-                                                  uint32_t* __restrict__ status)
+                                                  const uint32_t* __restrict__ hist, bh_orb_geom g, int sel_cap,
+                                                  uint32_t* __restrict__ sel_xy, float* __restrict__ sel_resp,
+                                                  int* __restrict__ sel_cnt, uint32_t* __restrict__ status)
 {
     __shared__ uint32_t s_xy[CAND_CAP];
     __shared__ float    s_resp[CAND_CAP];
     __shared__ uint32_t s_hs[256];
     __shared__ int s_wcnt[SEL_W];
-    __shared__ int s_thr, s_nout;
+    __shared__ int s_thr;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const size_t f = blockIdx.x;
+    const int level = blockIdx.x;
+    const size_t f = blockIdx.y;
     const size_t fb = f * g.pyr_stride;
-    bh_kp* okp = kps + f * max_kp;
-    uint32_t* ometa = kpmeta + f * max_kp;
-    if (tid == 0) s_nout = 0;
-
-    for (int level = 0; level < g.nlevels; level++) {
-        const bh_level_geom L = g.lv[level];
-        const int n2 = 2 * L.nfeat;
-        // (a) retainBest(2 n_l) threshold on the u8 FAST score: largest s with #(score >= s) >= 2 n_l
-        if (tid < 256) s_hs[tid] = hist[(f * g.nlevels + level) * 256 + tid];
-        if (tid == 0) s_thr = 1;
-        __syncthreads();
-        if (tid >= 1 && tid < 256) {
-            uint32_t suf = 0;
-            for (int b = tid; b < 256; b++) suf += s_hs[b];
-            const uint32_t suf1 = suf - s_hs[tid];                 // #(score >= tid+1)
-            if (suf >= (uint32_t)n2 && suf1 < (uint32_t)n2) s_thr = tid;
-        }
-        __syncthreads();
-        const uint32_t thr = n2 > 0 ? (uint32_t)s_thr : 256u;
-        // (b) pass A: per-wave count of kept candidates over its contiguous slice of the score map
-        const uint4* map = reinterpret_cast<const uint4*>(nms + fb + L.off);
-        const int nvec = (L.pitch * L.h) >> 4;
-        const int seg = (nvec + SEL_W - 1) / SEL_W;
-        const int v0 = wv * seg, v1 = min(v0 + seg, nvec);
-        int cnt = 0;
-        for (int v = v0 + lane; v < v1; v += 64) {
-            const uint4 q = map[v];
-            if (q.x | q.y | q.z | q.w) cnt += count_ge(q.x, thr) + count_ge(q.y, thr) + count_ge(q.z, thr) + count_ge(q.w, thr);
-        }
-        cnt = wave_sum(cnt);
-        if (lane == 0) s_wcnt[wv] = cnt;
-        __syncthreads();
-        int base = 0, total = 0;
-        for (int i = 0; i < SEL_W; i++) { const int c = s_wcnt[i]; if (i < wv) base += c; total += c; }
-        // (c) pass B: emit (x,y) in raster order
-        for (int vb = v0; vb < v1; vb += 64) {
-            const int v = vb + lane;
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (v < v1) q = map[v];
-            const uint32_t wds[4] = { q.x, q.y, q.z, q.w };
-            int c = 0;
-            if (q.x | q.y | q.z | q.w) c = count_ge(q.x, thr) + count_ge(q.y, thr) + count_ge(q.z, thr) + count_ge(q.w, thr);
-            if (__ballot(c != 0) == 0ull) continue;
-            int pos = base + wave_excl_scan(c, lane);
-            base += wave_sum(c);
-            if (c) {
-                const int byte0 = v << 4;
-                const int y = byte0 / L.pitch, xb = byte0 - y * L.pitch;
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const uint32_t s = (wds[k >> 2] >> (8 * (k & 3))) & 255u;
-                    if (s >= thr) { if (pos < CAND_CAP) s_xy[pos] = ((uint32_t)y << 16) | (uint32_t)(xb + k); pos++; }
-                }
-            }
-        }
-        if (total > CAND_CAP) { if (tid == 0) atomicOr(status, BH_ST_CAND_OVERFLOW); total = CAND_CAP; }
-        __syncthreads();
-        const int m = total;
-        // (d) Harris response, 7x7 block of 3x3 Sobel products
-        const uint8_t* img = pyr + fb + L.off;
-        for (int i = tid; i < m; i += SEL_T) {
-            const uint32_t xy = s_xy[i];
-            const int cx = xy & 0xffffu, cy = xy >> 16;
-            int a = 0, b = 0, c = 0;
-            int r0[9], r1[9], r2[9];
-            const uint8_t* p = img + (size_t)(cy - 4) * L.pitch + cx - 4;
-#pragma unroll
-            for (int k = 0; k < 9; k++) { r0[k] = p[k]; r1[k] = p[L.pitch + k]; }
-            for (int row = 2; row < 9; row++) {
-                const uint8_t* q = p + (size_t)row * L.pitch;
-#pragma unroll
-                for (int k = 0; k < 9; k++) r2[k] = q[k];
-#pragma unroll
-                for (int k = 1; k < 8; k++) {
-                    const int Ix = (r1[k + 1] - r1[k - 1]) * 2 + (r0[k + 1] - r0[k - 1]) + (r2[k + 1] - r2[k - 1]);
-                    const int Iy = (r2[k] - r0[k]) * 2 + (r2[k - 1] - r0[k - 1]) + (r2[k + 1] - r0[k + 1]);
-                    a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
-                }
-#pragma unroll
-                for (int k = 0; k < 9; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
-            }
-            const float scale = 1.f / ((1 << 2) * 7 * 255.f);
-            const float scale_sq_sq = scale * scale * scale * scale;
-            const float fa = (float)a, fbb = (float)b, fc = (float)c;
-            const float t1 = fa * fbb, t2 = fc * fc, s = fa + fbb;
-            const float t3 = (0.04f * s) * s;
-            s_resp[i] = ((t1 - t2) - t3) * scale_sq_sq;
-        }
-        __syncthreads();
-        // (e) retainBest(n_l): keep i iff fewer than n_l responses are strictly greater (ties at the cut all kept)
-        const int per = (m + SEL_T - 1) / SEL_T;          // consecutive entries per thread (<= 4)
-        const int i0 = tid * per;
-        int keep_mask = 0, kcnt = 0;
-        for (int e = 0; e < per; e++) {
-            const int i = i0 + e;
-            if (i >= m) break;
-            bool keep = true;
-            if (m > L.nfeat) {
-                const float r = s_resp[i];
-                int rank = 0;
-                for (int j = 0; j < m; j++) rank += (s_resp[j] > r);
-                keep = rank < L.nfeat;
-            }
-            if (keep) { keep_mask |= 1 << e; kcnt++; }
-        }
-        // block exclusive scan of kcnt
-        const int wpre = wave_excl_scan(kcnt, lane);
-        const int wtot = wave_sum(kcnt);
-        __syncthreads();                                   // s_wcnt reuse
-        if (lane == 0) s_wcnt[wv] = wtot;
-        __syncthreads();
-        int kbase = s_nout, ktotal = 0;
-        for (int i = 0; i < SEL_W; i++) { const int c = s_wcnt[i]; if (i < wv) kbase += c; ktotal += c; }
-        int pos = kbase + wpre;
-        for (int e = 0; e < per; e++) {
-            if (!(keep_mask & (1 << e))) continue;
-            if (pos < max_kp) {
-                const uint32_t xy = s_xy[i0 + e];
-                const int cx = xy & 0xffffu, cy = xy >> 16;
-                bh_kp k;
-                k.x = (float)cx * L.scale; k.y = (float)cy * L.scale;
-                k.size = patch_size * L.scale; k.angle = -1.f; k.response = s_resp[i0 + e]; k.octave = level;
-                okp[pos] = k;
-                ometa[pos] = ((uint32_t)level << 28) | ((uint32_t)cy << 14) | (uint32_t)cx;
-            }
-            pos++;
-        }
-        __syncthreads();
-        if (tid == 0) s_nout += ktotal;
-        __syncthreads();
+    const bh_level_geom L = g.lv[level];
+    const int n2 = 2 * L.nfeat;
+    // (a) retainBest(2 n_l) threshold on the u8 FAST score: largest s with #(score >= s) >= 2 n_l
+    if (tid < 256) s_hs[tid] = hist[(f * g.nlevels + level) * 256 + tid];
+    if (tid == 0) s_thr = 1;
+    __syncthreads();
+    if (tid >= 1 && tid < 256) {
+        uint32_t suf = 0;
+        for (int b = tid; b < 256; b++) suf += s_hs[b];
+        const uint32_t suf1 = suf - s_hs[tid];                 // #(score >= tid+1)
+        if (suf >= (uint32_t)n2 && suf1 < (uint32_t)n2) s_thr = tid;
     }
-    int nout = s_nout;
-    if (nout > max_kp) { if (tid == 0) atomicOr(status, BH_ST_KP_OVERFLOW); nout = max_kp; }
-    if (tid == 0) n_kp[f] = nout;
-    // (f) intensity-centroid angle, one wave per keypoint: lanes cover 2 rows x 32 columns per step
-    for (int k = wv; k < nout; k += SEL_W) {
-        const uint32_t meta = ometa[k];
-        const int level = meta >> 28, cy = (meta >> 14) & 0x3fff, cx = meta & 0x3fff;
-        const bh_level_geom L = g.lv[level];
-        const uint8_t* c = pyr + fb + L.off + (size_t)cy * L.pitch + cx;
-        const int u = (lane & 31) - 15;
-        int m10 = 0, m01 = 0;
-        for (int it = 0; it < 16; it++) {
-            const int v = it * 2 + (lane >> 5) - 15;
-            if (v <= 15 && (lane & 31) < 31) {
-                const int av = v < 0 ? -v : v;
-                if (u >= -UM.u[av] && u <= UM.u[av]) {
-                    const int I = c[v * L.pitch + u];
-                    m10 += u * I; m01 += v * I;
-                }
+    __syncthreads();
+    const uint32_t thr = n2 > 0 ? (uint32_t)s_thr : 256u;
+    // (b) pass A: per-wave count of kept candidates over its contiguous slice of the score map
+    const uint4* map = reinterpret_cast<const uint4*>(nms + fb + L.off);
+    const int nvec = (L.pitch * L.h) >> 4;
+    const int seg = (nvec + SEL_W - 1) / SEL_W;
+    const int v0 = wv * seg, v1 = min(v0 + seg, nvec);
+    int cnt = 0;
+    for (int v = v0 + lane; v < v1; v += 64) {
+        const uint4 q = map[v];
+        if (q.x | q.y | q.z | q.w) cnt += count_ge(q.x, thr) + count_ge(q.y, thr) + count_ge(q.z, thr) + count_ge(q.w, thr);
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0) s_wcnt[wv] = cnt;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int i = 0; i < SEL_W; i++) { const int c = s_wcnt[i]; if (i < wv) base += c; total += c; }
+    // (c) pass B: emit (x,y) in raster order
+    for (int vb = v0; vb < v1; vb += 64) {
+        const int v = vb + lane;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (v < v1) q = map[v];
+        const uint32_t wds[4] = { q.x, q.y, q.z, q.w };
+        int c = 0;
+        if (q.x | q.y | q.z | q.w) c = count_ge(q.x, thr) + count_ge(q.y, thr) + count_ge(q.z, thr) + count_ge(q.w, thr);
+        if (__ballot(c != 0) == 0ull) continue;
+        int pos = base + wave_excl_scan(c, lane);
+        base += wave_sum(c);
+        if (c) {
+            const int byte0 = v << 4;
+            const int y = byte0 / L.pitch, xb = byte0 - y * L.pitch;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t sc = (wds[k >> 2] >> (8 * (k & 3))) & 255u;
+                if (sc >= thr) { if (pos < CAND_CAP) s_xy[pos] = ((uint32_t)y << 16) | (uint32_t)(xb + k); pos++; }
             }
         }
-        m10 = wave_sum(m10); m01 = wave_sum(m01);
-        if (lane == 0) okp[k].angle = fast_atan2_deg((float)m01, (float)m10);
+    }
+    if (total > CAND_CAP) { if (tid == 0) atomicOr(status, BH_ST_CAND_OVERFLOW); total = CAND_CAP; }
+    __syncthreads();
+    const int m = total;
+    // (d) Harris response, 7x7 block of 3x3 Sobel products
+    const uint8_t* img = pyr + fb + L.off;
+    for (int i = tid; i < m; i += SEL_T) {
+        const uint32_t xy = s_xy[i];
+        const int cx = xy & 0xffffu, cy = xy >> 16;
+        int a = 0, b = 0, c = 0;
+        int r0[9], r1[9], r2[9];
+        const uint8_t* p = img + (size_t)(cy - 4) * L.pitch + cx - 4;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { r0[k] = p[k]; r1[k] = p[L.pitch + k]; }
+        for (int row = 2; row < 9; row++) {
+            const uint8_t* q = p + (size_t)row * L.pitch;
+#pragma unroll
+            for (int k = 0; k < 9; k++) r2[k] = q[k];
+#pragma unroll
+            for (int k = 1; k < 8; k++) {
+                const int Ix = (r1[k + 1] - r1[k - 1]) * 2 + (r0[k + 1] - r0[k - 1]) + (r2[k + 1] - r2[k - 1]);
+                const int Iy = (r2[k] - r0[k]) * 2 + (r2[k - 1] - r0[k - 1]) + (r2[k + 1] - r0[k + 1]);
+                a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
+        }
+        const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+        const float scale_sq_sq = scale * scale * scale * scale;
+        const float fa = (float)a, fbb = (float)b, fc = (float)c;
+        const float t1 = fa * fbb, t2 = fc * fc, sm = fa + fbb;
+        const float t3 = (0.04f * sm) * sm;
+        s_resp[i] = ((t1 - t2) - t3) * scale_sq_sq;
+    }
+    __syncthreads();
+    // (e) retainBest(n_l): keep i iff fewer than n_l responses are strictly greater (ties at the cut all kept)
+    const int per = (m + SEL_T - 1) / SEL_T;          // consecutive entries per thread
+    const int i0 = tid * per;
+    int keep_mask = 0, kcnt = 0;
+    for (int e = 0; e < per; e++) {
+        const int i = i0 + e;
+        if (i >= m) break;
+        bool keep = true;
+        if (m > L.nfeat) {
+            const float r = s_resp[i];
+            int rank = 0;
+            for (int j = 0; j < m; j++) rank += (s_resp[j] > r);
+            keep = rank < L.nfeat;
+        }
+        if (keep) { keep_mask |= 1 << e; kcnt++; }
+    }
+    const int wpre = wave_excl_scan(kcnt, lane);
+    const int wtot = wave_sum(kcnt);
+    __syncthreads();                                   // s_wcnt reuse
+    if (lane == 0) s_wcnt[wv] = wtot;
+    __syncthreads();
+    int kbase = 0, ktotal = 0;
+    for (int i = 0; i < SEL_W; i++) { const int c = s_wcnt[i]; if (i < wv) kbase += c; ktotal += c; }
+    int pos = kbase + wpre;
+    const size_t slot = (f * g.nlevels + level) * (size_t)sel_cap;
+    for (int e = 0; e < per; e++) {
+        if (!(keep_mask & (1 << e))) continue;
+        if (pos < sel_cap) { sel_xy[slot + pos] = s_xy[i0 + e]; sel_resp[slot + pos] = s_resp[i0 + e]; }
+        pos++;
+    }
+    if (tid == 0) {
+        if (ktotal > sel_cap) { atomicOr(status, BH_ST_KP_OVERFLOW); ktotal = sel_cap; }
+        sel_cnt[f * g.nlevels + level] = ktotal;
     }
 }
 
-// ------------------------------------------------------------------------------------------------ steered BRIEF
+// ------------------------------------------------------------------------------------------------ angle + steered BRIEF
 __constant__ signed char c_pattern[1024] = {
 #include "brief_pattern.h"
 };
 
-__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blur, bh_orb_geom g, int max_kp,
-                                               const bh_kp* __restrict__ kps, const int* __restrict__ n_kp,
-                                               uint8_t* __restrict__ desc)
+// One wave per (frame, level, slot).  The final keypoint index is the prefix of the per-level counts plus the slot
+// (canonical order: level-major, raster inside a level).  Intensity-centroid angle: lanes cover 2 rows x 32 columns of
+// the 31x31 patch per step, integer wave reduction, fastAtan2.  Steered BRIEF: lane l evaluates tests l, 64+l, 128+l,
+// 192+l; four ballots give the 32 descriptor bytes.
+__global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                  bh_orb_geom g, bh_umax UM, float patch_size, int sel_cap, int max_kp,
+                                                  const uint32_t* __restrict__ sel_xy, const float* __restrict__ sel_resp,
+                                                  const int* __restrict__ sel_cnt, bh_kp* __restrict__ kps,
+                                                  uint8_t* __restrict__ desc, int* __restrict__ n_kp,
+                                                  uint32_t* __restrict__ status)
 {
     const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);          // final keypoint index of this wave
     const size_t f = blockIdx.y;
-    if (k >= n_kp[f]) return;
-    const bh_kp kp = kps[f * max_kp + k];
-    const bh_level_geom L = g.lv[kp.octave];
+    const int* cnt = sel_cnt + f * g.nlevels;
+    int level = -1, slot = 0, before = 0, tot = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int c = cnt[l];
+        if (level < 0 && k < tot + c) { level = l; slot = k - tot; before = tot; }
+        tot += c;
+    }
+    if (k == 0 && lane == 0) { n_kp[f] = min(tot, max_kp); if (tot > max_kp) atomicOr(status, BH_ST_KP_OVERFLOW); }
+    if (level < 0 || k >= max_kp) return;
+    (void)before;
+    const bh_level_geom L = g.lv[level];
+    const size_t si = (f * g.nlevels + level) * (size_t)sel_cap + slot;
+    const uint32_t xy = sel_xy[si];
+    const int cx = xy & 0xffffu, cy = xy >> 16;
+    const size_t lbase = f * g.pyr_stride + L.off;
+    // ---- intensity-centroid angle
+    const uint8_t* c = pyr + lbase + (size_t)cy * L.pitch + cx;
+    const int u = (lane & 31) - 15;
+    int m10 = 0, m01 = 0;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+        const int v = it * 2 + (lane >> 5) - 15;             // v <= 16, u <= 16: always inside the level (31-px border)
+        const int av = min(v < 0 ? -v : v, 15);
+        const int I = c[v * L.pitch + u];                     // unconditional: all 16 loads are issued back to back
+        const bool in = v <= 15 && u >= -UM.u[av] && u <= UM.u[av];
+        m10 += in ? u * I : 0; m01 += in ? v * I : 0;
+    }
+    m10 = wave_sum(m10); m01 = wave_sum(m01);
+    const float angle_deg = fast_atan2_deg((float)m01, (float)m10);
+    bh_kp kp;
+    kp.x = (float)cx * L.scale; kp.y = (float)cy * L.scale;
+    kp.size = patch_size * L.scale; kp.angle = angle_deg; kp.response = sel_resp[si]; kp.octave = level;
+    if (lane == 0) kps[f * max_kp + k] = kp;
+    // ---- steered BRIEF on the blurred level (centre recomputed from the scaled float coordinates, as the reference does)
     const float inv = 1.f / L.scale;
-    const int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
-    float angle = kp.angle;
+    const int bx = __float2int_rn(kp.x * inv), by = __float2int_rn(kp.y * inv);
+    float angle = angle_deg;
     angle *= (float)(3.1415926535897932384626433832795 / 180.f);
     const float a = (float)cos((double)angle), b = (float)sin((double)angle);
-    const uint8_t* center = blur + f * g.pyr_stride + L.off + (size_t)cy * L.pitch + cx;
+    const uint8_t* center = blur + lbase + (size_t)by * L.pitch + bx;
     unsigned long long bits[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -734,7 +753,12 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
     BH_TRY(bh_reserve(ctx, &ctx->nms, ws));
     BH_TRY(bh_reserve(ctx, &ctx->blur, ws));
     BH_TRY(bh_reserve(ctx, &ctx->hist, sizeof(uint32_t) * 256 * g.nlevels * chunk));
-    BH_TRY(bh_reserve(ctx, &ctx->kpmeta, sizeof(uint32_t) * (size_t)max_kp * chunk));
+    int max_nf = 0;
+    for (int l = 0; l < g.nlevels; l++) max_nf = g.lv[l].nfeat > max_nf ? g.lv[l].nfeat : max_nf;
+    const int sel_cap = (max_nf + 64 + 7) & ~7;                 // per-level staging slots: n_l + room for ties at the cut
+    BH_TRY(bh_reserve(ctx, &ctx->sel_xy, sizeof(uint32_t) * (size_t)sel_cap * g.nlevels * chunk));
+    BH_TRY(bh_reserve(ctx, &ctx->sel_resp, sizeof(float) * (size_t)sel_cap * g.nlevels * chunk));
+    BH_TRY(bh_reserve(ctx, &ctx->sel_cnt, sizeof(int) * (size_t)g.nlevels * chunk));
     BH_TRY(bh_reserve(ctx, &ctx->status, 256));
     ctx->ws_frames = chunk;
 
@@ -782,10 +806,13 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
             BH_LAUNCH(ctx, BH_K_PYR, k_pyr_down, dim3((n + 255) / 256, nb), dim3(256), st, pyr, mpyr, g, l, (const uint32_t*)ctx->tab.p);
         }
         BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, nms, hist, g);
-        BH_LAUNCH(ctx, BH_K_BLUR, k_blur, dim3(g.ntiles, nb), dim3(256), st, pyr, blur, g, G);
-        BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(nb), dim3(SEL_T), st, pyr, nms, hist, g, UM, (float)params->patchSize, max_kp,
-                           d_kps, (uint32_t*)ctx->kpmeta.p, d_nkp, (uint32_t*)ctx->status.p);
-        BH_LAUNCH(ctx, BH_K_BRIEF, k_brief, dim3((max_kp + 3) / 4, nb), dim3(256), st, blur, g, max_kp, d_kps, d_nkp, d_desc);
+        BH_LAUNCH(ctx, BH_K_BLUR, k_blur<false>, dim3(g.bblk_total, nb), dim3(256), st, pyr, blur, g, G);
+        BH_LAUNCH(ctx, BH_K_BLUR, k_blur<true>, dim3(g.eblk_total, nb), dim3(256), st, pyr, blur, g, G);
+        BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, nms, hist, g, sel_cap, (uint32_t*)ctx->sel_xy.p,
+                  (float*)ctx->sel_resp.p, (int*)ctx->sel_cnt.p, (uint32_t*)ctx->status.p);
+        BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3((max_kp + 3) / 4, nb), dim3(256), st, pyr, blur, g, UM,
+                  (float)params->patchSize, sel_cap, max_kp, (const uint32_t*)ctx->sel_xy.p, (const float*)ctx->sel_resp.p,
+                  (const int*)ctx->sel_cnt.p, d_kps, d_desc, d_nkp, (uint32_t*)ctx->status.p);
         BH_HIP(ctx, hipGetLastError());
         if (mem == BH_MEM_HOST) {
             BH_HIP(ctx, hipMemcpyAsync(kps + (size_t)f0 * max_kp, d_kps, sizeof(bh_kp) * (size_t)max_kp * nb, hipMemcpyDeviceToHost, st));
