@@ -189,7 +189,11 @@ __device__ __forceinline__ int tile_level(const bh_orb_geom& g, int tile)
 #define FPX_H (TILE_H + 8)      //             y0-4 .. y0+35
 #define FSC_W (TILE_W + 2)      // score tile: x0-1 .. x0+64
 #define FSC_H (TILE_H + 2)
-#define FSC_P (FSC_W + 2)       // padded row
+#define FSC_P 72                // score-tile row pitch; tile column sx lives at byte sx+3 so output words are aligned
+#define FRG   12                // rows per lane in the sliding column pass (3 row groups x 66 columns)
+
+typedef short fs2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fs2 fswap(fs2 a) { return fs2{ a.y, a.x }; }
 
 __device__ __forceinline__ uint32_t contig9(uint32_t m)
 {
@@ -201,11 +205,13 @@ __device__ __forceinline__ uint32_t contig9(uint32_t m)
     return a & 0xffffu;
 }
 
+// One workgroup per 64x32 tile.  Each lane issues its 3 pixel-word loads and its 2 mask-word loads up front (the mask
+// words belong to the two output words the lane stores in phase 3), so no phase waits on a second global round trip.
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ mpyr,
                                               uint8_t* __restrict__ nms, uint32_t* __restrict__ hist, bh_orb_geom g)
 {
-    __shared__ uint32_t s_px[FPX_H * (FPX_W / 4)];
-    __shared__ uint8_t  s_sc[FSC_H * FSC_P];
+    __shared__ uint32_t s_px[(FPX_H + 2) * (FPX_W / 4)];        // +2 rows: the last row group reads past the tile (results unused)
+    __shared__ uint32_t s_scw[FSC_H * (FSC_P / 4)];
     __shared__ uint16_t s_list[FSC_H * FSC_W];
     __shared__ uint32_t s_hist[256];
     __shared__ int s_n;
@@ -216,40 +222,63 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
     const int t = blockIdx.x - L.tile_base;
     const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
     const int x0 = tx * TILE_W, y0 = ty * TILE_H;
-    const size_t fbase = (size_t)blockIdx.y * g.pyr_stride + L.off;
+    const int frame = blockIdx.y;
+    const size_t fbase = (size_t)frame * g.pyr_stride + L.off;
     const uint8_t* img = pyr + fbase;
 
-    s_hist[tid] = 0;
-    if (tid == 0) s_n = 0;
-    // load the pixel tile as aligned words; outside the image -> 0 (never used by a valid pixel)
-    for (int i = tid; i < FPX_H * (FPX_W / 4); i += 256) {
+    uint32_t pw[3], cm[2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int i = tid + 256 * j;
         const int r = i / (FPX_W / 4), c = i - r * (FPX_W / 4);
         const int y = y0 - 4 + r, x = x0 - 4 + c * 4;
-        uint32_t v = 0;
-        if (y >= 0 && y < L.h && x >= 0 && x < L.pitch) v = *reinterpret_cast<const uint32_t*>(img + (size_t)y * L.pitch + x);
-        s_px[i] = v;
+        uint32_t v = 0;                                          // outside the image -> 0 (never used by a valid pixel)
+        if (i < FPX_H * (FPX_W / 4) && y >= 0 && y < L.h && x >= 0 && x < L.pitch)
+            v = *reinterpret_cast<const uint32_t*>(img + (size_t)y * L.pitch + x);
+        pw[j] = v;
     }
-    for (int i = tid; i < FSC_H * FSC_P; i += 256) s_sc[i] = 0;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int wd = tid + 256 * j;
+        const int y = y0 + (wd >> 4), x = x0 + ((wd & 15) << 2);
+        uint32_t m = 0xffffffffu;
+        if (mpyr) m = y < L.h ? *reinterpret_cast<const uint32_t*>(mpyr + fbase + (size_t)y * L.pitch + x) : 0u;
+        cm[j] = m;
+    }
+    s_hist[tid] = 0;
+    if (tid == 0) s_n = 0;
+    for (int i = tid; i < FSC_H * (FSC_P / 4); i += 256) s_scw[i] = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { const int i = tid + 256 * j; if (i < FPX_H * (FPX_W / 4)) s_px[i] = pw[j]; }
+    const uint32_t cm0 = cm[0], cm1 = cm[1];
     __syncthreads();
 
     const uint8_t* px = reinterpret_cast<const uint8_t*>(s_px);
-    const int thr = g.fast_thr;
-    // phase 1: cheap necessary test on every pixel of the score tile (the opposite-pair rule of the reference detector:
-    // a 9-arc contains ring pixel k or k+8, so each opposite pair must hold a darker -- or a brighter -- pixel);
-    // pairs (0,8) and (4,12) reject ~97 % of the pixels; survivors go to an LDS list so that phase 2 runs dense.
-    for (int i = tid; i < FSC_H * FSC_W; i += 256) {
-        const int sy = i / FSC_W, sx = i - sy * FSC_W;
-        const int x = x0 - 1 + sx, y = y0 - 1 + sy;
-        if (x < 3 || x > L.w - 4 || y < 3 || y > L.h - 4) continue;
-        const uint8_t* c = px + (sy + 3) * FPX_W + (sx + 3);
-        const int v = c[0], lo = v - thr, hi = v + thr;
-        const int p0 = c[3 * FPX_W], p8 = c[-3 * FPX_W];
-        bool dk = (p0 < lo) | (p8 < lo), br = (p0 > hi) | (p8 > hi);
-        if (!(dk | br)) continue;
-        const int p4 = c[3], p12 = c[-3];
-        dk &= (p4 < lo) | (p12 < lo); br &= (p4 > hi) | (p12 > hi);
-        if (!(dk | br)) continue;
-        s_list[atomicAdd(&s_n, 1)] = (uint16_t)i;
+    uint8_t* s_sc = reinterpret_cast<uint8_t*>(s_scw);
+    const int thr = g.fast_thr, et = g.edge_thr;
+    // Only pixels that can survive the border filter, or suppress a survivor in the 3x3 NMS, need a score:
+    // [et-1, dim-et] intersected with the detector's own scan range [3, dim-4].
+    const int xlo = max(3, et - 1), xhi = min(L.w - 4, L.w - et), ylo = max(3, et - 1), yhi = min(L.h - 4, L.h - et);
+    // phase 1: cheap necessary test (opposite-pair rule of the reference detector: a 9-arc contains ring pixel k or k+8,
+    // so both pairs (0,8) and (4,12) must hold a darker -- or both a brighter -- pixel).  Branch-free, one lane walks
+    // 12 rows of one column with a 7-deep register window; survivors (a few %) go to an LDS list.
+    if (tid < 3 * FSC_W) {
+        const int rg = tid / FSC_W, col = tid - rg * FSC_W;
+        const int x = x0 - 1 + col;
+        const bool xok = x >= xlo && x <= xhi;
+        const uint8_t* cp = px + (rg * FRG) * FPX_W + (col + 3);        // px row of score row sy, ring row -3
+        int a0 = cp[0], a1 = cp[FPX_W], a2 = cp[2 * FPX_W], a3 = cp[3 * FPX_W], a4 = cp[4 * FPX_W], a5 = cp[5 * FPX_W];
+#pragma unroll
+        for (int r = 0; r < FRG; r++) {
+            const int sy = rg * FRG + r, y = y0 - 1 + sy;
+            const int a6 = cp[(r + 6) * FPX_W];
+            const int p4 = cp[(r + 3) * FPX_W + 3], p12 = cp[(r + 3) * FPX_W - 3];
+            const int v = a3, lo = v - thr, hi = v + thr;
+            const int dk = max(min(a6, a0), min(p4, p12)), br = min(max(a6, a0), max(p4, p12));
+            const bool pass = xok && sy < FSC_H && y >= ylo && y <= yhi && ((dk < lo) | (br > hi));
+            if (pass) s_list[atomicAdd(&s_n, 1)] = (uint16_t)(sy * FSC_W + col);
+            a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = a5; a5 = a6;
+        }
     }
     __syncthreads();
     // phase 2: full 16-pixel ring test on the survivors; corners get their score (largest threshold at which the pixel
@@ -265,53 +294,62 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
         d[4] = v - c[3];               d[5] = v - c[-FPX_W + 3];      d[6] = v - c[-2 * FPX_W + 2];  d[7] = v - c[-3 * FPX_W + 1];
         d[8] = v - c[-3 * FPX_W];      d[9] = v - c[-3 * FPX_W - 1];  d[10] = v - c[-2 * FPX_W - 2]; d[11] = v - c[-FPX_W - 3];
         d[12] = v - c[-3];             d[13] = v - c[FPX_W - 3];      d[14] = v - c[2 * FPX_W - 2];  d[15] = v - c[3 * FPX_W - 1];
-        uint32_t dm = 0, bm = 0;
+        // Packed 16-bit lanes: P[k] = (d[k], d[k+8]); the ring rotated by j is P[k+j], with P[8+i] = swap(P[i]).
+        // A = max over the 16 arcs of min(d over 9 ring pixels), Bn = min over arcs of max(d): the pixel is a corner iff
+        // A > thr or -Bn > thr, and its score (cornerScore<16>) is max(thr, A, -Bn) - 1.
+        fs2 P[8], mn[8], mx[8], t0[8], t1[8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) { dm |= (uint32_t)(d[k] > thr) << k; bm |= (uint32_t)(d[k] < -thr) << k; }
-        if (!(contig9(dm) | contig9(bm))) continue;
-        int mn2[16], mx2[16], mn4[16], mx4[16];
+        for (int k = 0; k < 8; k++) P[k] = fs2{ (short)d[k], (short)d[k + 8] };
 #pragma unroll
-        for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+        for (int k = 0; k < 8; k++) { const fs2 nx = k < 7 ? P[k + 1] : fswap(P[0]); mn[k] = __builtin_elementwise_min(P[k], nx); mx[k] = __builtin_elementwise_max(P[k], nx); }
 #pragma unroll
-        for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-        int a0 = thr, b0 = INT_MAX;
+        for (int k = 0; k < 8; k++) { t0[k] = __builtin_elementwise_min(mn[k], k < 6 ? mn[k + 2] : fswap(mn[k - 6])); t1[k] = __builtin_elementwise_max(mx[k], k < 6 ? mx[k + 2] : fswap(mx[k - 6])); }
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-            const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-            a0 = max(a0, mn9);
-            b0 = min(b0, mx9);
+        for (int k = 0; k < 8; k++) { mn[k] = __builtin_elementwise_min(t0[k], k < 4 ? t0[k + 4] : fswap(t0[k - 4])); mx[k] = __builtin_elementwise_max(t1[k], k < 4 ? t1[k + 4] : fswap(t1[k - 4])); }
+        fs2 am = fs2{ -32768, -32768 }, bm2 = fs2{ 32767, 32767 };
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const fs2 ninth = fswap(P[k]);                       // (d[k+8], d[k+16]) closes the 9-arc
+            am = __builtin_elementwise_max(am, __builtin_elementwise_min(mn[k], ninth));
+            bm2 = __builtin_elementwise_min(bm2, __builtin_elementwise_max(mx[k], ninth));
         }
-        b0 = min(b0, -a0);
-        s_sc[sy * FSC_P + sx] = (uint8_t)(-b0 - 1);
+        const int A = max((int)am.x, (int)am.y), Bn = min((int)bm2.x, (int)bm2.y);
+        if (!(A > thr || -Bn > thr)) continue;
+        const int a0 = max(thr, A);
+        const int b0 = min(Bn, -a0);
+        s_sc[sy * FSC_P + sx + 3] = (uint8_t)(-b0 - 1);
     }
     __syncthreads();
     // phase 3: strict 3x3 NMS, mask and border filter, dense score-map store (4 px per lane) + histogram
-    const uint8_t* msk = mpyr ? mpyr + fbase : nullptr;
-    const int et = g.edge_thr;
-    for (int wd = tid; wd < TILE_H * (TILE_W / 4); wd += 256) {
-        const int oy = wd / (TILE_W / 4), ox = (wd - oy * (TILE_W / 4)) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int wd = tid + 256 * j;
+        const int oy = wd >> 4, ox = (wd & 15) << 2;
         const int y = y0 + oy;
         if (y >= L.h) continue;
+        const uint32_t cm = j == 0 ? cm0 : cm1;
         uint32_t out = 0;
+        const uint32_t sc4 = s_scw[(oy + 1) * (FSC_P / 4) + (ox >> 2) + 1];        // tile columns ox+1 .. ox+4
+        if (sc4) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int x = x0 + ox + i;
-            const uint8_t* s = s_sc + (oy + 1) * FSC_P + (ox + i + 1);
-            const int sc = s[0];
-            if (sc == 0) continue;
-            const bool keep = sc > s[-1] && sc > s[1] && sc > s[-FSC_P - 1] && sc > s[-FSC_P] && sc > s[-FSC_P + 1] &&
-                              sc > s[FSC_P - 1] && sc > s[FSC_P] && sc > s[FSC_P + 1];
-            if (!keep) continue;
-            if (!(x >= et && x < L.w - et && y >= et && y < L.h - et)) continue;
-            if (msk && msk[(size_t)y * L.pitch + x] == 0) continue;
-            out |= (uint32_t)sc << (8 * i);
-            atomicAdd(&s_hist[sc], 1u);
+            for (int i = 0; i < 4; i++) {
+                const int sc = (sc4 >> (8 * i)) & 255;
+                if (sc == 0) continue;
+                const int x = x0 + ox + i;
+                const uint8_t* q = s_sc + (oy + 1) * FSC_P + (ox + i + 4);
+                const bool keep = sc > q[-1] && sc > q[1] && sc > q[-FSC_P - 1] && sc > q[-FSC_P] && sc > q[-FSC_P + 1] &&
+                                  sc > q[FSC_P - 1] && sc > q[FSC_P] && sc > q[FSC_P + 1];
+                if (!keep) continue;
+                if (!(x >= et && x < L.w - et && y >= et && y < L.h - et)) continue;
+                if (((cm >> (8 * i)) & 255u) == 0) continue;
+                out |= (uint32_t)sc << (8 * i);
+                atomicAdd(&s_hist[sc], 1u);
+            }
         }
         *reinterpret_cast<uint32_t*>(nms + fbase + (size_t)y * L.pitch + x0 + ox) = out;
     }
     __syncthreads();
-    if (s_hist[tid]) atomicAdd(&hist[((size_t)blockIdx.y * g.nlevels + level) * 256 + tid], s_hist[tid]);
+    if (s_hist[tid]) atomicAdd(&hist[((size_t)frame * g.nlevels + level) * 256 + tid], s_hist[tid]);
 }
 
 // ------------------------------------------------------------------------------------------------ 7x7 Gaussian blur
