@@ -28,7 +28,8 @@ static int align_up(int v, int a) { return (v + a - 1) / a * a; }
 static int build_geom(const bh_orb_params* p, int H, int W, bh_orb_geom* g)
 {
     if (!p || p->nlevels < 1 || p->nlevels > BH_MAX_LEVELS || p->firstLevel != 0 || p->patchSize != 31 ||
-        p->nfeatures < 0 || p->scaleFactor <= 1.0f || H < 1 || W < 1 || W > 16383 || H > 16383 ||
+        p->nfeatures < 0 || p->scaleFactor <= 1.0f || p->scaleFactor > 1.3f ||   // k_pyr_down: 4 outputs span <= 3 source words
+        H < 1 || W < 1 || W > 16383 || H > 16383 ||
         p->edgeThreshold < 19)   // Harris(4) / IC(15) / BRIEF(<=19) windows must stay inside the level image
         return BH_ERR_INVALID;
     memset(g, 0, sizeof(*g));
@@ -57,8 +58,8 @@ static int build_geom(const bh_orb_params* p, int H, int W, bh_orb_geom* g)
         L.nrb = (L.h + 15) / 16;
         L.bblk_base = bblk; bblk += (L.nsx_in * L.nrb + 255) / 256;
         L.eblk_base = eblk; eblk += (L.n_edge * L.nrb + 255) / 256;
-        L.tabx_off = tab; tab += L.w;
-        L.taby_off = tab; tab += L.h;
+        L.tabx_off = tab; tab += align_up(L.w, 4);
+        L.taby_off = tab; tab += align_up(L.h, 4);
         if (l < p->nlevels - 1) { L.nfeat = round_even_f(nd); sum += L.nfeat; nd *= factor; }
         else L.nfeat = p->nfeatures - sum > 0 ? p->nfeatures - sum : 0;
     }
@@ -136,6 +137,16 @@ __global__ __launch_bounds__(256) void k_gray_mask(const uint8_t* __restrict__ i
 
 // ------------------------------------------------------------------------------------------------ pyramid level l from l-1
 // INTER_LINEAR_EXACT arithmetic: horizontal 8.8 fixed point, vertical 16.16, round to nearest.
+// One lane produces 4 output pixels.  Its 4 coefficient entries come in one 16-B load; the <= 6 source columns they
+// reference lie inside 3 aligned words starting at (first column & ~3), so each of the two source rows is 3 word loads
+// per plane (image, mask) — 14 loads per lane, all issued before the first use — and the byte pairs are picked with
+// v_alignbyte instead of 16 single-byte loads per plane.
+__device__ __forceinline__ uint32_t pyr_pair(uint32_t W0, uint32_t W1, uint32_t W2, int rel)
+{   // bytes rel, rel+1 of the 12-byte window (rel <= 8); low 16 bits of the result
+    const uint32_t lo = rel < 4 ? W0 : W1, hi = rel < 4 ? W1 : W2;
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(rel & 3));
+}
+
 __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, uint8_t* __restrict__ mpyr,
                                                   bh_orb_geom g, int level, const uint32_t* __restrict__ tab)
 {
@@ -145,33 +156,49 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, uin
     const int y = idx / groups, x = (idx - y * groups) << 2;
     if (y >= D.h) return;
     const size_t fb = (size_t)blockIdx.y * g.pyr_stride;
+    const size_t o = fb + D.off + (size_t)y * D.pitch + x;
+    if (x >= D.w) {                                            // padding columns: keep them zero
+        *reinterpret_cast<uint32_t*>(pyr + o) = 0;
+        if (mpyr) *reinterpret_cast<uint32_t*>(mpyr + o) = 0;
+        return;
+    }
+    const uint4 tx4 = *reinterpret_cast<const uint4*>(tab + D.tabx_off + x);      // tabx_off is a multiple of 4, padded
     const uint32_t ty = tab[D.taby_off + y];
     const int r0 = ty >> 16, r1 = min(r0 + 1, S.h - 1);
     const uint32_t yc1 = ty & 0xffffu, yc0 = 256u - yc1;
-    const uint8_t* s0 = pyr + fb + S.off + (size_t)r0 * S.pitch;
-    const uint8_t* s1 = pyr + fb + S.off + (size_t)r1 * S.pitch;
-    const uint8_t* m0 = mpyr ? mpyr + fb + S.off + (size_t)r0 * S.pitch : nullptr;
-    const uint8_t* m1 = mpyr ? mpyr + fb + S.off + (size_t)r1 * S.pitch : nullptr;
+    const uint32_t txs[4] = { tx4.x, tx4.y, tx4.z, tx4.w };
+    const int base = (int)(tx4.x >> 16) & ~3;
+    const size_t s0 = fb + S.off + (size_t)r0 * S.pitch + base, s1 = fb + S.off + (size_t)r1 * S.pitch + base;
+    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(pyr + s0);
+    const uint32_t* p1 = reinterpret_cast<const uint32_t*>(pyr + s1);
+    const uint32_t A0 = p0[0], A1 = p0[1], A2 = p0[2], B0 = p1[0], B1 = p1[1], B2 = p1[2];
+    uint32_t MA0 = 0, MA1 = 0, MA2 = 0, MB0 = 0, MB1 = 0, MB2 = 0;
+    if (mpyr) {
+        const uint32_t* q0 = reinterpret_cast<const uint32_t*>(mpyr + s0);
+        const uint32_t* q1 = reinterpret_cast<const uint32_t*>(mpyr + s1);
+        MA0 = q0[0]; MA1 = q0[1]; MA2 = q0[2]; MB0 = q1[0]; MB1 = q1[1]; MB2 = q1[2];
+    }
     uint32_t o4 = 0, mo4 = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         if (x + i < D.w) {
-            const uint32_t tx = tab[D.tabx_off + x + i];
-            const int a = tx >> 16, b = min(a + 1, S.w - 1);
+            const uint32_t tx = txs[i];
+            const int rel = (int)(tx >> 16) - base;           // 0 .. 8
             const uint32_t c1 = tx & 0xffffu, c0 = 256u - c1;
-            uint32_t h0 = c0 * s0[a] + c1 * s0[b];
-            uint32_t h1 = c0 * s1[a] + c1 * s1[b];
+            uint32_t pa = pyr_pair(A0, A1, A2, rel), pb = pyr_pair(B0, B1, B2, rel);
+            uint32_t h0 = c0 * (pa & 255u) + c1 * ((pa >> 8) & 255u);
+            uint32_t h1 = c0 * (pb & 255u) + c1 * ((pb >> 8) & 255u);
             uint32_t v = (yc0 * h0 + yc1 * h1 + 32768u) >> 16;
             o4 |= v << (8 * i);
             if (mpyr) {
-                h0 = c0 * m0[a] + c1 * m0[b];
-                h1 = c0 * m1[a] + c1 * m1[b];
+                pa = pyr_pair(MA0, MA1, MA2, rel); pb = pyr_pair(MB0, MB1, MB2, rel);
+                h0 = c0 * (pa & 255u) + c1 * ((pa >> 8) & 255u);
+                h1 = c0 * (pb & 255u) + c1 * ((pb >> 8) & 255u);
                 v = (yc0 * h0 + yc1 * h1 + 32768u) >> 16;
                 mo4 |= (v > 254u ? v : 0u) << (8 * i);                 // THRESH_TOZERO at 254
             }
         }
     }
-    const size_t o = fb + D.off + (size_t)y * D.pitch + x;
     *reinterpret_cast<uint32_t*>(pyr + o) = o4;
     if (mpyr) *reinterpret_cast<uint32_t*>(mpyr + o) = mo4;
 }
@@ -734,12 +761,13 @@ static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
         return BH_OK;
     bh_orb_geom g;
     if (build_geom(p, H, W, &g) != BH_OK) return bh_set_err(ctx, BH_ERR_INVALID, "unsupported ORB parameters / image size");
-    uint32_t* tab = (uint32_t*)malloc(sizeof(uint32_t) * (g.tab_len + 1));
+    uint32_t* tab = (uint32_t*)calloc(g.tab_len + 4, sizeof(uint32_t));
     for (int l = 1; l < g.nlevels; l++) {
         lin_coeffs(g.lv[l - 1].w, g.lv[l].w, tab + g.lv[l].tabx_off);
+        for (int x = g.lv[l].w; x < align_up(g.lv[l].w, 4); x++) tab[g.lv[l].tabx_off + x] = tab[g.lv[l].tabx_off + g.lv[l].w - 1];
         lin_coeffs(g.lv[l - 1].h, g.lv[l].h, tab + g.lv[l].taby_off);
     }
-    int rc = bh_reserve(ctx, &ctx->tab, sizeof(uint32_t) * (g.tab_len + 1));
+    int rc = bh_reserve(ctx, &ctx->tab, sizeof(uint32_t) * (g.tab_len + 4));
     if (rc == BH_OK) {
         hipError_t e = hipMemcpyAsync(ctx->tab.p, tab, sizeof(uint32_t) * g.tab_len, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -786,8 +814,8 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
     const bool has_mask = mask != nullptr || depth != nullptr;
 
     const size_t ws = (size_t)g.pyr_stride * chunk;
-    BH_TRY(bh_reserve(ctx, &ctx->pyr, ws));
-    if (has_mask) BH_TRY(bh_reserve(ctx, &ctx->mpyr, ws));
+    BH_TRY(bh_reserve(ctx, &ctx->pyr, ws + 256));             // +256: the 12-byte resize windows may read past the last row
+    if (has_mask) BH_TRY(bh_reserve(ctx, &ctx->mpyr, ws + 256));
     BH_TRY(bh_reserve(ctx, &ctx->nms, ws));
     BH_TRY(bh_reserve(ctx, &ctx->blur, ws));
     BH_TRY(bh_reserve(ctx, &ctx->hist, sizeof(uint32_t) * 256 * g.nlevels * chunk));
