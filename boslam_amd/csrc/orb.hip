@@ -537,9 +537,14 @@ __global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ py
     const int seg = (nvec + SEL_W - 1) / SEL_W;
     const int v0 = wv * seg, v1 = min(v0 + seg, nvec);
     int cnt = 0;
-    for (int v = v0 + lane; v < v1; v += 64) {
-        const uint4 q = map[v];
-        if (q.x | q.y | q.z | q.w) cnt += count_ge(q.x, thr) + count_ge(q.y, thr) + count_ge(q.z, thr) + count_ge(q.w, thr);
+    for (int vb = v0; vb < v1; vb += 256) {                   // 4 independent 16-B loads in flight per lane
+        uint4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int v = vb + u * 64 + lane; q[u] = v < v1 ? map[v] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (q[u].x | q[u].y | q[u].z | q[u].w)
+                cnt += count_ge(q[u].x, thr) + count_ge(q[u].y, thr) + count_ge(q[u].z, thr) + count_ge(q[u].w, thr);
     }
     cnt = wave_sum(cnt);
     if (lane == 0) s_wcnt[wv] = cnt;
@@ -547,23 +552,28 @@ __global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ py
     int base = 0, total = 0;
     for (int i = 0; i < SEL_W; i++) { const int c = s_wcnt[i]; if (i < wv) base += c; total += c; }
     // (c) pass B: emit (x,y) in raster order
-    for (int vb = v0; vb < v1; vb += 64) {
-        const int v = vb + lane;
-        uint4 q = make_uint4(0, 0, 0, 0);
-        if (v < v1) q = map[v];
-        const uint32_t wds[4] = { q.x, q.y, q.z, q.w };
-        int c = 0;
-        if (q.x | q.y | q.z | q.w) c = count_ge(q.x, thr) + count_ge(q.y, thr) + count_ge(q.z, thr) + count_ge(q.w, thr);
-        if (__ballot(c != 0) == 0ull) continue;
-        int pos = base + wave_excl_scan(c, lane);
-        base += wave_sum(c);
-        if (c) {
-            const int byte0 = v << 4;
-            const int y = byte0 / L.pitch, xb = byte0 - y * L.pitch;
+    for (int vb4 = v0; vb4 < v1; vb4 += 256) {
+        uint4 q4[4];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t sc = (wds[k >> 2] >> (8 * (k & 3))) & 255u;
-                if (sc >= thr) { if (pos < CAND_CAP) s_xy[pos] = ((uint32_t)y << 16) | (uint32_t)(xb + k); pos++; }
+        for (int u = 0; u < 4; u++) { const int v = vb4 + u * 64 + lane; q4[u] = v < v1 ? map[v] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int v = vb4 + u * 64 + lane;
+            const uint4 q = q4[u];
+            const uint32_t wds[4] = { q.x, q.y, q.z, q.w };
+            int c = 0;
+            if (q.x | q.y | q.z | q.w) c = count_ge(q.x, thr) + count_ge(q.y, thr) + count_ge(q.z, thr) + count_ge(q.w, thr);
+            if (__ballot(c != 0) == 0ull) continue;
+            int pos = base + wave_excl_scan(c, lane);
+            base += wave_sum(c);
+            if (c) {
+                const int byte0 = v << 4;
+                const int y = byte0 / L.pitch, xb = byte0 - y * L.pitch;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t sc = (wds[k >> 2] >> (8 * (k & 3))) & 255u;
+                    if (sc >= thr) { if (pos < CAND_CAP) s_xy[pos] = ((uint32_t)y << 16) | (uint32_t)(xb + k); pos++; }
+                }
             }
         }
     }
@@ -580,6 +590,7 @@ __global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ py
         const uint8_t* p = img + (size_t)(cy - 4) * L.pitch + cx - 4;
 #pragma unroll
         for (int k = 0; k < 9; k++) { r0[k] = p[k]; r1[k] = p[L.pitch + k]; }
+#pragma unroll
         for (int row = 2; row < 9; row++) {
             const uint8_t* q = p + (size_t)row * L.pitch;
 #pragma unroll
@@ -642,6 +653,10 @@ __constant__ signed char c_pattern[1024] = {
 #include "brief_pattern.h"
 };
 
+// One wave per (frame, level, slot).  The final keypoint index is the prefix of the per-level counts plus the slot
+// (canonical order: level-major, raster inside a level).  Intensity-centroid angle: lanes cover 2 rows x 32 columns of
+// the 31x31 patch per step, integer wave reduction, fastAtan2.  Steered BRIEF: lane l evaluates tests l, 64+l, 128+l,
+// 192+l; four ballots give the 32 descriptor bytes.
 // One wave per (frame, level, slot).  The final keypoint index is the prefix of the per-level counts plus the slot
 // (canonical order: level-major, raster inside a level).  Intensity-centroid angle: lanes cover 2 rows x 32 columns of
 // the 31x31 patch per step, integer wave reduction, fastAtan2.  Steered BRIEF: lane l evaluates tests l, 64+l, 128+l,
