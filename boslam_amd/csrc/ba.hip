@@ -129,6 +129,12 @@ __device__ __forceinline__ double d_shfl_xor(double v, int m)
     lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double d_shfl_idx(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl(lo, src, 64); hi = __shfl(hi, src, 64);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double d_wave_sum(double v)
 {
 #pragma unroll
@@ -557,51 +563,162 @@ __global__ __launch_bounds__(256) void k_ba_schur_b(const int* __restrict__ c_st
     if (tid < 6) bs[6 * s + tid] = bp[6 * s + tid] - acc[tid];
 }
 
-// ---- k_ba_chol: one workgroup; in-place right-looking Cholesky of S (n x n, row-major, lower used) + two triangular solves
+// ---- k_ba_chol: one workgroup, blocked right-looking Cholesky of S (n x n, row-major, lower triangle) + both substitutions.
+// Per NB-column panel: the panel (n-j0 rows x NB) is staged in LDS; wave 0 factors the NB x NB diagonal block; one lane
+// per row does the triangular solve of the rows below; the trailing update A22 -= L21 L21' runs on the matrix cores
+// (v_mfma_f64_16x16x4_f64, one 16x16 tile per wave and step, operands straight from the LDS panel); the forward
+// substitution rides along panel by panel, the backward one re-stages the panels in reverse.  All sums in fixed order.
+typedef double ba_d4 __attribute__((ext_vector_type(4)));
+
+template <int NB>
 __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const double* __restrict__ bs, int n,
                                                   double* __restrict__ x, ba_state* __restrict__ St)
 {
-    __shared__ double s_col[2048];
+    extern __shared__ double sm[];
+    constexpr int PP = NB + 1;
+    double* P = sm;                                   // panel, row pitch NB+1
+    double* yv = sm + (size_t)n * PP;                 // right-hand side -> solution
+    double* part = yv + n;                            // [32][NB] partial sums of the backward pass
     __shared__ int s_fail;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_fail = St->chol_ok ? 0 : 1;
+    for (int i = tid; i < n; i += 1024) yv[i] = bs[i];
     __syncthreads();
-    for (int j = 0; j < n && !s_fail; j++) {
-        const double d = A[(size_t)j * n + j];
-        if (!(d > 0) || !isfinite(d)) { __syncthreads(); if (tid == 0) s_fail = 1; __syncthreads(); break; }
-        const double sd = sqrt(d);
-        for (int i = j + tid; i < n; i += 1024) {
-            const double l = (i == j) ? sd : A[(size_t)i * n + j] / sd;
-            s_col[i] = l;
-            A[(size_t)i * n + j] = l;
+    for (int j0 = 0; j0 < n && !s_fail; j0 += NB) {
+        const int nbw = min(NB, n - j0), m = n - j0;
+        for (int idx = tid; idx < m * NB; idx += 1024) {
+            const int r = idx / NB, c = idx - r * NB;
+            P[r * PP + c] = c < nbw ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
         }
         __syncthreads();
-        const int m = n - j - 1;                                  // trailing rows j+1 .. n-1, lower triangle only
-        for (int idx = tid; idx < m * m; idx += 1024) {
-            const int r = idx / m, c = idx - r * m;
-            if (c <= r) A[(size_t)(j + 1 + r) * n + j + 1 + c] -= s_col[j + 1 + r] * s_col[j + 1 + c];
+        if (wv == 0) {                                // diagonal block in registers: lane l owns row l
+            double row[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) row[k] = lane < nbw ? P[lane * PP + k] : 0.0;
+            double* colb = part;                       // exchange buffer (>= 64 doubles), wave-private here
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < NB; c++) {
+                if (c < nbw) {
+                    if (lane == c) colb[64] = row[c];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    const double d = colb[64];
+                    if (!(d > 0) || !isfinite(d)) bad = true;
+                    const double sd = sqrt(d);
+                    const double lc = lane == c ? sd : row[c] / sd;
+                    if (lane >= c) row[c] = lc;
+                    colb[lane] = lc;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+                    for (int c2 = c + 1; c2 < NB; c2++) if (c2 <= lane) row[c2] -= lc * colb[c2];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                }
+            }
+            if (lane < nbw) {
+#pragma unroll
+                for (int k = 0; k < NB; k++) P[lane * PP + k] = row[k];
+            }
+            if (bad && lane == 0) s_fail = 1;
+        }
+        __syncthreads();
+        if (s_fail) break;
+        for (int r = nbw + tid; r < m; r += 1024) {   // rows below the diagonal block: L21 = A21 * L11^-T, row in registers
+            double rw[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) rw[k] = P[r * PP + k];
+#pragma unroll
+            for (int c = 0; c < NB; c++) {
+                if (c < nbw) {
+                    double s2 = rw[c];
+#pragma unroll
+                    for (int k = 0; k < c; k++) s2 -= rw[k] * P[c * PP + k];
+                    rw[c] = s2 / P[c * PP + c];
+                } else rw[c] = 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < NB; k++) P[r * PP + k] = rw[k];
+        }
+        if (wv == 0) {                                // forward substitution inside the panel: lane l owns y[j0+l]
+            double yl = lane < nbw ? yv[j0 + lane] : 0.0;
+            for (int c = 0; c < nbw; c++) {
+                const double yc = d_shfl_idx(yl, c) / P[c * PP + c];
+                if (lane == c) yl = yc;
+                else if (lane > c && lane < nbw) yl -= P[lane * PP + c] * yc;
+            }
+            if (lane < nbw) yv[j0 + lane] = yl;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < m * nbw; idx += 1024) {
+            const int r = idx / nbw, c = idx - r * nbw;
+            A[(size_t)(j0 + r) * n + j0 + c] = P[r * PP + c];
+        }
+        for (int r = nbw + tid; r < m; r += 1024) {   // right-hand side below the panel
+            double s2 = yv[j0 + r];
+            for (int c = 0; c < nbw; c++) s2 -= P[r * PP + c] * yv[j0 + c];
+            yv[j0 + r] = s2;
+        }
+        // trailing update on the matrix cores: 16x16 tiles of the lower triangle, K = NB in steps of 4
+        const int mt = m - nbw, nt = (mt + 15) >> 4;
+        for (int t = wv; t < nt * (nt + 1) / 2; t += 16) {
+            int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+            while (ti * (ti + 1) / 2 > t) ti--;
+            while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+            const int tj = t - ti * (ti + 1) / 2;
+            const int ra = nbw + 16 * ti + (lane & 15), rb = nbw + 16 * tj + (lane & 15), kq = lane >> 4;
+            const int col = nbw + 16 * tj + (lane & 15);
+            double old[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {           // the tile's current values: in flight while the MFMAs run
+                const int row = nbw + 16 * ti + (lane >> 4) + 4 * rg;
+                old[rg] = (row < m && col < m && col <= row) ? A[(size_t)(j0 + row) * n + j0 + col] : 0.0;
+            }
+            ba_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int ks = 0; ks < NB / 4; ks++) {
+                const double av = ra < m ? P[ra * PP + 4 * ks + kq] : 0.0;
+                const double bv = rb < m ? P[rb * PP + 4 * ks + kq] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+                const int row = nbw + 16 * ti + (lane >> 4) + 4 * rg;
+                if (row < m && col < m && col <= row) A[(size_t)(j0 + row) * n + j0 + col] = old[rg] - acc[rg];
+            }
         }
         __syncthreads();
     }
     if (s_fail) { if (tid == 0) St->chol_ok = 0; for (int i = tid; i < n; i += 1024) x[i] = 0; return; }
-    // forward / backward substitution by one wave-ordered sweep (n is small)
-    for (int i = tid; i < n; i += 1024) s_col[i] = bs[i];
-    __syncthreads();
-    for (int i = 0; i < n; i++) {
-        if (tid == 0) s_col[i] = s_col[i] / A[(size_t)i * n + i];
+    // backward substitution L' x = y, panels in reverse
+    const int last = ((n - 1) / NB) * NB;
+    for (int j0 = last; j0 >= 0; j0 -= NB) {
+        const int nbw = min(NB, n - j0), m = n - j0;
+        for (int idx = tid; idx < m * nbw; idx += 1024) {
+            const int r = idx / nbw, c = idx - r * nbw;
+            P[r * PP + c] = A[(size_t)(j0 + r) * n + j0 + c];
+        }
         __syncthreads();
-        const double xi = s_col[i];
-        for (int r = i + 1 + tid; r < n; r += 1024) s_col[r] -= A[(size_t)r * n + i] * xi;
+        {   // part[p][c] = sum over rows r = nbw + p, nbw + p + 32, ... of L[r][c] * x[r]
+            const int c = tid & (NB - 1), p = tid / NB;             // 1024 / NB parts
+            constexpr int NP = 1024 / NB;
+            double s2 = 0;
+            if (c < nbw) for (int r = nbw + p; r < m; r += NP) s2 += P[r * PP + c] * yv[j0 + r];
+            part[p * NB + c] = s2;
+            __syncthreads();
+            if (tid < nbw) { double tot = 0; for (int q = 0; q < NP; q++) tot += part[q * NB + tid]; yv[j0 + tid] -= tot; }
+            __syncthreads();
+        }
+        if (wv == 0) {                                // backward substitution inside the panel
+            double yl = lane < nbw ? yv[j0 + lane] : 0.0;
+            for (int c = nbw - 1; c >= 0; c--) {
+                const double xc = d_shfl_idx(yl, c) / P[c * PP + c];
+                if (lane == c) yl = xc;
+                else if (lane < c) yl -= P[c * PP + lane] * xc;
+            }
+            if (lane < nbw) yv[j0 + lane] = yl;
+        }
         __syncthreads();
     }
-    for (int i = n - 1; i >= 0; i--) {
-        if (tid == 0) s_col[i] = s_col[i] / A[(size_t)i * n + i];
-        __syncthreads();
-        const double xi = s_col[i];
-        for (int r = tid; r < i; r += 1024) s_col[r] -= A[(size_t)i * n + r] * xi;
-        __syncthreads();
-    }
-    for (int i = tid; i < n; i += 1024) x[i] = s_col[i];
+    for (int i = tid; i < n; i += 1024) x[i] = yv[i];
 }
 
 // ---- k_ba_update: trial state = current state (+) step.  blocks [0, pblocks): points (back-substitution); rest: cameras
@@ -729,6 +846,9 @@ static void h_quat_from_R(const double* m, double* q)
 extern "C" int bh_ba_create(bh_ctx* ctx, const double K[5], bh_ba** out)
 {
     if (!ctx || !K || !out) return BH_ERR_INVALID;
+    (void)hipFuncSetAttribute((const void*)k_ba_chol<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_ba_chol<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_ba_chol<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
     bh_ba* ba = new bh_ba();
     ba->ctx = ctx; ba->K = { K[0], K[1], K[2], K[3] };
     *out = ba;
@@ -778,7 +898,7 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     for (int i = 0; i < C; i++) if (cam_used[i] && !fixed[i]) ba->cam_slot[i] = Cf++;
     for (int j = 0; j < P; j++) if (ba->pt_slot[j] == 0) ba->pt_slot[j] = Pa++;
     ba->Cf = Cf; ba->Pa = Pa; ba->Ea = E;
-    if (6 * Cf > 2048) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: %d free keyframes exceed the local-BA solver (341); global BA is a later row", Cf);
+    if (6 * Cf > 1536) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: %d free keyframes exceed the local-BA solver (256); global BA is a later row", Cf);
     std::vector<ba_cam> cams(C);
     for (int i = 0; i < C; i++) {
         memset(&cams[i], 0, sizeof(ba_cam));
@@ -886,7 +1006,15 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                           (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, n6, S);
                 BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_b, dim3(Cf), dim3(256), st, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)db,
                           (const double*)bp, bs);
-                BH_LAUNCH(ctx, BH_K_BA_SOLVE, k_ba_chol, dim3(1), dim3(1024), st, S, (const double*)bs, n6, dxp, state);
+                {   // panel width by LDS budget: panel n x (NB+1) + rhs n + 1024 partial sums, all f64
+                    const int nbsel = n6 <= 448 ? 32 : (n6 <= 896 ? 16 : 8);
+                    const size_t lds = sizeof(double) * ((size_t)n6 * (nbsel + 1) + n6 + 1024);
+                    bh_time_begin(ctx, BH_K_BA_SOLVE);
+                    if (nbsel == 32) hipLaunchKernelGGL(k_ba_chol<32>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, dxp, state);
+                    else if (nbsel == 16) hipLaunchKernelGGL(k_ba_chol<16>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, dxp, state);
+                    else hipLaunchKernelGGL(k_ba_chol<8>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, dxp, state);
+                    bh_time_end(ctx);
+                }
             }
             BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_update, dim3(pblocks + cblocks), dim3(256), st, cams, cams_t, pts, pts_t, cslot, C, Pa, pblocks,
                       p_start, p_edges, e_cam, (const double*)Hpl, (const double*)Dinv, (const double*)bl, (const double*)dxp, dxl, ba->K);
