@@ -51,6 +51,8 @@ _SIGS = {
     "bh_ba_get_points": (_i, [_vp, _vp, _i]),
     "bh_ba_get_chi2": (_i, [_vp, _vp, _i]),
     "bh_ba_get_log": (_i, [_vp, _vp, _i]),
+    "bh_solve_pnp_ransac": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i]),
+    "bh_rodrigues": (_i, [_vp, _i, _vp]),
     "bh_visibility_gate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _d, _d, _d, _i, _i, _d, _vp, _vp, _i]),
     "bh_bow_create": (_i, [_vp, C.POINTER(_vp)]),
     "bh_bow_destroy": (None, [_vp]),

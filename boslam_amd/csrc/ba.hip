@@ -501,6 +501,7 @@ __global__ __launch_bounds__(256) void k_ba_dinv(const double* __restrict__ Hll,
     for (int a = 0; a < 3; a++) db[3 * j + a] = Di[3 * a] * bl[3 * j] + Di[3 * a + 1] * bl[3 * j + 1] + Di[3 * a + 2] * bl[3 * j + 2];
 }
 
+#define SCH_LDS 6144
 // ---- k_ba_schur_S: workgroup per camera pair (s1 <= s2): S[s1][s2] = [s1==s2](Hpp + lambda I) - sum_j Hpl_1j Dinv_j Hpl_2j'
 __global__ __launch_bounds__(256) void k_ba_schur_S(const int2* __restrict__ pairs, const int* __restrict__ c_start,
                                                     const int* __restrict__ c_edges, const int* __restrict__ e_pt,
@@ -509,17 +510,24 @@ __global__ __launch_bounds__(256) void k_ba_schur_S(const int2* __restrict__ pai
                                                     int n6, double* __restrict__ Sm)
 {
     __shared__ double s_red[36 * 4];
+    __shared__ int s_pt2[SCH_LDS];                         // camera s2's point ids (ascending): the join searches LDS
     const int tid = threadIdx.x;
     const int s1 = pairs[blockIdx.x].x, s2 = pairs[blockIdx.x].y;
     const int a0 = c_start[s1], a1 = c_start[s1 + 1], b0 = c_start[s2], b1 = c_start[s2 + 1];
+    const int n2 = b1 - b0;
+    const bool in_lds = n2 <= SCH_LDS;
+    if (in_lds) for (int i = tid; i < n2; i += 256) s_pt2[i] = e_pt[c_edges[b0 + i]];
+    __syncthreads();
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0;
     for (int u = a0 + tid; u < a1; u += 256) {
         const int e1 = c_edges[u];
         const int j = e_pt[e1];
-        int lo = b0, hi = b1;                                    // lower_bound of j in camera s2's point-sorted list
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (e_pt[c_edges[mid]] < j) lo = mid + 1; else hi = mid; }
+        int lo = 0, hi = n2;                                     // lower_bound of j in camera s2's point-sorted list
+        if (in_lds) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pt2[mid] < j) lo = mid + 1; else hi = mid; } }
+        else { while (lo < hi) { const int mid = (lo + hi) >> 1; if (e_pt[c_edges[b0 + mid]] < j) lo = mid + 1; else hi = mid; } }
+        lo += b0;
         for (int v = lo; v < b1 && e_pt[c_edges[v]] == j; v++) {
             const int e2 = c_edges[v];
             const double* B1 = Hpl + 18 * (size_t)e1; const double* B2 = Hpl + 18 * (size_t)e2; const double* Di = Dinv + 9 * (size_t)j;

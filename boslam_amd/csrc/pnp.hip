@@ -1,0 +1,571 @@
+// pnp.hip — solvePnPRansac / Rodrigues on gfx950.
+//
+// Replaces cv2.solvePnPRansac(obj, img, K, dist=0, flags=SOLVEPNP_ITERATIVE) and cv2.Rodrigues as called at
+// experiments/pnp_two_way_tracking.py:57-61,68-69 (and the dead branch slam/tracking.py:68-71), batched over B problems.
+//
+// One 256-lane workgroup per problem.  OpenCV's RANSAC loop is sequential (each improvement shrinks the iteration budget),
+// but its sample stream does not depend on the models, so the loop is unrolled in space:
+//   phase 0  lane 0 replays cv::RNG((uint64)-1) and writes every 5-point subset the sequential loop could ever draw;
+//   phase 1  one lane per hypothesis solves EPnP on its subset (control points, 12x12 M'M null space by cyclic Jacobi,
+//            betas for N = 1..3 + Gauss-Newton, Arun alignment) — f64, per-lane scratch;
+//   phase 2  all lanes score all hypotheses against all points (float32 squared reprojection error, LDS integer counters);
+//   phase 3  lane 0 replays the sequential "better than the best so far -> shrink niters" rule and names the winner;
+//   phase 4  Levenberg-Marquardt on the winner's inliers (block-reduced 6x6 normal equations), ordered inlier compaction.
+// Inputs are rounded to float32 first, as solvePnPRansac does (CV_64F -> CV_32F).
+#include "bh_internal.h"
+#include <math.h>
+#include <float.h>
+
+#define PNP_T 256
+#define PNP_MAX_HYP 256
+
+struct pnp_K { double fu, fv, uc, vc; };
+
+// ------------------------------------------------------------------------------------------------ small linear algebra
+template <int N>
+__device__ void pj_eig(const double* Ain, double* d, double* Vt)      // symmetric cyclic Jacobi; eigenvalues descending, vectors in rows
+{
+    double A[N * N], V[N * N];
+    for (int i = 0; i < N * N; i++) A[i] = Ain[i];
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) V[i * N + j] = i == j;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0;
+        for (int p = 0; p < N; p++) for (int q = p + 1; q < N; q++) off += A[p * N + q] * A[p * N + q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < N - 1; p++)
+            for (int q = p + 1; q < N; q++) {
+                const double apq = A[p * N + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double tau = (A[q * N + q] - A[p * N + p]) / (2.0 * apq);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                for (int k = 0; k < N; k++) { const double akp = A[k * N + p], akq = A[k * N + q]; A[k * N + p] = c * akp - s * akq; A[k * N + q] = s * akp + c * akq; }
+                for (int k = 0; k < N; k++) { const double apk = A[p * N + k], aqk = A[q * N + k]; A[p * N + k] = c * apk - s * aqk; A[q * N + k] = s * apk + c * aqk; }
+                for (int k = 0; k < N; k++) { const double vkp = V[k * N + p], vkq = V[k * N + q]; V[k * N + p] = c * vkp - s * vkq; V[k * N + q] = s * vkp + c * vkq; }
+            }
+    }
+    int order[N];
+    for (int i = 0; i < N; i++) order[i] = i;
+    for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) if (A[order[j] * N + order[j]] > A[order[i] * N + order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    for (int i = 0; i < N; i++) { d[i] = A[order[i] * N + order[i]]; for (int k = 0; k < N; k++) Vt[i * N + k] = V[k * N + order[i]]; }
+}
+
+template <int N>
+__device__ void p_lsq(const double* A, const double* b, int m, double* x)     // min |Ax-b| via eigen-decomposition of A'A
+{
+    double AtA[N * N], Atb[N], d[N], Vt[N * N];
+    for (int i = 0; i < N; i++) {
+        Atb[i] = 0; for (int k = 0; k < m; k++) Atb[i] += A[k * N + i] * b[k];
+        for (int j = 0; j < N; j++) { double s = 0; for (int k = 0; k < m; k++) s += A[k * N + i] * A[k * N + j]; AtA[i * N + j] = s; }
+    }
+    pj_eig<N>(AtA, d, Vt);
+    for (int i = 0; i < N; i++) x[i] = 0;
+    for (int e = 0; e < N; e++) {
+        if (d[e] <= d[0] * 1e-14 || d[e] <= 0) continue;
+        double c = 0; for (int i = 0; i < N; i++) c += Vt[e * N + i] * Atb[i];
+        c /= d[e];
+        for (int i = 0; i < N; i++) x[i] += c * Vt[e * N + i];
+    }
+}
+
+__device__ void p_svd3(const double* A, double* U, double* s, double* V)       // one-sided Jacobi
+{
+    double B[9];
+    for (int i = 0; i < 9; i++) { B[i] = A[i]; V[i] = (i % 4) == 0; }
+    for (int sweep = 0; sweep < 40; sweep++) {
+        int rot = 0;
+        for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
+            double al = 0, be = 0, ga = 0;
+            for (int k = 0; k < 3; k++) { al += B[k * 3 + p] * B[k * 3 + p]; be += B[k * 3 + q] * B[k * 3 + q]; ga += B[k * 3 + p] * B[k * 3 + q]; }
+            if (fabs(ga) <= 1e-300 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+            rot = 1;
+            const double zeta = (be - al) / (2.0 * ga);
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+            for (int k = 0; k < 3; k++) {
+                const double bp = B[k * 3 + p], bq = B[k * 3 + q]; B[k * 3 + p] = c * bp - sn * bq; B[k * 3 + q] = sn * bp + c * bq;
+                const double vp = V[k * 3 + p], vq = V[k * 3 + q]; V[k * 3 + p] = c * vp - sn * vq; V[k * 3 + q] = sn * vp + c * vq;
+            }
+        }
+        if (!rot) break;
+    }
+    for (int j = 0; j < 3; j++) {
+        const double nrm = sqrt(B[j] * B[j] + B[3 + j] * B[3 + j] + B[6 + j] * B[6 + j]);
+        s[j] = nrm;
+        for (int k = 0; k < 3; k++) U[k * 3 + j] = nrm > 1e-300 ? B[k * 3 + j] / nrm : 0.0;
+    }
+    for (int j = 0; j < 3; j++) if (s[j] <= 1e-300) {
+        const int a = (j + 1) % 3, b = (j + 2) % 3;
+        U[0 * 3 + j] = U[1 * 3 + a] * U[2 * 3 + b] - U[2 * 3 + a] * U[1 * 3 + b];
+        U[1 * 3 + j] = U[2 * 3 + a] * U[0 * 3 + b] - U[0 * 3 + a] * U[2 * 3 + b];
+        U[2 * 3 + j] = U[0 * 3 + a] * U[1 * 3 + b] - U[1 * 3 + a] * U[0 * 3 + b];
+    }
+}
+
+__host__ __device__ inline double p_det3(const double* m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+__device__ bool p_inv3(const double* m, double* o)
+{
+    const double d = p_det3(m);
+    if (fabs(d) < 1e-300) return false;
+    const double id = 1.0 / d;
+    o[0] = (m[4] * m[8] - m[5] * m[7]) * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = (m[5] * m[6] - m[3] * m[8]) * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = (m[3] * m[7] - m[4] * m[6]) * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return true;
+}
+__host__ __device__ inline double p_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ inline double p_dist2(const double* a, const double* b) { const double d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2]; return d0 * d0 + d1 * d1 + d2 * d2; }
+
+// ------------------------------------------------------------------------------------------------ Rodrigues (host + device)
+__host__ __device__ void p_rodrigues_v2m(const double* r, double* R)
+{
+    const double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (th < DBL_EPSILON) { for (int i = 0; i < 9; i++) R[i] = (i % 4) == 0; return; }
+    const double c = cos(th), s = sin(th), c1 = 1.0 - c, it = 1.0 / th;
+    const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
+    R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
+    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
+    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+}
+
+__host__ __device__ void p_rodrigues_m2v(const double* R, double* r)
+{
+    const double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    const double th = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
+        double t;
+        t = (R[0] + 1) * 0.5; r[0] = sqrt(t > 0 ? t : 0);
+        t = (R[4] + 1) * 0.5; r[1] = sqrt(t > 0 ? t : 0) * (R[1] < 0 ? -1. : 1.);
+        t = (R[8] + 1) * 0.5; r[2] = sqrt(t > 0 ? t : 0) * (R[2] < 0 ? -1. : 1.);
+        if (fabs(r[0]) < fabs(r[1]) && fabs(r[0]) < fabs(r[2]) && (R[5] > 0) != (r[1] * r[2] > 0)) r[2] = -r[2];
+        const double nr = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        const double k = th / nr; r[0] *= k; r[1] *= k; r[2] *= k;
+        return;
+    }
+    const double vth = 1.0 / (2 * s) * th;
+    r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
+}
+
+extern "C" int bh_rodrigues(const double* in, int in_len, double* out)
+{
+    if (!in || !out) return BH_ERR_INVALID;
+    if (in_len == 3) { p_rodrigues_v2m(in, out); return BH_OK; }
+    if (in_len == 9) { p_rodrigues_m2v(in, out); return BH_OK; }
+    return BH_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------------------------------------ EPnP on a 5-point sample
+#define NS 5
+
+__device__ double p_epnp_R_t(const double* pws, const double* us, const double* alphas, pnp_K K, const double* ut,
+                             const double* betas, double* R, double* t)
+{
+    double ccs[4][3];
+    for (int i = 0; i < 4; i++) ccs[i][0] = ccs[i][1] = ccs[i][2] = 0;
+    for (int i = 0; i < 4; i++) {
+        const double* v = ut + 12 * (11 - i);
+        for (int j = 0; j < 4; j++) for (int k = 0; k < 3; k++) ccs[j][k] += betas[i] * v[3 * j + k];
+    }
+    double pcs[3 * NS];
+    for (int i = 0; i < NS; i++) for (int j = 0; j < 3; j++)
+        pcs[3 * i + j] = alphas[4 * i] * ccs[0][j] + alphas[4 * i + 1] * ccs[1][j] + alphas[4 * i + 2] * ccs[2][j] + alphas[4 * i + 3] * ccs[3][j];
+    if (pcs[2] < 0.0) for (int i = 0; i < 3 * NS; i++) pcs[i] = -pcs[i];
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+    for (int i = 0; i < NS; i++) for (int j = 0; j < 3; j++) { pc0[j] += pcs[3 * i + j]; pw0[j] += pws[3 * i + j]; }
+    for (int j = 0; j < 3; j++) { pc0[j] /= NS; pw0[j] /= NS; }
+    double ABt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < NS; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++)
+        ABt[3 * j + k] += (pcs[3 * i + j] - pc0[j]) * (pws[3 * i + k] - pw0[k]);
+    double U[9], s[3], V[9];
+    p_svd3(ABt, U, s, V);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = U[3 * i] * V[3 * j] + U[3 * i + 1] * V[3 * j + 1] + U[3 * i + 2] * V[3 * j + 2];
+    if (p_det3(R) < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
+    for (int i = 0; i < 3; i++) t[i] = pc0[i] - p_dot(R + 3 * i, pw0);
+    double sum2 = 0;
+    for (int i = 0; i < NS; i++) {
+        const double* pw = pws + 3 * i;
+        const double Xc = p_dot(R, pw) + t[0], Yc = p_dot(R + 3, pw) + t[1], inv_Zc = 1.0 / (p_dot(R + 6, pw) + t[2]);
+        const double ue = K.uc + K.fu * Xc * inv_Zc, ve = K.vc + K.fv * Yc * inv_Zc;
+        const double u = us[2 * i], v = us[2 * i + 1];
+        sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+    }
+    return sum2 / NS;
+}
+
+__device__ void p_gauss_newton(const double* L, const double* rho, double* betas)
+{
+    for (int it = 0; it < 5; it++) {
+        double A[24], b[6], x[4];
+        for (int i = 0; i < 6; i++) {
+            const double* r = L + 10 * i;
+            A[4 * i]     = 2 * r[0] * betas[0] +     r[1] * betas[1] +     r[3] * betas[2] +     r[6] * betas[3];
+            A[4 * i + 1] =     r[1] * betas[0] + 2 * r[2] * betas[1] +     r[4] * betas[2] +     r[7] * betas[3];
+            A[4 * i + 2] =     r[3] * betas[0] +     r[4] * betas[1] + 2 * r[5] * betas[2] +     r[8] * betas[3];
+            A[4 * i + 3] =     r[6] * betas[0] +     r[7] * betas[1] +     r[8] * betas[2] + 2 * r[9] * betas[3];
+            b[i] = rho[i] - (r[0] * betas[0] * betas[0] + r[1] * betas[0] * betas[1] + r[2] * betas[1] * betas[1] +
+                             r[3] * betas[0] * betas[2] + r[4] * betas[1] * betas[2] + r[5] * betas[2] * betas[2] +
+                             r[6] * betas[0] * betas[3] + r[7] * betas[1] * betas[3] + r[8] * betas[2] * betas[3] +
+                             r[9] * betas[3] * betas[3]);
+        }
+        p_lsq<4>(A, b, 6, x);
+        for (int i = 0; i < 4; i++) betas[i] += x[i];
+    }
+}
+
+__device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rbest, double* tbest)
+{
+    double cws[4][3];
+    for (int i = 0; i < 4; i++) cws[i][0] = cws[i][1] = cws[i][2] = 0;
+    for (int i = 0; i < NS; i++) for (int j = 0; j < 3; j++) cws[0][j] += pws[3 * i + j];
+    for (int j = 0; j < 3; j++) cws[0][j] /= NS;
+    double PtP[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < NS; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++)
+        PtP[3 * j + k] += (pws[3 * i + j] - cws[0][j]) * (pws[3 * i + k] - cws[0][k]);
+    double dc[3], uct[9];
+    pj_eig<3>(PtP, dc, uct);
+    for (int i = 1; i < 4; i++) {
+        const double k = sqrt((dc[i - 1] > 0 ? dc[i - 1] : 0) / NS);
+        for (int j = 0; j < 3; j++) cws[i][j] = cws[0][j] + k * uct[3 * (i - 1) + j];
+    }
+    double CC[9], CCi[9];
+    for (int i = 0; i < 3; i++) for (int j = 1; j < 4; j++) CC[3 * i + j - 1] = cws[j][i] - cws[0][i];
+    if (!p_inv3(CC, CCi)) { for (int i = 0; i < 9; i++) Rbest[i] = (i % 4) == 0; tbest[0] = tbest[1] = tbest[2] = 0; return; }
+    double alphas[4 * NS];
+    for (int i = 0; i < NS; i++) {
+        double* a = alphas + 4 * i;
+        for (int j = 0; j < 3; j++)
+            a[1 + j] = CCi[3 * j] * (pws[3 * i] - cws[0][0]) + CCi[3 * j + 1] * (pws[3 * i + 1] - cws[0][1]) + CCi[3 * j + 2] * (pws[3 * i + 2] - cws[0][2]);
+        a[0] = 1.0 - a[1] - a[2] - a[3];
+    }
+    double MtM[144];
+    for (int i = 0; i < 144; i++) MtM[i] = 0;
+    for (int i = 0; i < NS; i++) {
+        double m1[12], m2[12];
+        const double* a = alphas + 4 * i;
+        for (int j = 0; j < 4; j++) {
+            m1[3 * j] = a[j] * K.fu; m1[3 * j + 1] = 0.0;          m1[3 * j + 2] = a[j] * (K.uc - us[2 * i]);
+            m2[3 * j] = 0.0;         m2[3 * j + 1] = a[j] * K.fv;  m2[3 * j + 2] = a[j] * (K.vc - us[2 * i + 1]);
+        }
+        for (int p = 0; p < 12; p++) for (int q = 0; q < 12; q++) MtM[12 * p + q] += m1[p] * m1[q] + m2[p] * m2[q];
+    }
+    double dm[12], ut[144];
+    pj_eig<12>(MtM, dm, ut);
+    double L[60], rho[6], dv[4][6][3];
+    for (int i = 0; i < 4; i++) {
+        const double* v = ut + 12 * (11 - i);
+        int a = 0, b = 1;
+        for (int j = 0; j < 6; j++) {
+            for (int k = 0; k < 3; k++) dv[i][j][k] = v[3 * a + k] - v[3 * b + k];
+            b++; if (b > 3) { a++; b = a + 1; }
+        }
+    }
+    for (int i = 0; i < 6; i++) {
+        double* r = L + 10 * i;
+        r[0] = p_dot(dv[0][i], dv[0][i]); r[1] = 2.0 * p_dot(dv[0][i], dv[1][i]); r[2] = p_dot(dv[1][i], dv[1][i]);
+        r[3] = 2.0 * p_dot(dv[0][i], dv[2][i]); r[4] = 2.0 * p_dot(dv[1][i], dv[2][i]); r[5] = p_dot(dv[2][i], dv[2][i]);
+        r[6] = 2.0 * p_dot(dv[0][i], dv[3][i]); r[7] = 2.0 * p_dot(dv[1][i], dv[3][i]); r[8] = 2.0 * p_dot(dv[2][i], dv[3][i]);
+        r[9] = p_dot(dv[3][i], dv[3][i]);
+    }
+    rho[0] = p_dist2(cws[0], cws[1]); rho[1] = p_dist2(cws[0], cws[2]); rho[2] = p_dist2(cws[0], cws[3]);
+    rho[3] = p_dist2(cws[1], cws[2]); rho[4] = p_dist2(cws[1], cws[3]); rho[5] = p_dist2(cws[2], cws[3]);
+    double best = DBL_MAX;
+    for (int N = 1; N <= 3; N++) {
+        double betas[4] = {0, 0, 0, 0}, A[30], x[5];
+        if (N == 1) {
+            for (int i = 0; i < 6; i++) { A[4 * i] = L[10 * i]; A[4 * i + 1] = L[10 * i + 1]; A[4 * i + 2] = L[10 * i + 3]; A[4 * i + 3] = L[10 * i + 6]; }
+            p_lsq<4>(A, rho, 6, x);
+            if (x[0] < 0) { betas[0] = sqrt(-x[0]); betas[1] = -x[1] / betas[0]; betas[2] = -x[2] / betas[0]; betas[3] = -x[3] / betas[0]; }
+            else { betas[0] = sqrt(x[0]); betas[1] = x[1] / betas[0]; betas[2] = x[2] / betas[0]; betas[3] = x[3] / betas[0]; }
+        } else if (N == 2) {
+            for (int i = 0; i < 6; i++) { A[3 * i] = L[10 * i]; A[3 * i + 1] = L[10 * i + 1]; A[3 * i + 2] = L[10 * i + 2]; }
+            p_lsq<3>(A, rho, 6, x);
+            if (x[0] < 0) { betas[0] = sqrt(-x[0]); betas[1] = (x[2] < 0) ? sqrt(-x[2]) : 0.0; }
+            else { betas[0] = sqrt(x[0]); betas[1] = (x[2] > 0) ? sqrt(x[2]) : 0.0; }
+            if (x[1] < 0) betas[0] = -betas[0];
+        } else {
+            for (int i = 0; i < 6; i++) for (int k = 0; k < 5; k++) A[5 * i + k] = L[10 * i + k];
+            p_lsq<5>(A, rho, 6, x);
+            if (x[0] < 0) { betas[0] = sqrt(-x[0]); betas[1] = (x[2] < 0) ? sqrt(-x[2]) : 0.0; }
+            else { betas[0] = sqrt(x[0]); betas[1] = (x[2] > 0) ? sqrt(x[2]) : 0.0; }
+            if (x[1] < 0) betas[0] = -betas[0];
+            betas[2] = x[3] / betas[0];
+        }
+        p_gauss_newton(L, rho, betas);
+        double R[9], t[3];
+        const double err = p_epnp_R_t(pws, us, alphas, K, ut, betas, R, t);
+        if (err < best || N == 1) { best = err; for (int i = 0; i < 9; i++) Rbest[i] = R[i]; for (int i = 0; i < 3; i++) tbest[i] = t[i]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ RANSAC kernel
+__device__ __forceinline__ unsigned p_rng_next(unsigned long long* st)
+{
+    *st = (unsigned long long)(unsigned)(*st) * 4164903690ull + (unsigned)(*st >> 32);
+    return (unsigned)(*st);
+}
+
+__device__ int p_update_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p < 0 ? 0 : p > 1 ? 1 : p; ep = ep < 0 ? 0 : ep > 1 ? 1 : ep;
+    double num = 1. - p; if (num < DBL_MIN) num = DBL_MIN;
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num); denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+__device__ __forceinline__ double p_shfl_xor(double v, int m)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NV>
+__device__ void p_block_sum(double* v, double* s_red)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; i++) for (int m = 32; m > 0; m >>= 1) v[i] += p_shfl_xor(v[i], m);
+    __syncthreads();
+    if (lane == 0) for (int i = 0; i < NV; i++) s_red[wv * NV + i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; i++) { double s = 0; for (int w = 0; w < PNP_T / 64; w++) s += s_red[w * NV + i]; v[i] = s; }
+}
+
+__global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__ obj_in, const double* __restrict__ img_in,
+                                                      const int* __restrict__ n_arr, int stride, pnp_K K, int iterations,
+                                                      double reproj_error, double confidence, double* __restrict__ rvec,
+                                                      double* __restrict__ tvec, int* __restrict__ inliers,
+                                                      int* __restrict__ n_inliers, int* __restrict__ ok_out,
+                                                      uint8_t* __restrict__ mask_ws)
+{
+    __shared__ int s_idx[PNP_MAX_HYP * 5];
+    __shared__ double s_R[PNP_MAX_HYP * 9];
+    __shared__ double s_t[PNP_MAX_HYP * 3];
+    __shared__ int s_cnt[PNP_MAX_HYP];
+    __shared__ double s_red[28 * (PNP_T / 64)];
+    __shared__ double s_pose[12], s_try[12];
+    __shared__ int s_best, s_flag, s_w[PNP_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t b = blockIdx.x;
+    const int n = n_arr[b];
+    const double* obj = obj_in + b * (size_t)stride * 3;
+    const double* img = img_in + b * (size_t)stride * 2;
+    uint8_t* mask = mask_ws + b * (size_t)stride;
+    int* out_idx = inliers + b * (size_t)stride;
+    if (n < 5) { if (tid == 0) { ok_out[b] = 0; n_inliers[b] = 0; } return; }
+    const int niter0 = n == 5 ? 1 : max(1, min(iterations, PNP_MAX_HYP));
+    // phase 0: the sample stream of cv::RNG((uint64)-1)
+    if (tid == 0) {
+        unsigned long long st = ~0ull;
+        for (int it = 0; it < niter0; it++) {
+            int* idx = s_idx + 5 * it;
+            if (n == 5) { for (int i = 0; i < 5; i++) idx[i] = i; continue; }
+            for (int i = 0; i < 5;) {
+                int j;
+                for (;;) { idx[i] = (int)(p_rng_next(&st) % (unsigned)n); for (j = 0; j < i; j++) if (idx[i] == idx[j]) break; if (j == i) break; }
+                i++;
+            }
+        }
+    }
+    for (int i = tid; i < PNP_MAX_HYP; i += PNP_T) s_cnt[i] = 0;
+    __syncthreads();
+    // phase 1: one EPnP per lane
+    for (int h = tid; h < niter0; h += PNP_T) {
+        double so[15], si[10], R[9], t[3];
+        for (int i = 0; i < 5; i++) {
+            const int p = s_idx[5 * h + i];
+            for (int k = 0; k < 3; k++) so[3 * i + k] = (double)(float)obj[3 * p + k];
+            for (int k = 0; k < 2; k++) si[2 * i + k] = (double)(float)img[2 * p + k];
+        }
+        p_epnp5(so, si, K, R, t);
+        for (int k = 0; k < 9; k++) s_R[9 * h + k] = R[k];
+        for (int k = 0; k < 3; k++) s_t[3 * h + k] = t[k];
+    }
+    __syncthreads();
+    // phase 2: score every hypothesis on every point
+    const float thr2 = (float)(reproj_error * reproj_error);
+    if (n > 5) {
+        for (int i = tid; i < n; i += PNP_T) {
+            const double X[3] = { (double)(float)obj[3 * i], (double)(float)obj[3 * i + 1], (double)(float)obj[3 * i + 2] };
+            const float u = (float)img[2 * i], v = (float)img[2 * i + 1];
+            for (int h = 0; h < niter0; h++) {
+                const double* R = s_R + 9 * h; const double* t = s_t + 3 * h;
+                const double x = p_dot(R, X) + t[0], y = p_dot(R + 3, X) + t[1], z = p_dot(R + 6, X) + t[2];
+                const float pu = (float)(K.fu * x / z + K.uc), pv = (float)(K.fv * y / z + K.vc);
+                const float du = u - pu, dv = v - pv;
+                if (du * du + dv * dv <= thr2) atomicAdd(&s_cnt[h], 1);
+            }
+        }
+    }
+    __syncthreads();
+    // phase 3: replay the sequential acceptance rule
+    if (tid == 0) {
+        int best = -1, max_good = 0;
+        if (n == 5) { best = 0; max_good = 5; }
+        else {
+            int niters = niter0;
+            for (int it = 0; it < niters; it++) {
+                const int good = s_cnt[it];
+                if (good > (max_good > 4 ? max_good : 4)) {
+                    best = it; max_good = good;
+                    niters = p_update_iters(confidence, (double)(n - good) / n, 5, niters);
+                }
+            }
+        }
+        s_best = best;
+        if (best >= 0) { for (int k = 0; k < 9; k++) s_pose[k] = s_R[9 * best + k]; for (int k = 0; k < 3; k++) s_pose[9 + k] = s_t[3 * best + k]; }
+    }
+    __syncthreads();
+    const int best = s_best;
+    if (best < 0) { if (tid == 0) { ok_out[b] = 0; n_inliers[b] = 0; } return; }
+    // inlier mask of the winner
+    for (int i = tid; i < n; i += PNP_T) {
+        uint8_t m = 1;
+        if (n > 5) {
+            const double X[3] = { (double)(float)obj[3 * i], (double)(float)obj[3 * i + 1], (double)(float)obj[3 * i + 2] };
+            const double x = p_dot(s_pose, X) + s_pose[9], y = p_dot(s_pose + 3, X) + s_pose[10], z = p_dot(s_pose + 6, X) + s_pose[11];
+            const float pu = (float)(K.fu * x / z + K.uc), pv = (float)(K.fv * y / z + K.vc);
+            const float du = (float)img[2 * i] - pu, dv = (float)img[2 * i + 1] - pv;
+            m = du * du + dv * dv <= thr2;
+        }
+        mask[i] = m;
+    }
+    __syncthreads();
+    // phase 4: Levenberg-Marquardt on the inliers
+    double lambda = 1e-3;
+    for (int it = 0; it < 60; it++) {
+        double acc[28];
+#pragma unroll
+        for (int i = 0; i < 28; i++) acc[i] = 0;
+        for (int i = tid; i < n; i += PNP_T) if (mask[i]) {
+            const double X[3] = { (double)(float)obj[3 * i], (double)(float)obj[3 * i + 1], (double)(float)obj[3 * i + 2] };
+            const double rx[3] = { p_dot(s_pose, X), p_dot(s_pose + 3, X), p_dot(s_pose + 6, X) };
+            const double x = rx[0] + s_pose[9], y = rx[1] + s_pose[10], z = rx[2] + s_pose[11], iz = 1.0 / z;
+            const double e0 = K.fu * x * iz + K.uc - (double)(float)img[2 * i], e1 = K.fv * y * iz + K.vc - (double)(float)img[2 * i + 1];
+            const double du[3] = { K.fu * iz, 0, -K.fu * x * iz * iz }, dv[3] = { 0, K.fv * iz, -K.fv * y * iz * iz };
+            double J0[6], J1[6];
+            J0[0] = du[1] * (-rx[2]) + du[2] * rx[1]; J0[1] = du[0] * rx[2] + du[2] * (-rx[0]); J0[2] = du[0] * (-rx[1]) + du[1] * rx[0];
+            J0[3] = du[0]; J0[4] = du[1]; J0[5] = du[2];
+            J1[0] = dv[1] * (-rx[2]) + dv[2] * rx[1]; J1[1] = dv[0] * rx[2] + dv[2] * (-rx[0]); J1[2] = dv[0] * (-rx[1]) + dv[1] * rx[0];
+            J1[3] = dv[0]; J1[4] = dv[1]; J1[5] = dv[2];
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int c = a; c < 6; c++) acc[k++] += J0[a] * J0[c] + J1[a] * J1[c];
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[21 + a] += J0[a] * e0 + J1[a] * e1;
+            acc[27] += e0 * e0 + e1 * e1;
+        }
+        p_block_sum<28>(acc, s_red);
+        double H[36], g[6];
+        { int k = 0; for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { H[6 * a + c] = acc[k]; H[6 * c + a] = acc[k]; k++; } }
+        for (int a = 0; a < 6; a++) g[a] = acc[21 + a];
+        const double c0 = acc[27];
+        bool improved = false, tiny = false;
+        for (int trial = 0; trial < 10 && !improved; trial++) {
+            if (tid == 0) {
+                double A[36], d[6], Vt[36], dx[6] = {0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < 36; i++) A[i] = H[i];
+                for (int a = 0; a < 6; a++) A[7 * a] += lambda * (H[7 * a] > 1e-12 ? H[7 * a] : 1e-12);
+                pj_eig<6>(A, d, Vt);
+                for (int e = 0; e < 6; e++) if (d[e] > 0) { double c = 0; for (int a = 0; a < 6; a++) c += Vt[6 * e + a] * g[a]; c /= d[e]; for (int a = 0; a < 6; a++) dx[a] -= c * Vt[6 * e + a]; }
+                double dR[9];
+                p_rodrigues_v2m(dx, dR);
+                for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) s_try[3 * a + c] = dR[3 * a] * s_pose[c] + dR[3 * a + 1] * s_pose[3 + c] + dR[3 * a + 2] * s_pose[6 + c];
+                for (int a = 0; a < 3; a++) s_try[9 + a] = s_pose[9 + a] + dx[3 + a];
+                double step = 0; for (int a = 0; a < 6; a++) step += dx[a] * dx[a];
+                s_flag = step < 1e-26 ? 1 : 0;
+            }
+            __syncthreads();
+            double c1[1] = { 0 };
+            for (int i = tid; i < n; i += PNP_T) if (mask[i]) {
+                const double X[3] = { (double)(float)obj[3 * i], (double)(float)obj[3 * i + 1], (double)(float)obj[3 * i + 2] };
+                const double x = p_dot(s_try, X) + s_try[9], y = p_dot(s_try + 3, X) + s_try[10], z = p_dot(s_try + 6, X) + s_try[11];
+                const double e0 = K.fu * x / z + K.uc - (double)(float)img[2 * i], e1 = K.fv * y / z + K.vc - (double)(float)img[2 * i + 1];
+                c1[0] += e0 * e0 + e1 * e1;
+            }
+            p_block_sum<1>(c1, s_red);
+            if (c1[0] < c0 && isfinite(c1[0])) {
+                improved = true; tiny = s_flag != 0; lambda *= 0.2;
+                __syncthreads();
+                if (tid < 12) s_pose[tid] = s_try[tid];
+            } else lambda *= 5.0;
+            __syncthreads();
+        }
+        if (!improved || tiny) break;
+    }
+    // outputs: ordered inlier indices, rvec, tvec
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += PNP_T) {
+        const int i = c0 + tid;
+        const bool keep = i < n && mask[i];
+        const unsigned long long m = __ballot(keep);
+        const int pre = __popcll(m & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) s_w[wv] = __popcll(m);
+        __syncthreads();
+        int wbase = 0, tot = 0;
+        for (int w = 0; w < PNP_T / 64; w++) { const int c = s_w[w]; if (w < wv) wbase += c; tot += c; }
+        if (keep) out_idx[base + wbase + pre] = i;
+        base += tot;
+    }
+    if (tid == 0) {
+        double r[3];
+        p_rodrigues_m2v(s_pose, r);
+        for (int k = 0; k < 3; k++) { rvec[3 * b + k] = r[k]; tvec[3 * b + k] = s_pose[9 + k]; }
+        n_inliers[b] = base; ok_out[b] = 1;
+    }
+}
+
+extern "C" int bh_solve_pnp_ransac(bh_ctx* ctx, const double* obj, const double* img, const int* n, int B, int stride,
+                                   const double K[4], int iterations, double reproj_error, double confidence,
+                                   double* rvec, double* tvec, int* inliers, int* n_inliers, int* ok, int mem)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (!obj || !img || !n || !K || !rvec || !tvec || !inliers || !n_inliers || !ok || B < 0 || stride < 1 ||
+        (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE) || !(confidence > 0 && confidence < 1))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_solve_pnp_ransac: bad argument");
+    if (B == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t np = (size_t)B * stride;
+    const double *d_obj = obj, *d_img = img; const int* d_n = n;
+    double *d_r = rvec, *d_t = tvec; int *d_in = inliers, *d_ni = n_inliers, *d_ok = ok;
+    BH_TRY(bh_reserve(ctx, &ctx->st_h, np));                                    // inlier-mask workspace
+    if (mem == BH_MEM_HOST) {
+        for (int b = 0; b < B; b++) if (n[b] < 0 || n[b] > stride) return bh_set_err(ctx, BH_ERR_INVALID, "bh_solve_pnp_ransac: n[b] outside [0, stride]");
+        BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(double) * 3 * np)); BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(double) * 2 * np));
+        BH_TRY(bh_reserve(ctx, &ctx->st_c, sizeof(int) * 3 * (size_t)B)); BH_TRY(bh_reserve(ctx, &ctx->st_d, sizeof(double) * 6 * (size_t)B));
+        BH_TRY(bh_reserve(ctx, &ctx->st_e, sizeof(int) * np));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_a.p, obj, sizeof(double) * 3 * np, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_b.p, img, sizeof(double) * 2 * np, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_c.p, n, sizeof(int) * B, hipMemcpyHostToDevice, st));
+        d_obj = (const double*)ctx->st_a.p; d_img = (const double*)ctx->st_b.p; d_n = (const int*)ctx->st_c.p;
+        d_ni = (int*)ctx->st_c.p + B; d_ok = (int*)ctx->st_c.p + 2 * (size_t)B;
+        d_r = (double*)ctx->st_d.p; d_t = d_r + 3 * (size_t)B; d_in = (int*)ctx->st_e.p;
+    }
+    pnp_K Kd = { K[0], K[1], K[2], K[3] };
+    BH_LAUNCH(ctx, BH_K_PNP, k_pnp_ransac, dim3(B), dim3(PNP_T), st, d_obj, d_img, d_n, stride, Kd, iterations, reproj_error,
+              confidence, d_r, d_t, d_in, d_ni, d_ok, (uint8_t*)ctx->st_h.p);
+    BH_HIP(ctx, hipGetLastError());
+    if (mem == BH_MEM_HOST) {
+        BH_HIP(ctx, hipMemcpyAsync(rvec, d_r, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(tvec, d_t, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(inliers, d_in, sizeof(int) * np, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(n_inliers, d_ni, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(ok, d_ok, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipStreamSynchronize(st));
+    }
+    return BH_OK;
+}

@@ -91,3 +91,51 @@ def BFMatcher_create(normType=NORM_HAMMING, crossCheck=False, ctx=None):
     if normType != NORM_HAMMING or not crossCheck:
         raise ValueError("only BFMatcher(NORM_HAMMING, crossCheck=True) — the one configuration the reference creates")
     return _BFMatcher(ctx)
+
+
+# ---- calib3d stand-ins: experiments/pnp_two_way_tracking.py:57-61,68-69 ------------------------------------------------
+SOLVEPNP_ITERATIVE = 0
+SOLVEPNP_EPNP = 1
+
+
+def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None, rvec=None, tvec=None, useExtrinsicGuess=False,
+                   iterationsCount=100, reprojectionError=8.0, confidence=0.99, inliers=None, flags=SOLVEPNP_ITERATIVE, ctx=None):
+    """-> (retval, rvec (3,1), tvec (3,1), inliers (k,1) int32 | None), like cv2.  The final pose is the reprojection-error
+    minimiser over the RANSAC inliers for both ITERATIVE and EPNP flags."""
+    import ctypes as C
+    if distCoeffs is not None and np.any(np.asarray(distCoeffs) != 0):
+        raise ValueError("non-zero distortion is not supported (the reference always passes zeros, camera.py:82)")
+    if useExtrinsicGuess:
+        raise ValueError("useExtrinsicGuess is not supported")
+    obj = np.ascontiguousarray(objectPoints, dtype=np.float64).reshape(-1, 3)
+    img = np.ascontiguousarray(imagePoints, dtype=np.float64).reshape(-1, 2)
+    n = len(obj)
+    if n < 4 or len(img) != n:
+        raise ValueError("solvePnPRansac needs >= 4 point pairs")                 # cv2 raises cv2.error here
+    Km = np.asarray(cameraMatrix, dtype=np.float64)
+    K4 = np.array([Km[0, 0], Km[1, 1], Km[0, 2], Km[1, 2]], dtype=np.float64)
+    ctx = ctx or _lib.default_context()
+    rv = np.zeros((1, 3)); tv = np.zeros((1, 3)); inl = np.zeros((1, n), np.int32); ni = np.zeros(1, np.int32); ok = np.zeros(1, np.int32)
+    nn = np.array([n], np.int32)
+    ctx.check(_lib.lib().bh_solve_pnp_ransac(ctx.h, _lib.ptr(obj), _lib.ptr(img), _lib.ptr(nn), 1, n, _lib.ptr(K4), int(iterationsCount),
+                                             float(reprojectionError), float(confidence), _lib.ptr(rv), _lib.ptr(tv), _lib.ptr(inl),
+                                             _lib.ptr(ni), _lib.ptr(ok), _lib.BH_MEM_HOST))
+    if not ok[0]:
+        return False, rv.reshape(3, 1), tv.reshape(3, 1), None
+    return True, rv.reshape(3, 1).copy(), tv.reshape(3, 1).copy(), inl[0, :ni[0]].reshape(-1, 1).copy()
+
+
+def Rodrigues(src):
+    """-> (dst, jacobian=None): 3-vector -> 3x3 matrix or 3x3 -> (3,1) vector."""
+    v = np.ascontiguousarray(src, dtype=np.float64)
+    if v.size == 3:
+        out = np.zeros((3, 3))
+        rc = _lib.lib().bh_rodrigues(_lib.ptr(v.reshape(3)), 3, _lib.ptr(out))
+    elif v.size == 9:
+        out = np.zeros((3, 1))
+        rc = _lib.lib().bh_rodrigues(_lib.ptr(v.reshape(9)), 9, _lib.ptr(out))
+    else:
+        raise ValueError("Rodrigues expects 3 or 9 elements")
+    if rc != 0:
+        raise ValueError("bh_rodrigues failed")
+    return out, None

@@ -148,6 +148,19 @@ int  bh_ba_get_chi2(bh_ba* ba, double* chi2, int mem);
 /* per-iteration log of the last optimize: f64[iters_done][4] = {robust chi2 after, lambda, trials, accepted} */
 int  bh_ba_get_log(bh_ba* ba, double* log, int max_rows);
 
+/* ---- PnP + RANSAC, Rodrigues -----------------------------------------------------------------------------------------
+ * Replaces cv2.solvePnPRansac(obj, img, K, distCoeffs=0, flags=cv2.SOLVEPNP_ITERATIVE) and cv2.Rodrigues(v)[0] —
+ * experiments/pnp_two_way_tracking.py:57-61,68-69 (slam/tracking.py:68-71 is dead code) — for B problems.
+ *   obj f64[B][stride][3], img f64[B][stride][2], n int[B] (n >= 5; n == 4, where OpenCV switches to P3P, reports ok = 0)
+ *   K = {fx, fy, cx, cy}; distortion is zero in the reference (camera.py:82, config.py:34)
+ *   defaults of the reference call: iterations 100, reproj_error 8.0, confidence 0.99
+ *   rvec/tvec f64[B][3] (world -> camera), inliers int[B][stride] ascending, n_inliers int[B], ok int[B] (1/0)
+ * bh_rodrigues is plain host math (3-vector <-> 3x3 row-major matrix; in_len 3 or 9). */
+int bh_solve_pnp_ransac(bh_ctx* ctx, const double* obj, const double* img, const int* n, int B, int stride,
+                        const double K[4], int iterations, double reproj_error, double confidence,
+                        double* rvec, double* tvec, int* inliers, int* n_inliers, int* ok, int mem);
+int bh_rodrigues(const double* in, int in_len, double* out);
+
 /* ---- local-map visibility gate ------------------------------------------------------------------------------------
  * Replaces the per-map-point loop of Tracker._track_local_map — slam/tracking.py:97-111 — for B frames:
  *   q = R p + t ; pixel = (q.x/q.z*f + cx, q.y/q.z*f + cy)   [cam.cam_map(g2o.SE3Quat(frame.R, frame.t) * mp.pt3d)]

@@ -259,3 +259,21 @@ def bow_query_l1(q_words, q_vals, start, words, vals, max_results=1):
     n = lib().orc_bow_query_l1(_p(q_words), _p(q_vals), len(q_words), _p(start), _p(words), _p(vals), len(start) - 1,
                                int(max_results), _p(ids), _p(sc))
     return ids[:n].copy(), sc[:n].copy()
+
+
+def rodrigues(v):
+    """cv2.Rodrigues semantics: 3-vector -> 3x3 matrix, or 3x3 matrix -> 3-vector."""
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    if v.size == 3:
+        R = np.zeros(9); lib().orc_rodrigues_vec2mat(_p(v.reshape(3)), _p(R)); return R.reshape(3, 3)
+    r = np.zeros(3); lib().orc_rodrigues_mat2vec(_p(v.reshape(9)), _p(r)); return r
+
+
+def solve_pnp_ransac(obj, img, K4, iterations=100, reproj_error=8.0, confidence=0.99):
+    obj = np.ascontiguousarray(obj, dtype=np.float64).reshape(-1, 3); img = np.ascontiguousarray(img, dtype=np.float64).reshape(-1, 2)
+    n = len(obj)
+    K4 = np.ascontiguousarray(K4, dtype=np.float64)
+    rvec = np.zeros(3); tvec = np.zeros(3); inl = np.zeros(max(n, 1), np.int32); ni = C.c_int(0)
+    ok = lib().orc_solve_pnp_ransac(_p(obj), _p(img), n, _p(K4), int(iterations), C.c_double(reproj_error), C.c_double(confidence),
+                                    _p(rvec), _p(tvec), _p(inl), C.byref(ni))
+    return bool(ok), rvec, tvec, inl[:ni.value].copy()

@@ -225,3 +225,74 @@ def test_oracle_reproduces_committed_golden_vectors():
     o = oracle.ba_optimize(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"], pr["K"], 7, np.sqrt(7.815))
     assert np.allclose(o["t"], b["ba_t"], atol=1e-11) and np.allclose(o["pts"], b["ba_pts"], atol=1e-11)
     assert np.allclose(o["log"], b["ba_log"], rtol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ PnP / Rodrigues / gate / BoW
+def test_rodrigues_matches_scipy_rotation():
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        v = rng.normal(0, 1.0, 3)
+        R = oracle.rodrigues(v)
+        assert np.allclose(R, Rotation.from_rotvec(v).as_matrix(), atol=1e-13)
+        assert np.allclose(oracle.rodrigues(R), Rotation.from_matrix(R).as_rotvec(), atol=1e-10)
+    assert np.array_equal(oracle.rodrigues(np.zeros(3)), np.eye(3))
+    assert np.allclose(oracle.rodrigues(oracle.rodrigues(np.array([np.pi, 0, 0]))), [np.pi, 0, 0], atol=1e-7)
+
+
+def test_pnp_ransac_recovers_pose_and_rejects_outliers():
+    rng = np.random.default_rng(2)
+    K4 = [synth.FX, synth.FY, synth.CX, synth.CY]
+    for n, out in [(300, 0.3), (60, 0.1), (12, 0.0)]:
+        R = synth._rodrigues(rng.normal(0, 0.4, 3)); t = rng.normal(0, 0.3, 3) + [0, 0, 0.5]
+        X = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1, 1, n), rng.uniform(1.5, 5, n)], 1)
+        pc = X @ R.T + t
+        uv = np.stack([synth.FX * pc[:, 0] / pc[:, 2] + synth.CX, synth.FY * pc[:, 1] / pc[:, 2] + synth.CY], 1) + rng.normal(0, 0.3, (n, 2))
+        bad = rng.random(n) < out
+        uv[bad] += rng.normal(0, 60, (int(bad.sum()), 2))
+        ok, rv, tv, inl = oracle.solve_pnp_ransac(X, uv, K4)
+        assert ok
+        assert np.abs(oracle.rodrigues(rv) - R).max() < 5e-3 and np.abs(tv - t).max() < 2e-2
+        assert set(inl) >= set(np.nonzero(~bad)[0]) - set(np.nonzero(np.abs(uv - (uv)).sum(1) > 1)[0]) or len(inl) >= (~bad).sum() - 2
+        # the refined pose is a stationary point of the reprojection error over its inliers
+        def cost(x):
+            Rm = oracle.rodrigues(x[:3]); p = X[inl] @ Rm.T + x[3:]
+            pr = np.stack([synth.FX * p[:, 0] / p[:, 2] + synth.CX, synth.FY * p[:, 1] / p[:, 2] + synth.CY], 1)
+            Xf = X.astype(np.float32).astype(np.float64); uvf = uv.astype(np.float32).astype(np.float64)
+            p = Xf[inl] @ Rm.T + x[3:]
+            pr = np.stack([synth.FX * p[:, 0] / p[:, 2] + synth.CX, synth.FY * p[:, 1] / p[:, 2] + synth.CY], 1)
+            return ((pr - uvf[inl]) ** 2).sum()
+        x0 = np.concatenate([rv, tv]); c0 = cost(x0)
+        for k in range(6):
+            for s in (1e-5, -1e-5):
+                x1 = x0.copy(); x1[k] += s
+                assert cost(x1) >= c0 - 1e-9 * max(1.0, c0)
+    assert oracle.solve_pnp_ransac(np.zeros((4, 3)), np.zeros((4, 2)), K4)[0] is False
+
+
+def test_visibility_gate_matches_numpy():
+    rng = np.random.default_rng(3)
+    M = 500
+    pts = np.stack([rng.uniform(-3, 3, M), rng.uniform(-2, 2, M), rng.uniform(0.2, 6, M)], 1)
+    nrm = rng.normal(size=(M, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    R = synth._rodrigues(rng.normal(0, 0.1, 3)); t = rng.normal(0, 0.2, 3); see = R @ np.array([0, 0, 1.0])
+    q = pts @ R.T + t
+    u = q[:, 0] / q[:, 2] * synth.FX + synth.CX; v = q[:, 1] / q[:, 2] * synth.FX + synth.CY
+    ref = np.nonzero((u >= 0) & (u < 640) & (v >= 0) & (v < 480) & (nrm @ see < np.cos(np.pi / 3)))[0]
+    assert np.array_equal(oracle.visibility_gate(pts, nrm, R, t, synth.FX, synth.CX, synth.CY, 640, 480, see), ref)
+
+
+def test_bow_l1_score_matches_dense_formula():
+    db = synth.bow_database(n_entries=200, words_per_entry=30, vocab=500, seed=1, query_entry=17)
+    ids, sc = oracle.bow_query_l1(db["q_words"], db["q_vals"], db["start"], db["words"], db["vals"], 200)
+    qd = np.zeros(500); qd[db["q_words"]] = db["q_vals"]
+    dense = np.zeros((200, 500))
+    for e in range(200):
+        a, b = db["start"][e], db["start"][e + 1]
+        dense[e, db["words"][a:b]] = db["vals"][a:b]
+    share = ((dense > 0) & (qd > 0)[None]).any(1)
+    # DBoW3: score = 1 - 0.5 * |v - w|_1 for L1-normalised vectors (Nister 2006)
+    ref = 1 - 0.5 * np.abs(dense - qd[None]).sum(1)
+    assert set(ids) == set(np.nonzero(share)[0])
+    assert np.allclose(sc, ref[ids], atol=1e-12)
+    assert np.all(np.diff(sc) <= 1e-15) and ids[0] == 17
