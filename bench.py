@@ -141,8 +141,8 @@ def main():
         fps = world * B * args.steps / dt
         # dominant kernel by summed hipEvent time; its own compulsory traffic per frame
         per_frame_bytes = {"k_gray_mask": 921600 + 614400 + 2 * 307200, "k_pyr_down": 2 * (926546 + 643332),
-                           "k_fast": 2 * 950532, "k_blur": 2 * 950532, "k_select": 950532 + 56 * args.nfeatures,
-                           "k_brief": 56 * args.nfeatures, "k_match": 2 * 32 * args.nfeatures + 12 * args.nfeatures}
+                           "k_fast": 3 * 950532, "k_blur": 2 * 950532, "k_select": 950532 + 56 * args.nfeatures,
+                           "k_describe": 56 * args.nfeatures + 2 * 950532, "k_match": 2 * 32 * args.nfeatures + 12 * args.nfeatures}
         dom = max(ktimes, key=lambda k: ktimes[k][0])
         dom_ms, dom_n = ktimes[dom]
         launches_per_step = dom_n / args.steps
