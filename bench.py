@@ -176,7 +176,7 @@ def main():
                           "mean_matches_per_pair": float(n_match[1:].mean()) if B > 1 else 0.0,
                           "parallelism": f"frames sharded x{world}, no collective"},
                "roofline": roofline}
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:                # cpu_baseline: rank 0 at N=1 only
             ns = min(args.cpu_sample, B)
             bh = bgr[:ns].cpu().numpy(); dh = depth[:ns].cpu().numpy().view(np.uint16)
             cb, (okps, odesc, onk) = cpu_baseline(bh, dh, args.nfeatures, fe.max_kp)
@@ -186,7 +186,7 @@ def main():
             same = bool(np.array_equal(onk, n_kp[:ns])) and all(
                 np.array_equal(ddesc[f, :onk[f]], odesc[f, :onk[f]]) for f in range(ns))
             out["parity_sample_ok"] = same
-        if not args.no_ba:
+        if not args.no_ba and world == 1:                     # local BA does not shard (replicas only): N=1 figure
             from boslam_amd import ba_bench
             out["local_ba"] = ba_bench.run(ctx, dev)
         if args.bow:

@@ -45,6 +45,17 @@ class BowDatabase:
         self.n_entries = len(start) - 1
         self.ctx.check(_lib.lib().bh_bow_set_db(self.h, self.n_entries, _lib.ptr(start), _lib.ptr(words), _lib.ptr(vals), BH_MEM_HOST))
 
+    def add(self, words, vals):
+        """Database.add at the BoW-vector level -> entry id."""
+        words = np.ascontiguousarray(words, dtype=np.uint32); vals = np.ascontiguousarray(vals, dtype=np.float64)
+        eid = C.c_int(-1)
+        self.ctx.check(_lib.lib().bh_bow_add_entry(self.h, _lib.ptr(words), _lib.ptr(vals), len(words), C.byref(eid)))
+        self.n_entries = eid.value + 1
+        return eid.value
+
+    def erase(self, entry_id):
+        self.ctx.check(_lib.lib().bh_bow_erase_entry(self.h, int(entry_id)))
+
     def query(self, q_words, q_vals, max_results=1):
         q_words = np.ascontiguousarray(q_words, dtype=np.uint32); q_vals = np.ascontiguousarray(q_vals, dtype=np.float64)
         ids = np.zeros(max_results, np.int32); sc = np.zeros(max_results, np.float64); n = C.c_int(0)
@@ -91,3 +102,84 @@ def sharded_query(local_query, entry_base, k, dist=None, device="cpu"):
         a = a.cpu().numpy(); b = b.cpu().numpy()
         li.append(a[a >= 0]); ls.append(b[a >= 0])
     return merge_topk(li, ls, k)
+
+
+class Vocabulary:
+    """Device-resident vocabulary tree (DBoW3 Vocabulary stand-in): descriptors -> BoW vector."""
+
+    def __init__(self, ctx, voc):
+        self.ctx = ctx
+        cs = np.ascontiguousarray(voc["child_start"], dtype=np.int32); ci = np.ascontiguousarray(voc["child_idx"], dtype=np.int32)
+        nd = np.ascontiguousarray(voc["node_desc"], dtype=np.uint8); nw = np.ascontiguousarray(voc["node_weight"], dtype=np.float64)
+        ni = np.ascontiguousarray(voc["node_word"], dtype=np.int32)
+        h = C.c_void_p()
+        ctx.check(_lib.lib().bh_voc_create(ctx.h, len(cs) - 1, _lib.ptr(cs), _lib.ptr(ci), _lib.ptr(nd), _lib.ptr(nw), _lib.ptr(ni), C.byref(h)))
+        self.h = h
+
+    def transform_batch(self, desc, n):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8)
+        B, S = desc.shape[:2]
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        words = np.zeros((B, S), np.uint32); vals = np.zeros((B, S), np.float64); nw = np.zeros(B, np.int32)
+        self.ctx.check(_lib.lib().bh_voc_transform(self.h, _lib.ptr(desc), _lib.ptr(n), B, S, _lib.ptr(words), _lib.ptr(vals), _lib.ptr(nw), BH_MEM_HOST))
+        return words, vals, nw
+
+    def transform(self, desc):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(1, -1, 32)
+        if desc.shape[1] == 0:
+            return np.zeros(0, np.uint32), np.zeros(0)
+        w, v, n = self.transform_batch(desc, [desc.shape[1]])
+        return w[0, :n[0]].copy(), v[0, :n[0]].copy()
+
+    @staticmethod
+    def distance(f1, f2):
+        """Vocabulary.distance -> Hamming distance of two descriptors (slam/bow_db.py:44-45, slam/nodes.py medoid)."""
+        return int(np.unpackbits(np.bitwise_xor(np.asarray(f1, np.uint8).ravel(), np.asarray(f2, np.uint8).ravel())).sum())
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().bh_voc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Dbow:
+    """Mirror of the reference's slam/bow_db.py Dbow (add / erase / query / distance) over the HIP vocabulary + database.
+    `voc` is the flat tree dict (the reference loads /DBow3/orbvoc.dbow3, which is not in its repo)."""
+
+    def __init__(self, voc, ctx=None):
+        self.ctx = ctx or _lib.default_context()
+        self.voc = Vocabulary(self.ctx, voc)
+        self.db = BowDatabase(self.ctx)
+        self.entry2frame = {}
+        self.frame2entry = {}
+
+    def add(self, frame):
+        if frame.id not in self.frame2entry:
+            w, v = self.voc.transform(frame.des)
+            i = self.db.add(w, v)
+            self.entry2frame[i] = frame.id
+            self.frame2entry[frame.id] = i
+
+    def erase(self, i):
+        j = self.frame2entry[i]
+        self.db.erase(j)
+        del self.frame2entry[i]
+        del self.entry2frame[j]
+
+    def query(self, frame, subset_inds=()):
+        if len(subset_inds):
+            raise NotImplementedError("target_inds restriction of the DBoW3 fork is not supported")
+        w, v = self.voc.transform(frame.des)
+        ids, sc = self.db.query(w, v, 1)
+        if len(ids) > 0:
+            return self.entry2frame[int(ids[0])], float(sc[0])
+        return None, None
+
+    def distance(self, f1, f2):
+        return self.voc.distance(f1, f2)

@@ -104,8 +104,26 @@ extern "C" int bh_visibility_gate(bh_ctx* ctx, const double* pts, const double* 
 struct bh_bow {
     bh_ctx* ctx = nullptr;
     long long n_entries = 0, n_elems = 0;          // padded element count
+    std::vector<long long> h_pstart;               // host mirror of the padded row offsets (for appends)
     bh_buf pstart, words, vals, acc, qw, qv, res;
 };
+
+// grow a device buffer keeping its first `keep` bytes
+static int bow_grow(bh_ctx* ctx, bh_buf* b, size_t need, size_t keep)
+{
+    if (need <= b->cap) return BH_OK;
+    size_t want = b->cap ? b->cap : 4096;
+    while (want < need) want *= 2;
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) return bh_set_err(ctx, BH_ERR_NOMEM, "hipMalloc(%zu) failed", want);
+    if (b->p) {
+        if (keep && hipMemcpyAsync(p, b->p, keep, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { (void)hipFree(p); return bh_set_err(ctx, BH_ERR_HIP, "device copy failed"); }
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b->p);
+    }
+    b->p = p; b->cap = want;
+    return BH_OK;
+}
 
 __global__ __launch_bounds__(256) void k_bow_pack(const long long* __restrict__ start, const uint32_t* __restrict__ w,
                                                   const double* __restrict__ v, const long long* __restrict__ pstart,
@@ -251,7 +269,7 @@ extern "C" int bh_bow_set_db(bh_bow* bow, long long n_entries, const int64_t* st
         pst[e + 1] = pst[e] + ((n + 3) & ~3ll);
     }
     const long long nel = hstart[n_entries] - hstart[0], npad = pst[n_entries];
-    bow->n_entries = n_entries; bow->n_elems = npad;
+    bow->n_entries = n_entries; bow->n_elems = npad; bow->h_pstart = pst;
     BH_TRY(bh_reserve(ctx, &bow->pstart, sizeof(long long) * (n_entries + 1)));
     BH_TRY(bh_reserve(ctx, &bow->words, sizeof(uint32_t) * (npad + 4))); BH_TRY(bh_reserve(ctx, &bow->vals, sizeof(double) * (npad + 4)));
     BH_TRY(bh_reserve(ctx, &bow->acc, sizeof(double) * (n_entries + 1)));
@@ -317,5 +335,50 @@ extern "C" int bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const doubl
         BH_HIP(ctx, hipMemcpyAsync(n_results, d_n, sizeof(int), hipMemcpyDeviceToHost, st));
         BH_HIP(ctx, hipStreamSynchronize(st));
     }
+    return BH_OK;
+}
+
+// Database::add at the BoW-vector level (slam/bow_db.py:26 -> dbow3.cpp:138-140): appends one entry, returns its id.
+extern "C" int bh_bow_add_entry(bh_bow* bow, const uint32_t* words, const double* vals, int n, int* entry_id)
+{
+    if (!bow) return BH_ERR_INVALID;
+    bh_ctx* ctx = bow->ctx;
+    if (n < 0 || (n && (!words || !vals))) return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_add_entry: bad argument");
+    for (int i = 1; i < n; i++) if (words[i] <= words[i - 1]) return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_add_entry: words must be strictly ascending");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (bow->h_pstart.empty()) bow->h_pstart.push_back(0);
+    const long long a = bow->h_pstart.back(), npad = (n + 3) & ~3;
+    std::vector<uint32_t> w(npad, BOW_PAD_WORD); std::vector<double> v(npad, 0.0);
+    for (int i = 0; i < n; i++) { w[i] = words[i]; v[i] = vals[i]; }
+    BH_TRY(bow_grow(ctx, &bow->words, sizeof(uint32_t) * (size_t)(a + npad + 4), sizeof(uint32_t) * (size_t)a));
+    BH_TRY(bow_grow(ctx, &bow->vals, sizeof(double) * (size_t)(a + npad + 4), sizeof(double) * (size_t)a));
+    BH_TRY(bow_grow(ctx, &bow->pstart, sizeof(long long) * (size_t)(bow->n_entries + 2), sizeof(long long) * (size_t)(bow->n_entries + 1)));
+    BH_TRY(bow_grow(ctx, &bow->acc, sizeof(double) * (size_t)(bow->n_entries + 2), 0));
+    if (npad) {
+        BH_HIP(ctx, hipMemcpyAsync((uint32_t*)bow->words.p + a, w.data(), sizeof(uint32_t) * npad, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync((double*)bow->vals.p + a, v.data(), sizeof(double) * npad, hipMemcpyHostToDevice, st));
+    }
+    const long long ends[2] = { a, a + npad };
+    BH_HIP(ctx, hipMemcpyAsync((long long*)bow->pstart.p + bow->n_entries, ends, sizeof(ends), hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipStreamSynchronize(st));
+    bow->h_pstart.push_back(a + npad);
+    if (entry_id) *entry_id = (int)bow->n_entries;
+    bow->n_entries += 1; bow->n_elems = a + npad;
+    return BH_OK;
+}
+
+// Database::erase (the fork's method used at slam/bow_db.py:33 -> dbow3.cpp:142-145): the entry keeps its id but loses all
+// its words (its row becomes padding), so it can never appear in a result again.
+extern "C" int bh_bow_erase_entry(bh_bow* bow, int entry_id)
+{
+    if (!bow) return BH_ERR_INVALID;
+    bh_ctx* ctx = bow->ctx;
+    if (entry_id < 0 || entry_id >= bow->n_entries || (long long)bow->h_pstart.size() <= entry_id + 1)
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_erase_entry: no such entry");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    const long long a = bow->h_pstart[entry_id], e = bow->h_pstart[entry_id + 1];
+    if (e > a) BH_HIP(ctx, hipMemsetAsync((uint32_t*)bow->words.p + a, 0xff, sizeof(uint32_t) * (size_t)(e - a), ctx->stream));
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BH_OK;
 }

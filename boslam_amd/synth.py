@@ -210,3 +210,29 @@ def bow_database(n_entries=100000, words_per_entry=1000, vocab=10**6, seed=11, q
     qv = qv[ui] / qv[ui].sum()
     return dict(start=start, words=words.reshape(-1).astype(np.uint32), vals=vals.reshape(-1), q_words=qw.astype(np.uint32),
                 q_vals=qv, query_entry=qe)
+
+
+def vocabulary(k=10, L=4, seed=21, stop_frac=0.01):
+    """Synthetic k-ary vocabulary tree of depth L (the real /DBow3/orbvoc.dbow3, k=10 L=6, is not in the reference repo):
+    random 256-bit node descriptors, children stored contiguously in BFS order, leaf weights = idf-like U(0.5, 8), a few
+    stop words with weight 0.  Returns the flat arrays bh_voc_create / the oracle take."""
+    rng = np.random.default_rng(seed)
+    n_nodes = (k ** (L + 1) - 1) // (k - 1)
+    n_inner = (k ** L - 1) // (k - 1)
+    child_start = np.zeros(n_nodes + 1, np.int32)
+    child_start[1:n_inner + 1] = np.arange(1, n_inner + 1) * k
+    child_start[n_inner + 1:] = n_inner * k
+    child_idx = np.arange(1, n_inner * k + 1, dtype=np.int32)            # node i's children are 1 + i*k .. i*k + k
+    # children within a parent in a shuffled order, so that "first minimum in stored order" is exercised
+    child_idx = child_idx.reshape(n_inner, k)
+    for i in range(n_inner):
+        rng.shuffle(child_idx[i])
+    child_idx = child_idx.reshape(-1)
+    node_desc = rng.integers(0, 256, size=(n_nodes, 32), dtype=np.uint8)
+    node_weight = np.zeros(n_nodes); node_word = np.full(n_nodes, -1, np.int32)
+    leaves = np.arange(n_inner, n_nodes)
+    node_word[leaves] = rng.permutation(len(leaves)).astype(np.int32)
+    node_weight[leaves] = rng.uniform(0.5, 8.0, len(leaves))
+    node_weight[leaves[rng.random(len(leaves)) < stop_frac]] = 0.0
+    return dict(child_start=child_start, child_idx=child_idx, node_desc=node_desc, node_weight=node_weight, node_word=node_word,
+                k=k, L=L, n_words=len(leaves))

@@ -187,6 +187,26 @@ int  bh_bow_set_db(bh_bow* bow, long long n_entries, const int64_t* start, const
 int  bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, int max_results,
                      int* ids, double* scores, int* n_results, int mem);
 
+/* Database::add at the BoW-vector level — slam/bow_db.py:26 -> dbow3.cpp:138-140: appends one entry (host arrays, words
+ * strictly ascending), returns its entry id. */
+int  bh_bow_add_entry(bh_bow* bow, const uint32_t* words, const double* vals, int n, int* entry_id);
+/* Database::erase (fork method, slam/bow_db.py:33 -> dbow3.cpp:142-145): the entry keeps its id and loses its words. */
+int  bh_bow_erase_entry(bh_bow* bow, int entry_id);
+
+/* ---- vocabulary-tree quantisation ---------------------------------------------------------
+ * Replaces DBoW3 Vocabulary::transform behind Database.add(des) / Database.query(des, ...) — slam/bow_db.py:26,39 ->
+ * docker/pydbow3/src/dbow3.cpp:138-152: descriptors -> sparse BoW vector (TF-IDF weights, L1-normalised).
+ *   tree: node 0 is the root; children of node i are child_idx[child_start[i] .. child_start[i+1]) in their stored order
+ *   (first minimum wins); leaves carry (word id < 2^20, weight; weight <= 0 = stop word); node_desc u8[n_nodes][32].
+ *   bh_voc_transform: B descriptor sets (desc u8[B][stride][32], n[b] <= min(stride, 4096)) ->
+ *   words u32[B][stride] ascending, vals f64[B][stride], n_words[B]. */
+typedef struct bh_voc bh_voc;
+int  bh_voc_create(bh_ctx* ctx, int n_nodes, const int* child_start, const int* child_idx, const uint8_t* node_desc,
+                   const double* node_weight, const int* node_word, bh_voc** out);
+void bh_voc_destroy(bh_voc* voc);
+int  bh_voc_transform(bh_voc* voc, const uint8_t* desc, const int* n, int B, int stride, uint32_t* words, double* vals,
+                      int* n_words, int mem);
+
 #ifdef __cplusplus
 }
 #endif

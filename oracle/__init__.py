@@ -277,3 +277,14 @@ def solve_pnp_ransac(obj, img, K4, iterations=100, reproj_error=8.0, confidence=
     ok = lib().orc_solve_pnp_ransac(_p(obj), _p(img), n, _p(K4), int(iterations), C.c_double(reproj_error), C.c_double(confidence),
                                     _p(rvec), _p(tvec), _p(inl), C.byref(ni))
     return bool(ok), rvec, tvec, inl[:ni.value].copy()
+
+
+def voc_transform(voc, desc):
+    """voc: dict(child_start, child_idx, node_desc, node_weight, node_word) -> (words u32 ascending, vals f64)."""
+    desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+    cs = np.ascontiguousarray(voc["child_start"], dtype=np.int32); ci = np.ascontiguousarray(voc["child_idx"], dtype=np.int32)
+    nd = np.ascontiguousarray(voc["node_desc"], dtype=np.uint8); nw = np.ascontiguousarray(voc["node_weight"], dtype=np.float64)
+    ni = np.ascontiguousarray(voc["node_word"], dtype=np.int32)
+    words = np.zeros(max(len(desc), 1), np.uint32); vals = np.zeros(max(len(desc), 1), np.float64)
+    k = lib().orc_voc_transform(_p(cs), _p(ci), _p(nd), _p(nw), _p(ni), _p(desc), len(desc), _p(words), _p(vals))
+    return words[:k].copy(), vals[:k].copy()

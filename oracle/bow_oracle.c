@@ -71,3 +71,60 @@ int orc_bow_query_l1(const uint32_t* q_words, const double* q_vals, int nq,
     free(r);
     return nr;
 }
+
+/*
+ * (3) Vocabulary::transform (DBoW3 Vocabulary.cpp; reached from slam/bow_db.py:26 Database.add(frame.des) and :39 query):
+ *     every descriptor walks the tree from the root, at each node taking the child with the smallest Hamming distance
+ *     (children scanned in their stored order, strict '<': first minimum) until a leaf; the leaf's (word id, weight) is
+ *     accumulated v[word] += weight in descriptor order (weights <= 0 are stop words); TF-IDF + L1: v /= sum(|v|) with the
+ *     sum taken in ascending word order.  Tree layout here: children of node i are child_idx[child_start[i] ..
+ *     child_start[i+1]); leaves have no children.
+ */
+#include <string.h>
+static int orc_ham32(const uint8_t* a, const uint8_t* b)
+{
+    int d = 0;
+    for (int k = 0; k < 32; k += 8) { uint64_t x, y; memcpy(&x, a + k, 8); memcpy(&y, b + k, 8); d += __builtin_popcountll(x ^ y); }
+    return d;
+}
+
+typedef struct { uint32_t w; double v; int first; } orc_wv;
+static int orc_wv_cmp(const void* a, const void* b)
+{
+    const orc_wv* x = a; const orc_wv* y = b;
+    if (x->w != y->w) return x->w < y->w ? -1 : 1;
+    return (x->first > y->first) - (x->first < y->first);
+}
+
+/* desc u8[n][32] -> sparse BoW vector (words ascending); returns the number of distinct words */
+int orc_voc_transform(const int* child_start, const int* child_idx, const uint8_t* node_desc, const double* node_weight,
+                      const int* node_word, const uint8_t* desc, int n, uint32_t* words, double* vals)
+{
+    orc_wv* tmp = malloc(sizeof(orc_wv) * (size_t)(n > 0 ? n : 1));
+    int m = 0;
+    for (int r = 0; r < n; r++) {
+        int node = 0;
+        while (child_start[node + 1] > child_start[node]) {
+            int best = -1, best_d = 1 << 30;
+            for (int c = child_start[node]; c < child_start[node + 1]; c++) {
+                int id = child_idx[c];
+                int d = orc_ham32(desc + (size_t)r * 32, node_desc + (size_t)id * 32);
+                if (d < best_d) { best_d = d; best = id; }
+            }
+            node = best;
+        }
+        if (node_weight[node] > 0) { tmp[m].w = (uint32_t)node_word[node]; tmp[m].v = node_weight[node]; tmp[m].first = r; m++; }
+    }
+    qsort(tmp, m, sizeof(orc_wv), orc_wv_cmp);              /* by word, then by descriptor order: the order addWeight sums in */
+    int k = 0;
+    for (int i = 0; i < m; ) {
+        double acc = 0; int j = i;
+        while (j < m && tmp[j].w == tmp[i].w) { acc += tmp[j].v; j++; }
+        words[k] = tmp[i].w; vals[k] = acc; k++; i = j;
+    }
+    double norm = 0;
+    for (int i = 0; i < k; i++) norm += fabs(vals[i]);
+    if (norm > 0) for (int i = 0; i < k; i++) vals[i] /= norm;
+    free(tmp);
+    return k;
+}

@@ -67,3 +67,57 @@ def test_bow_config4_full_size_and_roofline(ctx):
     assert np.array_equal(ids, oi) and np.array_equal(sc, os_)
     assert ids[0] == 12345
     d.close()
+
+
+@pytest.mark.parametrize("k,L,n", [(10, 3, 600), (10, 4, 1000), (4, 5, 37), (7, 2, 4096)])
+def test_vocabulary_transform_matches_oracle(ctx, k, L, n):
+    voc = synth.vocabulary(k=k, L=L, seed=k * 10 + L)
+    v = bow.Vocabulary(ctx, voc)
+    d = synth.random_descriptors(n, n)
+    d[n // 3] = d[1]; d[n - 1] = d[1]                                 # repeated words: the accumulation order matters
+    for i in range(0, n, 7):
+        d[i] = voc["node_desc"][-1 - (i % voc["n_words"])]          # exact leaf descriptors: distance-0 walks and ties on the way
+    w, x = v.transform(d)
+    ow, ox = oracle.voc_transform(voc, d)
+    assert np.array_equal(w, ow)
+    assert np.array_equal(x.view(np.uint64), ox.view(np.uint64)), "BoW weights must be bit-identical"
+    assert abs(x.sum() - 1.0) < 1e-12 and np.all(np.diff(w.astype(np.int64)) > 0)
+    # batched, ragged
+    D = np.zeros((3, n, 32), np.uint8); D[0] = d; D[1, :5] = d[:5]; ns = [n, 5, 0]
+    W, X, NW = v.transform_batch(D, ns)
+    assert NW[0] == len(ow) and NW[2] == 0
+    w1, x1 = oracle.voc_transform(voc, d[:5])
+    assert np.array_equal(W[1, :NW[1]], w1) and np.array_equal(X[1, :NW[1]], x1)
+    v.close()
+
+
+def test_dbow_shim_end_to_end_relocalisation(ctx):
+    """slam/bow_db.py flow: add keyframes (descriptors -> tree -> database), query a noisy revisit, erase, query again."""
+    voc = synth.vocabulary(k=10, L=4, seed=5)
+
+    class Frame:
+        def __init__(self, i, des): self.id = 100 + i; self.des = des
+    rng = np.random.default_rng(9)
+    frames = [Frame(i, synth.random_descriptors(50 + i, 400 + 13 * i)) for i in range(12)]
+    db = bow.Dbow(voc, ctx=ctx)
+    for f in frames:
+        db.add(f)
+    db.add(frames[3])                                                  # second add of the same frame id is a no-op
+    assert len(db.frame2entry) == 12
+    q = frames[7].des.copy()
+    flip = rng.random(q.shape) < 0.02
+    q ^= (flip * (1 << rng.integers(0, 8, q.shape))).astype(np.uint8)  # a few bit errors per descriptor
+    probe = Frame(99, q)
+    fid, score = db.query(probe)
+    # oracle: same pipeline on the CPU
+    rows = [oracle.voc_transform(voc, f.des) for f in frames]
+    start = np.concatenate([[0], np.cumsum([len(r[0]) for r in rows])]).astype(np.int64)
+    words = np.concatenate([r[0] for r in rows]); vals = np.concatenate([r[1] for r in rows])
+    qw, qv = oracle.voc_transform(voc, q)
+    oi, os_ = oracle.bow_query_l1(qw, qv, start, words, vals, 1)
+    assert fid == frames[int(oi[0])].id == 107 and score == os_[0]
+    db.erase(107)
+    fid2, score2 = db.query(probe)
+    oi2, os2 = oracle.bow_query_l1(qw, qv, start, words, vals, 2)
+    assert fid2 == frames[int(oi2[1])].id and score2 == os2[1]
+    assert db.distance(frames[0].des[0], frames[0].des[0]) == 0 and db.distance(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256

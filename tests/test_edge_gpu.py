@@ -1,0 +1,122 @@
+"""GPU parity on edge cases: odd image sizes (unaligned width path), few levels, blank frames, tiny budgets, capacity errors,
+and the committed golden vectors."""
+import os
+import numpy as np
+import pytest
+
+import oracle
+from boslam_amd import BhError, frontend, synth, cv2_shim, ba, optimizer
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _check(ctx, imgs, mask, params_kw, max_kp=None):
+    params = frontend.make_params(**params_kw)
+    kps, desc, n = frontend.orb_detect_describe(ctx, imgs, mask=mask, params=params, max_kp=max_kp)
+    P = oracle.orb_params(**params_kw)
+    for f in range(len(imgs)):
+        ok, od, rc = oracle.orb_detect_describe(imgs[f], None if mask is None else mask[f], P, max_kp=4 * params_kw.get("nfeatures", 600) + 256)
+        assert rc == 0
+        assert n[f] == len(ok), (f, n[f], len(ok))
+        assert np.array_equal(desc[f, :n[f]], od)
+        for fld in ("x", "y", "angle", "response", "size"):
+            assert np.array_equal(kps[f, :n[f]][fld].view(np.uint32), ok[fld].view(np.uint32)), fld
+        assert np.array_equal(kps[f, :n[f]]["octave"], ok["octave"])
+    return n
+
+
+@pytest.mark.parametrize("H,W", [(241, 322), (200, 203), (130, 161), (480, 636)])
+def test_odd_sizes_gray_and_bgr(ctx, H, W):
+    rng = np.random.default_rng(H * 1000 + W)
+    bgr, _ = synth.render_batch(2)
+    oy, ox = min(7, 480 - H), min(11, 640 - W)
+    crop = np.ascontiguousarray(bgr[:, oy:oy + H, ox:ox + W])
+    mask = (rng.random((2, H, W)) > 0.1).astype(np.uint8) * 255
+    n = _check(ctx, crop, mask, dict(nfeatures=300))
+    assert n.sum() > 0
+    _check(ctx, np.ascontiguousarray(crop[..., 1]), None, dict(nfeatures=200))
+
+
+def test_single_level_and_three_levels(ctx):
+    bgr, depth = synth.render_batch(2)
+    mask = (depth > 0).astype(np.uint8) * 255
+    _check(ctx, bgr, mask, dict(nfeatures=400, nlevels=1))
+    _check(ctx, bgr, mask, dict(nfeatures=400, nlevels=3, scaleFactor=1.25, fastThreshold=30))
+    _check(ctx, bgr, None, dict(nfeatures=400, nlevels=12))              # top levels smaller than the 2x31-px border: no keypoints there
+
+
+def test_blank_and_fully_masked_frames(ctx):
+    imgs = np.zeros((3, 480, 640, 3), np.uint8); imgs[1] = 127
+    bgr, _ = synth.render_batch(1)
+    imgs[2] = bgr[0]
+    mask = np.full((3, 480, 640), 255, np.uint8); mask[2] = 0             # real frame, everything masked out
+    n = _check(ctx, imgs, mask, dict(nfeatures=600))
+    assert list(n) == [0, 0, 0]
+    kp, des = cv2_shim.ORB_create(nfeatures=600, ctx=ctx).detectAndCompute(imgs[0], None)
+    assert kp == [] and des is None                                       # experiments/pnp_two_way_tracking.py:38
+    kp, des = cv2_shim.ORB_create(nfeatures=600, ctx=ctx).detectAndCompute(bgr[0], None)
+    assert len(kp) == 600 and des.shape == (600, 32) and isinstance(kp[0].pt, tuple)
+
+
+def test_tiny_budget_and_capacity_error(ctx):
+    bgr, depth = synth.render_batch(1)
+    mask = (depth > 0).astype(np.uint8) * 255
+    _check(ctx, bgr, mask, dict(nfeatures=8))
+    _check(ctx, bgr, mask, dict(nfeatures=0))
+    with pytest.raises(BhError) as e:
+        frontend.orb_detect_describe(ctx, bgr, mask=mask, params=frontend.make_params(nfeatures=600), max_kp=100)
+    assert e.value.code == -3                                             # BH_ERR_CAPACITY
+    assert len(frontend.orb_detect_describe(ctx, bgr[:0], params=frontend.make_params())[2]) == 0      # empty batch
+
+
+def test_bf_matcher_shim_edge_cases(ctx):
+    m = cv2_shim.BFMatcher_create(cv2_shim.NORM_HAMMING, crossCheck=True, ctx=ctx)
+    d = synth.random_descriptors(1, 50)
+    assert m.match(d[:0], d) == [] and m.match(d, d[:0]) == [] and m.match(None, d) == []
+    r = m.match(d, d)
+    assert [x.queryIdx for x in r] == list(range(50)) and all(x.distance == 0.0 and x.trainIdx == x.queryIdx for x in r)
+    with pytest.raises(ValueError):
+        cv2_shim.BFMatcher_create(cv2_shim.NORM_HAMMING, crossCheck=False)
+
+
+def test_hip_reproduces_committed_golden_vectors(ctx):
+    g = np.load(os.path.join(GOLD, "frontend_golden.npz"))
+    bgr, depth = synth.render_batch(2)
+    kps, desc, n = frontend.orb_detect_describe(ctx, bgr, depth=depth, params=frontend.make_params(nfeatures=600))
+    for f in range(2):
+        assert np.array_equal(desc[f, :n[f]], g[f"desc{f}"])
+        for fld in ("x", "y", "angle", "response", "size"):
+            assert np.array_equal(kps[f, :n[f]][fld].view(np.uint32), g[f"kp{f}_{fld}"].view(np.uint32)), fld
+    qi, ti, d, nm = frontend.match_pairs(ctx, desc[1:2], n[1:2], desc[0:1], n[0:1])
+    assert np.array_equal(np.stack([qi[0, :nm[0]], ti[0, :nm[0]], d[0, :nm[0]]], 1), g["match_1_vs_0"])
+    b = np.load(os.path.join(GOLD, "ba_golden.npz"))
+    p = synth.pose_problem(n=120, seed=11)
+    R, t, chi2, inl, st = ba.pose_only_ba_batch(ctx, p["pix"][None], p["pts"][None], [120], p["K"])
+    assert np.allclose(R[0], b["pose_R"], atol=1e-9) and np.allclose(t[0], b["pose_t"], atol=1e-9) and np.array_equal(inl[0], b["pose_inlier"])
+    pr = synth.ba_problem(n_kf=6, n_pts=150, seed=1)
+    s = ba.LocalBA(ctx, pr["K"]); s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"]); s.optimize(7)
+    assert np.allclose(s.poses()[1], b["ba_t"], atol=1e-8) and np.allclose(s.points(), b["ba_pts"], atol=1e-8)
+    s.close()
+
+
+def test_ba_degenerate_inputs(ctx):
+    # no edges at all: optimise is a no-op, poses/points come back unchanged
+    s = ba.LocalBA(ctx, [synth.FX, synth.FY, synth.CX, synth.CY, synth.BASELINE])
+    R = np.eye(3)[None].repeat(2, 0); t = np.zeros((2, 3)); pts = np.ones((3, 3))
+    s.set_problem(R, t, [1, 0], pts, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2)))
+    assert s.optimize(5) == 0
+    assert np.array_equal(s.points(), pts) and np.allclose(s.poses()[0], R)
+    s.close()
+    # all keyframes fixed: only the points move (structure-only BA), must match the oracle
+    pr = synth.ba_problem(n_kf=5, n_pts=80, seed=8)
+    fixed = np.ones(5, np.uint8)
+    o = oracle.ba_optimize(pr["R"], pr["t"], fixed, pr["pts"], pr["ecam"], pr["ept"], pr["meas"], pr["K"], 5, ba.HUBER_DELTA)
+    s = ba.LocalBA(ctx, pr["K"]); s.set_problem(pr["R"], pr["t"], fixed, pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+    assert s.optimize(5) == o["iters_done"]
+    assert np.abs(s.points() - o["pts"]).max() < 1e-6 and np.array_equal(s.poses()[1], pr["t"])
+    s.close()
+    # CamOnlyBA with too few / degenerate points must not raise (reference swallows everything)
+    class Cam: fx, fy, cx, cy, baseline = synth.FX, synth.FY, synth.CX, synth.CY, synth.BASELINE
+    r = optimizer.CamOnlyBA(np.zeros((0, 2)), np.zeros((0, 3)), Cam, ctx=ctx)
+    assert r[0] in (True, False)

@@ -296,3 +296,25 @@ def test_bow_l1_score_matches_dense_formula():
     assert set(ids) == set(np.nonzero(share)[0])
     assert np.allclose(sc, ref[ids], atol=1e-12)
     assert np.all(np.diff(sc) <= 1e-15) and ids[0] == 17
+
+
+def test_voc_transform_matches_python_tree_walk():
+    voc = synth.vocabulary(k=5, L=3, seed=2)
+    d = synth.random_descriptors(4, 120)
+    d[50] = d[2]
+    w, x = oracle.voc_transform(voc, d)
+    acc = {}
+    for r in range(len(d)):
+        node = 0
+        while voc["child_start"][node + 1] > voc["child_start"][node]:
+            kids = voc["child_idx"][voc["child_start"][node]:voc["child_start"][node + 1]]
+            dist = np_ref.hamming_matrix(d[r:r + 1], voc["node_desc"][kids])[0]
+            node = int(kids[int(np.argmin(dist))])                       # argmin = first minimum in stored order
+        if voc["node_weight"][node] > 0:
+            acc.setdefault(int(voc["node_word"][node]), []).append(voc["node_weight"][node])
+    ref_w = np.array(sorted(acc), np.uint32)
+    ref_v = np.array([np.sum(np.array(acc[k])) if len(acc[k]) < 3 else sum(acc[k][1:], acc[k][0]) for k in sorted(acc)])
+    ref_v = ref_v / np.add.reduce(ref_v) if len(ref_v) < 2 else ref_v / sum(list(ref_v)[1:], ref_v[0])
+    assert np.array_equal(w, ref_w)
+    assert np.allclose(x, ref_v, rtol=1e-14, atol=0)
+    assert abs(x.sum() - 1) < 1e-12
