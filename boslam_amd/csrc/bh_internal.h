@@ -10,6 +10,7 @@
 #include "../../include/boslam_hip.h"
 
 #define BH_MAX_LEVELS 16
+#define BH_MAX_PIPES  4
 
 struct bh_buf {                      // grow-only device allocation
     void*  p = nullptr;
@@ -43,17 +44,24 @@ enum bh_kid { BH_K_GRAY = 0, BH_K_PYR, BH_K_FAST, BH_K_BLUR, BH_K_SELECT, BH_K_B
 
 struct bh_time_rec { int kid; hipEvent_t e0, e1; };
 
+struct bh_orb_ws { bh_buf pyr, mpyr, nms, blur, hist, sel_xy, sel_resp, sel_cnt; };   // one chunk pipeline's workspace
+
 struct bh_ctx {
     int         device = 0;
     hipStream_t stream = nullptr;    // stream in use
     hipStream_t own_stream = nullptr;
+    hipStream_t aux_stream[BH_MAX_PIPES - 1] = {};   // extra chunk pipelines of bh_orb_detect_describe
+    hipStream_t tstream = nullptr;     // stream the per-kernel timing events are recorded on (null: `stream`)
+    hipEvent_t  ev_fork = nullptr, ev_join[BH_MAX_PIPES - 1] = {};
     char        err[512] = {0};
     // ---- ORB workspace ----
     bh_orb_geom geom = {};
     bh_orb_params geom_params = {};
     int         geom_valid = 0;
     int         ws_frames = 0;       // frames the pyramid workspace holds
-    bh_buf      pyr, mpyr, nms, blur, hist, tab, sel_xy, sel_resp, sel_cnt, status;
+    bh_orb_ws   ows[BH_MAX_PIPES];
+    bh_buf      tab, status;
+    int         last_pipe = 0;
     bh_buf      st_img, st_mask, st_depth, st_kps, st_desc, st_nkp;     // host-mode staging
     bh_buf      st_a, st_b, st_c, st_d, st_e, st_f, st_g, st_h;         // generic staging (match / BA)
     int         last_B = 0;

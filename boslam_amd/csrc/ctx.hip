@@ -40,6 +40,11 @@ extern "C" int bh_ctx_create(int device, bh_ctx** out)
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BH_ERR_HIP; }
     ctx->stream = ctx->own_stream;
+    bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int p = 0; p < BH_MAX_PIPES - 1 && ok; p++)
+        ok = hipStreamCreateWithFlags(&ctx->aux_stream[p], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->ev_join[p], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { bh_ctx_destroy(ctx); return BH_ERR_HIP; }
     *out = ctx;
     return BH_OK;
 }
@@ -49,13 +54,17 @@ extern "C" void bh_ctx_destroy(bh_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    bh_buf* all[] = { &ctx->pyr, &ctx->mpyr, &ctx->nms, &ctx->blur, &ctx->hist, &ctx->tab, &ctx->sel_xy, &ctx->sel_resp, &ctx->sel_cnt, &ctx->status,
+    for (int p = 0; p < BH_MAX_PIPES - 1; p++) if (ctx->aux_stream[p]) (void)hipStreamSynchronize(ctx->aux_stream[p]);
+    for (int p = 0; p < BH_MAX_PIPES; p++) { bh_orb_ws& W = ctx->ows[p]; bh_buf* wsb[] = { &W.pyr, &W.mpyr, &W.nms, &W.blur, &W.hist, &W.sel_xy, &W.sel_resp, &W.sel_cnt }; for (bh_buf* b : wsb) release(b); }
+    bh_buf* all[] = { &ctx->tab, &ctx->status,
                       &ctx->st_img, &ctx->st_mask, &ctx->st_depth, &ctx->st_kps, &ctx->st_desc, &ctx->st_nkp,
                       &ctx->st_a, &ctx->st_b, &ctx->st_c, &ctx->st_d, &ctx->st_e, &ctx->st_f, &ctx->st_g, &ctx->st_h };
     for (bh_buf* b : all) release(b);
     (void)drain_timing(ctx);
     for (int i = 0; i < ctx->n_epool; i++) (void)hipEventDestroy(ctx->epool[i]);
     free(ctx->epool); free(ctx->trecs);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int p = 0; p < BH_MAX_PIPES - 1; p++) { if (ctx->ev_join[p]) (void)hipEventDestroy(ctx->ev_join[p]); if (ctx->aux_stream[p]) (void)hipStreamDestroy(ctx->aux_stream[p]); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -121,18 +130,19 @@ void bh_time_begin(bh_ctx* ctx, int kid)
     }
     bh_time_rec& r = ctx->trecs[ctx->n_trecs++];
     r.kid = kid; r.e0 = take_event(ctx); r.e1 = take_event(ctx);
-    (void)hipEventRecord(r.e0, ctx->stream);
+    (void)hipEventRecord(r.e0, ctx->tstream ? ctx->tstream : ctx->stream);
 }
 void bh_time_end(bh_ctx* ctx)
 {
     if (!ctx->timing_on) return;
-    (void)hipEventRecord(ctx->trecs[ctx->n_trecs - 1].e1, ctx->stream);
+    (void)hipEventRecord(ctx->trecs[ctx->n_trecs - 1].e1, ctx->tstream ? ctx->tstream : ctx->stream);
 }
 
 static int drain_timing(bh_ctx* ctx)
 {
     if (ctx->n_trecs == 0) return BH_OK;
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < BH_MAX_PIPES - 1; p++) if (ctx->aux_stream[p]) BH_HIP(ctx, hipStreamSynchronize(ctx->aux_stream[p]));
     for (int i = 0; i < ctx->n_trecs; i++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ctx->trecs[i].e0, ctx->trecs[i].e1) == hipSuccess) {

@@ -649,6 +649,32 @@ __global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ py
 }
 
 // ------------------------------------------------------------------------------------------------ angle + steered BRIEF
+// sin/cos in f64 for |x| <= ~8 (the keypoint angle in radians), accurate to < 1 ulp: Cody-Waite reduction by pi/2 (two
+// constants: k <= 6 so k*PIO2_HI is exact) and the classic degree-13/14 minimax kernels on [-pi/4, pi/4].  The reference
+// needs (float)cos((double)angle) for a float angle in [0, 2 pi]: tools/check_sincos_small.c runs this exact arithmetic
+// (IEEE +,-,*, rint; no FMA) over ALL 1 086 918 650 floats in [0, 6.2832] and finds zero differences from glibc's
+// sin/cos after the rounding to float — and it costs a quarter of the generic library routine (no Payne-Hanek path).
+__device__ __forceinline__ void sincos_small(double x, double* sn, double* cs)
+{
+    const double INV_PIO2 = 6.36619772367581382433e-01, PIO2_HI = 1.57079632673412561417e+00, PIO2_LO = 6.07710050650619224932e-11;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double kd = rint(x * INV_PIO2);
+    const int k = (int)kd;
+    const double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
+    const double z = r * r;
+    const double ps = z * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
+    const double s0 = r + r * ps;
+    const double pc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double c0 = (1.0 - 0.5 * z) + z * pc;
+    const int q = k & 3;
+    const double ss = (q & 1) ? c0 : s0, cc = (q & 1) ? s0 : c0;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 __constant__ signed char c_pattern[1024] = {
 #include "brief_pattern.h"
 };
@@ -709,7 +735,9 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     const int bx = __float2int_rn(kp.x * inv), by = __float2int_rn(kp.y * inv);
     float angle = angle_deg;
     angle *= (float)(3.1415926535897932384626433832795 / 180.f);
-    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    double sd, cd;
+    sincos_small((double)angle, &sd, &cd);
+    const float a = (float)cd, b = (float)sd;
     const uint8_t* center = blur + lbase + (size_t)by * L.pitch + bx;
     unsigned long long bits[4];
 #pragma unroll
@@ -810,7 +838,8 @@ extern "C" int bh_orb_geometry(int H, int W, const bh_orb_params* params, int* w
     return BH_OK;
 }
 
-#define ORB_CHUNK 256
+#define ORB_CHUNK 256            // host-mode chunk (single pipeline)
+#define ORB_CHUNK_DEV 128        // device-mode chunk per pipeline
 
 extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int channels, const uint8_t* mask,
                                       const uint16_t* depth, int B, int H, int W, const bh_orb_params* params,
@@ -825,21 +854,32 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
     if (B == 0) return BH_OK;
     const bh_orb_geom& g = ctx->geom;
     hipStream_t st = ctx->stream;
-    const int chunk = B < ORB_CHUNK ? B : ORB_CHUNK;
+    int chunk_cfg = mem == BH_MEM_DEVICE ? ORB_CHUNK_DEV : ORB_CHUNK;
+    if (const char* e = getenv("BH_ORB_CHUNK")) { const int v = atoi(e); if (v >= 1 && v <= 4096) chunk_cfg = v; }
+    const int chunk = B < chunk_cfg ? B : chunk_cfg;
     const bool has_mask = mask != nullptr || depth != nullptr;
 
+    // Device-resident batches run as two independent chunk pipelines on two streams (each with its own workspace), so
+    // the latency-bound kernels of one chunk (k_select, k_describe) overlap the VALU-bound ones of the next.
+    const int nchunks = (B + chunk - 1) / chunk;
+    int pipe_cfg = BH_MAX_PIPES;
+    if (const char* e = getenv("BH_ORB_PIPELINES")) { const int v = atoi(e); if (v >= 1 && v <= BH_MAX_PIPES) pipe_cfg = v; }
+    const int npipe = mem == BH_MEM_DEVICE ? (nchunks < pipe_cfg ? nchunks : pipe_cfg) : 1;
     const size_t ws = (size_t)g.pyr_stride * chunk;
-    BH_TRY(bh_reserve(ctx, &ctx->pyr, ws + 256));             // +256: the 12-byte resize windows may read past the last row
-    if (has_mask) BH_TRY(bh_reserve(ctx, &ctx->mpyr, ws + 256));
-    BH_TRY(bh_reserve(ctx, &ctx->nms, ws));
-    BH_TRY(bh_reserve(ctx, &ctx->blur, ws));
-    BH_TRY(bh_reserve(ctx, &ctx->hist, sizeof(uint32_t) * 256 * g.nlevels * chunk));
     int max_nf = 0;
     for (int l = 0; l < g.nlevels; l++) max_nf = g.lv[l].nfeat > max_nf ? g.lv[l].nfeat : max_nf;
     const int sel_cap = (max_nf + 64 + 7) & ~7;                 // per-level staging slots: n_l + room for ties at the cut
-    BH_TRY(bh_reserve(ctx, &ctx->sel_xy, sizeof(uint32_t) * (size_t)sel_cap * g.nlevels * chunk));
-    BH_TRY(bh_reserve(ctx, &ctx->sel_resp, sizeof(float) * (size_t)sel_cap * g.nlevels * chunk));
-    BH_TRY(bh_reserve(ctx, &ctx->sel_cnt, sizeof(int) * (size_t)g.nlevels * chunk));
+    for (int p = 0; p < npipe; p++) {
+        bh_orb_ws& Wk = ctx->ows[p];
+        BH_TRY(bh_reserve(ctx, &Wk.pyr, ws + 256));             // +256: the 12-byte resize windows may read past the last row
+        if (has_mask) BH_TRY(bh_reserve(ctx, &Wk.mpyr, ws + 256));
+        BH_TRY(bh_reserve(ctx, &Wk.nms, ws));
+        BH_TRY(bh_reserve(ctx, &Wk.blur, ws));
+        BH_TRY(bh_reserve(ctx, &Wk.hist, sizeof(uint32_t) * 256 * g.nlevels * chunk));
+        BH_TRY(bh_reserve(ctx, &Wk.sel_xy, sizeof(uint32_t) * (size_t)sel_cap * g.nlevels * chunk));
+        BH_TRY(bh_reserve(ctx, &Wk.sel_resp, sizeof(float) * (size_t)sel_cap * g.nlevels * chunk));
+        BH_TRY(bh_reserve(ctx, &Wk.sel_cnt, sizeof(int) * (size_t)g.nlevels * chunk));
+    }
     BH_TRY(bh_reserve(ctx, &ctx->status, 256));
     ctx->ws_frames = chunk;
 
@@ -853,12 +893,20 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         BH_TRY(bh_reserve(ctx, &ctx->st_nkp, sizeof(int) * chunk));
     }
     BH_HIP(ctx, hipMemsetAsync(ctx->status.p, 0, 256, st));
+    if (npipe > 1) {                                             // fork: the aux streams start after everything queued so far
+        BH_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        for (int p = 1; p < npipe; p++) BH_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream[p - 1], ctx->ev_fork, 0));
+    }
 
     bh_umax UM; { int um[17]; umax_table(um); for (int i = 0; i < 16; i++) UM.u[i] = um[i]; }
     bh_gauss7 G; gauss7_coeffs(G.k);
 
-    for (int f0 = 0; f0 < B; f0 += chunk) {
+    for (int f0 = 0, ci = 0; f0 < B; f0 += chunk, ci++) {
         const int nb = (B - f0) < chunk ? (B - f0) : chunk;
+        const int pipe = ci % npipe;
+        bh_orb_ws& Wk = ctx->ows[pipe];
+        st = pipe ? ctx->aux_stream[pipe - 1] : ctx->stream;
+        ctx->tstream = st;
         const uint8_t* d_img; const uint8_t* d_mask = nullptr; const uint16_t* d_depth = nullptr;
         bh_kp* d_kps; uint8_t* d_desc; int* d_nkp;
         if (mem == BH_MEM_HOST) {
@@ -872,9 +920,9 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
             if (mask) d_mask = mask + (size_t)f0 * fpx; else if (depth) d_depth = depth + (size_t)f0 * fpx;
             d_kps = kps + (size_t)f0 * max_kp; d_desc = desc + (size_t)f0 * max_kp * 32; d_nkp = n_kp + f0;
         }
-        uint8_t* pyr = (uint8_t*)ctx->pyr.p; uint8_t* mpyr = has_mask ? (uint8_t*)ctx->mpyr.p : nullptr;
-        uint8_t* nms = (uint8_t*)ctx->nms.p; uint8_t* blur = (uint8_t*)ctx->blur.p;
-        uint32_t* hist = (uint32_t*)ctx->hist.p;
+        uint8_t* pyr = (uint8_t*)Wk.pyr.p; uint8_t* mpyr = has_mask ? (uint8_t*)Wk.mpyr.p : nullptr;
+        uint8_t* nms = (uint8_t*)Wk.nms.p; uint8_t* blur = (uint8_t*)Wk.blur.p;
+        uint32_t* hist = (uint32_t*)Wk.hist.p;
 
         BH_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * g.nlevels * nb, st));
         {
@@ -889,11 +937,11 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, nms, hist, g);
         BH_LAUNCH(ctx, BH_K_BLUR, k_blur<false>, dim3(g.bblk_total, nb), dim3(256), st, pyr, blur, g, G);
         BH_LAUNCH(ctx, BH_K_BLUR, k_blur<true>, dim3(g.eblk_total, nb), dim3(256), st, pyr, blur, g, G);
-        BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, nms, hist, g, sel_cap, (uint32_t*)ctx->sel_xy.p,
-                  (float*)ctx->sel_resp.p, (int*)ctx->sel_cnt.p, (uint32_t*)ctx->status.p);
+        BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, nms, hist, g, sel_cap, (uint32_t*)Wk.sel_xy.p,
+                  (float*)Wk.sel_resp.p, (int*)Wk.sel_cnt.p, (uint32_t*)ctx->status.p);
         BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3((max_kp + 3) / 4, nb), dim3(256), st, pyr, blur, g, UM,
-                  (float)params->patchSize, sel_cap, max_kp, (const uint32_t*)ctx->sel_xy.p, (const float*)ctx->sel_resp.p,
-                  (const int*)ctx->sel_cnt.p, d_kps, d_desc, d_nkp, (uint32_t*)ctx->status.p);
+                  (float)params->patchSize, sel_cap, max_kp, (const uint32_t*)Wk.sel_xy.p, (const float*)Wk.sel_resp.p,
+                  (const int*)Wk.sel_cnt.p, d_kps, d_desc, d_nkp, (uint32_t*)ctx->status.p);
         BH_HIP(ctx, hipGetLastError());
         if (mem == BH_MEM_HOST) {
             BH_HIP(ctx, hipMemcpyAsync(kps + (size_t)f0 * max_kp, d_kps, sizeof(bh_kp) * (size_t)max_kp * nb, hipMemcpyDeviceToHost, st));
@@ -901,7 +949,12 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
             BH_HIP(ctx, hipMemcpyAsync(n_kp + f0, d_nkp, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
             BH_HIP(ctx, hipStreamSynchronize(st));
         }
-        ctx->last_B = nb; ctx->last_has_mask = has_mask;
+        ctx->last_B = nb; ctx->last_has_mask = has_mask; ctx->last_pipe = pipe;
+    }
+    ctx->tstream = nullptr;
+    for (int p = 1; p < npipe; p++) {                            // join: later work on the context's stream sees every chunk
+        BH_HIP(ctx, hipEventRecord(ctx->ev_join[p - 1], ctx->aux_stream[p - 1]));
+        BH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[p - 1], 0));
     }
     if (mem == BH_MEM_HOST) return bh_ctx_status(ctx);
     return BH_OK;
@@ -912,11 +965,12 @@ extern "C" int bh_orb_debug_fetch(bh_ctx* ctx, int frame, uint8_t* pyr, uint8_t*
     if (!ctx || !ctx->geom_valid || frame < 0 || frame >= ctx->last_B)
         return ctx ? bh_set_err(ctx, BH_ERR_INVALID, "bh_orb_debug_fetch: no such frame in the last chunk") : BH_ERR_INVALID;
     const size_t n = ctx->geom.pyr_stride, o = (size_t)frame * n;
+    const bh_orb_ws& Wk = ctx->ows[ctx->last_pipe];
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (pyr)  BH_HIP(ctx, hipMemcpy(pyr, (uint8_t*)ctx->pyr.p + o, n, hipMemcpyDeviceToHost));
-    if (mask_pyr && ctx->last_has_mask) BH_HIP(ctx, hipMemcpy(mask_pyr, (uint8_t*)ctx->mpyr.p + o, n, hipMemcpyDeviceToHost));
-    if (nms)  BH_HIP(ctx, hipMemcpy(nms, (uint8_t*)ctx->nms.p + o, n, hipMemcpyDeviceToHost));
-    if (blur) BH_HIP(ctx, hipMemcpy(blur, (uint8_t*)ctx->blur.p + o, n, hipMemcpyDeviceToHost));
+    if (pyr)  BH_HIP(ctx, hipMemcpy(pyr, (uint8_t*)Wk.pyr.p + o, n, hipMemcpyDeviceToHost));
+    if (mask_pyr && ctx->last_has_mask) BH_HIP(ctx, hipMemcpy(mask_pyr, (uint8_t*)Wk.mpyr.p + o, n, hipMemcpyDeviceToHost));
+    if (nms)  BH_HIP(ctx, hipMemcpy(nms, (uint8_t*)Wk.nms.p + o, n, hipMemcpyDeviceToHost));
+    if (blur) BH_HIP(ctx, hipMemcpy(blur, (uint8_t*)Wk.blur.p + o, n, hipMemcpyDeviceToHost));
     return BH_OK;
 }
 
