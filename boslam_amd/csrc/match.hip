@@ -148,3 +148,80 @@ extern "C" int bh_match_hamming_crosscheck(bh_ctx* ctx, const uint8_t* q, const 
     }
     return BH_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ map-point medoid descriptor
+// Replaces the Python double loop of MapPoint.add_observation — slam/nodes.py:142-154: for every
+// map point, among its k <= 10 stored observation descriptors pick the one whose column of the (uint8) Hamming distance
+// matrix has the smallest median (numpy semantics: mean of the two middle values for even k; first minimum).
+// One lane per map point: 45 xor+popcount distances, a 10-element insertion sort per column, integer compare of 2*median.
+#define MEDOID_K 10
+__global__ __launch_bounds__(256) void k_medoid(const uint8_t* __restrict__ desc, const int* __restrict__ k_arr, int M,
+                                                int* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int k = min(k_arr[i], MEDOID_K);
+    if (k <= 0) { out[i] = -1; return; }
+    const uint4* d = reinterpret_cast<const uint4*>(desc + (size_t)i * MEDOID_K * 32);
+    int D[MEDOID_K][MEDOID_K];
+#pragma unroll
+    for (int a = 0; a < MEDOID_K; a++) {
+        D[a][a] = 0;
+#pragma unroll
+        for (int b = a + 1; b < MEDOID_K; b++) {
+            int v = 0;
+            if (b < k) {
+                const uint4 p0 = d[2 * a], p1 = d[2 * a + 1], q0 = d[2 * b], q1 = d[2 * b + 1];
+                v = __popc(p0.x ^ q0.x) + __popc(p0.y ^ q0.y) + __popc(p0.z ^ q0.z) + __popc(p0.w ^ q0.w) +
+                    __popc(p1.x ^ q1.x) + __popc(p1.y ^ q1.y) + __popc(p1.z ^ q1.z) + __popc(p1.w ^ q1.w);
+                v &= 255;                                   // the reference keeps the matrix in uint8
+            }
+            D[a][b] = v; D[b][a] = v;
+        }
+    }
+    int best = 0, best_m2 = 1 << 30;
+#pragma unroll
+    for (int c = 0; c < MEDOID_K; c++) {
+        if (c < k) {
+            int col[MEDOID_K];
+#pragma unroll
+            for (int r = 0; r < MEDOID_K; r++) col[r] = r < k ? D[r][c] : 1 << 20;     // padding sorts to the end
+#pragma unroll
+            for (int a = 0; a < MEDOID_K - 1; a++)                                     // odd-even style fixed network (bubble passes)
+#pragma unroll
+                for (int b = 0; b < MEDOID_K - 1 - a; b++) { const int lo = min(col[b], col[b + 1]), hi = max(col[b], col[b + 1]); col[b] = lo; col[b + 1] = hi; }
+            int m2 = 0;
+#pragma unroll
+            for (int r = 0; r < MEDOID_K; r++) {
+                if ((k & 1) && r == k / 2) m2 = 2 * col[r];
+                if (!(k & 1) && (r == k / 2 - 1 || r == k / 2)) m2 += col[r];
+            }
+            if (m2 < best_m2) { best_m2 = m2; best = c; }
+        }
+    }
+    out[i] = best;
+}
+
+extern "C" int bh_medoid_descriptor(bh_ctx* ctx, const uint8_t* desc, const int* k, int M, int* medoid_idx, int mem)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (!desc || !k || !medoid_idx || M < 0 || (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_medoid_descriptor: bad argument");
+    if (M == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint8_t* d_desc = desc; const int* d_k = k; int* d_out = medoid_idx;
+    if (mem == BH_MEM_HOST) {
+        BH_TRY(bh_reserve(ctx, &ctx->st_a, (size_t)M * MEDOID_K * 32)); BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(int) * 2 * (size_t)M));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_a.p, desc, (size_t)M * MEDOID_K * 32, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(ctx->st_b.p, k, sizeof(int) * M, hipMemcpyHostToDevice, st));
+        d_desc = (const uint8_t*)ctx->st_a.p; d_k = (const int*)ctx->st_b.p; d_out = (int*)ctx->st_b.p + M;
+    }
+    BH_LAUNCH(ctx, BH_K_MATCH, k_medoid, dim3((M + 255) / 256), dim3(256), st, d_desc, d_k, M, d_out);
+    BH_HIP(ctx, hipGetLastError());
+    if (mem == BH_MEM_HOST) {
+        BH_HIP(ctx, hipMemcpyAsync(medoid_idx, d_out, sizeof(int) * M, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipStreamSynchronize(st));
+    }
+    return BH_OK;
+}

@@ -138,13 +138,14 @@ __global__ __launch_bounds__(256) void k_gray_mask(const uint8_t* __restrict__ i
 // ------------------------------------------------------------------------------------------------ pyramid level l from l-1
 // INTER_LINEAR_EXACT arithmetic: horizontal 8.8 fixed point, vertical 16.16, round to nearest.
 // One lane produces 4 output pixels.  Its 4 coefficient entries come in one 16-B load; the <= 6 source columns they
-// reference lie inside 3 aligned words starting at (first column & ~3), so each of the two source rows is 3 word loads
-// per plane (image, mask) — 14 loads per lane, all issued before the first use — and the byte pairs are picked with
-// v_alignbyte instead of 16 single-byte loads per plane.
-__device__ __forceinline__ uint32_t pyr_pair(uint32_t W0, uint32_t W1, uint32_t W2, int rel)
-{   // bytes rel, rel+1 of the 12-byte window (rel <= 8); low 16 bits of the result
-    const uint32_t lo = rel < 4 ? W0 : W1, hi = rel < 4 ? W1 : W2;
-    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(rel & 3));
+// reference fit one 8-byte window starting at the first column, so each of the two source rows is ONE (unaligned) 8-byte
+// load per plane (image, mask) — 6 loads per lane, all issued before the first use — and the byte pairs are picked with a
+// 64-bit shift instead of 16 single-byte loads per plane.
+__device__ __forceinline__ unsigned long long pyr_load8(const uint8_t* p)
+{   // 8 bytes from a byte-aligned address (global memory tolerates unaligned dword accesses on gfx9)
+    unsigned long long v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
 }
 
 __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, uint8_t* __restrict__ mpyr,
@@ -165,36 +166,34 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, uin
     const uint4 tx4 = *reinterpret_cast<const uint4*>(tab + D.tabx_off + x);      // tabx_off is a multiple of 4, padded
     const uint32_t ty = tab[D.taby_off + y];
     const int r0 = ty >> 16, r1 = min(r0 + 1, S.h - 1);
-    const uint32_t yc1 = ty & 0xffffu, yc0 = 256u - yc1;
+    const uint32_t yc1 = ty & 0xffffu;
     const uint32_t txs[4] = { tx4.x, tx4.y, tx4.z, tx4.w };
-    const int base = (int)(tx4.x >> 16) & ~3;
+    // the 4 outputs reference source columns a0 .. a0+5 (scale <= 1.3): one 8-byte window per source row and plane
+    const int base = (int)(tx4.x >> 16);
     const size_t s0 = fb + S.off + (size_t)r0 * S.pitch + base, s1 = fb + S.off + (size_t)r1 * S.pitch + base;
-    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(pyr + s0);
-    const uint32_t* p1 = reinterpret_cast<const uint32_t*>(pyr + s1);
-    const uint32_t A0 = p0[0], A1 = p0[1], A2 = p0[2], B0 = p1[0], B1 = p1[1], B2 = p1[2];
-    uint32_t MA0 = 0, MA1 = 0, MA2 = 0, MB0 = 0, MB1 = 0, MB2 = 0;
-    if (mpyr) {
-        const uint32_t* q0 = reinterpret_cast<const uint32_t*>(mpyr + s0);
-        const uint32_t* q1 = reinterpret_cast<const uint32_t*>(mpyr + s1);
-        MA0 = q0[0]; MA1 = q0[1]; MA2 = q0[2]; MB0 = q1[0]; MB1 = q1[1]; MB2 = q1[2];
-    }
+    const unsigned long long A = pyr_load8(pyr + s0), Bv = pyr_load8(pyr + s1);
+    unsigned long long MA = 0, MB = 0;
+    if (mpyr) { MA = pyr_load8(mpyr + s0); MB = pyr_load8(mpyr + s1); }
     uint32_t o4 = 0, mo4 = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         if (x + i < D.w) {
             const uint32_t tx = txs[i];
-            const int rel = (int)(tx >> 16) - base;           // 0 .. 8
-            const uint32_t c1 = tx & 0xffffu, c0 = 256u - c1;
-            uint32_t pa = pyr_pair(A0, A1, A2, rel), pb = pyr_pair(B0, B1, B2, rel);
-            uint32_t h0 = c0 * (pa & 255u) + c1 * ((pa >> 8) & 255u);
-            uint32_t h1 = c0 * (pb & 255u) + c1 * ((pb >> 8) & 255u);
-            uint32_t v = (yc0 * h0 + yc1 * h1 + 32768u) >> 16;
+            const int sh = ((int)(tx >> 16) - base) << 3;       // 0 .. 32 bits
+            const uint32_t c1 = tx & 0xffffu;
+            // c0*p0 + c1*p1 with c0 = 256 - c1  ==  (p0 << 8) + c1*(p1 - p0); same for the vertical pass (exact integers)
+            uint32_t pa = (uint32_t)(A >> sh), pb = (uint32_t)(Bv >> sh);
+            int p0 = (int)(pa & 255u), q0 = (int)(pb & 255u);
+            int h0 = (p0 << 8) + (int)c1 * ((int)((pa >> 8) & 255u) - p0);
+            int h1 = (q0 << 8) + (int)c1 * ((int)((pb >> 8) & 255u) - q0);
+            uint32_t v = (uint32_t)((h0 << 8) + (int)yc1 * (h1 - h0) + 32768) >> 16;
             o4 |= v << (8 * i);
             if (mpyr) {
-                pa = pyr_pair(MA0, MA1, MA2, rel); pb = pyr_pair(MB0, MB1, MB2, rel);
-                h0 = c0 * (pa & 255u) + c1 * ((pa >> 8) & 255u);
-                h1 = c0 * (pb & 255u) + c1 * ((pb >> 8) & 255u);
-                v = (yc0 * h0 + yc1 * h1 + 32768u) >> 16;
+                pa = (uint32_t)(MA >> sh); pb = (uint32_t)(MB >> sh);
+                p0 = (int)(pa & 255u); q0 = (int)(pb & 255u);
+                h0 = (p0 << 8) + (int)c1 * ((int)((pa >> 8) & 255u) - p0);
+                h1 = (q0 << 8) + (int)c1 * ((int)((pb >> 8) & 255u) - q0);
+                v = (uint32_t)((h0 << 8) + (int)yc1 * (h1 - h0) + 32768) >> 16;
                 mo4 |= (v > 254u ? v : 0u) << (8 * i);                 // THRESH_TOZERO at 254
             }
         }
@@ -413,7 +412,14 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
     const uint8_t* img = pyr + fbase;
     const uint32_t K03 = (uint32_t)G.k[0] | ((uint32_t)G.k[1] << 8) | ((uint32_t)G.k[2] << 16) | ((uint32_t)G.k[3] << 24);
     const uint32_t K46 = (uint32_t)G.k[4] | ((uint32_t)G.k[5] << 8) | ((uint32_t)G.k[6] << 16);
-    uint32_t hs[7][4];
+    // column pass with v_dot2_u32_u16: consecutive row sums are kept as 16-bit pairs P[q] = (h_q, h_q+1); the 7 taps of
+    // output row y are dot2(P[y-3],(k0,k1)) + dot2(P[y-1],(k2,k3)) + dot2(P[y+1],(k4,k5)) + k6*h[y+3]  (20 ops per strip row
+    // instead of 28 multiply-adds)
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 K01 = { (unsigned short)G.k[0], (unsigned short)G.k[1] }, K23 = { (unsigned short)G.k[2], (unsigned short)G.k[3] },
+              K45 = { (unsigned short)G.k[4], (unsigned short)G.k[5] };
+    uint32_t pr[6][4];                      // pr[q % 6] = P[q]
+    uint32_t hprev[4] = { 0, 0, 0, 0 };
 #pragma unroll
     for (int r = 0; r < BL_R + 6; r++) {
         const int yr = reflect101(y0 - 3 + r, L.h);
@@ -431,24 +437,31 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
                 W2 |= (uint32_t)row[reflect101(x0 + 4 + k, L.w)] << (8 * k);
             }
         }
-        uint32_t* h = hs[r % 7];
+        uint32_t h[4];
         h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 1), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 1), K46, 0u, false), false);
         h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 2), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 2), K46, 0u, false), false);
         h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 3), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 3), K46, 0u, false), false);
         h[3] = __builtin_amdgcn_udot4(W1, K03, __builtin_amdgcn_udot4(W2, K46, 0u, false), false);
+        if (r >= 1) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) pr[(r - 1) % 6][i] = hprev[i] | (h[i] << 16);       // P[r-1] = (h_{r-1}, h_r)
+        }
         if (r >= 6) {
             const int y = y0 + r - 6;
             uint32_t out = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                uint32_t s = 32768u;
-#pragma unroll
-                for (int k = 0; k < 7; k++) s += __umul24(hs[(r - 6 + k) % 7][i], (uint32_t)G.k[k]);
+                uint32_t s = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pr[(r - 6) % 6][i]), K01, 32768u, false);
+                s = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pr[(r - 4) % 6][i]), K23, s, false);
+                s = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pr[(r - 2) % 6][i]), K45, s, false);
+                s += __umul24(h[i], (uint32_t)G.k[6]);
                 s >>= 16;
                 out |= min(s, 255u) << (8 * i);
             }
             if (y < L.h) *reinterpret_cast<uint32_t*>(blur + fbase + (size_t)y * L.pitch + x0) = out;
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++) hprev[i] = h[i];
     }
 }
 
@@ -476,7 +489,7 @@ __device__ __forceinline__ int count_ge(uint32_t w, uint32_t thr)
     return (int)(((w & 255u) >= thr) + (((w >> 8) & 255u) >= thr) + (((w >> 16) & 255u) >= thr) + ((w >> 24) >= thr));
 }
 
-struct bh_umax { int u[16]; };
+struct bh_umax { int u[16]; unsigned long long packed; };   // packed: 4 bits per row half-width
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
@@ -721,7 +734,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         const int v = it * 2 + (lane >> 5) - 15;             // v <= 16, u <= 16: always inside the level (31-px border)
         const int av = min(v < 0 ? -v : v, 15);
         const int I = c[v * L.pitch + u];                     // unconditional: all 16 loads are issued back to back
-        const bool in = v <= 15 && u >= -UM.u[av] && u <= UM.u[av];
+        const int um = (int)((UM.packed >> (4 * av)) & 15ull);
+        const bool in = v <= 15 && u >= -um && u <= um;
         m10 += in ? u * I : 0; m01 += in ? v * I : 0;
     }
     m10 = wave_sum(m10); m01 = wave_sum(m01);
@@ -898,7 +912,7 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         for (int p = 1; p < npipe; p++) BH_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream[p - 1], ctx->ev_fork, 0));
     }
 
-    bh_umax UM; { int um[17]; umax_table(um); for (int i = 0; i < 16; i++) UM.u[i] = um[i]; }
+    bh_umax UM; { int um[17]; umax_table(um); UM.packed = 0; for (int i = 0; i < 16; i++) { UM.u[i] = um[i]; UM.packed |= (unsigned long long)(um[i] & 15) << (4 * i); } }
     bh_gauss7 G; gauss7_coeffs(G.k);
 
     for (int f0 = 0, ci = 0; f0 < B; f0 += chunk, ci++) {

@@ -128,3 +128,12 @@ class DeviceFrontEnd:
                 self.desc.data_ptr(), self.n_kp.data_ptr(), self.max_kp, self.B - 1,
                 self.qidx.data_ptr() + 4 * self.max_kp, self.tidx.data_ptr() + 4 * self.max_kp,
                 self.dist.data_ptr() + 4 * self.max_kp, self.n_match.data_ptr() + 4, self.max_kp, BH_MEM_DEVICE))
+
+
+def medoid_descriptors(ctx, desc, k):
+    """MapPoint.add_observation's medoid choice (slam/nodes.py:142-154) for a batch: desc u8[M][10][32], k int[M] -> idx int[M]."""
+    desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 10, 32)
+    k = np.ascontiguousarray(k, dtype=np.int32)
+    out = np.zeros(len(k), np.int32)
+    ctx.check(_lib.lib().bh_medoid_descriptor(ctx.h, _lib.ptr(desc), _lib.ptr(k), len(k), _lib.ptr(out), BH_MEM_HOST))
+    return out

@@ -112,6 +112,11 @@ int bh_match_hamming_crosscheck(bh_ctx* ctx, const uint8_t* q, const int* nq, in
                                 const uint8_t* t, const int* nt, int t_stride, int B,
                                 int* qidx, int* tidx, int* dist, int* n_match, int out_stride, int mem);
 
+/* Map-point medoid descriptor — replaces the double loop of MapPoint.add_observation,
+ * slam/nodes.py:142-154: for M map points with k[m] <= 10 stored descriptors each (desc u8[M][10][32]) the index of the
+ * descriptor whose column of the uint8 Hamming matrix has the smallest numpy-median (first minimum); -1 when k[m] <= 0. */
+int bh_medoid_descriptor(bh_ctx* ctx, const uint8_t* desc, const int* k, int M, int* medoid_idx, int mem);
+
 /* ---- pose-only bundle adjustment ----------------------------------------------------------------------------------
  * Replaces CamOnlyBA(pixels, points, cam, ...) — slam/optimizer.py:82-142, called at slam/tracking.py:73,128 —
  * for B independent problems (one free VertexCam initialised to identity, n fixed points, EdgeProjectP2MC,

@@ -288,3 +288,8 @@ def voc_transform(voc, desc):
     words = np.zeros(max(len(desc), 1), np.uint32); vals = np.zeros(max(len(desc), 1), np.float64)
     k = lib().orc_voc_transform(_p(cs), _p(ci), _p(nd), _p(nw), _p(ni), _p(desc), len(desc), _p(words), _p(vals))
     return words[:k].copy(), vals[:k].copy()
+
+
+def medoid_index(desc):
+    desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+    return int(lib().orc_medoid_index(_p(desc), len(desc)))

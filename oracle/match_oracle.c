@@ -68,3 +68,22 @@ void orc_match_consecutive(const uint8_t* desc, const int* n, int B, int max_kp,
                                           qidx + (size_t)b * max_kp, tidx + (size_t)b * max_kp,
                                           dist + (size_t)b * max_kp);
 }
+
+/*
+ * Map-point medoid descriptor — slam/nodes.py:142-154 (MapPoint.add_observation): among k <= 10 observation descriptors,
+ * dists[i][j] = uint8(Hamming(f_i, f_j)) (the reference stores the distance in a uint8 matrix: 256 wraps to 0), median of
+ * every column (numpy: mean of the two middle values for even k), first argmin.  Returns the index of the medoid.
+ */
+int orc_medoid_index(const uint8_t* desc /* [k][32] */, int k)
+{
+    if (k <= 0) return -1;
+    int best = 0, best_m2 = 1 << 30;
+    for (int c = 0; c < k; c++) {
+        int col[16];
+        for (int r = 0; r < k; r++) col[r] = r == c ? 0 : (orc_hamming32(desc + 32 * r, desc + 32 * c) & 255);
+        for (int i = 1; i < k; i++) { int v = col[i], j = i - 1; while (j >= 0 && col[j] > v) { col[j + 1] = col[j]; j--; } col[j + 1] = v; }
+        int m2 = (k & 1) ? 2 * col[k / 2] : col[k / 2 - 1] + col[k / 2];          /* twice the median */
+        if (m2 < best_m2) { best_m2 = m2; best = c; }
+    }
+    return best;
+}

@@ -92,3 +92,26 @@ def test_backproject_matches_oracle(ctx):
         oc = oracle.backproject(depth[f], oxy, synth.FX, synth.FY, synth.CX, synth.CY)
         assert np.array_equal(cloud[f, :n[f]], oc)
         assert (oc[:, 2] > 0).all()            # the ORB mask keeps keypoints off depth holes
+
+
+def test_medoid_descriptor_matches_oracle_and_numpy(ctx):
+    rng = np.random.default_rng(12)
+    M = 700
+    desc = rng.integers(0, 256, size=(M, 10, 32), dtype=np.uint8)
+    k = rng.integers(0, 11, size=M).astype(np.int32)
+    for m in range(0, M, 5):                                           # clustered observations: near-duplicates and exact ties
+        base = desc[m, 0].copy()
+        for j in range(1, 10):
+            desc[m, j] = base ^ (rng.random(32) < 0.03 * j).astype(np.uint8) * np.uint8(1 << (j % 8))
+    desc[3, 1] = ~desc[3, 0]                                           # distance 256 wraps to 0 in the reference's uint8 matrix
+    k[3] = 2
+    got = frontend.medoid_descriptors(ctx, desc, k)
+    for m in range(M):
+        ref = oracle.medoid_index(desc[m, :k[m]]) if k[m] > 0 else -1
+        assert got[m] == ref, (m, k[m], got[m], ref)
+        if 0 < k[m] and m % 7 == 0:                                    # numpy restatement of nodes.py:147-153
+            d = np.zeros((k[m], k[m]), np.uint8)
+            for a in range(k[m]):
+                for b in range(a + 1, k[m]):
+                    d[a, b] = d[b, a] = np.unpackbits(desc[m, a] ^ desc[m, b]).sum() & 255
+            assert got[m] == int(np.argmin(np.median(d, axis=0)))
