@@ -357,6 +357,8 @@ struct bh_ba {
     bh_buf Hpl, Hll, bl, Hpp, bp, pdiag, cdiag;
     bh_buf Dinv, db, S, bs, dxp, dxl, state, pairs;
     int npairs = 0;
+    int bw = 0;                        // scalar half-bandwidth of the reduced camera system (6*max|s1-s2| + 5)
+    int chol_nb = 32;                  // panel width chosen for the LDS budget
     int last_err_sel = 0;              // which err buffer holds "the last computeActiveErrors"
 };
 
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_S(const int2* __restrict__ pai
                                                     const int* __restrict__ c_edges, const int* __restrict__ e_pt,
                                                     const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                                                     const double* __restrict__ Hpp, const ba_state* __restrict__ St,
-                                                    int n6, double* __restrict__ Sm)
+                                                    int bw, double* __restrict__ Sm)
 {
     __shared__ double s_red[36 * 4];
     __shared__ int s_pt2[SCH_LDS];                         // camera s2's point ids (ascending): the join searches LDS
@@ -547,8 +549,9 @@ __global__ __launch_bounds__(256) void k_ba_schur_S(const int2* __restrict__ pai
         const int a = tid / 6, bb = tid - a * 6;
         double v = -acc[tid];
         if (s1 == s2) { v += Hpp[36 * (size_t)s1 + tid]; if (a == bb) v += St->lambda; }
-        Sm[(size_t)(6 * s1 + a) * n6 + 6 * s2 + bb] = v;
-        if (s1 != s2) Sm[(size_t)(6 * s2 + bb) * n6 + 6 * s1 + a] = v;
+        // lower band storage: element (row, col), row >= col, at Sm[row*LD + (col - row + bw)]; s1 <= s2
+        const int row = 6 * s2 + bb, col = 6 * s1 + a;
+        if (col <= row) Sm[(size_t)row * (bw + 1) + (col - row + bw)] = v;
     }
 }
 
@@ -571,39 +574,43 @@ __global__ __launch_bounds__(256) void k_ba_schur_b(const int* __restrict__ c_st
     if (tid < 6) bs[6 * s + tid] = bp[6 * s + tid] - acc[tid];
 }
 
-// ---- k_ba_chol: one workgroup, blocked right-looking Cholesky of S (n x n, row-major, lower triangle) + both substitutions.
-// Per NB-column panel: the panel (n-j0 rows x NB) is staged in LDS; wave 0 factors the NB x NB diagonal block; one lane
-// per row does the triangular solve of the rows below; the trailing update A22 -= L21 L21' runs on the matrix cores
-// (v_mfma_f64_16x16x4_f64, one 16x16 tile per wave and step, operands straight from the LDS panel); the forward
-// substitution rides along panel by panel, the backward one re-stages the panels in reverse.  All sums in fixed order.
+// ---- k_ba_chol: one workgroup, blocked right-looking Cholesky of the BANDED reduced camera system + both substitutions.
+// S is stored as a lower band: row i holds columns i-bw .. i at A[i*LD + (c - i + bw)], LD = bw+1 (bw = n-1 is the dense
+// case).  Per NB-column panel: the in-band part of the panel (min(n-j0, NB+bw) rows x NB) is staged in LDS; wave 0 factors
+// the NB x NB diagonal block in registers; one lane per row does the triangular solve of the rows below; the trailing update
+// A22 -= L21 L21' runs on the matrix cores (v_mfma_f64_16x16x4_f64, one 16x16 tile per wave and step, operands straight
+// from the LDS panel); the forward substitution rides along panel by panel, the backward one re-stages the panels in
+// reverse.  The right-hand side / solution lives in global memory (x).  All sums in fixed order.
 typedef double ba_d4 __attribute__((ext_vector_type(4)));
+#define AB(i, c) A[(size_t)(i) * LD + ((c) - (i) + bw)]
 
 template <int NB>
-__global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const double* __restrict__ bs, int n,
+__global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const double* __restrict__ bs, int n, int bw,
                                                   double* __restrict__ x, ba_state* __restrict__ St)
 {
     extern __shared__ double sm[];
     constexpr int PP = NB + 1;
+    const int LD = bw + 1;
+    const int mmax = min(n, NB + bw);
     double* P = sm;                                   // panel, row pitch NB+1
-    double* yv = sm + (size_t)n * PP;                 // right-hand side -> solution
-    double* part = yv + n;                            // [32][NB] partial sums of the backward pass
+    double* part = sm + (size_t)mmax * PP;            // [1024/NB][NB] partial sums of the backward pass / exchange buffer
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_fail = St->chol_ok ? 0 : 1;
-    for (int i = tid; i < n; i += 1024) yv[i] = bs[i];
+    for (int i = tid; i < n; i += 1024) x[i] = bs[i];
     __syncthreads();
     for (int j0 = 0; j0 < n && !s_fail; j0 += NB) {
-        const int nbw = min(NB, n - j0), m = n - j0;
+        const int nbw = min(NB, n - j0), m = min(n - j0, NB + bw);
         for (int idx = tid; idx < m * NB; idx += 1024) {
             const int r = idx / NB, c = idx - r * NB;
-            P[r * PP + c] = c < nbw ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
+            P[r * PP + c] = (c < nbw && c <= r && c >= r - bw) ? AB(j0 + r, j0 + c) : 0.0;      // in-band lower part only
         }
         __syncthreads();
         if (wv == 0) {                                // diagonal block in registers: lane l owns row l
             double row[NB];
 #pragma unroll
             for (int k = 0; k < NB; k++) row[k] = lane < nbw ? P[lane * PP + k] : 0.0;
-            double* colb = part;                       // exchange buffer (>= 64 doubles), wave-private here
+            double* colb = part;                       // exchange buffer (>= 65 doubles), wave-private here
             bool bad = false;
 #pragma unroll
             for (int c = 0; c < NB; c++) {
@@ -647,23 +654,23 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
             for (int k = 0; k < NB; k++) P[r * PP + k] = rw[k];
         }
         if (wv == 0) {                                // forward substitution inside the panel: lane l owns y[j0+l]
-            double yl = lane < nbw ? yv[j0 + lane] : 0.0;
+            double yl = lane < nbw ? x[j0 + lane] : 0.0;
             for (int c = 0; c < nbw; c++) {
                 const double yc = d_shfl_idx(yl, c) / P[c * PP + c];
                 if (lane == c) yl = yc;
                 else if (lane > c && lane < nbw) yl -= P[lane * PP + c] * yc;
             }
-            if (lane < nbw) yv[j0 + lane] = yl;
+            if (lane < nbw) x[j0 + lane] = yl;
         }
         __syncthreads();
         for (int idx = tid; idx < m * nbw; idx += 1024) {
             const int r = idx / nbw, c = idx - r * nbw;
-            A[(size_t)(j0 + r) * n + j0 + c] = P[r * PP + c];
+            if (c <= r && c >= r - bw) AB(j0 + r, j0 + c) = P[r * PP + c];
         }
         for (int r = nbw + tid; r < m; r += 1024) {   // right-hand side below the panel
-            double s2 = yv[j0 + r];
-            for (int c = 0; c < nbw; c++) s2 -= P[r * PP + c] * yv[j0 + c];
-            yv[j0 + r] = s2;
+            double s2 = x[j0 + r];
+            for (int c = 0; c < nbw; c++) s2 -= P[r * PP + c] * x[j0 + c];
+            x[j0 + r] = s2;
         }
         // trailing update on the matrix cores: 16x16 tiles of the lower triangle, K = NB in steps of 4
         const int mt = m - nbw, nt = (mt + 15) >> 4;
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) {           // the tile's current values: in flight while the MFMAs run
                 const int row = nbw + 16 * ti + (lane >> 4) + 4 * rg;
-                old[rg] = (row < m && col < m && col <= row) ? A[(size_t)(j0 + row) * n + j0 + col] : 0.0;
+                old[rg] = (row < m && col < m && col <= row) ? AB(j0 + row, j0 + col) : 0.0;
             }
             ba_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
@@ -690,7 +697,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) {
                 const int row = nbw + 16 * ti + (lane >> 4) + 4 * rg;
-                if (row < m && col < m && col <= row) A[(size_t)(j0 + row) * n + j0 + col] = old[rg] - acc[rg];
+                if (row < m && col < m && col <= row) AB(j0 + row, j0 + col) = old[rg] - acc[rg];
             }
         }
         __syncthreads();
@@ -699,35 +706,35 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
     // backward substitution L' x = y, panels in reverse
     const int last = ((n - 1) / NB) * NB;
     for (int j0 = last; j0 >= 0; j0 -= NB) {
-        const int nbw = min(NB, n - j0), m = n - j0;
+        const int nbw = min(NB, n - j0), m = min(n - j0, NB + bw);
         for (int idx = tid; idx < m * nbw; idx += 1024) {
             const int r = idx / nbw, c = idx - r * nbw;
-            P[r * PP + c] = A[(size_t)(j0 + r) * n + j0 + c];
+            P[r * PP + c] = (c <= r && c >= r - bw) ? AB(j0 + r, j0 + c) : 0.0;
         }
         __syncthreads();
-        {   // part[p][c] = sum over rows r = nbw + p, nbw + p + 32, ... of L[r][c] * x[r]
+        {   // part[p][c] = sum over rows r = nbw + p, nbw + p + NP, ... of L[r][c] * x[r]
             const int c = tid & (NB - 1), p = tid / NB;             // 1024 / NB parts
             constexpr int NP = 1024 / NB;
             double s2 = 0;
-            if (c < nbw) for (int r = nbw + p; r < m; r += NP) s2 += P[r * PP + c] * yv[j0 + r];
+            if (c < nbw) for (int r = nbw + p; r < m; r += NP) s2 += P[r * PP + c] * x[j0 + r];
             part[p * NB + c] = s2;
             __syncthreads();
-            if (tid < nbw) { double tot = 0; for (int q = 0; q < NP; q++) tot += part[q * NB + tid]; yv[j0 + tid] -= tot; }
+            if (tid < nbw) { double tot = 0; for (int q = 0; q < NP; q++) tot += part[q * NB + tid]; x[j0 + tid] -= tot; }
             __syncthreads();
         }
         if (wv == 0) {                                // backward substitution inside the panel
-            double yl = lane < nbw ? yv[j0 + lane] : 0.0;
+            double yl = lane < nbw ? x[j0 + lane] : 0.0;
             for (int c = nbw - 1; c >= 0; c--) {
                 const double xc = d_shfl_idx(yl, c) / P[c * PP + c];
                 if (lane == c) yl = xc;
                 else if (lane < c) yl -= P[c * PP + lane] * xc;
             }
-            if (lane < nbw) yv[j0 + lane] = yl;
+            if (lane < nbw) x[j0 + lane] = yl;
         }
         __syncthreads();
     }
-    for (int i = tid; i < n; i += 1024) x[i] = yv[i];
 }
+#undef AB
 
 // ---- k_ba_update: trial state = current state (+) step.  blocks [0, pblocks): points (back-substitution); rest: cameras
 __global__ __launch_bounds__(256) void k_ba_update(const ba_cam* __restrict__ cams, ba_cam* __restrict__ cams_t,
@@ -854,9 +861,9 @@ static void h_quat_from_R(const double* m, double* q)
 extern "C" int bh_ba_create(bh_ctx* ctx, const double K[5], bh_ba** out)
 {
     if (!ctx || !K || !out) return BH_ERR_INVALID;
-    (void)hipFuncSetAttribute((const void*)k_ba_chol<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_ba_chol<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_ba_chol<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_ba_chol<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_ba_chol<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_ba_chol<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     bh_ba* ba = new bh_ba();
     ba->ctx = ctx; ba->K = { K[0], K[1], K[2], K[3] };
     *out = ba;
@@ -906,7 +913,6 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     for (int i = 0; i < C; i++) if (cam_used[i] && !fixed[i]) ba->cam_slot[i] = Cf++;
     for (int j = 0; j < P; j++) if (ba->pt_slot[j] == 0) ba->pt_slot[j] = Pa++;
     ba->Cf = Cf; ba->Pa = Pa; ba->Ea = E;
-    if (6 * Cf > 1536) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: %d free keyframes exceed the local-BA solver (256); global BA is a later row", Cf);
     std::vector<ba_cam> cams(C);
     for (int i = 0; i < C; i++) {
         memset(&cams[i], 0, sizeof(ba_cam));
@@ -940,6 +946,17 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     std::vector<int2> pairs;
     for (int a = 0; a < Cf; a++) for (int b = a; b < Cf; b++) if (cov[(size_t)a * Cf + b] || a == b) pairs.push_back(make_int2(a, b));
     ba->npairs = (int)pairs.size();
+    int bwb = 0;
+    for (const int2& pr : pairs) bwb = (pr.y - pr.x) > bwb ? (pr.y - pr.x) : bwb;
+    const int n6i = 6 * Cf;
+    ba->bw = n6i > 0 ? std::min(n6i - 1, 6 * bwb + 5) : 0;
+    {   // panel width by LDS budget: min(n, NB+bw) x (NB+1) panel + 1024 partial sums, f64, <= 150 KB
+        int nb = 32;
+        while (nb >= 8 && sizeof(double) * ((size_t)std::min(n6i, nb + ba->bw) * (nb + 1) + 1100) > 150 * 1024) nb >>= 1;
+        if (nb < 8) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: reduced camera system too wide for the single-workgroup banded solver "
+                                      "(%d free keyframes, covisibility half-bandwidth %d keyframes)", Cf, bwb);
+        ba->chol_nb = nb;
+    }
 
     BH_TRY(upload(ctx, &ba->cams[0], cams)); BH_TRY(bh_reserve(ctx, &ba->cams[1], sizeof(ba_cam) * (C + 1)));
     BH_TRY(upload(ctx, &ba->pts[0], pts)); BH_TRY(bh_reserve(ctx, &ba->pts[1], sizeof(double) * 3 * (Pa + 1)));
@@ -955,12 +972,12 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     BH_TRY(bh_reserve(ctx, &ba->Hpp, sizeof(double) * 36 * ((size_t)Cf + 1))); BH_TRY(bh_reserve(ctx, &ba->bp, sizeof(double) * (n6 + 6)));
     BH_TRY(bh_reserve(ctx, &ba->pdiag, sizeof(double) * (Pa + 1))); BH_TRY(bh_reserve(ctx, &ba->cdiag, sizeof(double) * (Cf + 1)));
     BH_TRY(bh_reserve(ctx, &ba->Dinv, sizeof(double) * 9 * ((size_t)Pa + 1))); BH_TRY(bh_reserve(ctx, &ba->db, sizeof(double) * 3 * ((size_t)Pa + 1)));
-    BH_TRY(bh_reserve(ctx, &ba->S, sizeof(double) * (n6 * n6 + 1))); BH_TRY(bh_reserve(ctx, &ba->bs, sizeof(double) * (n6 + 6)));
+    BH_TRY(bh_reserve(ctx, &ba->S, sizeof(double) * (n6 * (size_t)(ba->bw + 1) + 1))); BH_TRY(bh_reserve(ctx, &ba->bs, sizeof(double) * (n6 + 6)));
     BH_TRY(bh_reserve(ctx, &ba->dxp, sizeof(double) * (n6 + 6))); BH_TRY(bh_reserve(ctx, &ba->dxl, sizeof(double) * 3 * ((size_t)Pa + 1)));
     BH_TRY(bh_reserve(ctx, &ba->state, sizeof(ba_state)));
     BH_HIP(ctx, hipMemsetAsync(ba->state.p, 0, sizeof(ba_state), ctx->stream));
     BH_HIP(ctx, hipMemsetAsync(ba->err[0].p, 0, sizeof(double) * 2 * (E + 1), ctx->stream));
-    BH_HIP(ctx, hipMemsetAsync(ba->S.p, 0, sizeof(double) * (n6 * n6 + 1), ctx->stream));
+    BH_HIP(ctx, hipMemsetAsync(ba->S.p, 0, sizeof(double) * (n6 * (size_t)(ba->bw + 1) + 1), ctx->stream));
     BH_HIP(ctx, hipMemsetAsync(ba->dxp.p, 0, sizeof(double) * (n6 + 6), ctx->stream));
     if (C) hipLaunchKernelGGL(k_ba_cam_init, dim3((C + 63) / 64), dim3(64), 0, ctx->stream, (ba_cam*)ba->cams[0].p, C, ba->K);
     BH_HIP(ctx, hipGetLastError());
@@ -1009,18 +1026,18 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
             ba_cam* cams_t = (ba_cam*)ba->cams[ba->cur ^ 1].p; double* pts_t = (double*)ba->pts[ba->cur ^ 1].p;
             BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_dinv, dim3(pblocks), dim3(256), st, (const double*)Hll, (const double*)bl, Pa, state, Dinv, db);
             if (Cf) {
-                BH_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double) * (size_t)n6 * n6, st));     // pairs without a common point stay zero
+                BH_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double) * (size_t)n6 * (ba->bw + 1), st));     // blocks without a common point stay zero
                 BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_S, dim3(ba->npairs), dim3(256), st, (const int2*)ba->pairs.p, c_start, c_edges, e_pt,
-                          (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, n6, S);
+                          (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, S);
                 BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_b, dim3(Cf), dim3(256), st, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)db,
                           (const double*)bp, bs);
-                {   // panel width by LDS budget: panel n x (NB+1) + rhs n + 1024 partial sums, all f64
-                    const int nbsel = n6 <= 448 ? 32 : (n6 <= 896 ? 16 : 8);
-                    const size_t lds = sizeof(double) * ((size_t)n6 * (nbsel + 1) + n6 + 1024);
+                {
+                    const int nbsel = ba->chol_nb, bw = ba->bw;
+                    const size_t lds = sizeof(double) * ((size_t)std::min(n6, nbsel + bw) * (nbsel + 1) + 1100);
                     bh_time_begin(ctx, BH_K_BA_SOLVE);
-                    if (nbsel == 32) hipLaunchKernelGGL(k_ba_chol<32>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, dxp, state);
-                    else if (nbsel == 16) hipLaunchKernelGGL(k_ba_chol<16>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, dxp, state);
-                    else hipLaunchKernelGGL(k_ba_chol<8>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, dxp, state);
+                    if (nbsel == 32) hipLaunchKernelGGL(k_ba_chol<32>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
+                    else if (nbsel == 16) hipLaunchKernelGGL(k_ba_chol<16>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
+                    else hipLaunchKernelGGL(k_ba_chol<8>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     bh_time_end(ctx);
                 }
             }

@@ -236,3 +236,43 @@ def vocabulary(k=10, L=4, seed=21, stop_frac=0.01):
     node_weight[leaves[rng.random(len(leaves)) < stop_frac]] = 0.0
     return dict(child_start=child_start, child_idx=child_idx, node_desc=node_desc, node_weight=node_weight, node_word=node_word,
                 k=k, L=L, n_words=len(leaves))
+
+
+def ba_problem_sequence(n_kf=5000, n_pts=500000, obs_per_pt=8, window=20, seed=13, pix_noise=1.0, rot_noise=0.005,
+                        trans_noise=0.02, pt_noise=0.02, n_fixed=2):
+    """SURVEY.md §8(d) config 5 generator: keyframes along a smooth 3-D path, every landmark seen by `obs_per_pt` keyframes
+    within +-`window` of a centre keyframe, so the reduced camera system is block-banded (half-bandwidth 2*window).
+    Fully vectorised (4 M observations in a few seconds)."""
+    rng = np.random.default_rng(seed)
+    i = np.arange(n_kf)
+    pos = np.stack([0.1 * i, 0.3 * np.sin(0.013 * i), 0.2 * np.sin(0.021 * i + 1.0)], axis=1)
+    yaw = 0.15 * np.sin(0.009 * i)
+    Rgt = np.zeros((n_kf, 3, 3))
+    Rgt[:, 0, 0] = np.cos(yaw); Rgt[:, 0, 2] = np.sin(yaw); Rgt[:, 1, 1] = 1.0; Rgt[:, 2, 0] = -np.sin(yaw); Rgt[:, 2, 2] = np.cos(yaw)
+    tgt = pos.copy()
+    centre = rng.integers(0, n_kf, size=n_pts)
+    local = np.stack([rng.uniform(-1.0, 1.0, n_pts), rng.uniform(-0.7, 0.7, n_pts), rng.uniform(2.5, 5.0, n_pts)], axis=1)
+    Xgt = tgt[centre] + np.einsum('pij,pj->pi', Rgt[centre], local)
+    offs = np.argsort(rng.random((n_pts, 2 * window + 1)), axis=1)[:, :obs_per_pt] - window
+    cams = np.clip(centre[:, None] + offs, 0, n_kf - 1)
+    cams = np.sort(cams, axis=1)
+    keep = np.ones_like(cams, dtype=bool); keep[:, 1:] = cams[:, 1:] != cams[:, :-1]          # clipping may duplicate a keyframe
+    pid = np.repeat(np.arange(n_pts), obs_per_pt).reshape(n_pts, obs_per_pt)
+    ecam = cams[keep].astype(np.int32); ept = pid[keep].astype(np.int32)
+    pc = np.einsum('eji,ej->ei', Rgt[ecam], Xgt[ept] - tgt[ecam])                               # R'(X - t)
+    uv = np.stack([FX * pc[:, 0] / pc[:, 2] + CX, FY * pc[:, 1] / pc[:, 2] + CY], axis=1)
+    vis = (pc[:, 2] > 0.1) & (uv[:, 0] >= 0) & (uv[:, 0] < WIDTH) & (uv[:, 1] >= 0) & (uv[:, 1] < HEIGHT)
+    ecam, ept, uv = ecam[vis], ept[vis], uv[vis]
+    meas = uv + rng.normal(0, pix_noise, uv.shape)
+    R0 = Rgt.copy(); t0 = tgt.copy()
+    w = rng.normal(0, rot_noise, (n_kf, 3)); w[:n_fixed] = 0
+    th = np.linalg.norm(w, axis=1); th[th < 1e-12] = 1e-12
+    k = w / th[:, None]
+    Kx = np.zeros((n_kf, 3, 3)); Kx[:, 0, 1] = -k[:, 2]; Kx[:, 0, 2] = k[:, 1]; Kx[:, 1, 0] = k[:, 2]; Kx[:, 1, 2] = -k[:, 0]; Kx[:, 2, 0] = -k[:, 1]; Kx[:, 2, 1] = k[:, 0]
+    dR = np.eye(3)[None] + np.sin(th)[:, None, None] * Kx + (1 - np.cos(th))[:, None, None] * (Kx @ Kx)
+    R0 = Rgt @ dR
+    dt = rng.normal(0, trans_noise, (n_kf, 3)); dt[:n_fixed] = 0
+    t0 = tgt + dt
+    fixed = np.zeros(n_kf, np.uint8); fixed[:n_fixed] = 1
+    return dict(Rgt=Rgt, tgt=tgt, Xgt=Xgt, R=R0, t=t0, pts=Xgt + rng.normal(0, pt_noise, Xgt.shape), fixed=fixed,
+                ecam=ecam, ept=ept, meas=meas, K=np.array([FX, FY, CX, CY, BASELINE]), window=window)

@@ -153,3 +153,37 @@ def test_bundle_adjustment_shim_mirrors_reference_api(ctx):
         assert _rel(opt.get_point(100 + pj), o["pts"][pj]) < RTOL
     bad = {(10 + pr["ecam"][e], 100 + pr["ept"][e]) for e, c in zip(kept, o["chi2"]) if c > 7.815}
     assert set(opt.outlier_edges()) == bad
+
+
+def test_banded_ba_matches_dense_oracle(ctx):
+    """Sequence-shaped problem (block-banded reduced camera system): the banded HIP solver vs the dense CPU oracle."""
+    pr = synth.ba_problem_sequence(n_kf=150, n_pts=4000, window=6, seed=3)
+    o = oracle.ba_optimize(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"], pr["K"], 6, ba.HUBER_DELTA)
+    s = ba.LocalBA(ctx, pr["K"])
+    s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+    done = s.optimize(6)
+    R, t = s.poses(); pts = s.points(); lg = s.log()[:done]
+    assert done == o["iters_done"] and np.array_equal(lg[:, 2:], o["log"][:, 2:])
+    assert _rel(R, o["R"]) < RTOL and _rel(t, o["t"]) < RTOL and _rel(pts, o["pts"]) < RTOL
+    assert np.allclose(lg[:, 0], o["log"][:, 0], rtol=1e-8)
+    s.close()
+
+
+def test_global_ba_scale_properties(ctx):
+    """A slice of BASELINE configs[4] (1 000 keyframes x 100 k landmarks x ~800 k observations, band +-40): too big for the
+    dense oracle, checked through size-independent properties: monotone robust chi2, every step accepted, errors shrink,
+    bitwise reproducibility."""
+    pr = synth.ba_problem_sequence(n_kf=1000, n_pts=100000, window=20, seed=5)
+    outs = []
+    for _ in range(2):
+        s = ba.LocalBA(ctx, pr["K"])
+        s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+        done = s.optimize(5)
+        lg = s.log()[:done]
+        outs.append((s.poses()[1].copy(), s.points().copy(), lg.copy()))
+        s.close()
+    t, pts, lg = outs[0]
+    assert len(lg) == 5 and (lg[:, 3] == 1).all() and np.all(np.diff(lg[:, 0]) < 0)
+    assert np.array_equal(t, outs[1][0]) and np.array_equal(pts, outs[1][1])
+    assert np.abs(t - pr["tgt"]).mean() < 0.5 * np.abs(pr["t"] - pr["tgt"]).mean()
+    assert np.abs(pts - pr["Xgt"]).mean() < np.abs(pr["pts"] - pr["Xgt"]).mean()
