@@ -52,6 +52,9 @@ _SIGS = {
     "bh_ba_get_points": (_i, [_vp, _vp, _i]),
     "bh_ba_get_chi2": (_i, [_vp, _vp, _i]),
     "bh_ba_get_log": (_i, [_vp, _vp, _i]),
+    "bh_ctx_copy": (_i, [_vp, _vp, _vp, C.c_size_t, _i]),
+    "bh_ba_set_allreduce": (_i, [_vp, _vp, _vp, _i, _i]),
+    "bh_ba_get_comm": (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_longlong)]),
     "bh_solve_pnp_ransac": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i]),
     "bh_rodrigues": (_i, [_vp, _i, _vp]),
     "bh_visibility_gate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _d, _d, _d, _i, _i, _d, _vp, _vp, _i]),
@@ -75,11 +78,34 @@ def exported_symbols():
     return sorted(_SIGS)
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Whichever copy is loaded first serves
+    the whole process, and torch does not see the GPU through the system copy; so when a torch install exists and is not
+    imported yet, load ITS runtime before libboslam_hip.so pulls in the system one.  torch itself is not imported."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("BH_NO_TORCH_HIP_PRELOAD"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    for root in (spec.submodule_search_locations or []) if spec else []:
+        cand = os.path.join(root, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def lib():
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise BhError(BH_ERR_HIP, f"{LIB_PATH} is not built (run __graft_entry__.build()); there is no CPU fallback")
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name, None)

@@ -93,3 +93,86 @@ class LocalBA:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------- multi-GPU global BA
+_AR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int)
+
+
+class _DeviceF64:
+    """A raw device address presented through __cuda_array_interface__ so torch can wrap it without a copy."""
+
+    def __init__(self, addr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(addr), False), "version": 2}
+
+
+def make_allreduce_hook(ctx, dist, device=None):
+    """bh_allreduce_fn over torch.distributed.  With a device-capable backend ("nccl" = RCCL over xGMI) the library's device
+    buffer is reduced in place; with "gloo" it is staged through host memory (CPU rehearsals)."""
+    import torch
+    on_device = dist.get_backend() == "nccl"
+    L = _lib.lib()
+
+    def hook(user, dev, count, op):
+        try:
+            rop = dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM
+            if on_device:
+                t = torch.as_tensor(_DeviceF64(dev, count), device=device or "cuda")
+                dist.all_reduce(t, op=rop)
+                torch.cuda.current_stream(t.device).synchronize()
+            else:
+                h = np.empty(int(count), np.float64)
+                if L.bh_ctx_copy(ctx.h, _lib.ptr(h), C.c_void_p(dev), 8 * int(count), 0) != 0:
+                    return 2
+                t = torch.from_numpy(h)
+                dist.all_reduce(t, op=rop)
+                if L.bh_ctx_copy(ctx.h, C.c_void_p(dev), _lib.ptr(h), 8 * int(count), 1) != 0:
+                    return 2
+            return 0
+        except Exception:                       # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    return _AR_FN(hook)
+
+
+class GlobalBA(LocalBA):
+    """Landmark-sharded global BA (BASELINE configs[4]): every rank holds all keyframes and the landmarks
+    j with j % world == rank (plus their observations); S, b~, Hpp, bp and the LM scalars are all-reduced once per
+    Levenberg trial through the hook; the banded Cholesky and the keyframe update are replicated."""
+
+    def __init__(self, ctx, K, dist, device=None):
+        super().__init__(ctx, K)
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self._hook = make_allreduce_hook(ctx, dist, device)          # keep the CFUNCTYPE object alive
+        ctx.check(_lib.lib().bh_ba_set_allreduce(self.h, C.cast(self._hook, C.c_void_p), None, self.rank, self.world))
+
+    def set_problem(self, R, t, fixed, points, edge_pose, edge_point, meas):
+        """Takes the WHOLE problem on every rank and keeps this rank's landmark shard."""
+        points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        edge_pose = np.ascontiguousarray(edge_pose, dtype=np.int32); edge_point = np.ascontiguousarray(edge_point, dtype=np.int32)
+        meas = np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 2)
+        self._P_all = len(points)
+        self.local_points = np.arange(self.rank, len(points), self.world)
+        self.local_edges = np.nonzero(edge_point % self.world == self.rank)[0]
+        super().set_problem(R, t, fixed, points[self.local_points], edge_pose[self.local_edges],
+                            edge_point[self.local_edges] // self.world, meas[self.local_edges])
+
+    def points_all(self):
+        """All landmarks after optimisation (each rank contributes its shard; sum all-reduce of a zero-filled array)."""
+        import torch
+        out = np.zeros((self._P_all, 3))
+        out[self.local_points] = self.points()
+        t = torch.from_numpy(out)
+        if self.dist.get_backend() == "nccl":
+            d = t.cuda(); self.dist.all_reduce(d); out = d.cpu().numpy()
+        else:
+            self.dist.all_reduce(t)
+        return out
+
+    def comm(self):
+        ms = C.c_double(0); nb = C.c_longlong(0)
+        self.ctx.check(_lib.lib().bh_ba_get_comm(self.h, C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value

@@ -33,3 +33,38 @@ def run(ctx, dev=None, repeats=5):
            "pose_err_before_m": float(np.abs(pr["t"] - pr["tgt"]).max()), "pose_err_after_m": float(np.abs(t - pr["tgt"]).max())}
     s.close()
     return out
+
+
+def run_global(ctx, n_kf=5000, n_pts=500000, iters=5, window=20):
+    """BASELINE configs[4] on one GPU: 5 000 keyframes x 500 k landmarks (~3.9 M observations, band +-2*window keyframes).
+    The dense oracle cannot hold this size; correctness is carried by the banded-vs-dense parity test plus the properties
+    reported here (monotone chi2, every step accepted, errors shrink)."""
+    pr = synth.ba_problem_sequence(n_kf=n_kf, n_pts=n_pts, window=window)
+    s = ba.LocalBA(ctx, pr["K"])
+    t0 = time.perf_counter()
+    s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+    ctx.synchronize()
+    t_setup = time.perf_counter() - t0
+    s.optimize(1)                                                                      # warm-up
+    s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    done = s.optimize(iters)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.timing(True)
+    s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+    s.optimize(iters)
+    kt = ctx.timing_read()
+    ctx.timing(False)
+    lg = s.log()[:done]
+    _, t = s.poses(); pts = s.points()
+    out = {"metric": "global_ba_lm_iters_per_sec", "value": round(done / dt, 2), "unit": "iters/s", "iters": int(done),
+           "ms_per_iter": round(dt / done * 1e3, 2), "dtype": "f64", "set_problem_s": round(t_setup, 2),
+           "workload": f"configs[4]: {n_kf} keyframes x {n_pts} landmarks x {len(pr['ecam'])} observations, band +-{2 * window} keyframes",
+           "robust_chi2": [float(v) for v in lg[:, 0]], "accepted": [int(v) for v in lg[:, 3]], "trials": int(lg[:, 2].sum()),
+           "kernel_ms_per_iter": {k: round(v[0] / done, 3) for k, v in sorted(kt.items()) if k.startswith("k_ba")},
+           "pose_err_mean_before_m": float(np.abs(pr["t"] - pr["tgt"]).mean()), "pose_err_mean_after_m": float(np.abs(t - pr["tgt"]).mean()),
+           "point_err_mean_before_m": float(np.abs(pr["pts"] - pr["Xgt"]).mean()), "point_err_mean_after_m": float(np.abs(pts - pr["Xgt"]).mean())}
+    s.close()
+    return out

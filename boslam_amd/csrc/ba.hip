@@ -23,6 +23,8 @@
 #include <float.h>
 #include <vector>
 #include <algorithm>
+#include <chrono>
+#include <cstddef>
 
 struct ba_cam {
     double q[4];            // x y z w
@@ -334,6 +336,7 @@ extern "C" int bh_pose_only_ba(bh_ctx* ctx, const double* pix, const double* pts
 struct ba_state {                 // device-resident LM control block
     double lambda, ni, chi_cur, chi_trial, rho, scale, max_diag;
     int qmax, accepted, again, terminate, chol_ok, pad;
+    double red[4];                // partial sums handed to the all-reduce hook (multi-GPU global BA)
 };
 
 struct bh_ba {
@@ -360,6 +363,11 @@ struct bh_ba {
     int bw = 0;                        // scalar half-bandwidth of the reduced camera system (6*max|s1-s2| + 5)
     int chol_nb = 32;                  // panel width chosen for the LDS budget
     int last_err_sel = 0;              // which err buffer holds "the last computeActiveErrors"
+    // landmark-sharded multi-GPU mode (bh_ba_set_allreduce)
+    bh_allreduce_fn ar = nullptr;
+    void* ar_user = nullptr;
+    int rank = 0, world = 1;
+    double comm_ms = 0; long long comm_bytes = 0;
 };
 
 // ---- k_ba_point: 8 lanes per active point; residual + Huber + Jacobians; Hll, bl, per-edge Hpl, per-edge error/chi
@@ -450,16 +458,18 @@ __global__ __launch_bounds__(256) void k_ba_cam(const ba_cam* __restrict__ cams,
 
 // ---- k_ba_prep: chi at the current state; lambda init on the first iteration
 __global__ __launch_bounds__(1024) void k_ba_prep(const double* __restrict__ chi_e, int Ea, const double* __restrict__ pdiag, int Pa,
-                                                  const double* __restrict__ cdiag, int Cf, int first, ba_state* __restrict__ S)
+                                                  const double* __restrict__ cdiag, int Cf, int first, int phase,
+                                                  ba_state* __restrict__ S)
 {
+    // phase 0: single GPU (sums + decision in one launch); 1: partial sums -> S->red; 2: decision from the all-reduced S->red
     __shared__ double s_red[16];
     __shared__ double s_max[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double v[1] = { 0 };
-    for (int e = tid; e < Ea; e += 1024) v[0] += chi_e[e];
+    if (phase != 2) for (int e = tid; e < Ea; e += 1024) v[0] += chi_e[e];
     d_block_sum<1, 1024>(v, s_red);
     double md = 0;
-    if (first) {
+    if (first && phase != 2) {
         for (int j = tid; j < Pa; j += 1024) md = fmax(md, pdiag[j]);
         for (int c = tid; c < Cf; c += 1024) md = fmax(md, cdiag[c]);
         for (int m = 32; m > 0; m >>= 1) md = fmax(md, d_shfl_xor(md, m));
@@ -468,6 +478,8 @@ __global__ __launch_bounds__(1024) void k_ba_prep(const double* __restrict__ chi
         md = 0; for (int w = 0; w < 16; w++) md = fmax(md, s_max[w]);
     }
     if (tid == 0) {
+        if (phase == 1) { S->red[0] = v[0]; S->red[1] = md; return; }
+        if (phase == 2) { v[0] = S->red[0]; md = S->red[1]; }
         S->chi_cur = v[0];
         if (first) { S->max_diag = md; S->lambda = 1e-5 * md; S->ni = 2; }
         S->qmax = 0; S->accepted = 0; S->again = 0; S->terminate = 0; S->rho = 0; S->chol_ok = 1;
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_S(const int2* __restrict__ pai
                                                     const int* __restrict__ c_edges, const int* __restrict__ e_pt,
                                                     const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                                                     const double* __restrict__ Hpp, const ba_state* __restrict__ St,
-                                                    int bw, double* __restrict__ Sm)
+                                                    int bw, int add_diag, double* __restrict__ Sm)
 {
     __shared__ double s_red[36 * 4];
     __shared__ int s_pt2[SCH_LDS];                         // camera s2's point ids (ascending): the join searches LDS
@@ -548,7 +560,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_S(const int2* __restrict__ pai
     if (tid < 36) {
         const int a = tid / 6, bb = tid - a * 6;
         double v = -acc[tid];
-        if (s1 == s2) { v += Hpp[36 * (size_t)s1 + tid]; if (a == bb) v += St->lambda; }
+        if (s1 == s2 && add_diag) { v += Hpp[36 * (size_t)s1 + tid]; if (a == bb) v += St->lambda; }
         // lower band storage: element (row, col), row >= col, at Sm[row*LD + (col - row + bw)]; s1 <= s2
         const int row = 6 * s2 + bb, col = 6 * s1 + a;
         if (col <= row) Sm[(size_t)row * (bw + 1) + (col - row + bw)] = v;
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_S(const int2* __restrict__ pai
 __global__ __launch_bounds__(256) void k_ba_schur_b(const int* __restrict__ c_start, const int* __restrict__ c_edges,
                                                     const int* __restrict__ e_pt, const double* __restrict__ Hpl,
                                                     const double* __restrict__ db, const double* __restrict__ bp,
-                                                    double* __restrict__ bs)
+                                                    int use_bp, double* __restrict__ bs)
 {
     __shared__ double s_red[6 * 4];
     const int s = blockIdx.x, tid = threadIdx.x;
@@ -571,7 +583,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_b(const int* __restrict__ c_st
         for (int a = 0; a < 6; a++) acc[a] += B[3 * a] * d[0] + B[3 * a + 1] * d[1] + B[3 * a + 2] * d[2];
     }
     d_block_sum<6, 256>(acc, s_red);
-    if (tid < 6) bs[6 * s + tid] = bp[6 * s + tid] - acc[tid];
+    if (tid < 6) bs[6 * s + tid] = (use_bp ? bp[6 * s + tid] : 0.0) - acc[tid];
 }
 
 // ---- k_ba_chol: one workgroup, blocked right-looking Cholesky of the BANDED reduced camera system + both substitutions.
@@ -793,17 +805,23 @@ __global__ __launch_bounds__(256) void k_ba_err(const ba_cam* __restrict__ cams,
 // ---- k_ba_decide: Levenberg gain ratio and lambda schedule (OptimizationAlgorithmLevenberg::solve)
 __global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxp,
                                                     const double* __restrict__ bp, int n6, const double* __restrict__ dxl,
-                                                    const double* __restrict__ bl, int n3, ba_state* __restrict__ S)
+                                                    const double* __restrict__ bl, int n3, int phase, int cam_part,
+                                                    ba_state* __restrict__ S)
 {
+    // phases as in k_ba_prep; cam_part: this rank contributes the (replicated) camera part of the gain-ratio denominator
     __shared__ double s_red[2 * 16];
     const int tid = threadIdx.x;
     const double lambda = S->lambda;
     double v[2] = { 0, 0 };
-    for (int e = tid; e < Ea; e += 1024) v[0] += chi_e[e];
-    for (int i = tid; i < n6; i += 1024) v[1] += dxp[i] * (lambda * dxp[i] + bp[i]);
-    for (int i = tid; i < n3; i += 1024) v[1] += dxl[i] * (lambda * dxl[i] + bl[i]);
+    if (phase != 2) {
+        for (int e = tid; e < Ea; e += 1024) v[0] += chi_e[e];
+        if (cam_part) for (int i = tid; i < n6; i += 1024) v[1] += dxp[i] * (lambda * dxp[i] + bp[i]);
+        for (int i = tid; i < n3; i += 1024) v[1] += dxl[i] * (lambda * dxl[i] + bl[i]);
+    }
     d_block_sum<2, 1024>(v, s_red);
     if (tid == 0) {
+        if (phase == 1) { S->red[0] = v[0]; S->red[1] = v[1]; S->red[2] = S->chol_ok ? 0.0 : 1.0; return; }
+        if (phase == 2) { v[0] = S->red[0]; v[1] = S->red[1]; if (S->red[2] > 0) S->chol_ok = 0; }
         double tempChi = v[0];
         if (!S->chol_ok) tempChi = DBL_MAX;
         double rho = S->chi_cur - tempChi;
@@ -822,6 +840,16 @@ __global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ c
         S->terminate = (!S->again && (S->qmax == 10 || rho == 0)) ? 1 : 0;
         S->chol_ok = 1;                                  // re-arm for the next trial
     }
+}
+
+// multi-GPU: per-camera max |diag| of the all-reduced Hpp
+__global__ void k_ba_cdiag(const double* __restrict__ Hpp, int Cf, double* __restrict__ cdiag)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= Cf) return;
+    double md = 0;
+    for (int a = 0; a < 6; a++) md = fmax(md, fabs(Hpp[36 * (size_t)s + 7 * a]));
+    cdiag[s] = md;
 }
 
 __global__ void k_ba_cam_init(ba_cam* cams, int C, ba_K K)
@@ -883,6 +911,36 @@ extern "C" void bh_ba_destroy(bh_ba* ba)
     delete ba;
 }
 
+extern "C" int bh_ba_set_allreduce(bh_ba* ba, bh_allreduce_fn fn, void* user, int rank, int world)
+{
+    if (!ba) return BH_ERR_INVALID;
+    if (fn && (world < 1 || rank < 0 || rank >= world)) return bh_set_err(ba->ctx, BH_ERR_INVALID, "bh_ba_set_allreduce: bad rank/world");
+    ba->ar = fn; ba->ar_user = user; ba->rank = fn ? rank : 0; ba->world = fn ? world : 1;
+    ba->have_problem = 0;                                  // the camera slots depend on the mode
+    return BH_OK;
+}
+
+extern "C" int bh_ba_get_comm(bh_ba* ba, double* ms, long long* bytes)
+{
+    if (!ba) return BH_ERR_INVALID;
+    if (ms) *ms = ba->comm_ms;
+    if (bytes) *bytes = ba->comm_bytes;
+    return BH_OK;
+}
+
+// stream idle -> hook -> reduced values visible to later work on the stream
+static int ba_allreduce(bh_ba* ba, void* dev, long long count, int op)
+{
+    bh_ctx* ctx = ba->ctx;
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int r = ba->ar(ba->ar_user, dev, count, op);
+    ba->comm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ba->comm_bytes += 8 * count;
+    if (r != 0) return bh_set_err(ctx, BH_ERR_INVALID, "global BA: the all-reduce hook failed (%d)", r);
+    return BH_OK;
+}
+
 template <typename T>
 static int upload(bh_ctx* ctx, bh_buf* b, const std::vector<T>& v)
 {
@@ -909,6 +967,10 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     ba->cam_slot.assign(C, -1); ba->pt_slot.assign(P, -1); ba->edge_user.clear();
     std::vector<char> cam_used(C, 0);
     for (int e = 0; e < E; e++) { cam_used[edge_pose[e]] = 1; ba->pt_slot[edge_point[e]] = 0; }
+    if (ba->ar) {                                          // sharded: every rank must number the free cameras identically
+        if (E == 0) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: a rank of a sharded problem needs at least one edge");
+        for (int i = 0; i < C; i++) cam_used[i] = 1;
+    }
     int Cf = 0, Pa = 0;
     for (int i = 0; i < C; i++) if (cam_used[i] && !fixed[i]) ba->cam_slot[i] = Cf++;
     for (int j = 0; j < P; j++) if (ba->pt_slot[j] == 0) ba->pt_slot[j] = Pa++;
@@ -948,6 +1010,16 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     ba->npairs = (int)pairs.size();
     int bwb = 0;
     for (const int2& pr : pairs) bwb = (pr.y - pr.x) > bwb ? (pr.y - pr.x) : bwb;
+    BH_TRY(bh_reserve(ctx, &ba->state, sizeof(ba_state)));
+    if (ba->ar) {                                          // the band must be the same everywhere: max over ranks
+        double v = (double)bwb;
+        double* red = (double*)((char*)ba->state.p + offsetof(ba_state, red));
+        BH_HIP(ctx, hipMemcpyAsync(red, &v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        BH_TRY(ba_allreduce(ba, red, 1, 1));
+        BH_HIP(ctx, hipMemcpyAsync(&v, red, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        bwb = (int)v;
+    }
     const int n6i = 6 * Cf;
     ba->bw = n6i > 0 ? std::min(n6i - 1, 6 * bwb + 5) : 0;
     {   // panel width by LDS budget: min(n, NB+bw) x (NB+1) panel + 1024 partial sums, f64, <= 150 KB
@@ -974,7 +1046,6 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     BH_TRY(bh_reserve(ctx, &ba->Dinv, sizeof(double) * 9 * ((size_t)Pa + 1))); BH_TRY(bh_reserve(ctx, &ba->db, sizeof(double) * 3 * ((size_t)Pa + 1)));
     BH_TRY(bh_reserve(ctx, &ba->S, sizeof(double) * (n6 * (size_t)(ba->bw + 1) + 1))); BH_TRY(bh_reserve(ctx, &ba->bs, sizeof(double) * (n6 + 6)));
     BH_TRY(bh_reserve(ctx, &ba->dxp, sizeof(double) * (n6 + 6))); BH_TRY(bh_reserve(ctx, &ba->dxl, sizeof(double) * 3 * ((size_t)Pa + 1)));
-    BH_TRY(bh_reserve(ctx, &ba->state, sizeof(ba_state)));
     BH_HIP(ctx, hipMemsetAsync(ba->state.p, 0, sizeof(ba_state), ctx->stream));
     BH_HIP(ctx, hipMemsetAsync(ba->err[0].p, 0, sizeof(double) * 2 * (E + 1), ctx->stream));
     BH_HIP(ctx, hipMemsetAsync(ba->S.p, 0, sizeof(double) * (n6 * (size_t)(ba->bw + 1) + 1), ctx->stream));
@@ -1005,6 +1076,10 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
     double *pdiag = (double*)ba->pdiag.p, *cdiag = (double*)ba->cdiag.p, *Dinv = (double*)ba->Dinv.p, *db = (double*)ba->db.p;
     double *S = (double*)ba->S.p, *bs = (double*)ba->bs.p, *dxp = (double*)ba->dxp.p, *dxl = (double*)ba->dxl.p;
     ba_state* state = (ba_state*)ba->state.p;
+    double* red = (double*)((char*)ba->state.p + offsetof(ba_state, red));
+    const bool dist = ba->ar != nullptr;
+    const int lead = ba->rank == 0 ? 1 : 0;              // the rank that contributes the replicated camera terms
+    ba->comm_ms = 0; ba->comm_bytes = 0;
     const int pblocks = (Pa + 255) / 256, cblocks = (C + 255) / 256;
     int rc = BH_OK;
     for (int it = 0; it < iters; it++) {
@@ -1013,8 +1088,18 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                   p_edges, Pa, ba->K, huber_delta, Hpl, Hll, bl, (double*)ba->err[0].p, (double*)ba->chi_e[0].p, pdiag);
         if (Cf) BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_ba_cam, dim3(Cf), dim3(256), st, cams, pts, e_cam, e_pt, e_meas, c_start, c_edges, ba->K,
                           huber_delta, Hpp, bp, cdiag);
+        if (dist && Cf) {                                  // Hpp, bp: partial over this rank's edges -> full on every rank
+            BH_TRY(ba_allreduce(ba, Hpp, 36LL * Cf, 0)); BH_TRY(ba_allreduce(ba, bp, n6, 0));
+            hipLaunchKernelGGL(k_ba_cdiag, dim3((Cf + 63) / 64), dim3(64), 0, st, (const double*)Hpp, Cf, cdiag);
+        }
         BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_prep, dim3(1), dim3(1024), st, (const double*)ba->chi_e[0].p, Ea, (const double*)pdiag, Pa,
-                  (const double*)cdiag, Cf, it == 0 ? 1 : 0, state);
+                  (const double*)cdiag, Cf, it == 0 ? 1 : 0, dist ? 1 : 0, state);
+        if (dist) {
+            BH_TRY(ba_allreduce(ba, red, 1, 0));
+            if (it == 0) BH_TRY(ba_allreduce(ba, red + 1, 1, 1));
+            BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_prep, dim3(1), dim3(1024), st, (const double*)ba->chi_e[0].p, Ea, (const double*)pdiag, Pa,
+                      (const double*)cdiag, Cf, it == 0 ? 1 : 0, 2, state);
+        }
         ba_state hs;
         if (it == 0) {
             BH_HIP(ctx, hipMemcpyAsync(&hs, state, sizeof(hs), hipMemcpyDeviceToHost, st));
@@ -1028,9 +1113,10 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
             if (Cf) {
                 BH_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double) * (size_t)n6 * (ba->bw + 1), st));     // blocks without a common point stay zero
                 BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_S, dim3(ba->npairs), dim3(256), st, (const int2*)ba->pairs.p, c_start, c_edges, e_pt,
-                          (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, S);
+                          (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S);
                 BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_b, dim3(Cf), dim3(256), st, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)db,
-                          (const double*)bp, bs);
+                          (const double*)bp, dist ? lead : 1, bs);
+                if (dist) { BH_TRY(ba_allreduce(ba, S, (long long)n6 * (ba->bw + 1), 0)); BH_TRY(ba_allreduce(ba, bs, n6, 0)); }
                 {
                     const int nbsel = ba->chol_nb, bw = ba->bw;
                     const size_t lds = sizeof(double) * ((size_t)std::min(n6, nbsel + bw) * (nbsel + 1) + 1100);
@@ -1046,7 +1132,12 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
             BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_err, dim3((Ea + 255) / 256), dim3(256), st, (const ba_cam*)cams_t, (const double*)pts_t, e_cam, e_pt,
                       e_meas, Ea, huber_delta, (double*)ba->err[1].p, (double*)ba->chi_e[1].p);
             BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_decide, dim3(1), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxp, (const double*)bp,
-                      n6, (const double*)dxl, (const double*)bl, 3 * Pa, state);
+                      n6, (const double*)dxl, (const double*)bl, 3 * Pa, dist ? 1 : 0, dist ? lead : 1, state);
+            if (dist) {
+                BH_TRY(ba_allreduce(ba, red, 3, 0));
+                BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_decide, dim3(1), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxp, (const double*)bp,
+                          n6, (const double*)dxl, (const double*)bl, 3 * Pa, 2, lead, state);
+            }
             BH_HIP(ctx, hipGetLastError());
             BH_HIP(ctx, hipMemcpyAsync(&hs, state, sizeof(hs), hipMemcpyDeviceToHost, st));
             BH_HIP(ctx, hipStreamSynchronize(st));

@@ -86,6 +86,14 @@ extern "C" int bh_ctx_synchronize(bh_ctx* ctx)
     return BH_OK;
 }
 
+extern "C" int bh_ctx_copy(bh_ctx* ctx, void* dst, const void* src, size_t bytes, int to_device)
+{
+    if (!ctx || (bytes && (!dst || !src))) return BH_ERR_INVALID;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes) BH_HIP(ctx, hipMemcpy(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+    return BH_OK;
+}
+
 extern "C" int bh_ctx_status(bh_ctx* ctx)
 {
     if (!ctx) return BH_ERR_INVALID;

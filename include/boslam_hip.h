@@ -67,6 +67,9 @@ const char* bh_last_error(const bh_ctx* ctx);
 /* Adopt an existing hipStream_t (e.g. the caller's torch stream); NULL restores the context's own stream. */
 int         bh_ctx_set_stream(bh_ctx* ctx, void* hip_stream);
 int         bh_ctx_synchronize(bh_ctx* ctx);
+/* Blocking copy between host and device memory on the context's device (to_device != 0: host -> device).  For callers
+ * without a HIP runtime binding of their own, e.g. an all-reduce hook that stages through host memory. */
+int         bh_ctx_copy(bh_ctx* ctx, void* dst, const void* src, size_t bytes, int to_device);
 /* Deferred status of BH_MEM_DEVICE work (capacity flags raised on the device); synchronises the stream. */
 int         bh_ctx_status(bh_ctx* ctx);
 const char* bh_version(void);
@@ -152,6 +155,20 @@ int  bh_ba_get_points(bh_ba* ba, double* points, int mem);
 int  bh_ba_get_chi2(bh_ba* ba, double* chi2, int mem);
 /* per-iteration log of the last optimize: f64[iters_done][4] = {robust chi2 after, lambda, trials, accepted} */
 int  bh_ba_get_log(bh_ba* ba, double* log, int max_rows);
+
+/* Global BA over several GPUs (BASELINE configs[4]; no counterpart in the reference, whose covisibility_graph.py:186-235
+ * optimises on one CPU).  The problem is sharded BY LANDMARK: every rank passes all C poses (same order, same fixed flags)
+ * and its own subset of points with all their edges to bh_ba_set_problem.  The library then calls `fn` at the exchange
+ * points of every Levenberg trial: sum of the reduced camera system S (lower band, f64[6Cf][bw+1]) and of b~ (f64[6Cf]),
+ * sum of Hpp/bp, and a few scalars (chi2, gain-ratio denominator, max diagonal).  The Cholesky of S and the camera update are
+ * replicated (identical inputs, deterministic kernel -> identical poses on every rank); landmarks are updated by their owner.
+ *   fn(user, dev_buf, count, op): all-reduce `count` f64 at device address `dev_buf` in place; op 0 = sum, 1 = max.
+ *   The library's stream is idle when fn is called; fn returns (0 = ok) when the reduced values are visible to the device.
+ * Call before bh_ba_set_problem.  fn == NULL restores the single-GPU behaviour. */
+typedef int (*bh_allreduce_fn)(void* user, void* dev_buf, long long count, int op);
+int  bh_ba_set_allreduce(bh_ba* ba, bh_allreduce_fn fn, void* user, int rank, int world);
+/* wall time spent inside fn and bytes handed to it since the last bh_ba_optimize began */
+int  bh_ba_get_comm(bh_ba* ba, double* ms, long long* bytes);
 
 /* ---- PnP + RANSAC, Rodrigues -----------------------------------------------------------------------------------------
  * Replaces cv2.solvePnPRansac(obj, img, K, distCoeffs=0, flags=cv2.SOLVEPNP_ITERATIVE) and cv2.Rodrigues(v)[0] —

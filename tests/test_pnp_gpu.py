@@ -86,4 +86,5 @@ def test_config1_two_way_tracking_plumbing(ctx):
         R = (R_ab + np.linalg.inv(R_ba)) / 2; t = (tab - tba) / 2                                              # :71-72
         # the camera moved 5 mm in x between frames (plane at 2 m): the fused estimate must say so
         assert np.abs(R - np.eye(3)).max() < 0.02
-        assert abs(float(t[0]) + 0.005) < 0.01 and abs(float(t[1])) < 0.01 and abs(float(t[2])) < 0.02
+        tv = np.asarray(t).ravel()
+        assert abs(tv[0] + 0.005) < 0.01 and abs(tv[1]) < 0.01 and abs(tv[2]) < 0.02
