@@ -9,7 +9,9 @@ weak scaling, no data-path collective); rank 0 prints ONE JSON line.
 The JSON line also carries
   roofline      the dominant kernel's algorithmic bytes / its hipEvent-measured duration vs the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (OpenMP over frames) timed on the host cores on a bounded sample of the same frames
-  local_ba      secondary metric of BASELINE.json: LM iterations/s of the local BA on config 3 (when built)
+  local_ba      secondary metric of BASELINE.json: LM iterations/s of the local BA on config 3 (N=1)
+  global_ba     configs[4] (5 000 keyframes x 500 k landmarks): LM iterations/s, landmark-sharded over the N ranks with
+                RCCL all-reduce of the reduced camera system (strong scaling; every N)
 """
 import argparse
 import json
@@ -89,6 +91,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1000, help="frames in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--pipelines", type=int, default=0, help="chunk pipelines (streams) inside the library; 0 = library default (4)")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-global-ba", action="store_true", help="skip the configs[4] global BA (landmark-sharded over the ranks)")
     ap.add_argument("--bow", action="store_true", help="also time the config-4 BoW L1 query (adds ~20 s of data generation)")
     args = ap.parse_args()
 
@@ -154,6 +157,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    global_ba = None
+    if not args.no_global_ba:                                 # every rank takes part: the landmarks are sharded over the ranks
+        from boslam_amd import ba_bench
+        global_ba = ba_bench.run_global(ctx, dist=dist, device=dev)
+
     if rank == 0:
         n_kp = fe.n_kp.cpu().numpy(); n_match = fe.n_match.cpu().numpy()
         fps = world * B * args.steps / dt
@@ -211,6 +219,8 @@ def main():
         if not args.no_ba and world == 1:                     # local BA does not shard (replicas only): N=1 figure
             from boslam_amd import ba_bench
             out["local_ba"] = ba_bench.run(ctx, dev)
+        if global_ba is not None:
+            out["global_ba"] = global_ba
         if args.bow:
             from boslam_amd import bow_bench
             out["bow_query"] = bow_bench.run(ctx)
