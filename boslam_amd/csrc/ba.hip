@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstddef>
+#include <utility>
 
 struct ba_cam {
     double q[4];            // x y z w
@@ -337,6 +338,7 @@ struct ba_state {                 // device-resident LM control block
     double lambda, ni, chi_cur, chi_trial, rho, scale, max_diag;
     int qmax, accepted, again, terminate, chol_ok, pad;
     double red[4];                // partial sums handed to the all-reduce hook (multi-GPU global BA)
+    long long dbg[8];             // k_ba_chol_sw phase clocks (bh_ba_debug_band_solve)
 };
 
 struct bh_ba {
@@ -358,10 +360,12 @@ struct bh_ba {
     bh_buf p_start, p_edges, c_start, c_edges;
     bh_buf err[2], chi_e[2];           // [0] at the current state (iteration start), [1] at the trial state
     bh_buf Hpl, Hll, bl, Hpp, bp, pdiag, cdiag;
-    bh_buf Dinv, db, S, bs, dxp, dxl, state, pairs;
+    bh_buf Dinv, db, S, bs, dxp, dxl, state, pairs, part;
     int npairs = 0;
     int bw = 0;                        // scalar half-bandwidth of the reduced camera system (6*max|s1-s2| + 5)
     int chol_nb = 32;                  // panel width chosen for the LDS budget
+    int chol_window = 0;               // on-chip sliding-window banded Cholesky (k_ba_chol_sw) instead of the panel kernel
+    int schur_wave = 0;                // one wave per camera pair (many short edge lists) instead of a 256-thread workgroup
     int last_err_sel = 0;              // which err buffer holds "the last computeActiveErrors"
     // landmark-sharded multi-GPU mode (bh_ba_set_allreduce)
     bh_allreduce_fn ar = nullptr;
@@ -456,17 +460,41 @@ __global__ __launch_bounds__(256) void k_ba_cam(const ba_cam* __restrict__ cams,
     }
 }
 
+// ---- k_ba_partial: first stage of the big sums (global-BA sizes): block b sums its contiguous slice of the edges / points
+// in a fixed order into part[b] = {sum chi, sum dx (lambda dx + b)}; k_ba_prep / k_ba_decide add the BA_NPART partials.
+#define BA_NPART 256
+__global__ __launch_bounds__(1024) void k_ba_partial(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxl,
+                                                     const double* __restrict__ bl, int n3, const ba_state* __restrict__ S,
+                                                     double* __restrict__ part)
+{
+    __shared__ double s_red[2 * 16];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    double v[2] = { 0, 0 };
+    { const int per = (Ea + BA_NPART - 1) / BA_NPART, lo = b * per, hi = min(Ea, lo + per);
+      for (int e = lo + tid; e < hi; e += 1024) v[0] += chi_e[e]; }
+    if (dxl) {
+        const double lambda = S->lambda;
+        const int per = (n3 + BA_NPART - 1) / BA_NPART, lo = b * per, hi = min(n3, lo + per);
+        for (int i = lo + tid; i < hi; i += 1024) v[1] += dxl[i] * (lambda * dxl[i] + bl[i]);
+    }
+    d_block_sum<2, 1024>(v, s_red);
+    if (tid == 0) { part[2 * b] = v[0]; part[2 * b + 1] = v[1]; }
+}
+
 // ---- k_ba_prep: chi at the current state; lambda init on the first iteration
 __global__ __launch_bounds__(1024) void k_ba_prep(const double* __restrict__ chi_e, int Ea, const double* __restrict__ pdiag, int Pa,
                                                   const double* __restrict__ cdiag, int Cf, int first, int phase,
-                                                  ba_state* __restrict__ S)
+                                                  const double* __restrict__ part, ba_state* __restrict__ S)
 {
     // phase 0: single GPU (sums + decision in one launch); 1: partial sums -> S->red; 2: decision from the all-reduced S->red
     __shared__ double s_red[16];
     __shared__ double s_max[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double v[1] = { 0 };
-    if (phase != 2) for (int e = tid; e < Ea; e += 1024) v[0] += chi_e[e];
+    if (phase != 2) {
+        if (part) { if (tid < BA_NPART) v[0] = part[2 * tid]; }
+        else for (int e = tid; e < Ea; e += 1024) v[0] += chi_e[e];
+    }
     d_block_sum<1, 1024>(v, s_red);
     double md = 0;
     if (first && phase != 2) {
@@ -517,25 +545,27 @@ __global__ __launch_bounds__(256) void k_ba_dinv(const double* __restrict__ Hll,
 
 #define SCH_LDS 6144
 // ---- k_ba_schur_S: workgroup per camera pair (s1 <= s2): S[s1][s2] = [s1==s2](Hpp + lambda I) - sum_j Hpl_1j Dinv_j Hpl_2j'
-__global__ __launch_bounds__(256) void k_ba_schur_S(const int2* __restrict__ pairs, const int* __restrict__ c_start,
+template <int NT, int NLDS>
+__global__ __launch_bounds__(NT) void k_ba_schur_S(const int2* __restrict__ pairs, const int* __restrict__ c_start,
                                                     const int* __restrict__ c_edges, const int* __restrict__ e_pt,
                                                     const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                                                     const double* __restrict__ Hpp, const ba_state* __restrict__ St,
                                                     int bw, int add_diag, double* __restrict__ Sm)
 {
-    __shared__ double s_red[36 * 4];
-    __shared__ int s_pt2[SCH_LDS];                         // camera s2's point ids (ascending): the join searches LDS
+    // NT = 256 for a few long edge lists (local BA), one wave per pair for many short ones (global BA)
+    __shared__ double s_red[36 * (NT / 64)];
+    __shared__ int s_pt2[NLDS];                            // camera s2's point ids (ascending): the join searches LDS
     const int tid = threadIdx.x;
     const int s1 = pairs[blockIdx.x].x, s2 = pairs[blockIdx.x].y;
     const int a0 = c_start[s1], a1 = c_start[s1 + 1], b0 = c_start[s2], b1 = c_start[s2 + 1];
     const int n2 = b1 - b0;
-    const bool in_lds = n2 <= SCH_LDS;
-    if (in_lds) for (int i = tid; i < n2; i += 256) s_pt2[i] = e_pt[c_edges[b0 + i]];
+    const bool in_lds = n2 <= NLDS;
+    if (in_lds) for (int i = tid; i < n2; i += NT) s_pt2[i] = e_pt[c_edges[b0 + i]];
     __syncthreads();
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0;
-    for (int u = a0 + tid; u < a1; u += 256) {
+ for (int u = a0 + tid; u < a1; u += NT) {
         const int e1 = c_edges[u];
         const int j = e_pt[e1];
         int lo = 0, hi = n2;                                     // lower_bound of j in camera s2's point-sorted list
@@ -556,7 +586,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_S(const int2* __restrict__ pai
                 for (int bb = 0; bb < 6; bb++) acc[6 * a + bb] += BD[3 * a] * B2[3 * bb] + BD[3 * a + 1] * B2[3 * bb + 1] + BD[3 * a + 2] * B2[3 * bb + 2];
         }
     }
-    d_block_sum<36, 256>(acc, s_red);
+    d_block_sum<36, NT>(acc, s_red);
     if (tid < 36) {
         const int a = tid / 6, bb = tid - a * 6;
         double v = -acc[tid];
@@ -748,6 +778,345 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
 }
 #undef AB
 
+// ---- k_ba_chol_sw: banded Cholesky with the whole trailing window ON CHIP (global-BA sizes: n >> bw, bw <= 256).
+// The panel kernel above streams the bw x bw trailing window through global memory once per panel; here it never leaves
+// the CU.  16x16 tiles; block column J is owned by wave J mod 16.  Tile (J+d, J), d = 0..D (D = ceil-band in blocks <= 16):
+//   d < 8   lives in the owner's registers (MFMA accumulator layout) from the moment the wave adopts the column,
+//   d >= 8  lives in an LDS ring slot, allocated when the first update reaches it (step J+d-D) - 45 slots in all.
+// Step Jc: [A] the owner dumps its column into the LDS operand buffer Lc, factors the diagonal tile in registers (row per
+// lane, v_readlane broadcasts) and forward-substitutes the rhs block; [B] one thread per row below does the triangular
+// solve against the diagonal tile, the rhs update and the store of the final L row; [C] every wave updates the tiles of
+// its own column on the matrix cores: T(J+d, J) -= L(J+d, Jc) L(J, Jc)' (v_mfma_f64_16x16x4_f64, operands from Lc), while
+// the former owner adopts column Jc+16.  The backward substitution re-reads L column by column.  Fixed summation order.
+#define SW_P 17
+__device__ __forceinline__ double d_readlane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <int C> __device__ __forceinline__ double d_row_bcast(double v)      // lane (lane & ~15) + C of every 16-lane row
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + C, 0xf, 0xf, false);    // row_newbcast:C
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + C, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <typename F, int... Is> __device__ __forceinline__ void sw_static_for(F&& f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+__device__ __forceinline__ ba_d4 sw_load_tile(const double* __restrict__ A, int n, int bw, int Ri, int Rj, int lane)
+{
+    ba_d4 v;
+    const int c = 16 * Rj + (lane & 15), r0 = 16 * Ri + (lane >> 4);
+    // interior tile (wave-uniform test): strictly below the diagonal tile, inside the matrix and inside the band:
+    // element (r, c) sits at A[r*LD + c - r + bw] = A[r*(LD-1) + c + bw]  ->  four loads a constant stride apart
+    if (Ri > Rj && 16 * Ri + 16 <= n && 16 * (Ri - Rj) + 15 <= bw) {
+        const double* p = A + (size_t)r0 * bw + (c + bw);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) v[rg] = p[(size_t)4 * rg * bw];
+        return v;
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+        const int r = r0 + 4 * rg;
+        const int rr = r > c ? r : c, cc = r > c ? c : r;  // the diagonal tile is delivered symmetric (both triangles)
+        double xv = 0.0;
+        if (rr < n) { if (rr - cc <= bw) xv = A[(size_t)rr * (bw + 1) + (cc - rr + bw)]; }
+        else if (r == c) xv = 1.0;                         // padding rows/columns: identity
+        v[rg] = xv;
+    }
+    return v;
+}
+__device__ __forceinline__ int sw_slot(int d, int J)      // ring slot of LDS tile (J+d, J), 8 <= d <= 16
+{
+    const int base = (d - 8) * 9 - (d - 8) * (d - 9) / 2;  // sum_{e=8}^{d-1} (17 - e)
+    return base + J % (17 - d);
+}
+
+#define SW_NT 512                                     // 8 waves: 256 VGPRs each, two block columns (16 register tiles) per wave
+#define SW_LDS_DOUBLES (272 * SW_P + 45 * 256 + 288 + 16 + 16 + 512 + 512 + 7 * 256)
+__global__ __launch_bounds__(SW_NT) void k_ba_chol_sw(double* __restrict__ A, const double* __restrict__ bs, int n, int bw,
+                                                      double* __restrict__ x, ba_state* __restrict__ St)
+{
+    extern __shared__ double sm[];
+    const int D = (bw + 15) >> 4, NBLK = (n + 15) >> 4, LD = bw + 1;
+    double* Lc = sm;                                  // [(D+1)*16][SW_P] operand buffer: the factored block column
+    double* slots = Lc + 272 * SW_P;                  // 45 tiles x 256 (accumulator layout [reg][lane])
+    double* xr = slots + 45 * 256;                    // rhs ring: global row mod 288
+    double* invd = xr + 288;                          // 1 / L[c][c] of the current diagonal tile
+    double* ybuf = invd + 16;                         // forward-substituted rhs of the current block
+    double* part = ybuf + 16;                         // [32][16] partial dot products of the backward pass
+    double* lastb = part + 512;                       // [2][256] outermost tile (d = D) of the next two columns to be factored
+    double* rdump = lastb + 512;                      // [7][256] the owner's register tiles d = 1..7, accumulator layout
+    __shared__ int s_fail;
+    __shared__ long long dbgl[4];
+    const int tid = threadIdx.x, wv = tid >> 6;
+    // lane_v is made opaque once per step (asm below): every per-lane LDS address is then recomputed where it is used instead
+    // of being hoisted out of the step loop as ~100 loop-invariant VGPRs, which is what pushed the tiles into scratch
+    int lane_v = tid & 63;
+#define SW_LANE const int lane = lane_v, col = lane_v & 15, r0 = lane_v >> 4; (void)lane; (void)col; (void)r0
+    if (tid == 0) { s_fail = St->chol_ok ? 0 : 1; dbgl[0] = dbgl[1] = dbgl[2] = 0; }
+    // block column J lives in wave J & 7, register set (J >> 3) & 1
+    ba_d4 T0[8], T1[8];
+    int J0 = wv, J1 = wv + 8;
+
+    auto load_col = [&](ba_d4 (&T)[8], int J) {
+        SW_LANE;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            if (J < NBLK && d <= D) T[d] = sw_load_tile(A, n, bw, J + d, J, lane);
+            else { T[d][0] = 0; T[d][1] = 0; T[d][2] = 0; T[d][3] = 0; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto init_slots = [&](int J) {                    // LDS tiles that are live before the loop's first-touch rule applies
+        SW_LANE;
+#pragma unroll
+        for (int d = 8; d <= 16; d++)
+            if (d < D && J < NBLK && J + d - D < 0) {
+                const ba_d4 v = sw_load_tile(A, n, bw, J + d, J, lane);
+                double* sl = slots + 256 * sw_slot(d, J);
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) sl[64 * rg + lane] = v[rg];
+            }
+    };
+    load_col(T0, J0); load_col(T1, J1);
+    init_slots(J0); init_slots(J1);
+    if (wv == 0 && D >= 8) {
+        SW_LANE;
+        const ba_d4 v = sw_load_tile(A, n, bw, D, 0, lane);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) lastb[64 * rg + lane] = v[rg];
+    }
+    for (int i = tid; i < 16 * (D + 1); i += SW_NT) xr[i] = i < n ? bs[i] : 0.0;
+    __syncthreads();
+
+    // while the owner factors: bring in the tiles of column J (q = J - Jc >= 1) that the window reaches next
+    auto prefetch = [&](int J, int q) {
+        if (J >= NBLK) return;
+        SW_LANE;
+        const int dnew = D - q;                       // the tile of the column that this step's update touches first
+        if (dnew >= 8 && dnew < D) {
+            const ba_d4 v = sw_load_tile(A, n, bw, J + dnew, J, lane);
+            double* sl = slots + 256 * sw_slot(dnew, J);
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) sl[64 * rg + lane] = v[rg];
+        }
+        if (q == 1 && D >= 8) {                       // next step's owner: its outermost tile (never updated) for the dump
+            const ba_d4 v = sw_load_tile(A, n, bw, J + D, J, lane);
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) lastb[256 * (J & 1) + 64 * rg + lane] = v[rg];
+        }
+    };
+
+    // ---- [A] owner: factor the diagonal tile in place, dump the column into Lc, adopt column Jc+16, forward-substitute
+    auto phase_a = [&](ba_d4 (&T)[8], int Jc) {
+        SW_LANE;
+        long long a0 = wall_clock64();
+        bool bad = false;
+        double myinv = 0.0;
+        // right-looking on the symmetric tile (accumulator layout: lane holds column lane&15, rows (lane>>4)+4*rg): column C by
+        // row comes from a DPP row broadcast, row C by column from one ds_bpermute; both are issued before the pivot's rsqrt
+        // chain completes
+        sw_static_for([&](auto cc) {
+            constexpr int Cc = decltype(cc)::value;
+            const double dg = d_readlane(T[0][Cc >> 2], 16 * (Cc & 3) + Cc);
+            const double rowc = d_shfl_idx(T[0][Cc >> 2], 16 * (Cc & 3) + col);
+            double bc[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) bc[rg] = d_row_bcast<Cc>(T[0][rg]);
+            bad = bad | !(dg > 0) | !(dg < 1.0e300);
+            // sqrt and 1/sqrt together (Goldschmidt from the hardware seed): g -> sqrt(dg), h -> 1/(2 sqrt(dg)); 5 dependent ops
+            const double y0 = __builtin_amdgcn_rsq(dg);
+            double g = dg * y0, h = 0.5 * y0;
+            double rr = __builtin_fma(-g, h, 0.5); g = __builtin_fma(g, rr, g); h = __builtin_fma(h, rr, h);
+            rr = __builtin_fma(-g, h, 0.5); g = __builtin_fma(g, rr, g); h = __builtin_fma(h, rr, h);
+            const double sd = g, id = h + h;
+            myinv = lane == Cc ? id : myinv;
+            // branch-free: masked operands instead of divergent control flow (the chain is latency-bound)
+            const double lcolm = col > Cc ? rowc * id : 0.0;
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+                const int r = r0 + 4 * rg;
+                const double lr = bc[rg] * id;
+                const double upd = __builtin_fma(-(r > Cc ? lr : 0.0), lcolm, T[0][rg]);
+                const double fin = r == Cc ? sd : (r > Cc ? lr : T[0][rg]);
+                T[0][rg] = col == Cc ? fin : upd;
+            }
+        }, std::make_integer_sequence<int, 16>{});
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {                            // final L of the diagonal tile to global
+            const int r = r0 + 4 * rg, grow = 16 * Jc + r;
+            if (col <= r && grow < n) A[(size_t)grow * LD + (col - r + bw)] = T[0][rg];
+        }
+        { const long long a1 = wall_clock64(); if (lane == 0) dbgl[0] += a1 - a0; a0 = a1; }
+        // share the column: the diagonal tile (lower triangle) goes to Lc, the register tiles below it to rdump; the LDS tiles
+        // (slots, lastb) are read in place by [B]
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) { const int r = r0 + 4 * rg; Lc[r * SW_P + col] = col > r ? 0.0 : T[0][rg]; }
+#pragma unroll
+        for (int d = 1; d < 8; d++)
+            if (d <= D) {
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) rdump[256 * (d - 1) + 64 * rg + lane] = T[d][rg];
+            }
+        load_col(T, Jc + 16);                          // adopt the next column: its register tiles start from S
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        { const long long a1 = wall_clock64(); if (lane == 0) dbgl[1] += a1 - a0; a0 = a1; }
+        // forward substitution of the rhs block: lane l < 16 owns y[16 Jc + l]
+        double yl = xr[(16 * Jc + col) % 288];
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const double yc = d_readlane(yl, c) * d_readlane(myinv, c);
+            yl = col == c ? yc : __builtin_fma(-(col > c ? Lc[col * SW_P + c] : 0.0), yc, yl);
+            if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (lane < 16) {
+            invd[lane] = myinv; ybuf[lane] = yl; xr[(16 * Jc + lane) % 288] = yl;
+            if (16 * Jc + lane < n) x[16 * Jc + lane] = yl;
+        }
+        if (bad && lane == 0) s_fail = 1;
+        { const long long a1 = wall_clock64(); if (lane == 0) dbgl[2] += a1 - a0; }
+    };
+
+    // ---- [C] trailing update of column Jm (q blocks ahead of the factored one) on the matrix cores
+    auto phase_c = [&](ba_d4 (&T)[8], int Jm, int qq) {
+        if (Jm >= NBLK || qq > D) return;
+        SW_LANE;
+        double bv[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) bv[ks] = Lc[(16 * qq + col) * SW_P + 4 * ks + r0];
+#pragma unroll
+        for (int d = 0; d < 8; d++)
+            if (qq + d <= D) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++)
+                    T[d] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lc[(16 * (qq + d) + col) * SW_P + 4 * ks + r0], bv[ks], T[d], 0, 0, 0);
+                if (d & 1) __builtin_amdgcn_sched_barrier(0);     // two tiles' operands in flight at most: the scheduler otherwise
+            }                                                     // hoists every LDS read of the phase and spills
+#pragma unroll
+        for (int d = 8; d <= 16; d++)
+            if (qq + d <= D && d < D) {
+                double* sl = slots + 256 * sw_slot(d, Jm);
+                ba_d4 acc;
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) acc[rg] = sl[64 * rg + lane];
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lc[(16 * (qq + d) + col) * SW_P + 4 * ks + r0], bv[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) sl[64 * rg + lane] = acc[rg];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    long long tA = 0, tB = 0, tC = 0, tBack = 0, t0 = 0;
+    for (int Jc = 0; Jc < NBLK; Jc++) {
+        const int wo = Jc & 7, so = (Jc >> 3) & 1;
+        asm volatile("" : "+v"(lane_v));
+        SW_LANE;
+        if (tid == 0) t0 = wall_clock64();
+        if (wv == ((wo + 2) & 7) && Jc >= 1 && lane < 16) {    // rhs block entering the window (kept off the owner's critical path)
+            const int row = 16 * (Jc + D) + lane; xr[row % 288] = row < n ? bs[row] : 0.0;
+        }
+        if (!(wv == wo && so == 0)) prefetch(J0, J0 - Jc);
+        if (!(wv == wo && so == 1)) prefetch(J1, J1 - Jc);
+        if (wv == wo) { if (so == 0) phase_a(T0, Jc); else phase_a(T1, Jc); }
+        __syncthreads();
+        if (tid == 0) { const long long t1 = wall_clock64(); tA += t1 - t0; t0 = t1; }
+        if (s_fail) break;
+        // ---- [B] tiles below the diagonal: L21 = A21 L11^-T, tile by tile in the accumulator layout (column C scaled, broadcast
+        // along the rows by DPP, eliminated from the columns to its right), rhs update, final L to global
+        for (int d = wv + 1; d <= D; d += 8) {
+            ba_d4 t;
+            const double* src = d < 8 ? rdump + 256 * (d - 1) : (d == D ? lastb + 256 * (Jc & 1) : slots + 256 * sw_slot(d, Jc));
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) t[rg] = src[64 * rg + lane];
+            sw_static_for([&](auto cc) {
+                constexpr int Cc = decltype(cc)::value;
+                const double lm = col > Cc ? Lc[col * SW_P + Cc] : 0.0, sc = col == Cc ? invd[Cc] : 1.0;
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) t[rg] *= sc;
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) t[rg] = __builtin_fma(-d_row_bcast<Cc>(t[rg]), lm, t[rg]);
+                if ((Cc & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }, std::make_integer_sequence<int, 16>{});
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+                const int r = 16 * d + r0 + 4 * rg, grow = 16 * Jc + r, gc = 16 * Jc + col;
+                Lc[r * SW_P + col] = t[rg];
+                if (grow < n && grow - gc <= bw) A[(size_t)grow * LD + (gc - grow + bw)] = t[rg];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { const long long t1 = wall_clock64(); tB += t1 - t0; t0 = t1; }
+        if (tid >= 16 && tid < 16 * (D + 1)) {        // rhs below the block: b -= L21 y, one row per thread
+            double s2 = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) s2 += Lc[tid * SW_P + k] * ybuf[k];
+            xr[(16 * Jc + tid) % 288] -= s2;
+        }
+        if (wv == wo) { if (so == 0) J0 = Jc + 16; else J1 = Jc + 16; }
+        phase_c(T0, J0, J0 - Jc);
+        phase_c(T1, J1, J1 - Jc);
+        __syncthreads();
+        if (tid == 0) { const long long t1 = wall_clock64(); tC += t1 - t0; t0 = t1; }
+    }
+    if (s_fail) { if (tid == 0) St->chol_ok = 0; for (int i = tid; i < n; i += SW_NT) x[i] = 0; return; }
+
+    // ---- backward substitution L' x = y, block columns in reverse; the next column's tiles are prefetched into registers
+    if (tid == 0) t0 = wall_clock64();
+    SW_LANE;
+    for (int i = tid; i < 288; i += SW_NT) xr[i] = 0.0;
+    const int rows = 16 * (D + 1);
+    auto gload = [&](int Jb, int e) -> double {
+        const int r = e >> 4, k = e & 15, grow = 16 * Jb + r, gc = 16 * Jb + k;
+        if (r >= rows) return 0.0;
+        if (grow < n && gc < n) return (gc <= grow && grow - gc <= bw) ? A[(size_t)grow * LD + (gc - grow + bw)] : 0.0;
+        return grow == gc ? 1.0 : 0.0;
+    };
+    double nxt[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) nxt[i] = gload(NBLK - 1, tid + SW_NT * i);
+    double ynext = (tid < 16 && 16 * (NBLK - 1) + tid < n) ? x[16 * (NBLK - 1) + tid] : 0.0;
+    __syncthreads();
+    for (int Jc = NBLK - 1; Jc >= 0; Jc--) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) { const int e = tid + SW_NT * i; if (e < rows * 16) Lc[(e >> 4) * SW_P + (e & 15)] = nxt[i]; }
+        const double ycur = ynext;
+        if (Jc > 0) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) nxt[i] = gload(Jc - 1, tid + SW_NT * i);
+            ynext = (tid < 16 && 16 * (Jc - 1) + tid < n) ? x[16 * (Jc - 1) + tid] : 0.0;
+        }
+        __syncthreads();
+        {
+            const int k = tid & 15, p = tid >> 4;
+            double s2 = 0;
+            for (int r = 16 + p; r < rows; r += 32) s2 += Lc[r * SW_P + k] * xr[(16 * Jc + r) % 288];
+            part[p * 16 + k] = s2;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            double t = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) t += part[(8 * r0 + i) * 16 + col];
+            t += d_shfl_xor(t, 16); t += d_shfl_xor(t, 32);
+            double yl = d_shfl_idx(ycur, col) - t;               // ycur lives in lanes 0..15 of wave 0
+            const double myinv = 1.0 / Lc[col * SW_P + col];
+#pragma unroll
+            for (int c = 15; c >= 0; c--) {
+                const double xc = d_readlane(yl, c) * d_readlane(myinv, c);
+                if (col == c) yl = xc; else if (col < c) yl -= Lc[c * SW_P + col] * xc;
+            }
+            if (lane < 16) { xr[(16 * Jc + lane) % 288] = yl; if (16 * Jc + lane < n) x[16 * Jc + lane] = yl; }
+        }
+        __syncthreads();
+    }
+#undef SW_LANE
+    if (tid == 0) { tBack = wall_clock64() - t0; St->dbg[0] = tA; St->dbg[1] = tB; St->dbg[2] = tC; St->dbg[3] = tBack; St->dbg[4] = dbgl[0]; St->dbg[5] = dbgl[1]; St->dbg[6] = dbgl[2]; }
+}
+
 // ---- k_ba_update: trial state = current state (+) step.  blocks [0, pblocks): points (back-substitution); rest: cameras
 __global__ __launch_bounds__(256) void k_ba_update(const ba_cam* __restrict__ cams, ba_cam* __restrict__ cams_t,
                                                    const double* __restrict__ pts, double* __restrict__ pts_t,
@@ -806,7 +1175,7 @@ __global__ __launch_bounds__(256) void k_ba_err(const ba_cam* __restrict__ cams,
 __global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxp,
                                                     const double* __restrict__ bp, int n6, const double* __restrict__ dxl,
                                                     const double* __restrict__ bl, int n3, int phase, int cam_part,
-                                                    ba_state* __restrict__ S)
+                                                    const double* __restrict__ part, ba_state* __restrict__ S)
 {
     // phases as in k_ba_prep; cam_part: this rank contributes the (replicated) camera part of the gain-ratio denominator
     __shared__ double s_red[2 * 16];
@@ -814,9 +1183,12 @@ __global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ c
     const double lambda = S->lambda;
     double v[2] = { 0, 0 };
     if (phase != 2) {
-        for (int e = tid; e < Ea; e += 1024) v[0] += chi_e[e];
         if (cam_part) for (int i = tid; i < n6; i += 1024) v[1] += dxp[i] * (lambda * dxp[i] + bp[i]);
-        for (int i = tid; i < n3; i += 1024) v[1] += dxl[i] * (lambda * dxl[i] + bl[i]);
+        if (part) { if (tid < BA_NPART) { v[0] = part[2 * tid]; v[1] += part[2 * tid + 1]; } }
+        else {
+            for (int e = tid; e < Ea; e += 1024) v[0] += chi_e[e];
+            for (int i = tid; i < n3; i += 1024) v[1] += dxl[i] * (lambda * dxl[i] + bl[i]);
+        }
     }
     d_block_sum<2, 1024>(v, s_red);
     if (tid == 0) {
@@ -892,6 +1264,7 @@ extern "C" int bh_ba_create(bh_ctx* ctx, const double K[5], bh_ba** out)
     (void)hipFuncSetAttribute((const void*)k_ba_chol<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute((const void*)k_ba_chol<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute((const void*)k_ba_chol<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_ba_chol_sw, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     bh_ba* ba = new bh_ba();
     ba->ctx = ctx; ba->K = { K[0], K[1], K[2], K[3] };
     *out = ba;
@@ -906,7 +1279,7 @@ extern "C" void bh_ba_destroy(bh_ba* ba)
     bh_buf* all[] = { &ba->cams[0], &ba->cams[1], &ba->pts[0], &ba->pts[1], &ba->e_cam, &ba->e_pt, &ba->e_meas, &ba->cslot,
                       &ba->p_start, &ba->p_edges, &ba->c_start, &ba->c_edges, &ba->err[0], &ba->err[1], &ba->chi_e[0],
                       &ba->chi_e[1], &ba->Hpl, &ba->Hll, &ba->bl, &ba->Hpp, &ba->bp, &ba->pdiag, &ba->cdiag, &ba->Dinv,
-                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs };
+                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part };
     for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     delete ba;
 }
@@ -1008,6 +1381,7 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     std::vector<int2> pairs;
     for (int a = 0; a < Cf; a++) for (int b = a; b < Cf; b++) if (cov[(size_t)a * Cf + b] || a == b) pairs.push_back(make_int2(a, b));
     ba->npairs = (int)pairs.size();
+    ba->schur_wave = (Cf > 0 && ba->npairs >= 4096 && c_start[Cf] / Cf < 1024) ? 1 : 0;
     int bwb = 0;
     for (const int2& pr : pairs) bwb = (pr.y - pr.x) > bwb ? (pr.y - pr.x) : bwb;
     BH_TRY(bh_reserve(ctx, &ba->state, sizeof(ba_state)));
@@ -1022,7 +1396,14 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     }
     const int n6i = 6 * Cf;
     ba->bw = n6i > 0 ? std::min(n6i - 1, 6 * bwb + 5) : 0;
-    {   // panel width by LDS budget: min(n, NB+bw) x (NB+1) panel + 1024 partial sums, f64, <= 150 KB
+    {   // narrow band, long matrix: the trailing window stays on chip (BH_BA_CHOL=panel|window overrides)
+        const char* ev = getenv("BH_BA_CHOL");
+        const bool fits = (ba->bw + 15) / 16 <= 16 && ba->bw >= 15;
+        ba->chol_window = (fits && n6i >= 256) ? 1 : 0;
+        if (ev && !strcmp(ev, "panel")) ba->chol_window = 0;
+        if (ev && !strcmp(ev, "window") && fits) ba->chol_window = 1;
+    }
+    if (!ba->chol_window) {   // panel width by LDS budget: min(n, NB+bw) x (NB+1) panel + 1024 partial sums, f64, <= 150 KB
         int nb = 32;
         while (nb >= 8 && sizeof(double) * ((size_t)std::min(n6i, nb + ba->bw) * (nb + 1) + 1100) > 150 * 1024) nb >>= 1;
         if (nb < 8) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: reduced camera system too wide for the single-workgroup banded solver "
@@ -1046,6 +1427,7 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     BH_TRY(bh_reserve(ctx, &ba->Dinv, sizeof(double) * 9 * ((size_t)Pa + 1))); BH_TRY(bh_reserve(ctx, &ba->db, sizeof(double) * 3 * ((size_t)Pa + 1)));
     BH_TRY(bh_reserve(ctx, &ba->S, sizeof(double) * (n6 * (size_t)(ba->bw + 1) + 1))); BH_TRY(bh_reserve(ctx, &ba->bs, sizeof(double) * (n6 + 6)));
     BH_TRY(bh_reserve(ctx, &ba->dxp, sizeof(double) * (n6 + 6))); BH_TRY(bh_reserve(ctx, &ba->dxl, sizeof(double) * 3 * ((size_t)Pa + 1)));
+    BH_TRY(bh_reserve(ctx, &ba->part, sizeof(double) * 2 * BA_NPART));
     BH_HIP(ctx, hipMemsetAsync(ba->state.p, 0, sizeof(ba_state), ctx->stream));
     BH_HIP(ctx, hipMemsetAsync(ba->err[0].p, 0, sizeof(double) * 2 * (E + 1), ctx->stream));
     BH_HIP(ctx, hipMemsetAsync(ba->S.p, 0, sizeof(double) * (n6 * (size_t)(ba->bw + 1) + 1), ctx->stream));
@@ -1078,6 +1460,7 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
     ba_state* state = (ba_state*)ba->state.p;
     double* red = (double*)((char*)ba->state.p + offsetof(ba_state, red));
     const bool dist = ba->ar != nullptr;
+    double* part = Ea > 262144 ? (double*)ba->part.p : nullptr;      // two-stage sums above this size
     const int lead = ba->rank == 0 ? 1 : 0;              // the rank that contributes the replicated camera terms
     ba->comm_ms = 0; ba->comm_bytes = 0;
     const int pblocks = (Pa + 255) / 256, cblocks = (C + 255) / 256;
@@ -1092,13 +1475,15 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
             BH_TRY(ba_allreduce(ba, Hpp, 36LL * Cf, 0)); BH_TRY(ba_allreduce(ba, bp, n6, 0));
             hipLaunchKernelGGL(k_ba_cdiag, dim3((Cf + 63) / 64), dim3(64), 0, st, (const double*)Hpp, Cf, cdiag);
         }
+        if (part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_partial, dim3(BA_NPART), dim3(1024), st, (const double*)ba->chi_e[0].p, Ea, (const double*)nullptr,
+                            (const double*)nullptr, 0, (const ba_state*)state, part);
         BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_prep, dim3(1), dim3(1024), st, (const double*)ba->chi_e[0].p, Ea, (const double*)pdiag, Pa,
-                  (const double*)cdiag, Cf, it == 0 ? 1 : 0, dist ? 1 : 0, state);
+                  (const double*)cdiag, Cf, it == 0 ? 1 : 0, dist ? 1 : 0, (const double*)part, state);
         if (dist) {
             BH_TRY(ba_allreduce(ba, red, 1, 0));
             if (it == 0) BH_TRY(ba_allreduce(ba, red + 1, 1, 1));
             BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_prep, dim3(1), dim3(1024), st, (const double*)ba->chi_e[0].p, Ea, (const double*)pdiag, Pa,
-                      (const double*)cdiag, Cf, it == 0 ? 1 : 0, 2, state);
+                      (const double*)cdiag, Cf, it == 0 ? 1 : 0, 2, (const double*)part, state);
         }
         ba_state hs;
         if (it == 0) {
@@ -1112,8 +1497,12 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
             BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_dinv, dim3(pblocks), dim3(256), st, (const double*)Hll, (const double*)bl, Pa, state, Dinv, db);
             if (Cf) {
                 BH_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double) * (size_t)n6 * (ba->bw + 1), st));     // blocks without a common point stay zero
-                BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_S, dim3(ba->npairs), dim3(256), st, (const int2*)ba->pairs.p, c_start, c_edges, e_pt,
-                          (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S);
+                if (ba->schur_wave)
+                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<64, 1024>), dim3(ba->npairs), dim3(64), st, (const int2*)ba->pairs.p, c_start, c_edges, e_pt,
+                              (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S);
+                else
+                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<256, SCH_LDS>), dim3(ba->npairs), dim3(256), st, (const int2*)ba->pairs.p, c_start, c_edges, e_pt,
+                              (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S);
                 BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_b, dim3(Cf), dim3(256), st, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)db,
                           (const double*)bp, dist ? lead : 1, bs);
                 if (dist) { BH_TRY(ba_allreduce(ba, S, (long long)n6 * (ba->bw + 1), 0)); BH_TRY(ba_allreduce(ba, bs, n6, 0)); }
@@ -1121,7 +1510,10 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                     const int nbsel = ba->chol_nb, bw = ba->bw;
                     const size_t lds = sizeof(double) * ((size_t)std::min(n6, nbsel + bw) * (nbsel + 1) + 1100);
                     bh_time_begin(ctx, BH_K_BA_SOLVE);
-                    if (nbsel == 32) hipLaunchKernelGGL(k_ba_chol<32>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
+                    if (ba->chol_window)
+                        hipLaunchKernelGGL(k_ba_chol_sw, dim3(1), dim3(SW_NT), sizeof(double) * SW_LDS_DOUBLES, st, S,
+                                           (const double*)bs, n6, bw, dxp, state);
+                    else if (nbsel == 32) hipLaunchKernelGGL(k_ba_chol<32>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     else if (nbsel == 16) hipLaunchKernelGGL(k_ba_chol<16>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     else hipLaunchKernelGGL(k_ba_chol<8>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     bh_time_end(ctx);
@@ -1131,12 +1523,14 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                       p_start, p_edges, e_cam, (const double*)Hpl, (const double*)Dinv, (const double*)bl, (const double*)dxp, dxl, ba->K);
             BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_err, dim3((Ea + 255) / 256), dim3(256), st, (const ba_cam*)cams_t, (const double*)pts_t, e_cam, e_pt,
                       e_meas, Ea, huber_delta, (double*)ba->err[1].p, (double*)ba->chi_e[1].p);
+            if (part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_partial, dim3(BA_NPART), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxl,
+                                (const double*)bl, 3 * Pa, (const ba_state*)state, part);
             BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_decide, dim3(1), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxp, (const double*)bp,
-                      n6, (const double*)dxl, (const double*)bl, 3 * Pa, dist ? 1 : 0, dist ? lead : 1, state);
+                      n6, (const double*)dxl, (const double*)bl, 3 * Pa, dist ? 1 : 0, dist ? lead : 1, (const double*)part, state);
             if (dist) {
                 BH_TRY(ba_allreduce(ba, red, 3, 0));
                 BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_decide, dim3(1), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxp, (const double*)bp,
-                          n6, (const double*)dxl, (const double*)bl, 3 * Pa, 2, lead, state);
+                          n6, (const double*)dxl, (const double*)bl, 3 * Pa, 2, lead, (const double*)part, state);
             }
             BH_HIP(ctx, hipGetLastError());
             BH_HIP(ctx, hipMemcpyAsync(&hs, state, sizeof(hs), hipMemcpyDeviceToHost, st));
@@ -1154,6 +1548,43 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
     if (iters_done) *iters_done = ba->iters_done;
     ba->verbose_last = verbose_errors;
     return rc;
+}
+
+// Test hook: solve one banded SPD system with the BA solver kernels (mode 0 = panel kernel, 1 = sliding-window kernel).
+extern "C" int bh_ba_debug_band_solve(bh_ctx* ctx, const double* band, const double* rhs, int n, int bw, int mode, double* x, long long* clocks)
+{
+    if (!ctx || !band || !rhs || !x || n <= 0 || bw < 0 || bw >= n) return BH_ERR_INVALID;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t nb = sizeof(double) * (size_t)n * (bw + 1);
+    BH_TRY(bh_reserve(ctx, &ctx->st_a, nb)); BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(double) * 2 * (size_t)n + sizeof(ba_state)));
+    double* dA = (double*)ctx->st_a.p; double* db = (double*)ctx->st_b.p; double* dx = db + n; ba_state* dS = (ba_state*)(dx + n);
+    ba_state hs; memset(&hs, 0, sizeof(hs)); hs.chol_ok = 1;
+    BH_HIP(ctx, hipMemcpyAsync(dA, band, nb, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipMemcpyAsync(db, rhs, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipMemcpyAsync(dS, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+    if (mode == 1) {
+        if ((bw + 15) / 16 > 16 || bw < 15) return bh_set_err(ctx, BH_ERR_INVALID, "band solve: the window kernel needs 15 <= bw <= 256");
+        (void)hipFuncSetAttribute((const void*)k_ba_chol_sw, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        hipLaunchKernelGGL(k_ba_chol_sw, dim3(1), dim3(SW_NT), sizeof(double) * SW_LDS_DOUBLES, st, dA, (const double*)db, n, bw, dx, dS);
+    } else {
+        int nbsel = 32;
+        while (nbsel >= 8 && sizeof(double) * ((size_t)std::min(n, nbsel + bw) * (nbsel + 1) + 1100) > 150 * 1024) nbsel >>= 1;
+        if (nbsel < 8) return bh_set_err(ctx, BH_ERR_INVALID, "band solve: band too wide");
+        const size_t lds = sizeof(double) * ((size_t)std::min(n, nbsel + bw) * (nbsel + 1) + 1100);
+        (void)hipFuncSetAttribute((const void*)k_ba_chol<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_ba_chol<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_ba_chol<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        if (nbsel == 32) hipLaunchKernelGGL(k_ba_chol<32>, dim3(1), dim3(1024), lds, st, dA, (const double*)db, n, bw, dx, dS);
+        else if (nbsel == 16) hipLaunchKernelGGL(k_ba_chol<16>, dim3(1), dim3(1024), lds, st, dA, (const double*)db, n, bw, dx, dS);
+        else hipLaunchKernelGGL(k_ba_chol<8>, dim3(1), dim3(1024), lds, st, dA, (const double*)db, n, bw, dx, dS);
+    }
+    BH_HIP(ctx, hipGetLastError());
+    BH_HIP(ctx, hipMemcpyAsync(x, dx, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    BH_HIP(ctx, hipMemcpyAsync(&hs, dS, sizeof(hs), hipMemcpyDeviceToHost, st));
+    BH_HIP(ctx, hipStreamSynchronize(st));
+    if (clocks) for (int i = 0; i < 8; i++) clocks[i] = hs.dbg[i];
+    return hs.chol_ok ? BH_OK : bh_set_err(ctx, BH_ERR_NUMERIC, "band solve: not positive definite");
 }
 
 extern "C" int bh_ba_get_poses(bh_ba* ba, double* R, double* t, int mem)

@@ -156,6 +156,12 @@ int  bh_ba_get_chi2(bh_ba* ba, double* chi2, int mem);
 /* per-iteration log of the last optimize: f64[iters_done][4] = {robust chi2 after, lambda, trials, accepted} */
 int  bh_ba_get_log(bh_ba* ba, double* log, int max_rows);
 
+/* Test hook: one banded SPD solve S x = rhs with the reduced-camera-system kernels.  band f64[n][bw+1] holds the lower band,
+ * element (r, c) at band[r*(bw+1) + c - r + bw]; mode 0 = panel kernel, 1 = on-chip sliding-window kernel (15 <= bw <= 256);
+ * clocks (may be NULL) receives i64[8] phase clocks of the window kernel (100 MHz ticks). */
+int  bh_ba_debug_band_solve(bh_ctx* ctx, const double* band, const double* rhs, int n, int bw, int mode, double* x,
+                            long long* clocks);
+
 /* Global BA over several GPUs (BASELINE configs[4]; no counterpart in the reference, whose covisibility_graph.py:186-235
  * optimises on one CPU).  The problem is sharded BY LANDMARK: every rank passes all C poses (same order, same fixed flags)
  * and its own subset of points with all their edges to bh_ba_set_problem.  The library then calls `fn` at the exchange

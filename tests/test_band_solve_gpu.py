@@ -1,0 +1,58 @@
+"""The two reduced-camera-system solvers (panel kernel, on-chip sliding-window kernel) against scipy on random banded SPD
+systems, including sizes that are not multiples of the 16x16 tile and the widest band the window kernel takes."""
+import ctypes as C
+import numpy as np
+import pytest
+from scipy.linalg import solveh_banded
+
+from boslam_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def band_system(n, bw, seed):
+    rng = np.random.default_rng(seed)
+    low = rng.normal(size=(n, bw + 1))                    # low[r, bw - k] = element (r, r - k)
+    for k in range(1, bw + 1):
+        low[:k, bw - k] = 0.0
+    low[:, bw] = np.abs(low[:, :bw]).sum(axis=1) + np.abs(low[:, bw]) + 1.0 + 2.0 * bw ** 0.5   # diagonally dominant enough
+    # make strictly SPD: add column sums too
+    colsum = np.zeros(n)
+    for k in range(1, bw + 1):
+        colsum[:n - k] += np.abs(low[k:, bw - k])
+    low[:, bw] += colsum
+    rhs = rng.normal(size=n)
+    return np.ascontiguousarray(low), rhs
+
+
+def scipy_solve(low, rhs, bw):
+    n = len(rhs)
+    ab = np.zeros((bw + 1, n))                            # scipy lower form: ab[k, j] = a[j + k, j]
+    for k in range(bw + 1):
+        ab[k, :n - k] = low[k:, bw - k]
+    return solveh_banded(ab, rhs, lower=True)
+
+
+def gpu_solve(ctx, low, rhs, bw, mode):
+    n = len(rhs)
+    x = np.zeros(n); clocks = np.zeros(8, np.int64)
+    ctx.check(_lib.lib().bh_ba_debug_band_solve(ctx.h, _lib.ptr(low), _lib.ptr(rhs), n, bw, mode, _lib.ptr(x), _lib.ptr(clocks)))
+    return x, clocks
+
+
+@pytest.mark.parametrize("n,bw", [(300, 15), (777, 77), (1000, 245), (2048, 251), (2500, 256), (530, 130), (4099, 245)])
+def test_window_and_panel_kernels_match_scipy(ctx, n, bw):
+    low, rhs = band_system(n, bw, seed=n + bw)
+    ref = scipy_solve(low, rhs, bw)
+    for mode in (0, 1):
+        x, _ = gpu_solve(ctx, low, rhs, bw, mode)
+        assert np.abs(x - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), (mode, np.abs(x - ref).max())
+
+
+def test_not_positive_definite_is_reported(ctx):
+    low, rhs = band_system(600, 40, seed=1)
+    low[300, 40] = -5.0
+    for mode in (0, 1):
+        x = np.zeros(600)
+        rc = _lib.lib().bh_ba_debug_band_solve(ctx.h, _lib.ptr(low), _lib.ptr(rhs), 600, 40, mode, _lib.ptr(x), None)
+        assert rc == -5
