@@ -184,7 +184,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom)
+                per_frame = json.load(open(pmc)).get(dom)          # HBM bytes per frame from the PMC passes (tools/pmc_traffic.py)
+                traffic = int(per_frame * frames_per_launch / ((params.nlevels - 1) if dom == "k_pyr_down" else 1)) if per_frame else None
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import sys; import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
 import numpy as np, time
 from boslam_amd import Context
 from test_band_solve_gpu import band_system, gpu_solve, scipy_solve

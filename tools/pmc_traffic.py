@@ -1,0 +1,26 @@
+"""profiles/pmc_traffic.json from a tools/prof_pmc.sh run: HBM bytes PER FRAME for every front-end kernel.
+
+FETCH_SIZE / WRITE_SIZE are in KiB (MI355X guide, HBM/rocprofv3 section).  gfx950 correction: FETCH_SIZE under-reports by 2x
+for kernels whose global loads are >= 8 B per lane (calibrated on k_gray_mask, whose input bytes are known exactly); kernels
+with dword-or-narrower loads are taken as reported.  Usage: python tools/pmc_traffic.py gpurun_out/<pmc dir> <frames per launch>"""
+import json, subprocess, sys, os
+
+root, fpl = sys.argv[1], int(sys.argv[2])
+here = os.path.dirname(os.path.abspath(__file__))
+d = json.loads(subprocess.run([sys.executable, os.path.join(here, "pmc_summary.py"), root], capture_output=True, text=True, check=True).stdout)
+WIDE = {"k_gray_mask": 2, "k_pyr_down": 2, "k_select": 2}
+out = {"_note": "HBM bytes per FRAME = (FETCH_SIZE x factor + WRITE_SIZE) KiB per launch / frames per launch; rocprofv3 --pmc, FETCH_SIZE and "
+                "WRITE_SIZE in separate passes, bench.py --frames 256 --pipelines 1 (launches of %d frames); k_pyr_down and k_blur are "
+                "summed over their launches per frame batch.  factor 2 = kernels with >= 8 B/lane loads (gfx950 FETCH_SIZE correction, "
+                "calibrated on k_gray_mask), 1 otherwise." % fpl, "_factors": WIDE}
+agg = {}
+for k, v in d.items():
+    base = k.split("<")[0]
+    if base.startswith("k_ba") or "FETCH_SIZE" not in v:
+        continue
+    per_launch = (v["FETCH_SIZE"] * WIDE.get(base, 1) + v.get("WRITE_SIZE", 0.0)) * 1024.0
+    launches_per_batch = 7 if base == "k_pyr_down" else 1
+    agg[base] = agg.get(base, 0.0) + per_launch * launches_per_batch / fpl
+for k, v in sorted(agg.items()):
+    out[k] = int(round(v))
+print(json.dumps(out, indent=1))
