@@ -153,9 +153,13 @@ print("rank", rank, "ok")
 def test_two_rank_gloo_sharded_matching_equals_single_process(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="2")
+    import socket
+    with socket.socket() as sk:                      # a free port: a fixed one can still sit in TIME_WAIT from an earlier run
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", str(script), ROOT]
+           "--master-port", port, str(script), ROOT]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
