@@ -99,7 +99,8 @@ def main():
 
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("BH_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # BH_BENCH_DEVICE: rehearsals of N ranks on one GPU
+    backend = os.environ.get("BH_BENCH_BACKEND", "nccl")                               # "gloo" for such rehearsals (RCCL refuses two ranks per GPU)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
     torch.cuda.set_device(local)
@@ -108,7 +109,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend=backend)
 
     from boslam_amd import Context, frontend
     ctx = Context(local)
@@ -155,7 +159,7 @@ def main():
     else:
         os.environ.pop("BH_ORB_PIPELINES", None)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
