@@ -35,7 +35,32 @@ def main():
     b = oracle.ba_optimize(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"], pr["K"], 7, np.sqrt(7.815))
     np.savez_compressed(os.path.join(HERE, "ba_golden.npz"), pose_R=o["R"], pose_t=o["t"], pose_inlier=o["inlier"],
                         pose_chi2=o["chi2"], ba_R=b["R"], ba_t=b["t"], ba_pts=b["pts"], ba_chi2=b["chi2"], ba_log=b["log"])
+    np.savez_compressed(os.path.join(HERE, "config1_golden.npz"), **config1_oracle(100))
     print("golden vectors written to", HERE)
+
+
+def config1_oracle(nfr):
+    """BASELINE configs[0] on the CPU oracle: the replay of boslam_amd.two_way_tracking with oracle back ends."""
+    from boslam_amd import two_way_tracking
+    bgr, depth = synth.render_batch(nfr, traj="config1")
+    P = oracle.orb_params(nfeatures=600)
+    kps, desc, nk, rc = oracle.orb_batch(bgr, depth, P, 768)
+    assert np.all(np.asarray(rc) == 0)
+    xy = np.zeros((nfr, 768, 2), np.int64); cloud = np.zeros((nfr, 768, 3))
+    for f in range(nfr):
+        xy[f, :nk[f]] = oracle.kp_to_int(kps[f, :nk[f]])
+        cloud[f, :nk[f]] = oracle.backproject(depth[f], xy[f, :nk[f]], synth.FX, synth.FY, synth.CX, synth.CY)
+    K4 = np.array([synth.FX, synth.FY, synth.CX, synth.CY])
+
+    def match_fn(p, f):
+        return oracle.match_crosscheck(desc[p, :nk[p]], desc[f, :nk[f]])
+
+    def pnp2_fn(a, b, b1, a1):
+        return oracle.solve_pnp_ransac(a, b, K4), oracle.solve_pnp_ransac(b1, a1, K4)
+
+    log = two_way_tracking.replay(desc, nk, xy, cloud, match_fn, pnp2_fn, oracle.rodrigues)
+    log["n_kp"] = nk
+    return log
 
 
 if __name__ == "__main__":

@@ -318,3 +318,16 @@ def test_voc_transform_matches_python_tree_walk():
     assert np.array_equal(w, ref_w)
     assert np.allclose(x, ref_v, rtol=1e-14, atol=0)
     assert abs(x.sum() - 1) < 1e-12
+
+
+def test_config1_replay_is_pinned_by_the_golden_fixture():
+    """BASELINE configs[0]: the oracle's 100-frame two-way tracking replay reproduces tests/golden/config1_golden.npz (first 12
+    frames here to keep the CPU suite short; make_golden.py regenerates all 100)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config1_golden.npz"))
+    log = mg.config1_oracle(12)
+    for k in ("state", "num_matches", "num_inliers", "num_union", "n_kp"):
+        assert np.array_equal(log[k], g[k][:12]), k
+    assert np.array_equal(log["R"], g["R"][:12]) and np.array_equal(log["t"], g["t"][:12]) and np.array_equal(log["point_diff"], g["point_diff"][:12])
