@@ -1,5 +1,6 @@
 """Secondary metric of BASELINE.json: local-BA Levenberg iterations per second on configs[2]
 (50 keyframes x 10 k landmarks x ~80 k observations, 10 LM iterations, Huber sqrt(7.815), f64)."""
+import os
 import time
 import numpy as np
 from . import ba, synth
@@ -70,5 +71,17 @@ def run_global(ctx, n_kf=5000, n_pts=500000, iters=5, window=20, dist=None, devi
            "kernel_ms_per_iter": {k: round(v[0] / done, 3) for k, v in sorted(kt.items()) if k.startswith("k_ba")},
            "pose_err_mean_before_m": float(np.abs(pr["t"] - pr["tgt"]).mean()), "pose_err_mean_after_m": float(np.abs(t - pr["tgt"]).mean()),
            "point_err_mean_before_m": float(np.abs(pr["pts"] - pr["Xgt"]).mean()), "point_err_mean_after_m": float(np.abs(pts - pr["Xgt"]).mean())}
+    # matrix-core roofline of the reduced-camera-system solve (the only GEMM-shaped stage): the sliding-window kernel issues 4
+    # v_mfma_f64_16x16x4 per 16x16 tile, D(D+1)/2 tiles per block column (D = band in tiles); it runs on ONE CU by design
+    n6 = 6 * int((1 - pr["fixed"]).sum()); bw = min(n6 - 1, 6 * 2 * window + 5); D = (bw + 15) // 16; nblk = (n6 + 15) // 16
+    flops = nblk * D * (D + 1) // 2 * 4 * 2048
+    ms = out["kernel_ms_per_iter"].get("k_ba_solve", 0.0)
+    if ms > 0 and D <= 16:
+        cus = 2 if (D == 16 and nblk >= 96 and os.environ.get("BH_BA_CHOL_TWOWAY") != "0") else 1      # two-way schedule: one CU per end
+        out["solve_roofline"] = {"bound": "mfma", "kernel": "k_ba_chol_sw", "achieved": round(flops / (ms * 1e-3) / 1e12, 5), "unit": "TFLOP/s",
+                                 "peak": 78.6, "frac": round(flops / (ms * 1e-3) / 78.6e12, 6), "cus_used": cus,
+                                 "peak_of_cus_used": round(78.6 * cus / 256, 4), "frac_of_cus_used": round(flops / (ms * 1e-3) / (78.6e12 * cus / 256), 4),
+                                 "mfma_flops_per_solve": int(flops),
+                                 "note": "two dependency chains of ~%d block columns, one CU each; the dense f64 MFMA peak of 78.6 TFLOP/s is for 256 CUs" % (nblk // cus)}
     s.close()
     return out

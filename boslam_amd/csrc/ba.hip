@@ -360,7 +360,8 @@ struct bh_ba {
     bh_buf p_start, p_edges, c_start, c_edges;
     bh_buf err[2], chi_e[2];           // [0] at the current state (iteration start), [1] at the trial state
     bh_buf Hpl, Hll, bl, Hpp, bp, pdiag, cdiag;
-    bh_buf Dinv, db, S, bs, dxp, dxl, state, pairs, part;
+    bh_buf Dinv, db, S, bs, dxp, dxl, state, pairs, part, xch;
+    int chol_split = 0;                // two-way window solve: first block column of the separator (0 = one workgroup)
     int npairs = 0;
     int bw = 0;                        // scalar half-bandwidth of the reduced camera system (6*max|s1-s2| + 5)
     int chol_nb = 32;                  // panel width chosen for the LDS budget
@@ -804,16 +805,40 @@ template <typename F, int... Is> __device__ __forceinline__ void sw_static_for(F
 {
     (f(std::integral_constant<int, Is>{}), ...);
 }
-__device__ __forceinline__ ba_d4 sw_load_tile(const double* __restrict__ A, int n, int bw, int Ri, int Rj, int lane)
+// One workgroup's logical matrix: lower element (r, c), r >= c, of a band matrix padded to npad = 16*ceil(n/16) rows.  rev = 0: the
+// stored matrix itself.  rev = 1: the same matrix with rows and columns in reverse order (r -> npad-1-r), still banded and SPD;
+// its lower element (r, c) is the stored lower element (npad-1-c, npad-1-r).  Rows >= nl (the leading principal submatrix this
+// workgroup works on) and rows that map beyond n behave as identity padding.
+struct sw_view {
+    long long base, sr, sc;                  // band-array index of (r, c) = base + r*sr + c*sc
+    int nl, npad, n, bw, rev;
+    __device__ __forceinline__ long long idx(int r, int c) const { return base + (long long)r * sr + (long long)c * sc; }
+    __device__ __forceinline__ int vec(int r) const { return rev ? npad - 1 - r : r; }            // index into rhs / solution
+    __device__ __forceinline__ bool vec_ok(int r) const { return r < nl && vec(r) < n; }
+    __device__ __forceinline__ bool stored(int r, int c) const                                    // r >= c: inside matrix and band
+    {
+        return r < nl && r - c <= bw && (rev ? npad - 1 - c : r) < n;
+    }
+    __device__ __forceinline__ bool padding(int r, int c) const { return r >= nl || (rev ? npad - 1 - c : r) >= n; }
+};
+__device__ __forceinline__ sw_view sw_make_view(int n, int bw, int nl, int rev)
+{
+    sw_view v;
+    v.n = n; v.bw = bw; v.nl = nl; v.rev = rev; v.npad = ((n + 15) >> 4) << 4;
+    if (!rev) { v.base = bw; v.sr = bw; v.sc = 1; }                      // r*(bw+1) + c - r + bw
+    else { v.base = (long long)(v.npad - 1) * (bw + 1) + bw; v.sr = -1; v.sc = -bw; }      // (npad-1-c)*(bw+1) + c - r + bw
+    return v;
+}
+__device__ __forceinline__ ba_d4 sw_load_tile(const double* __restrict__ A, const sw_view& V, int Ri, int Rj, int lane)
 {
     ba_d4 v;
     const int c = 16 * Rj + (lane & 15), r0 = 16 * Ri + (lane >> 4);
-    // interior tile (wave-uniform test): strictly below the diagonal tile, inside the matrix and inside the band:
-    // element (r, c) sits at A[r*LD + c - r + bw] = A[r*(LD-1) + c + bw]  ->  four loads a constant stride apart
-    if (Ri > Rj && 16 * Ri + 16 <= n && 16 * (Ri - Rj) + 15 <= bw) {
-        const double* p = A + (size_t)r0 * bw + (c + bw);
+    // interior tile (wave-uniform test): strictly below the diagonal tile, inside the matrix and the band -> four loads a
+    // constant stride apart
+    if (Ri > Rj && 16 * Ri + 16 <= V.nl && 16 * (Ri - Rj) + 15 <= V.bw && (V.rev ? 16 * Rj >= V.npad - V.n : 16 * Ri + 16 <= V.n)) {
+        const double* p = A + V.idx(r0, c);
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++) v[rg] = p[(size_t)4 * rg * bw];
+        for (int rg = 0; rg < 4; rg++) v[rg] = p[4 * rg * V.sr];
         return v;
     }
 #pragma unroll
@@ -821,7 +846,7 @@ __device__ __forceinline__ ba_d4 sw_load_tile(const double* __restrict__ A, int 
         const int r = r0 + 4 * rg;
         const int rr = r > c ? r : c, cc = r > c ? c : r;  // the diagonal tile is delivered symmetric (both triangles)
         double xv = 0.0;
-        if (rr < n) { if (rr - cc <= bw) xv = A[(size_t)rr * (bw + 1) + (cc - rr + bw)]; }
+        if (!V.padding(rr, cc)) { if (rr - cc <= V.bw) xv = A[V.idx(rr, cc)]; }
         else if (r == c) xv = 1.0;                         // padding rows/columns: identity
         v[rg] = xv;
     }
@@ -835,11 +860,28 @@ __device__ __forceinline__ int sw_slot(int d, int J)      // ring slot of LDS ti
 
 #define SW_NT 512                                     // 8 waves: 256 VGPRs each, two block columns (16 register tiles) per wave
 #define SW_LDS_DOUBLES (272 * SW_P + 45 * 256 + 288 + 16 + 16 + 512 + 512 + 7 * 256)
-__global__ __launch_bounds__(SW_NT) void k_ba_chol_sw(double* __restrict__ A, const double* __restrict__ bs, int n, int bw,
-                                                      double* __restrict__ x, ba_state* __restrict__ St)
+// Two-way solve (split > 0, D == 16, three launches on one stream instead of one):
+//   phase 1, grid 2: workgroup 0 eliminates block columns 0 .. split-1 of the matrix top-down, workgroup 1 the first
+//            NB2 = NBLK-split-16 block columns of the REVERSED matrix (the stored matrix bottom-up).  The 16 block columns in
+//            between (>= the bandwidth) separate the two eliminations completely; each side stops with its trailing window =
+//            A22 minus its own Schur update, and writes window + rhs rows to xch;
+//   k_sw_separator + k_ba_chol<32>: the 256 x 256 separator system  W_top + W_bottom - A22  is assembled and solved;
+//   phase 2, grid 2: both sides back-substitute their own part with the separator's solution in place.
+// No extra flops, two CUs instead of one.  phase 0 = everything in one workgroup.
+#define SW_XCH_TILE(side, q, d) (65536 * (side) + 256 * (16 * (q) + (d)))       // window tile (column q, distance d), row-major 16x16
+#define SW_XCH_RHS(side) (2 * 65536 + 256 * (side))
+#define SW_XCH_DOUBLES (2 * 65536 + 512)
+// REV is a template parameter: with the ordering known at compile time the tile addresses fold into immediates; as a run-time
+// flag the generic strides cost ~100 address registers and spill the window tiles.
+template <int REV>
+__device__ __forceinline__ void sw_body(double* __restrict__ sm, double* __restrict__ A, const double* __restrict__ bs, int n, int bw,
+                                        double* __restrict__ x, ba_state* __restrict__ St, int phase, int split, int side,
+                                        double* __restrict__ xch)
 {
-    extern __shared__ double sm[];
-    const int D = (bw + 15) >> 4, NBLK = (n + 15) >> 4, LD = bw + 1;
+    const int D = (bw + 15) >> 4, NB_ALL = (n + 15) >> 4;
+    const int NFACT = !phase ? NB_ALL : split;        // block columns this workgroup eliminates (`split` = nfact of this side)
+    const int NBLK = !phase ? NB_ALL : NFACT + 16;    // ... out of a leading submatrix of this many
+    const sw_view V = sw_make_view(n, bw, 16 * NBLK, REV);
     double* Lc = sm;                                  // [(D+1)*16][SW_P] operand buffer: the factored block column
     double* slots = Lc + 272 * SW_P;                  // 45 tiles x 256 (accumulator layout [reg][lane])
     double* xr = slots + 45 * 256;                    // rhs ring: global row mod 288
@@ -864,7 +906,7 @@ __global__ __launch_bounds__(SW_NT) void k_ba_chol_sw(double* __restrict__ A, co
         SW_LANE;
 #pragma unroll
         for (int d = 0; d < 8; d++) {
-            if (J < NBLK && d <= D) T[d] = sw_load_tile(A, n, bw, J + d, J, lane);
+            if (J < NBLK && d <= D) T[d] = sw_load_tile(A, V, J + d, J, lane);
             else { T[d][0] = 0; T[d][1] = 0; T[d][2] = 0; T[d][3] = 0; }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -874,21 +916,20 @@ __global__ __launch_bounds__(SW_NT) void k_ba_chol_sw(double* __restrict__ A, co
 #pragma unroll
         for (int d = 8; d <= 16; d++)
             if (d < D && J < NBLK && J + d - D < 0) {
-                const ba_d4 v = sw_load_tile(A, n, bw, J + d, J, lane);
+                const ba_d4 v = sw_load_tile(A, V, J + d, J, lane);
                 double* sl = slots + 256 * sw_slot(d, J);
 #pragma unroll
                 for (int rg = 0; rg < 4; rg++) sl[64 * rg + lane] = v[rg];
             }
     };
-    load_col(T0, J0); load_col(T1, J1);
-    init_slots(J0); init_slots(J1);
-    if (wv == 0 && D >= 8) {
+    if (phase != 2) { load_col(T0, J0); load_col(T1, J1); init_slots(J0); init_slots(J1); }
+    if (phase != 2 && wv == 0 && D >= 8) {
         SW_LANE;
-        const ba_d4 v = sw_load_tile(A, n, bw, D, 0, lane);
+        const ba_d4 v = sw_load_tile(A, V, D, 0, lane);
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) lastb[64 * rg + lane] = v[rg];
     }
-    for (int i = tid; i < 16 * (D + 1); i += SW_NT) xr[i] = i < n ? bs[i] : 0.0;
+    for (int i = tid; i < 16 * (D + 1); i += SW_NT) xr[i] = V.vec_ok(i) ? bs[V.vec(i)] : 0.0;
     __syncthreads();
 
     // while the owner factors: bring in the tiles of column J (q = J - Jc >= 1) that the window reaches next
@@ -897,13 +938,13 @@ __global__ __launch_bounds__(SW_NT) void k_ba_chol_sw(double* __restrict__ A, co
         SW_LANE;
         const int dnew = D - q;                       // the tile of the column that this step's update touches first
         if (dnew >= 8 && dnew < D) {
-            const ba_d4 v = sw_load_tile(A, n, bw, J + dnew, J, lane);
+            const ba_d4 v = sw_load_tile(A, V, J + dnew, J, lane);
             double* sl = slots + 256 * sw_slot(dnew, J);
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) sl[64 * rg + lane] = v[rg];
         }
         if (q == 1 && D >= 8) {                       // next step's owner: its outermost tile (never updated) for the dump
-            const ba_d4 v = sw_load_tile(A, n, bw, J + D, J, lane);
+            const ba_d4 v = sw_load_tile(A, V, J + D, J, lane);
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) lastb[256 * (J & 1) + 64 * rg + lane] = v[rg];
         }
@@ -947,7 +988,7 @@ __global__ __launch_bounds__(SW_NT) void k_ba_chol_sw(double* __restrict__ A, co
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {                            // final L of the diagonal tile to global
             const int r = r0 + 4 * rg, grow = 16 * Jc + r;
-            if (col <= r && grow < n) A[(size_t)grow * LD + (col - r + bw)] = T[0][rg];
+            if (col <= r && V.stored(grow, 16 * Jc + col)) A[V.idx(grow, 16 * Jc + col)] = T[0][rg];
         }
         { const long long a1 = wall_clock64(); if (lane == 0) dbgl[0] += a1 - a0; a0 = a1; }
         // share the column: the diagonal tile (lower triangle) goes to Lc, the register tiles below it to rdump; the LDS tiles
@@ -973,7 +1014,7 @@ __global__ __launch_bounds__(SW_NT) void k_ba_chol_sw(double* __restrict__ A, co
         }
         if (lane < 16) {
             invd[lane] = myinv; ybuf[lane] = yl; xr[(16 * Jc + lane) % 288] = yl;
-            if (16 * Jc + lane < n) x[16 * Jc + lane] = yl;
+            if (V.vec_ok(16 * Jc + lane)) x[V.vec(16 * Jc + lane)] = yl;
         }
         if (bad && lane == 0) s_fail = 1;
         { const long long a1 = wall_clock64(); if (lane == 0) dbgl[2] += a1 - a0; }
@@ -1011,13 +1052,13 @@ __global__ __launch_bounds__(SW_NT) void k_ba_chol_sw(double* __restrict__ A, co
     };
 
     long long tA = 0, tB = 0, tC = 0, tBack = 0, t0 = 0;
-    for (int Jc = 0; Jc < NBLK; Jc++) {
+    for (int Jc = 0; Jc < (phase == 2 ? 0 : NFACT); Jc++) {
         const int wo = Jc & 7, so = (Jc >> 3) & 1;
         asm volatile("" : "+v"(lane_v));
         SW_LANE;
         if (tid == 0) t0 = wall_clock64();
         if (wv == ((wo + 2) & 7) && Jc >= 1 && lane < 16) {    // rhs block entering the window (kept off the owner's critical path)
-            const int row = 16 * (Jc + D) + lane; xr[row % 288] = row < n ? bs[row] : 0.0;
+            const int row = 16 * (Jc + D) + lane; xr[row % 288] = V.vec_ok(row) ? bs[V.vec(row)] : 0.0;
         }
         if (!(wv == wo && so == 0)) prefetch(J0, J0 - Jc);
         if (!(wv == wo && so == 1)) prefetch(J1, J1 - Jc);
@@ -1045,7 +1086,7 @@ __global__ __launch_bounds__(SW_NT) void k_ba_chol_sw(double* __restrict__ A, co
             for (int rg = 0; rg < 4; rg++) {
                 const int r = 16 * d + r0 + 4 * rg, grow = 16 * Jc + r, gc = 16 * Jc + col;
                 Lc[r * SW_P + col] = t[rg];
-                if (grow < n && grow - gc <= bw) A[(size_t)grow * LD + (gc - grow + bw)] = t[rg];
+                if (V.stored(grow, gc)) A[V.idx(grow, gc)] = t[rg];
             }
         }
         __syncthreads();
@@ -1062,32 +1103,61 @@ __global__ __launch_bounds__(SW_NT) void k_ba_chol_sw(double* __restrict__ A, co
         __syncthreads();
         if (tid == 0) { const long long t1 = wall_clock64(); tC += t1 - t0; t0 = t1; }
     }
-    if (s_fail) { if (tid == 0) St->chol_ok = 0; for (int i = tid; i < n; i += SW_NT) x[i] = 0; return; }
+    if (s_fail) { if (tid == 0) St->chol_ok = 0; if (side == 0) for (int i = tid; i < n; i += SW_NT) x[i] = 0; return; }
+    SW_LANE;
+    if (phase == 1) {
+        // hand the window (block columns NFACT .. NFACT+15: every tile inside the separator is live when D == 16) and the rhs over
+        auto dump_col = [&](ba_d4 (&T)[8], int J) {
+            if (J < NFACT || J >= NFACT + 16) return;
+            const int qp = J - NFACT;
+#pragma unroll
+            for (int d = 0; d < 16; d++) {
+                if (qp + d > 15) continue;
+                double* w = xch + SW_XCH_TILE(side, qp, d);
+                if (d < 8) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) w[16 * (r0 + 4 * rg) + col] = T[d < 8 ? d : 0][rg];
+                } else {
+                    const double* sl = slots + 256 * sw_slot(d, J);
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) w[16 * (r0 + 4 * rg) + col] = sl[64 * rg + lane];
+                }
+            }
+        };
+        dump_col(T0, J0); dump_col(T1, J1);
+        if (tid < 256) xch[SW_XCH_RHS(side) + tid] = xr[(16 * NFACT + tid) % 288];
+        return;
+    }
 
     // ---- backward substitution L' x = y, block columns in reverse; the next column's tiles are prefetched into registers
     if (tid == 0) t0 = wall_clock64();
-    SW_LANE;
     for (int i = tid; i < 288; i += SW_NT) xr[i] = 0.0;
+    __syncthreads();
+    if (phase == 2 && tid < 256) {                    // the separator's solution sits "below" this side's part
+        const int r = 16 * NFACT + tid;
+        xr[r % 288] = V.vec_ok(r) ? x[V.vec(r)] : 0.0;
+    }
     const int rows = 16 * (D + 1);
     auto gload = [&](int Jb, int e) -> double {
         const int r = e >> 4, k = e & 15, grow = 16 * Jb + r, gc = 16 * Jb + k;
         if (r >= rows) return 0.0;
-        if (grow < n && gc < n) return (gc <= grow && grow - gc <= bw) ? A[(size_t)grow * LD + (gc - grow + bw)] : 0.0;
+        if (gc > grow) return 0.0;
+        if (!V.padding(grow, gc)) return grow - gc <= bw ? A[V.idx(grow, gc)] : 0.0;
         return grow == gc ? 1.0 : 0.0;
     };
     double nxt[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) nxt[i] = gload(NBLK - 1, tid + SW_NT * i);
-    double ynext = (tid < 16 && 16 * (NBLK - 1) + tid < n) ? x[16 * (NBLK - 1) + tid] : 0.0;
+    for (int i = 0; i < 9; i++) nxt[i] = gload(NFACT - 1, tid + SW_NT * i);
+    double ynext = (tid < 16 && V.vec_ok(16 * (NFACT - 1) + tid)) ? x[V.vec(16 * (NFACT - 1) + tid)] : 0.0;
     __syncthreads();
-    for (int Jc = NBLK - 1; Jc >= 0; Jc--) {
+    for (int Jc = NFACT - 1; Jc >= 0; Jc--) {
 #pragma unroll
         for (int i = 0; i < 9; i++) { const int e = tid + SW_NT * i; if (e < rows * 16) Lc[(e >> 4) * SW_P + (e & 15)] = nxt[i]; }
         const double ycur = ynext;
         if (Jc > 0) {
 #pragma unroll
             for (int i = 0; i < 9; i++) nxt[i] = gload(Jc - 1, tid + SW_NT * i);
-            ynext = (tid < 16 && 16 * (Jc - 1) + tid < n) ? x[16 * (Jc - 1) + tid] : 0.0;
+            ynext = (tid < 16 && V.vec_ok(16 * (Jc - 1) + tid)) ? x[V.vec(16 * (Jc - 1) + tid)] : 0.0;
         }
         __syncthreads();
         {
@@ -1109,12 +1179,90 @@ __global__ __launch_bounds__(SW_NT) void k_ba_chol_sw(double* __restrict__ A, co
                 const double xc = d_readlane(yl, c) * d_readlane(myinv, c);
                 if (col == c) yl = xc; else if (col < c) yl -= Lc[c * SW_P + col] * xc;
             }
-            if (lane < 16) { xr[(16 * Jc + lane) % 288] = yl; if (16 * Jc + lane < n) x[16 * Jc + lane] = yl; }
+            if (lane < 16) { xr[(16 * Jc + lane) % 288] = yl; if (V.vec_ok(16 * Jc + lane)) x[V.vec(16 * Jc + lane)] = yl; }
         }
         __syncthreads();
     }
 #undef SW_LANE
-    if (tid == 0) { tBack = wall_clock64() - t0; St->dbg[0] = tA; St->dbg[1] = tB; St->dbg[2] = tC; St->dbg[3] = tBack; St->dbg[4] = dbgl[0]; St->dbg[5] = dbgl[1]; St->dbg[6] = dbgl[2]; }
+    if (tid == 0 && side == 0 && phase != 2) { tBack = wall_clock64() - t0; St->dbg[0] = tA; St->dbg[1] = tB; St->dbg[2] = tC; St->dbg[3] = tBack; St->dbg[4] = dbgl[0]; St->dbg[5] = dbgl[1]; St->dbg[6] = dbgl[2]; }
+}
+
+__global__ __launch_bounds__(SW_NT) void k_ba_chol_sw(double* __restrict__ A, const double* __restrict__ bs, int n, int bw,
+                                                      double* __restrict__ x, ba_state* __restrict__ St, int phase, int nfact0,
+                                                      double* __restrict__ A1, const double* __restrict__ bs1, int n1,
+                                                      double* __restrict__ x1, int nfact1, double* __restrict__ xch)
+{
+    // phase 0: one workgroup, the whole system (A, bs, n, x).  phases 1 / 2 (two-way solve): workgroup 0 works on (A, bs, n, x) and
+    // eliminates / back-substitutes its first nfact0 block columns; workgroup 1 does the same on (A1, bs1, n1, x1), the physically
+    // reversed copy of the other end of the matrix (k_sw_reverse), with nfact1 block columns.
+    extern __shared__ double sm[];
+    if (phase && blockIdx.x == 1) sw_body<0>(sm, A1, bs1, n1, bw, x1, St, phase, nfact1, 1, xch);
+    else sw_body<0>(sm, A, bs, n, bw, x, St, phase, nfact0, 0, xch);
+}
+
+// ---- k_sw_separator: the 256 x 256 separator system of the two-way solve, in the band layout of k_ba_chol (n = 256, bw = 255):
+// S2 = W_top + W_bottom - A22 and b2 likewise.  The bottom window is in reversed coordinates: element (i, j) of the top tile
+// (column q, distance d) is element (15-j, 15-i) of the bottom tile (column 15-q-d, same d).
+__global__ __launch_bounds__(256) void k_sw_separator(const double* __restrict__ A, const double* __restrict__ bs, int bw, int split,
+                                                      const double* __restrict__ xch, double* __restrict__ Ssep, double* __restrict__ bsep)
+{
+    const int r = blockIdx.x, c = threadIdx.x;       // r >= c only
+    if (c == 0) bsep[r] = xch[SW_XCH_RHS(0) + r] + xch[SW_XCH_RHS(1) + 255 - r] - bs[16 * split + r];
+    if (c > r) return;
+    const int q = c >> 4, d = (r >> 4) - q, i = r & 15, j = c & 15;
+    const double wt = xch[SW_XCH_TILE(0, q, d) + 16 * i + j];
+    const double wb = xch[SW_XCH_TILE(1, 15 - q - d, d) + 16 * (15 - j) + (15 - i)];
+    const size_t gr = 16 * (size_t)split + r, gc = 16 * (size_t)split + c;
+    const double a = r - c <= bw ? A[gr * (bw + 1) + (gc - gr + bw)] : 0.0;
+    Ssep[(size_t)r * 256 + (c - r + 255)] = wt + wb - a;
+}
+
+// ---- two-way solve helpers: the far end of the system in reversed order, physically (row r' of the copy = row npad-1-r' of
+// the stored matrix read backwards; rows that map beyond n become identity padding), so that both workgroups run the same code
+__global__ __launch_bounds__(256) void k_sw_reverse(const double* __restrict__ S, const double* __restrict__ bs, int n, int bw, int npad,
+                                                    int n1, double* __restrict__ S1, double* __restrict__ bs1)
+{
+    const int rp = blockIdx.x;                       // row of the reversed copy, < n1
+    const int co = npad - 1 - rp;                    // stored column of all its elements' mirror images
+    for (int k = threadIdx.x; k <= bw; k += 256) {   // element (rp, rp - k)  <-  stored (co + k, co)
+        const int ro = co + k;
+        double v = 0.0;
+        if (rp - k >= 0) v = ro < n ? S[(size_t)ro * (bw + 1) + (bw - k)] : (k == 0 ? 1.0 : 0.0);
+        S1[(size_t)rp * (bw + 1) + (bw - k)] = v;
+    }
+    if (threadIdx.x == 0) bs1[rp] = co < n ? bs[co] : 0.0;
+}
+// mode 0: separator solution x[16 split .. +256) -> x1[n1-256 .. n1) (reversed);  mode 1: x1[0 .. n1-256) -> x (reversed)
+__global__ void k_sw_rev_vec(double* __restrict__ x, double* __restrict__ x1, int n, int npad, int n1, int mode)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (mode == 0) { if (i < 256) x1[n1 - 256 + i] = x[npad - 1 - (n1 - 256 + i)]; }
+    else if (i < n1 - 256 && npad - 1 - i < n) x[npad - 1 - i] = x1[i];
+}
+
+// host: one reduced-camera-system solve with the window kernel; split > 0 selects the two-way schedule (scratch: xch)
+#define SW_SCRATCH_DOUBLES(n, bw) ((size_t)SW_XCH_DOUBLES + 65536 + 256 + ((size_t)(n) / 2 + 512) * ((bw) + 3))
+static int sw_solve(bh_ctx* ctx, hipStream_t st, double* S, const double* bs, int n, int bw, double* x, ba_state* state, int split,
+                    double* xch)
+{
+    const size_t lds = sizeof(double) * SW_LDS_DOUBLES;
+    if (!split) {
+        hipLaunchKernelGGL(k_ba_chol_sw, dim3(1), dim3(SW_NT), lds, st, S, bs, n, bw, x, state, 0, 0, (double*)nullptr, (const double*)nullptr, 0,
+                           (double*)nullptr, 0, xch);
+        return BH_OK;
+    }
+    const int nblk = (n + 15) / 16, npad = 16 * nblk, nb2 = nblk - split - 16, n1 = 16 * (nb2 + 16);
+    double* Ssep = xch + SW_XCH_DOUBLES; double* bsep = Ssep + 65536;
+    double* S1 = bsep + 256; double* bs1 = S1 + (size_t)n1 * (bw + 1); double* x1 = bs1 + n1;
+    hipLaunchKernelGGL(k_sw_reverse, dim3(n1), dim3(256), 0, st, (const double*)S, bs, n, bw, npad, n1, S1, bs1);
+    hipLaunchKernelGGL(k_ba_chol_sw, dim3(2), dim3(SW_NT), lds, st, S, bs, n, bw, x, state, 1, split, S1, (const double*)bs1, n1, x1, nb2, xch);
+    hipLaunchKernelGGL(k_sw_separator, dim3(256), dim3(256), 0, st, (const double*)S, bs, bw, split, (const double*)xch, Ssep, bsep);
+    hipLaunchKernelGGL(k_ba_chol<32>, dim3(1), dim3(1024), sizeof(double) * ((size_t)256 * 33 + 1100), st, Ssep, (const double*)bsep, 256, 255,
+                       x + 16 * (size_t)split, state);
+    hipLaunchKernelGGL(k_sw_rev_vec, dim3(1), dim3(256), 0, st, x, x1, n, npad, n1, 0);
+    hipLaunchKernelGGL(k_ba_chol_sw, dim3(2), dim3(SW_NT), lds, st, S, bs, n, bw, x, state, 2, split, S1, (const double*)bs1, n1, x1, nb2, xch);
+    hipLaunchKernelGGL(k_sw_rev_vec, dim3((n1 + 255) / 256), dim3(256), 0, st, x, x1, n, npad, n1, 1);
+    return BH_OK;
 }
 
 // ---- k_ba_update: trial state = current state (+) step.  blocks [0, pblocks): points (back-substitution); rest: cameras
@@ -1279,7 +1427,7 @@ extern "C" void bh_ba_destroy(bh_ba* ba)
     bh_buf* all[] = { &ba->cams[0], &ba->cams[1], &ba->pts[0], &ba->pts[1], &ba->e_cam, &ba->e_pt, &ba->e_meas, &ba->cslot,
                       &ba->p_start, &ba->p_edges, &ba->c_start, &ba->c_edges, &ba->err[0], &ba->err[1], &ba->chi_e[0],
                       &ba->chi_e[1], &ba->Hpl, &ba->Hll, &ba->bl, &ba->Hpp, &ba->bp, &ba->pdiag, &ba->cdiag, &ba->Dinv,
-                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part };
+                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch };
     for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     delete ba;
 }
@@ -1402,7 +1550,12 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
         ba->chol_window = (fits && n6i >= 256) ? 1 : 0;
         if (ev && !strcmp(ev, "panel")) ba->chol_window = 0;
         if (ev && !strcmp(ev, "window") && fits) ba->chol_window = 1;
+        // two workgroups eliminating from both ends when the band spans exactly 16 tiles and the matrix is long (BH_BA_CHOL_TWOWAY=0 disables)
+        const int nblk = (n6i + 15) / 16;
+        const char* tw = getenv("BH_BA_CHOL_TWOWAY");
+        ba->chol_split = (ba->chol_window && (ba->bw + 15) / 16 == 16 && nblk >= 96 && !(tw && !strcmp(tw, "0"))) ? (nblk - 16) / 2 : 0;
     }
+    BH_TRY(bh_reserve(ctx, &ba->xch, sizeof(double) * SW_SCRATCH_DOUBLES(n6i, ba->bw)));
     if (!ba->chol_window) {   // panel width by LDS budget: min(n, NB+bw) x (NB+1) panel + 1024 partial sums, f64, <= 150 KB
         int nb = 32;
         while (nb >= 8 && sizeof(double) * ((size_t)std::min(n6i, nb + ba->bw) * (nb + 1) + 1100) > 150 * 1024) nb >>= 1;
@@ -1510,9 +1663,7 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                     const int nbsel = ba->chol_nb, bw = ba->bw;
                     const size_t lds = sizeof(double) * ((size_t)std::min(n6, nbsel + bw) * (nbsel + 1) + 1100);
                     bh_time_begin(ctx, BH_K_BA_SOLVE);
-                    if (ba->chol_window)
-                        hipLaunchKernelGGL(k_ba_chol_sw, dim3(1), dim3(SW_NT), sizeof(double) * SW_LDS_DOUBLES, st, S,
-                                           (const double*)bs, n6, bw, dxp, state);
+                    if (ba->chol_window) (void)sw_solve(ctx, st, S, (const double*)bs, n6, bw, dxp, state, ba->chol_split, (double*)ba->xch.p);
                     else if (nbsel == 32) hipLaunchKernelGGL(k_ba_chol<32>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     else if (nbsel == 16) hipLaunchKernelGGL(k_ba_chol<16>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     else hipLaunchKernelGGL(k_ba_chol<8>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
@@ -1563,10 +1714,14 @@ extern "C" int bh_ba_debug_band_solve(bh_ctx* ctx, const double* band, const dou
     BH_HIP(ctx, hipMemcpyAsync(dA, band, nb, hipMemcpyHostToDevice, st));
     BH_HIP(ctx, hipMemcpyAsync(db, rhs, sizeof(double) * n, hipMemcpyHostToDevice, st));
     BH_HIP(ctx, hipMemcpyAsync(dS, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
-    if (mode == 1) {
+    if (mode >= 1) {
         if ((bw + 15) / 16 > 16 || bw < 15) return bh_set_err(ctx, BH_ERR_INVALID, "band solve: the window kernel needs 15 <= bw <= 256");
+        const int nblk = (n + 15) / 16;
+        if (mode == 3 && ((bw + 15) / 16 != 16 || nblk < 40)) return bh_set_err(ctx, BH_ERR_INVALID, "band solve: two-way mode needs a 16-tile band and >= 40 block columns");
+        BH_TRY(bh_reserve(ctx, &ctx->st_c, sizeof(double) * SW_SCRATCH_DOUBLES(n, bw)));
         (void)hipFuncSetAttribute((const void*)k_ba_chol_sw, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        hipLaunchKernelGGL(k_ba_chol_sw, dim3(1), dim3(SW_NT), sizeof(double) * SW_LDS_DOUBLES, st, dA, (const double*)db, n, bw, dx, dS);
+        (void)hipFuncSetAttribute((const void*)k_ba_chol<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        BH_TRY(sw_solve(ctx, st, dA, (const double*)db, n, bw, dx, dS, mode == 3 ? (nblk - 16) / 2 : 0, (double*)ctx->st_c.p));
     } else {
         int nbsel = 32;
         while (nbsel >= 8 && sizeof(double) * ((size_t)std::min(n, nbsel + bw) * (nbsel + 1) + 1100) > 150 * 1024) nbsel >>= 1;

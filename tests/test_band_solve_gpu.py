@@ -44,7 +44,8 @@ def gpu_solve(ctx, low, rhs, bw, mode):
 def test_window_and_panel_kernels_match_scipy(ctx, n, bw):
     low, rhs = band_system(n, bw, seed=n + bw)
     ref = scipy_solve(low, rhs, bw)
-    for mode in (0, 1):
+    modes = [0, 1] + ([3] if (bw + 15) // 16 == 16 and (n + 15) // 16 >= 40 else [])
+    for mode in modes:                                   # panel, window, two-way window
         x, _ = gpu_solve(ctx, low, rhs, bw, mode)
         assert np.abs(x - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), (mode, np.abs(x - ref).max())
 
@@ -56,3 +57,12 @@ def test_not_positive_definite_is_reported(ctx):
         x = np.zeros(600)
         rc = _lib.lib().bh_ba_debug_band_solve(ctx.h, _lib.ptr(low), _lib.ptr(rhs), 600, 40, mode, _lib.ptr(x), None)
         assert rc == -5
+    # two-way mode: a bad pivot in the top part, in the bottom part and inside the separator - every case must return (no
+    # workgroup left waiting for the other) and report the failure
+    n, bw = 1600, 245
+    for bad_row in (100, 1500, 800):
+        low, rhs = band_system(n, bw, seed=2)
+        low[bad_row, bw] = -5.0
+        x = np.zeros(n)
+        rc = _lib.lib().bh_ba_debug_band_solve(ctx.h, _lib.ptr(low), _lib.ptr(rhs), n, bw, 3, _lib.ptr(x), None)
+        assert rc == -5, bad_row
