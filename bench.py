@@ -94,8 +94,19 @@ def main():
     ap.add_argument("--pipelines", type=int, default=0, help="chunk pipelines (streams) inside the library; 0 = library default (4)")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-global-ba", action="store_true", help="skip the configs[4] global BA (landmark-sharded over the ranks)")
+    ap.add_argument("--global-ba-timeout", type=float, default=240.0, help="watchdog for the global BA section, seconds")
     ap.add_argument("--bow", action="store_true", help="also time the config-4 BoW L1 query (adds ~20 s of data generation)")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON result: anything native libraries print there (RCCL / gloo banners) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(obj), flush=True)
 
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,11 +174,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    global_ba = None
-    if not args.no_global_ba:                                 # every rank takes part: the landmarks are sharded over the ranks
-        from boslam_amd import ba_bench
-        global_ba = ba_bench.run_global(ctx, dist=dist, device=dev)
-
+    out = None
     if rank == 0:
         n_kp = fe.n_kp.cpu().numpy(); n_match = fe.n_match.cpu().numpy()
         fps = world * B * args.steps / dt
@@ -226,12 +233,41 @@ def main():
         if not args.no_ba and world == 1:                     # local BA does not shard (replicas only): N=1 figure
             from boslam_amd import ba_bench
             out["local_ba"] = ba_bench.run(ctx, dev)
-        if global_ba is not None:
-            out["global_ba"] = global_ba
         if args.bow:
             from boslam_amd import bow_bench
             out["bow_query"] = bow_bench.run(ctx)
-        print(json.dumps(out), flush=True)
+
+    # configs[4] global BA: every rank takes part (landmarks sharded over the ranks, RCCL all-reduce hook).  It runs after the
+    # headline measurement is complete and under a watchdog: should the multi-GPU collective path stall, rank 0 still prints the
+    # JSON line (with the reason) and every rank leaves, instead of losing the run to a time-out.
+    if not args.no_global_ba:
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["global_ba"] = {"error": f"no result within {args.global_ba_timeout} s (watchdog)"}
+                emit(out)
+            os._exit(0)
+
+        dog = threading.Timer(args.global_ba_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            from boslam_amd import ba_bench
+            res = ba_bench.run_global(ctx, dist=dist, device=dev)
+        except Exception as e:                                  # noqa: BLE001 - reported in the line, the headline stands
+            res = {"error": f"{type(e).__name__}: {e}"}
+            if world > 1:                                       # the other ranks may be inside a collective: do not join them again
+                dog.cancel()
+                if rank == 0:
+                    out["global_ba"] = res
+                    emit(out)
+                os._exit(0)
+        dog.cancel()
+        if rank == 0:
+            out["global_ba"] = res
+    if rank == 0:
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
