@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void k_ba_dinv(const double* __restrict__ Hll,
 #define SCH_LDS 6144
 // ---- k_ba_schur_S: workgroup per camera pair (s1 <= s2): S[s1][s2] = [s1==s2](Hpp + lambda I) - sum_j Hpl_1j Dinv_j Hpl_2j'
 template <int NT, int NLDS>
-__global__ __launch_bounds__(NT) void k_ba_schur_S(const int2* __restrict__ pairs, const int* __restrict__ c_start,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_ba_schur_S(const int2* __restrict__ pairs, const int* __restrict__ c_start,
                                                     const int* __restrict__ c_edges, const int* __restrict__ e_pt,
                                                     const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                                                     const double* __restrict__ Hpp, const ba_state* __restrict__ St,
@@ -587,10 +587,20 @@ __global__ __launch_bounds__(NT) void k_ba_schur_S(const int2* __restrict__ pair
                 for (int bb = 0; bb < 6; bb++) acc[6 * a + bb] += BD[3 * a] * B2[3 * bb] + BD[3 * a + 1] * B2[3 * bb + 1] + BD[3 * a + 2] * B2[3 * bb + 2];
         }
     }
-    d_block_sum<36, NT>(acc, s_red);
+    // wave sums, then thread e < 36 adds the waves' partials of element e in wave order (same order as d_block_sum; reading the
+    // result as acc[tid] would index the accumulator array dynamically and move all 36 accumulators to scratch memory)
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = d_wave_sum(acc[i]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 36; i++) s_red[(tid >> 6) * 36 + i] = acc[i];
+    }
+    __syncthreads();
     if (tid < 36) {
         const int a = tid / 6, bb = tid - a * 6;
-        double v = -acc[tid];
+        double v = 0;
+        for (int w = 0; w < NT / 64; w++) v += s_red[w * 36 + tid];
+        v = -v;
         if (s1 == s2 && add_diag) { v += Hpp[36 * (size_t)s1 + tid]; if (a == bb) v += St->lambda; }
         // lower band storage: element (row, col), row >= col, at Sm[row*LD + (col - row + bw)]; s1 <= s2
         const int row = 6 * s2 + bb, col = 6 * s1 + a;
