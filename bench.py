@@ -10,6 +10,7 @@ The JSON line also carries
   roofline      the dominant kernel's algorithmic bytes / its hipEvent-measured duration vs the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (OpenMP over frames) timed on the host cores on a bounded sample of the same frames
   local_ba      secondary metric of BASELINE.json: LM iterations/s of the local BA on config 3 (N=1)
+  tracking      pose-only BA and solvePnPRansac problems/s at the reference's live problem size (N=1)
   global_ba     configs[4] (5 000 keyframes x 500 k landmarks): LM iterations/s, landmark-sharded over the N ranks with
                 RCCL all-reduce of the reduced camera system (strong scaling; every N)
 """
@@ -233,6 +234,9 @@ def main():
         if not args.no_ba and world == 1:                     # local BA does not shard (replicas only): N=1 figure
             from boslam_amd import ba_bench
             out["local_ba"] = ba_bench.run(ctx, dev)
+        if not args.no_ba and world == 1:                     # tracking stages (pose-only BA, PnP-RANSAC): N=1 figures
+            from boslam_amd import track_bench
+            out["tracking"] = track_bench.run(ctx)
         if args.bow:
             from boslam_amd import bow_bench
             out["bow_query"] = bow_bench.run(ctx)

@@ -16,7 +16,7 @@
 #include <math.h>
 #include <float.h>
 
-#define PNP_T 256
+#define PNP_T 64            // one wave per problem: RANSAC iterations in sequence (as OpenCV runs them), each one wave-parallel
 #define PNP_MAX_HYP 256
 
 struct pnp_K { double fu, fv, uc, vc; };
@@ -25,29 +25,107 @@ struct pnp_K { double fu, fv, uc, vc; };
 template <int N>
 __device__ void pj_eig(const double* Ain, double* d, double* Vt)      // symmetric cyclic Jacobi; eigenvalues descending, vectors in rows
 {
+    // Every index below is a compile-time constant after unrolling, so A and V live in registers.  (With run-time indices the
+    // two arrays sit in scratch memory and one 6x6 decomposition costs thousands of dependent scratch round trips.)
     double A[N * N], V[N * N];
+#pragma unroll
     for (int i = 0; i < N * N; i++) A[i] = Ain[i];
-    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) V[i * N + j] = i == j;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j < N; j++) V[i * N + j] = i == j;
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0;
-        for (int p = 0; p < N; p++) for (int q = p + 1; q < N; q++) off += A[p * N + q] * A[p * N + q];
+#pragma unroll
+        for (int p = 0; p < N; p++)
+#pragma unroll
+            for (int q = p + 1; q < N; q++) off += A[p * N + q] * A[p * N + q];
         if (off < 1e-300) break;
+        bool rot = false;
+#pragma unroll
         for (int p = 0; p < N - 1; p++)
+#pragma unroll
             for (int q = p + 1; q < N; q++) {
                 const double apq = A[p * N + q];
-                if (fabs(apq) < 1e-300) continue;
+                // standard threshold of the cyclic method: a rotation this small cannot change a double any more
+                if (fabs(apq) < 1e-300 || fabs(apq) <= 1e-17 * sqrt(fabs(A[p * N + p] * A[q * N + q]))) continue;
+                rot = true;
                 const double tau = (A[q * N + q] - A[p * N + p]) / (2.0 * apq);
                 const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
                 const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+#pragma unroll
                 for (int k = 0; k < N; k++) { const double akp = A[k * N + p], akq = A[k * N + q]; A[k * N + p] = c * akp - s * akq; A[k * N + q] = s * akp + c * akq; }
+#pragma unroll
                 for (int k = 0; k < N; k++) { const double apk = A[p * N + k], aqk = A[q * N + k]; A[p * N + k] = c * apk - s * aqk; A[q * N + k] = s * apk + c * aqk; }
+#pragma unroll
                 for (int k = 0; k < N; k++) { const double vkp = V[k * N + p], vkq = V[k * N + q]; V[k * N + p] = c * vkp - s * vkq; V[k * N + q] = s * vkp + c * vkq; }
             }
+        if (!rot) break;
+    }
+    // the reference's exchange sort (descending, strict '>'), replayed on (value, column) pairs at compile-time positions
+    double dv[N]; int oi[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { dv[i] = A[i * N + i]; oi[i] = i; }
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = i + 1; j < N; j++) {
+            const bool sw = dv[j] > dv[i];
+            const double tv = dv[i]; const int ti = oi[i];
+            dv[i] = sw ? dv[j] : dv[i]; oi[i] = sw ? oi[j] : oi[i];
+            dv[j] = sw ? tv : dv[j]; oi[j] = sw ? ti : oi[j];
+        }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        d[i] = dv[i];
+#pragma unroll
+        for (int c = 0; c < N; c++)
+            if (oi[i] == c) {
+#pragma unroll
+                for (int k = 0; k < N; k++) Vt[i * N + k] = V[k * N + c];
+            }
+    }
+}
+
+// 12x12 symmetric cyclic Jacobi, the same rotation sequence and per-element arithmetic as pj_eig<12>, executed by one wave with
+// the matrices in LDS: lanes 0..11 rotate the column pair, then the row pair; lanes 16..27 rotate the eigenvector columns.
+// (The per-lane version keeps two 144-element arrays in scratch memory and walks them ~600 rotations x 36 elements long.)
+// Every lane must call it with the same arguments (one-wave workgroup: __syncthreads is a wave barrier).
+__device__ void pj_eig12_wave(double* sA, double* sV, double* sd, double* sVt)
+{
+    constexpr int N = 12;
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < N * N; i += 64) sV[i] = (i / N) == (i % N) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0;
+        for (int p = 0; p < N; p++) for (int q = p + 1; q < N; q++) off += sA[p * N + q] * sA[p * N + q];
+        if (off < 1e-300) break;
+        bool rot = false;
+        for (int p = 0; p < N - 1; p++)
+            for (int q = p + 1; q < N; q++) {
+                const double apq = sA[p * N + q];
+                if (fabs(apq) < 1e-300 || fabs(apq) <= 1e-17 * sqrt(fabs(sA[p * N + p] * sA[q * N + q]))) continue;
+                rot = true;
+                const double tau = (sA[q * N + q] - sA[p * N + p]) / (2.0 * apq);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                __syncthreads();
+                if (lane < N) { const int k = lane; const double akp = sA[k * N + p], akq = sA[k * N + q]; sA[k * N + p] = c * akp - s * akq; sA[k * N + q] = s * akp + c * akq; }
+                else if (lane >= 16 && lane < 16 + N) { const int k = lane - 16; const double vkp = sV[k * N + p], vkq = sV[k * N + q]; sV[k * N + p] = c * vkp - s * vkq; sV[k * N + q] = s * vkp + c * vkq; }
+                __syncthreads();
+                if (lane < N) { const int k = lane; const double apk = sA[p * N + k], aqk = sA[q * N + k]; sA[p * N + k] = c * apk - s * aqk; sA[q * N + k] = s * apk + c * aqk; }
+                __syncthreads();
+            }
+        if (!rot) break;
     }
     int order[N];
     for (int i = 0; i < N; i++) order[i] = i;
-    for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) if (A[order[j] * N + order[j]] > A[order[i] * N + order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
-    for (int i = 0; i < N; i++) { d[i] = A[order[i] * N + order[i]]; for (int k = 0; k < N; k++) Vt[i * N + k] = V[k * N + order[i]]; }
+    for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) if (sA[order[j] * N + order[j]] > sA[order[i] * N + order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    __syncthreads();
+    for (int e = lane; e < N * N; e += 64) { const int i = e / N, k = e % N; sVt[e] = sV[k * N + order[i]]; }
+    if (lane < N) sd[lane] = sA[order[lane] * N + order[lane]];
+    __syncthreads();
 }
 
 template <int N>
@@ -219,7 +297,8 @@ __device__ void p_gauss_newton(const double* L, const double* rho, double* betas
     }
 }
 
-__device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rbest, double* tbest)
+// Called by every lane of the wave with the same arguments (wave-uniform); ws = LDS workspace of 3*144 + 12 doubles
+__device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rbest, double* tbest, double* ws)
 {
     double cws[4][3];
     for (int i = 0; i < 4; i++) cws[i][0] = cws[i][1] = cws[i][2] = 0;
@@ -244,19 +323,27 @@ __device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rb
             a[1 + j] = CCi[3 * j] * (pws[3 * i] - cws[0][0]) + CCi[3 * j + 1] * (pws[3 * i + 1] - cws[0][1]) + CCi[3 * j + 2] * (pws[3 * i + 2] - cws[0][2]);
         a[0] = 1.0 - a[1] - a[2] - a[3];
     }
-    double MtM[144];
-    for (int i = 0; i < 144; i++) MtM[i] = 0;
-    for (int i = 0; i < NS; i++) {
-        double m1[12], m2[12];
-        const double* a = alphas + 4 * i;
-        for (int j = 0; j < 4; j++) {
-            m1[3 * j] = a[j] * K.fu; m1[3 * j + 1] = 0.0;          m1[3 * j + 2] = a[j] * (K.uc - us[2 * i]);
-            m2[3 * j] = 0.0;         m2[3 * j + 1] = a[j] * K.fv;  m2[3 * j + 2] = a[j] * (K.vc - us[2 * i + 1]);
+    // MtM (12x12) straight into LDS: lane e accumulates element e over the 5 points in point order (the per-lane loop's order)
+    double* sA = ws; double* sV = ws + 144; double* ut = ws + 288; double* dm = ws + 432;
+    {
+        double m1[NS][12], m2[NS][12];
+        for (int i = 0; i < NS; i++) {
+            const double* a = alphas + 4 * i;
+            for (int j = 0; j < 4; j++) {
+                m1[i][3 * j] = a[j] * K.fu; m1[i][3 * j + 1] = 0.0;          m1[i][3 * j + 2] = a[j] * (K.uc - us[2 * i]);
+                m2[i][3 * j] = 0.0;         m2[i][3 * j + 1] = a[j] * K.fv;  m2[i][3 * j + 2] = a[j] * (K.vc - us[2 * i + 1]);
+            }
         }
-        for (int p = 0; p < 12; p++) for (int q = 0; q < 12; q++) MtM[12 * p + q] += m1[p] * m1[q] + m2[p] * m2[q];
+        __syncthreads();                              // the previous hypothesis' readers of ws are done
+        for (int e = (int)(threadIdx.x & 63); e < 144; e += 64) {
+            const int pp = e / 12, qq = e % 12;
+            double acc = 0;
+            for (int i = 0; i < NS; i++) acc += m1[i][pp] * m1[i][qq] + m2[i][pp] * m2[i][qq];
+            sA[e] = acc;
+        }
+        __syncthreads();
     }
-    double dm[12], ut[144];
-    pj_eig<12>(MtM, dm, ut);
+    pj_eig12_wave(sA, sV, dm, ut);
     double L[60], rho[6], dv[4][6][3];
     for (int i = 0; i < 4; i++) {
         const double* v = ut + 12 * (11 - i);
@@ -346,12 +433,10 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
                                                       double reproj_error, double confidence, double* __restrict__ rvec,
                                                       double* __restrict__ tvec, int* __restrict__ inliers,
                                                       int* __restrict__ n_inliers, int* __restrict__ ok_out,
-                                                      uint8_t* __restrict__ mask_ws)
+                                                      uint8_t* __restrict__ mask_ws, int lm_max)
 {
     __shared__ int s_idx[PNP_MAX_HYP * 5];
-    __shared__ double s_R[PNP_MAX_HYP * 9];
-    __shared__ double s_t[PNP_MAX_HYP * 3];
-    __shared__ int s_cnt[PNP_MAX_HYP];
+    __shared__ double s_ws[3 * 144 + 12];
     __shared__ double s_red[28 * (PNP_T / 64)];
     __shared__ double s_pose[12], s_try[12];
     __shared__ int s_best, s_flag, s_w[PNP_T / 64];
@@ -377,53 +462,48 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
             }
         }
     }
-    for (int i = tid; i < PNP_MAX_HYP; i += PNP_T) s_cnt[i] = 0;
     __syncthreads();
-    // phase 1: one EPnP per lane
-    for (int h = tid; h < niter0; h += PNP_T) {
-        double so[15], si[10], R[9], t[3];
-        for (int i = 0; i < 5; i++) {
-            const int p = s_idx[5 * h + i];
-            for (int k = 0; k < 3; k++) so[3 * i + k] = (double)(float)obj[3 * p + k];
-            for (int k = 0; k < 2; k++) si[2 * i + k] = (double)(float)img[2 * p + k];
-        }
-        p_epnp5(so, si, K, R, t);
-        for (int k = 0; k < 9; k++) s_R[9 * h + k] = R[k];
-        for (int k = 0; k < 3; k++) s_t[3 * h + k] = t[k];
-    }
-    __syncthreads();
-    // phase 2: score every hypothesis on every point
+    // phases 1-3: the RANSAC iterations in sequence, exactly as the reference runs them (an accepted model shrinks niters, so a
+    // typical tracking problem needs a handful of hypotheses, not all `iterations`); inside an iteration the wave cooperates:
+    // EPnP's 12x12 eigen-decomposition in LDS, the reprojection test one point per lane
     const float thr2 = (float)(reproj_error * reproj_error);
-    if (n > 5) {
-        for (int i = tid; i < n; i += PNP_T) {
-            const double X[3] = { (double)(float)obj[3 * i], (double)(float)obj[3 * i + 1], (double)(float)obj[3 * i + 2] };
-            const float u = (float)img[2 * i], v = (float)img[2 * i + 1];
-            for (int h = 0; h < niter0; h++) {
-                const double* R = s_R + 9 * h; const double* t = s_t + 3 * h;
-                const double x = p_dot(R, X) + t[0], y = p_dot(R + 3, X) + t[1], z = p_dot(R + 6, X) + t[2];
-                const float pu = (float)(K.fu * x / z + K.uc), pv = (float)(K.fv * y / z + K.vc);
-                const float du = u - pu, dv = v - pv;
-                if (du * du + dv * dv <= thr2) atomicAdd(&s_cnt[h], 1);
+    {
+        int best = -1, max_good = 0, niters = niter0;
+        double bR[9], bt[3];
+        for (int it = 0; it < niters; it++) {
+            double so[15], si[10], R[9], t[3];
+            for (int i = 0; i < 5; i++) {
+                const int p = s_idx[5 * it + i];
+                for (int k = 0; k < 3; k++) so[3 * i + k] = (double)(float)obj[3 * p + k];
+                for (int k = 0; k < 2; k++) si[2 * i + k] = (double)(float)img[2 * p + k];
             }
-        }
-    }
-    __syncthreads();
-    // phase 3: replay the sequential acceptance rule
-    if (tid == 0) {
-        int best = -1, max_good = 0;
-        if (n == 5) { best = 0; max_good = 5; }
-        else {
-            int niters = niter0;
-            for (int it = 0; it < niters; it++) {
-                const int good = s_cnt[it];
-                if (good > (max_good > 4 ? max_good : 4)) {
-                    best = it; max_good = good;
-                    niters = p_update_iters(confidence, (double)(n - good) / n, 5, niters);
+            p_epnp5(so, si, K, R, t, s_ws);
+            int good;
+            if (n == 5) good = 5;
+            else {
+                int cnt = 0;
+                for (int i = tid; i < n; i += PNP_T) {
+                    const double X[3] = { (double)(float)obj[3 * i], (double)(float)obj[3 * i + 1], (double)(float)obj[3 * i + 2] };
+                    const float u = (float)img[2 * i], v = (float)img[2 * i + 1];
+                    const double x = p_dot(R, X) + t[0], y = p_dot(R + 3, X) + t[1], z = p_dot(R + 6, X) + t[2];
+                    const float pu = (float)(K.fu * x / z + K.uc), pv = (float)(K.fv * y / z + K.vc);
+                    const float du = u - pu, dv = v - pv;
+                    if (du * du + dv * dv <= thr2) cnt++;
                 }
+                for (int m = 32; m > 0; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
+                good = cnt;
+            }
+            if (n == 5 || good > (max_good > 4 ? max_good : 4)) {
+                best = it; max_good = good;
+                for (int k = 0; k < 9; k++) bR[k] = R[k];
+                for (int k = 0; k < 3; k++) bt[k] = t[k];
+                if (n > 5) niters = p_update_iters(confidence, (double)(n - good) / n, 5, niters);
             }
         }
-        s_best = best;
-        if (best >= 0) { for (int k = 0; k < 9; k++) s_pose[k] = s_R[9 * best + k]; for (int k = 0; k < 3; k++) s_pose[9 + k] = s_t[3 * best + k]; }
+        if (tid == 0) {
+            s_best = best;
+            if (best >= 0) { for (int k = 0; k < 9; k++) s_pose[k] = bR[k]; for (int k = 0; k < 3; k++) s_pose[9 + k] = bt[k]; }
+        }
     }
     __syncthreads();
     const int best = s_best;
@@ -443,7 +523,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
     __syncthreads();
     // phase 4: Levenberg-Marquardt on the inliers
     double lambda = 1e-3;
-    for (int it = 0; it < 60; it++) {
+    for (int it = 0; it < lm_max; it++) {
         double acc[28];
 #pragma unroll
         for (int i = 0; i < 28; i++) acc[i] = 0;
@@ -557,7 +637,7 @@ extern "C" int bh_solve_pnp_ransac(bh_ctx* ctx, const double* obj, const double*
     }
     pnp_K Kd = { K[0], K[1], K[2], K[3] };
     BH_LAUNCH(ctx, BH_K_PNP, k_pnp_ransac, dim3(B), dim3(PNP_T), st, d_obj, d_img, d_n, stride, Kd, iterations, reproj_error,
-              confidence, d_r, d_t, d_in, d_ni, d_ok, (uint8_t*)ctx->st_h.p);
+              confidence, d_r, d_t, d_in, d_ni, d_ok, (uint8_t*)ctx->st_h.p, getenv("BH_PNP_LM") ? atoi(getenv("BH_PNP_LM")) : 60);
     BH_HIP(ctx, hipGetLastError());
     if (mem == BH_MEM_HOST) {
         BH_HIP(ctx, hipMemcpyAsync(rvec, d_r, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));

@@ -35,12 +35,15 @@ static void jacobi_eig(const double* Ain, int n, double* d, double* Vt)
     for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = i == j;
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0;
+        int rot = 0;
         for (int p = 0; p < n; p++) for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
         if (off < 1e-300) break;
         for (int p = 0; p < n - 1; p++)
             for (int q = p + 1; q < n; q++) {
                 double apq = A[p * n + q];
-                if (fabs(apq) < 1e-300) continue;
+                /* standard threshold of the cyclic method: a rotation this small cannot change a double any more */
+                if (fabs(apq) < 1e-300 || fabs(apq) <= 1e-17 * sqrt(fabs(A[p * n + p] * A[q * n + q]))) continue;
+                rot = 1;
                 double tau = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
                 double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
                 double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
@@ -57,6 +60,7 @@ static void jacobi_eig(const double* Ain, int n, double* d, double* Vt)
                     V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
                 }
             }
+        if (!rot) break;
     }
     int order[12];
     for (int i = 0; i < n; i++) order[i] = i;

@@ -146,7 +146,7 @@ ri, rs = oracle.bow_query_l1(db["q_words"], db["q_vals"], db["start"], db["words
 assert np.array_equal(gi, ri) and np.array_equal(gs, rs), (gi, ri)
 td.barrier()
 td.destroy_process_group()
-print("rank", rank, "ok")
+os.write(1, ("rank %d ok\n" % rank).encode())        # one write(): two ranks share the pipe, print() would interleave
 '''
 
 
