@@ -187,3 +187,27 @@ def test_global_ba_scale_properties(ctx):
     assert np.array_equal(t, outs[1][0]) and np.array_equal(pts, outs[1][1])
     assert np.abs(t - pr["tgt"]).mean() < 0.5 * np.abs(pr["t"] - pr["tgt"]).mean()
     assert np.abs(pts - pr["Xgt"]).mean() < np.abs(pr["pts"] - pr["Xgt"]).mean()
+
+
+def test_global_ba_config5_full_size(ctx):
+    """BASELINE configs[4] at its full size (5 000 keyframes, 500 k landmarks, 3.9 M observations): too big for the dense oracle;
+    the two solve schedules (one workgroup / two-way elimination from both ends) must agree, chi2 must fall monotonically with
+    every step accepted, and the estimate must move towards the ground truth."""
+    import os
+    pr = synth.ba_problem_sequence()
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["BH_BA_CHOL_TWOWAY"] = mode
+        try:
+            s = ba.LocalBA(ctx, pr["K"])
+            s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+            done = s.optimize(4)
+            res[mode] = (s.poses()[1].copy(), s.points().copy(), s.log()[:done].copy())
+            s.close()
+        finally:
+            os.environ.pop("BH_BA_CHOL_TWOWAY", None)
+    t, pts, lg = res["1"]
+    assert len(lg) == 4 and (lg[:, 3] == 1).all() and np.all(np.diff(lg[:, 0]) < 0)
+    assert np.array_equal(lg[:, 2:], res["0"][2][:, 2:]) and np.allclose(lg[:, 0], res["0"][2][:, 0], rtol=1e-10)
+    assert np.abs(t - res["0"][0]).max() < 1e-8 and np.abs(pts - res["0"][1]).max() < 1e-8
+    assert np.abs(t - pr["tgt"]).mean() < 0.2 * np.abs(pr["t"] - pr["tgt"]).mean()

@@ -115,3 +115,46 @@ def test_medoid_descriptor_matches_oracle_and_numpy(ctx):
                 for b in range(a + 1, k[m]):
                     d[a, b] = d[b, a] = np.unpackbits(desc[m, a] ^ desc[m, b]).sum() & 255
             assert got[m] == int(np.argmin(np.median(d, axis=0)))
+
+
+def test_config2_full_size_batch(ctx):
+    """BASELINE configs[1] at its full size: one 1000-frame batch through both entry modes.  40 distinct rendered frames are tiled
+    to 1000 (shuffled); the oracle pins the 40, and size-independent properties pin the rest: a frame's result does not depend on
+    where it sits in the batch (chunks of 128 / 256 frames, up to four stream pipelines), the HBM-resident path (BH_MEM_DEVICE)
+    equals the host path bit for bit, and a frame matched against itself is the identity with distance 0."""
+    import torch
+    nd, B = 40, 1000
+    bgr, depth = synth.render_batch(nd)
+    rng = np.random.default_rng(7)
+    pick = np.concatenate([np.arange(nd), rng.integers(0, nd, B - nd)])
+    rng.shuffle(pick)
+    params = frontend.make_params(nfeatures=1000)
+    big_bgr = bgr[pick]; big_depth = depth[pick]
+    kps, desc, n = frontend.orb_detect_describe(ctx, big_bgr, depth=big_depth, params=params)
+    P = oracle.orb_params(nfeatures=1000)
+    first = {}
+    for i, f in enumerate(pick):
+        if f not in first:
+            first[f] = i
+            okp, odesc, rc = oracle.orb_detect_describe(bgr[f], (depth[f] > 0).astype(np.uint8) * 255, P)
+            assert rc == 0 and n[i] == len(okp) and np.array_equal(desc[i, :n[i]], odesc)
+            for fld in ("x", "y", "angle", "response", "size", "octave"):
+                assert np.array_equal(kps[fld][i, :n[i]].view(np.uint32), okp[fld].view(np.uint32)), fld
+        else:
+            j = first[f]
+            assert n[i] == n[j] and np.array_equal(desc[i], desc[j]) and np.array_equal(kps[i].tobytes(), kps[j].tobytes())
+    # HBM-resident path, consecutive-frame matching included
+    fe = frontend.DeviceFrontEnd(ctx, B, 480, 640, params)
+    fe.run(torch.from_numpy(big_bgr).cuda(), torch.from_numpy(big_depth.view(np.int16)).cuda())
+    torch.cuda.synchronize(); ctx.synchronize(); ctx.status()
+    assert np.array_equal(fe.n_kp.cpu().numpy(), n) and np.array_equal(fe.desc.cpu().numpy(), desc)
+    nm = fe.n_match.cpu().numpy(); qi = fe.qidx.cpu().numpy(); ti = fe.tidx.cpu().numpy(); dd = fe.dist.cpu().numpy()
+    same = np.nonzero(pick[1:] == pick[:-1])[0] + 1                       # a frame followed by its own copy
+    assert len(same) > 5
+    for i in same:
+        # every match of a frame against itself has distance 0 and pairs identical descriptors (duplicates may swap partners)
+        assert nm[i] > 0 and (dd[i, :nm[i]] == 0).all()
+        assert np.array_equal(desc[i][qi[i, :nm[i]]], desc[i - 1][ti[i, :nm[i]]])
+    for i in (1, 500, 999):                                               # and the matcher against the oracle on a few pairs
+        oq, ot, od = oracle.match_crosscheck(desc[i, :n[i]], desc[i - 1, :n[i - 1]])
+        assert np.array_equal(qi[i, :nm[i]], oq) and np.array_equal(ti[i, :nm[i]], ot) and np.array_equal(dd[i, :nm[i]], od)
