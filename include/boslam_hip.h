@@ -177,6 +177,24 @@ int  bh_ba_set_allreduce(bh_ba* ba, bh_allreduce_fn fn, void* user, int rank, in
 /* wall time spent inside fn and bytes handed to it since the last bh_ba_optimize began */
 int  bh_ba_get_comm(bh_ba* ba, double* ms, long long* bytes);
 
+/* ---- local-BA window and problem construction ----------------------------------------------
+ * Replaces CovisibilityGraph.get_local_map(kf, flag_inner_outer=True, flag_with_input_kf=False) — slam/covisibility_graph.py:51-78
+ * — and the graph walk of optimize_local — :188-218 — up to the add_pose / add_point / add_edge calls.
+ *   covisibility graph, CSR over K keyframes: nbr_start i32[K+1], nbr_id i32[], nbr_common i32[] (kf2kf_num_common_mps of the
+ *     pair; a pair that is not listed counts 0, as the reference's defaultdict does)
+ *   observations, CSR over keyframes: obs_start i32[K+1], obs_mp i32[] (map point id < n_mp), obs_px i64[][2] (kf.mp2kp[mp])
+ *   kf: the keyframe being optimised; min_common: 15 in the reference (:65,69)
+ * Outputs (the reference walks Python sets; here every set is enumerated in ascending id):
+ *   win_kf i32[cap_kf] = [kf] + inner + (outer minus inner), win_fixed u8[cap_kf] (outer empty: kf fixed, :195; else outer fixed,
+ *     :197-199), pt_mp i32[cap_pt] = map points seen by more than one window keyframe in order of first appearance along that
+ *     chain (:205-215), edges (index into win_kf, index into pt_mp, pixel) in chain order (:216)
+ *   counts i32[5] = {n_window, n_inner, n_outer, n_points, n_edges}; n_window == 0 is the reference's "nothing to optimize".
+ * Host arrays only (the graph lives in Python objects in the reference); BH_ERR_CAPACITY if an output is too small. */
+int bh_ba_window_problem(bh_ctx* ctx, int K, const int* nbr_start, const int* nbr_id, const int* nbr_common,
+                         const int* obs_start, const int* obs_mp, const long long* obs_px, int n_mp, int kf, int min_common,
+                         int cap_kf, int* win_kf, uint8_t* win_fixed, int cap_pt, int* pt_mp, int cap_e, int* edge_pose,
+                         int* edge_point, long long* edge_px, int* counts);
+
 /* ---- PnP + RANSAC, Rodrigues -----------------------------------------------------------------------------------------
  * Replaces cv2.solvePnPRansac(obj, img, K, distCoeffs=0, flags=cv2.SOLVEPNP_ITERATIVE) and cv2.Rodrigues(v)[0] —
  * experiments/pnp_two_way_tracking.py:57-61,68-69 (slam/tracking.py:68-71 is dead code) — for B problems.

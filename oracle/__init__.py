@@ -293,3 +293,41 @@ def voc_transform(voc, desc):
 def medoid_index(desc):
     desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
     return int(lib().orc_medoid_index(_p(desc), len(desc)))
+
+
+def window_problem(nbr_start, nbr_id, nbr_common, obs_start, obs_mp, obs_px, kf, min_common=15):
+    """Pure-Python restatement of slam/covisibility_graph.py:51-78 (get_local_map, flag_inner_outer=True, flag_with_input_kf=False)
+    and :188-218 (the walk of optimize_local up to the add_* calls), with every Python set enumerated in ascending id.
+    TEST INFRASTRUCTURE.  PARITY UNPINNED (the reference holds no fixture for it; this follows its source line by line)."""
+    from collections import Counter
+    nbrs = lambda k: [(int(nbr_id[e]), int(nbr_common[e])) for e in range(nbr_start[k], nbr_start[k + 1])]
+    common_with_kf = {i: c for i, c in nbrs(kf)}                                     # kf2kf_num_common_mps[(i, kf)], defaultdict -> 0
+    inner, outer = {kf}, set()
+    for kf1, c1 in nbrs(kf):                                                          # :64
+        if c1 >= min_common:                                                          # :65
+            inner.add(kf1)
+            for kf2, _ in nbrs(kf1):                                                  # :67
+                if kf2 != kf and common_with_kf.get(kf2, 0) >= min_common:            # :68-69
+                    outer.add(kf2)
+    inner.remove(kf)                                                                  # :72-73
+    outer = outer - inner                                                             # :76
+    inner, outer = sorted(inner), sorted(outer)
+    if not outer and not inner:                                                       # :191-194
+        return dict(win_kf=np.zeros(0, np.int32), win_fixed=np.zeros(0, bool), n_inner=0, n_outer=0, pt_mp=np.zeros(0, np.int32),
+                    edge_pose=np.zeros(0, np.int32), edge_point=np.zeros(0, np.int32), edge_px=np.zeros((0, 2), np.int64))
+    chain = [kf] + inner + outer                                                      # :203
+    fixed = [len(outer) == 0] + [False] * len(inner) + [True] * len(outer)            # :195-201
+    counter = Counter(); pairs = []
+    for w, i in enumerate(chain):                                                     # :205-208
+        mps = [int(m) for m in obs_mp[obs_start[i]:obs_start[i + 1]]]
+        counter.update(mps)
+        pairs.extend((w, m, obs_start[i] + j) for j, m in enumerate(mps))
+    slot, pt_mp, e_pose, e_pt, e_px = {}, [], [], [], []
+    for w, m, src in pairs:                                                           # :211-216
+        if counter[m] > 1:
+            if m not in slot:
+                slot[m] = len(pt_mp); pt_mp.append(m)
+            e_pose.append(w); e_pt.append(slot[m]); e_px.append(obs_px[src])
+    return dict(win_kf=np.array(chain, np.int32), win_fixed=np.array(fixed, bool), n_inner=len(inner), n_outer=len(outer),
+                pt_mp=np.array(pt_mp, np.int32), edge_pose=np.array(e_pose, np.int32), edge_point=np.array(e_pt, np.int32),
+                edge_px=np.array(e_px, np.int64).reshape(-1, 2))
