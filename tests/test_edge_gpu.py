@@ -120,3 +120,51 @@ def test_ba_degenerate_inputs(ctx):
     class Cam: fx, fy, cx, cy, baseline = synth.FX, synth.FY, synth.CX, synth.CY, synth.BASELINE
     r = optimizer.CamOnlyBA(np.zeros((0, 2)), np.zeros((0, 3)), Cam, ctx=ctx)
     assert r[0] in (True, False)
+
+
+def test_new_entry_points_reject_bad_arguments(ctx):
+    """Error behaviour of the round-1 additions: every bad call returns a negative code with a message, nothing crashes."""
+    import ctypes as C
+    from boslam_amd import _lib, window
+    L = _lib.lib()
+    # window problem: capacity too small -> BH_ERR_CAPACITY with the needed sizes in the message
+    nbr_start = np.array([0, 1, 2], np.int32); nbr_id = np.array([1, 0], np.int32); nbr_common = np.array([20, 20], np.int32)
+    obs_start = np.array([0, 2, 4], np.int32); obs_mp = np.array([0, 1, 1, 0], np.int32); obs_px = np.zeros((4, 2), np.int64)
+    win = np.zeros(1, np.int32); fix = np.zeros(1, np.uint8); pt = np.zeros(1, np.int32); ep = np.zeros(1, np.int32); ept = np.zeros(1, np.int32)
+    epx = np.zeros((1, 2), np.int64); cnt = np.zeros(5, np.int32)
+    rc = L.bh_ba_window_problem(ctx.h, 2, _lib.ptr(nbr_start), _lib.ptr(nbr_id), _lib.ptr(nbr_common), _lib.ptr(obs_start), _lib.ptr(obs_mp),
+                                _lib.ptr(obs_px), 2, 0, 15, 1, _lib.ptr(win), _lib.ptr(fix), 1, _lib.ptr(pt), 1, _lib.ptr(ep), _lib.ptr(ept),
+                                _lib.ptr(epx), _lib.ptr(cnt))
+    assert rc == -3 and b"capacity" in L.bh_last_error(ctx.h)
+    assert cnt[0] == 2 and cnt[1] == 1                                    # the needed window size is still reported
+    # ... and with room it is the two keyframes, two shared points, four edges
+    w = window.window_problem(ctx, nbr_start, nbr_id, nbr_common, obs_start, obs_mp, obs_px, n_mp=2, kf=0)
+    assert list(w["win_kf"]) == [0, 1] and list(w["win_fixed"]) == [True, False] and len(w["edge_pose"]) == 4
+    # out-of-range ids
+    bad = obs_mp.copy(); bad[0] = 7
+    rc = L.bh_ba_window_problem(ctx.h, 2, _lib.ptr(nbr_start), _lib.ptr(nbr_id), _lib.ptr(nbr_common), _lib.ptr(obs_start), _lib.ptr(bad),
+                                _lib.ptr(obs_px), 2, 0, 15, 4, _lib.ptr(np.zeros(4, np.int32)), _lib.ptr(np.zeros(4, np.uint8)), 4,
+                                _lib.ptr(np.zeros(4, np.int32)), 4, _lib.ptr(np.zeros(4, np.int32)), _lib.ptr(np.zeros(4, np.int32)),
+                                _lib.ptr(np.zeros((4, 2), np.int64)), _lib.ptr(cnt))
+    assert rc == -1
+    # band solve: window kernel outside its band range, two-way mode on a short matrix
+    low = np.ones((64, 9)); rhs = np.ones(64); x = np.zeros(64)
+    assert L.bh_ba_debug_band_solve(ctx.h, _lib.ptr(low), _lib.ptr(rhs), 64, 8, 1, _lib.ptr(x), None) == -1
+    low = np.ones((600, 246)); rhs = np.ones(600); x = np.zeros(600)
+    assert L.bh_ba_debug_band_solve(ctx.h, _lib.ptr(low), _lib.ptr(rhs), 600, 245, 3, _lib.ptr(x), None) == -1
+    # all-reduce hook registration: bad rank; a sharded problem without edges
+    from boslam_amd import ba, synth
+    s = ba.LocalBA(ctx, np.array([synth.FX, synth.FY, synth.CX, synth.CY, 0.0]))
+    cb = ba._AR_FN(lambda user, dev, count, op: 0)
+    assert L.bh_ba_set_allreduce(s.h, C.cast(cb, C.c_void_p), None, 3, 2) == -1
+    assert L.bh_ba_set_allreduce(s.h, C.cast(cb, C.c_void_p), None, 0, 2) == 0
+    with pytest.raises(Exception):
+        s.set_problem(np.eye(3)[None], np.zeros((1, 3)), np.zeros(1, np.uint8), np.zeros((0, 3)), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2)))
+    assert L.bh_ba_set_allreduce(s.h, None, None, 0, 1) == 0               # back to the single-GPU behaviour
+    s.close()
+    # bh_ctx_copy round trip
+    a = np.arange(100, dtype=np.float64); b = np.zeros(100)
+    import torch
+    d = torch.zeros(100, dtype=torch.float64, device="cuda")
+    assert L.bh_ctx_copy(ctx.h, C.c_void_p(d.data_ptr()), _lib.ptr(a), 800, 1) == 0
+    assert L.bh_ctx_copy(ctx.h, _lib.ptr(b), C.c_void_p(d.data_ptr()), 800, 0) == 0 and np.array_equal(a, b)
