@@ -32,6 +32,19 @@ def run(ctx, dev=None, repeats=5):
            "final_robust_chi2": float(lg[-1, 0]), "trials": int(lg[:, 2].sum()),
            "kernel_ms_per_iter": {k: round(v[0] / iters, 4) for k, v in sorted(kt.items()) if k.startswith("k_ba")},
            "pose_err_before_m": float(np.abs(pr["t"] - pr["tgt"]).max()), "pose_err_after_m": float(np.abs(t - pr["tgt"]).max())}
+    # matrix-core roofline of the dense reduced-camera solve (panel kernel, NB = 32): per panel the trailing update issues
+    # nt(nt+1)/2 tiles x 8 v_mfma_f64_16x16x4 (nt = rows below the panel / 16); one workgroup = one CU by design
+    n6 = 6 * int((1 - pr["fixed"]).sum())
+    flops = 0
+    for j0 in range(0, n6, 32):
+        nt = (max(n6 - j0 - 32, 0) + 15) // 16
+        flops += nt * (nt + 1) // 2 * 8 * 2048
+    ms = out["kernel_ms_per_iter"].get("k_ba_solve", 0.0)
+    if ms > 0:
+        out["solve_roofline"] = {"bound": "mfma", "kernel": "k_ba_chol<32>", "achieved": round(flops / (ms * 1e-3) / 1e12, 6), "unit": "TFLOP/s",
+                                 "peak": 78.6, "frac": round(flops / (ms * 1e-3) / 78.6e12, 7), "cus_used": 1,
+                                 "frac_of_cus_used": round(flops / (ms * 1e-3) / (78.6e12 / 256), 4), "mfma_flops_per_solve": int(flops),
+                                 "note": "a %d x %d dense system: 9 dependent panels on one CU, latency-bound; the iteration as a whole is launch/latency-bound (2.4 MB of algorithmic traffic)" % (n6, n6)}
     s.close()
     return out
 
