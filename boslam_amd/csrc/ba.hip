@@ -138,6 +138,10 @@ __device__ __forceinline__ double d_shfl_idx(double v, int src)
     lo = __shfl(lo, src, 64); hi = __shfl(hi, src, 64);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double d_readlane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double d_wave_sum(double v)
 {
 #pragma unroll
@@ -659,33 +663,35 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
             P[r * PP + c] = (c < nbw && c <= r && c >= r - bw) ? AB(j0 + r, j0 + c) : 0.0;      // in-band lower part only
         }
         __syncthreads();
-        if (wv == 0) {                                // diagonal block in registers: lane l owns row l
-            double row[NB];
+        if (wv == 0) {                                // diagonal block in registers: lane l owns row l; column c is broadcast with
+            double row[NB];                           // v_readlane (no LDS round trip, no fences), sqrt and 1/sqrt by a Goldschmidt chain
 #pragma unroll
-            for (int k = 0; k < NB; k++) row[k] = lane < nbw ? P[lane * PP + k] : 0.0;
-            double* colb = part;                       // exchange buffer (>= 65 doubles), wave-private here
+            for (int k = 0; k < NB; k++) row[k] = lane < nbw ? P[lane * PP + k] : (k == lane ? 1.0 : 0.0);     // padding rows: identity
             bool bad = false;
+            double myinv = 0.0;
 #pragma unroll
             for (int c = 0; c < NB; c++) {
-                if (c < nbw) {
-                    if (lane == c) colb[64] = row[c];
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    const double d = colb[64];
-                    if (!(d > 0) || !isfinite(d)) bad = true;
-                    const double sd = sqrt(d);
-                    const double lc = lane == c ? sd : row[c] / sd;
-                    if (lane >= c) row[c] = lc;
-                    colb[lane] = lc;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                const double dg = d_readlane(row[c], c);
+                bad = bad | (c < nbw && (!(dg > 0) | !(dg < 1.0e300)));
+                const double y0 = __builtin_amdgcn_rsq(dg);
+                double g = dg * y0, h = 0.5 * y0;
+                double rr = __builtin_fma(-g, h, 0.5); g = __builtin_fma(g, rr, g); h = __builtin_fma(h, rr, h);
+                rr = __builtin_fma(-g, h, 0.5); g = __builtin_fma(g, rr, g); h = __builtin_fma(h, rr, h);
+                const double id = h + h;
+                myinv = lane == c ? id : myinv;
+                const double lc = lane == c ? g : row[c] * id;
+                row[c] = lane >= c ? lc : row[c];
 #pragma unroll
-                    for (int c2 = c + 1; c2 < NB; c2++) if (c2 <= lane) row[c2] -= lc * colb[c2];
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                for (int c2 = c + 1; c2 < NB; c2++) {
+                    const double l2 = d_readlane(lc, c2);
+                    row[c2] = lane >= c2 ? __builtin_fma(-lc, l2, row[c2]) : row[c2];
                 }
             }
             if (lane < nbw) {
 #pragma unroll
                 for (int k = 0; k < NB; k++) P[lane * PP + k] = row[k];
             }
+            if (lane < NB) part[128 + lane] = myinv;  // 1 / L[c][c] for the rows below and the forward substitution
             if (bad && lane == 0) s_fail = 1;
         }
         __syncthreads();
@@ -700,7 +706,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
                     double s2 = rw[c];
 #pragma unroll
                     for (int k = 0; k < c; k++) s2 -= rw[k] * P[c * PP + k];
-                    rw[c] = s2 / P[c * PP + c];
+                    rw[c] = s2 * part[128 + c];
                 } else rw[c] = 0.0;
             }
 #pragma unroll
@@ -709,7 +715,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
         if (wv == 0) {                                // forward substitution inside the panel: lane l owns y[j0+l]
             double yl = lane < nbw ? x[j0 + lane] : 0.0;
             for (int c = 0; c < nbw; c++) {
-                const double yc = d_shfl_idx(yl, c) / P[c * PP + c];
+                const double yc = d_shfl_idx(yl, c) * part[128 + c];
                 if (lane == c) yl = yc;
                 else if (lane > c && lane < nbw) yl -= P[lane * PP + c] * yc;
             }
@@ -800,10 +806,6 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
 // its own column on the matrix cores: T(J+d, J) -= L(J+d, Jc) L(J, Jc)' (v_mfma_f64_16x16x4_f64, operands from Lc), while
 // the former owner adopts column Jc+16.  The backward substitution re-reads L column by column.  Fixed summation order.
 #define SW_P 17
-__device__ __forceinline__ double d_readlane(double v, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
 template <int C> __device__ __forceinline__ double d_row_bcast(double v)      // lane (lane & ~15) + C of every 16-lane row
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
