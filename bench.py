@@ -11,6 +11,8 @@ The JSON line also carries
   cpu_baseline  the CPU oracle (OpenMP over frames) timed on the host cores on a bounded sample of the same frames
   local_ba      secondary metric of BASELINE.json: LM iterations/s of the local BA on config 3 (N=1)
   tracking      pose-only BA and solvePnPRansac problems/s at the reference's live problem size (N=1)
+  bow_query     configs[3] (1 query vs 100 k entries x 1000 words): queries/s, entries sharded over the N ranks, per-rank top-k
+                all-gathered and merged (every N)
   global_ba     configs[4] (5 000 keyframes x 500 k landmarks): LM iterations/s, landmark-sharded over the N ranks with
                 RCCL all-reduce of the reduced camera system (strong scaling; every N)
 """
@@ -95,8 +97,8 @@ def main():
     ap.add_argument("--pipelines", type=int, default=0, help="chunk pipelines (streams) inside the library; 0 = library default (4)")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-global-ba", action="store_true", help="skip the configs[4] global BA (landmark-sharded over the ranks)")
-    ap.add_argument("--global-ba-timeout", type=float, default=240.0, help="watchdog for the global BA section, seconds")
-    ap.add_argument("--bow", action="store_true", help="also time the config-4 BoW L1 query (adds ~20 s of data generation)")
+    ap.add_argument("--global-ba-timeout", type=float, default=240.0, help="watchdog for the sharded extras (BoW query, global BA), seconds")
+    ap.add_argument("--no-bow", action="store_true", help="skip the configs[3] BoW L1 query (entries sharded over the ranks)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON result: anything native libraries print there (RCCL / gloo banners) goes to stderr
@@ -237,39 +239,47 @@ def main():
         if not args.no_ba and world == 1:                     # tracking stages (pose-only BA, PnP-RANSAC): N=1 figures
             from boslam_amd import track_bench
             out["tracking"] = track_bench.run(ctx)
-        if args.bow:
-            from boslam_amd import bow_bench
-            out["bow_query"] = bow_bench.run(ctx)
 
-    # configs[4] global BA: every rank takes part (landmarks sharded over the ranks, RCCL all-reduce hook).  It runs after the
-    # headline measurement is complete and under a watchdog: should the multi-GPU collective path stall, rank 0 still prints the
-    # JSON line (with the reason) and every rank leaves, instead of losing the run to a time-out.
+    # Sharded extras, every N: configs[3] BoW query (entries sharded, per-rank top-k all-gathered) and configs[4] global BA (landmarks
+    # sharded, RCCL all-reduce hook).  They run after the headline measurement is complete and under a watchdog: should a multi-GPU
+    # collective path stall or a rank fail, rank 0 still prints the JSON line (with the reason) and every rank leaves, instead of
+    # losing the run to a time-out.
+    extras = [] if args.no_bow else ["bow_query"]
     if not args.no_global_ba:
+        extras.append("global_ba")
+    if extras:
         import threading
+        stage = {"name": extras[0]}
 
         def bail():
             if rank == 0:
-                out["global_ba"] = {"error": f"no result within {args.global_ba_timeout} s (watchdog)"}
+                out[stage["name"]] = {"error": f"no result within {args.global_ba_timeout} s (watchdog)"}
                 emit(out)
             os._exit(0)
 
         dog = threading.Timer(args.global_ba_timeout, bail)
         dog.daemon = True
         dog.start()
-        try:
-            from boslam_amd import ba_bench
-            res = ba_bench.run_global(ctx, dist=dist, device=dev)
-        except Exception as e:                                  # noqa: BLE001 - reported in the line, the headline stands
-            res = {"error": f"{type(e).__name__}: {e}"}
-            if world > 1:                                       # the other ranks may be inside a collective: do not join them again
-                dog.cancel()
-                if rank == 0:
-                    out["global_ba"] = res
-                    emit(out)
-                os._exit(0)
+        for name in extras:
+            stage["name"] = name
+            try:
+                if name == "bow_query":
+                    from boslam_amd import bow_bench
+                    res = bow_bench.run_sharded(ctx, dist=dist, device=dev)
+                else:
+                    from boslam_amd import ba_bench
+                    res = ba_bench.run_global(ctx, dist=dist, device=dev)
+            except Exception as e:                              # noqa: BLE001 - reported in the line, the headline stands
+                res = {"error": f"{type(e).__name__}: {e}"}
+                if world > 1:                                   # the other ranks may be inside a collective: do not join them again
+                    dog.cancel()
+                    if rank == 0:
+                        out[name] = res
+                        emit(out)
+                    os._exit(0)
+            if rank == 0:
+                out[name] = res
         dog.cancel()
-        if rank == 0:
-            out["global_ba"] = res
     if rank == 0:
         emit(out)
     if dist is not None:

@@ -45,6 +45,11 @@ class BowDatabase:
         self.n_entries = len(start) - 1
         self.ctx.check(_lib.lib().bh_bow_set_db(self.h, self.n_entries, _lib.ptr(start), _lib.ptr(words), _lib.ptr(vals), BH_MEM_HOST))
 
+    def set_db_device(self, start, words, vals):
+        """Same, from device tensors (torch used as the allocator only): start i64[E+1], words i32/u32[nnz], vals f64[nnz]."""
+        self.n_entries = int(start.numel()) - 1
+        self.ctx.check(_lib.lib().bh_bow_set_db(self.h, self.n_entries, _lib.ptr(start), _lib.ptr(words), _lib.ptr(vals), _lib.BH_MEM_DEVICE))
+
     def add(self, words, vals):
         """Database.add at the BoW-vector level -> entry id."""
         words = np.ascontiguousarray(words, dtype=np.uint32); vals = np.ascontiguousarray(vals, dtype=np.float64)

@@ -28,3 +28,65 @@ def run(ctx, n_entries=100000, repeats=20):
                          "note": "algorithmic bytes = 12 B per (word, weight) pair (SURVEY 8d); the kernel streams only the 4-B word ids "
                                  "and touches weights on hits"},
             "top1": int(ids[0]), "top1_score": float(sc[0])}
+
+
+def _entry_block(torch, blk, dev, words_per_entry=1000, vocab=10**6, block=1000):
+    """Entries [blk*block, (blk+1)*block) of the benchmark database, generated on the device from a per-block seed (any rank can
+    regenerate any block): `words_per_entry` distinct ascending word ids, weights U(0,1) L1-normalised."""
+    g = torch.Generator(device=dev); g.manual_seed(1100 + blk)
+    w = torch.randint(0, vocab, (block, words_per_entry), generator=g, device=dev, dtype=torch.int64).sort(dim=1).values
+    dup = torch.zeros_like(w); dup[:, 1:] = (w[:, 1:] == w[:, :-1]).to(torch.int64)
+    w = w + dup.cumsum(dim=1)                                      # sorted + #earlier duplicates: strictly ascending, hence distinct
+    v = torch.rand((block, words_per_entry), generator=g, device=dev, dtype=torch.float64)
+    v = v / v.sum(dim=1, keepdim=True)
+    return w, v
+
+
+def run_sharded(ctx, dist=None, device="cuda:0", n_entries=100000, repeats=20, k=10, query_entry=12345):
+    """BASELINE configs[3]: 1 query against 100 k entries x 1000 words, entries sharded over the ranks (contiguous ranges), per-rank
+    top-k all-gathered and merged (bow.sharded_query).  The database is generated on the GPU (per-block seeds)."""
+    import torch
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    block = 1000
+    nblk = n_entries // block
+    b0, b1 = nblk * rank // world, nblk * (rank + 1) // world
+    ws, vs = zip(*[_entry_block(torch, b, device) for b in range(b0, b1)])
+    words = torch.cat(ws).reshape(-1).to(torch.int32).contiguous(); vals = torch.cat(vs).reshape(-1).contiguous()
+    n_loc = (b1 - b0) * block
+    start = (torch.arange(n_loc + 1, dtype=torch.int64, device=device) * 1000).contiguous()
+    torch.cuda.synchronize()
+    d = bow.BowDatabase(ctx)
+    d.set_db_device(start, words, vals)
+    # the query: entry `query_entry` with every fifth word re-drawn (every rank regenerates the same block)
+    qw, qv = _entry_block(torch, query_entry // block, device)
+    qw = qw[query_entry % block].clone(); qv = qv[query_entry % block].clone()
+    g = torch.Generator(device=device); g.manual_seed(7)
+    qw[::5] = torch.randint(0, 10**6, (len(qw[::5]),), generator=g, device=device, dtype=torch.int64)
+    qw, idx = torch.unique(qw, return_inverse=False, sorted=True), None
+    q_words = qw.cpu().numpy().astype(np.uint32)
+    q_vals = np.full(len(q_words), 1.0 / len(q_words))
+    local = lambda: d.query(q_words, q_vals, k)
+    ids, sc = bow.sharded_query(local, b0 * block, k, dist, device)
+    ctx.timing(True)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        ids, sc = bow.sharded_query(local, b0 * block, k, dist, device)
+    if dist is not None:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / repeats
+    kt = ctx.timing_read(); ctx.timing(False)
+    scan_ms = kt["k_bow_scan"][0] / kt["k_bow_scan"][1]
+    alg = n_loc * 1000 * 12.0
+    d.close()
+    return {"metric": "bow_l1_queries_per_sec", "value": round(1.0 / dt, 1), "unit": "queries/s", "n_gpus": world, "scaling": "strong",
+            "workload": f"configs[3]: 1 query ({len(q_words)} words) vs {n_entries} entries x 1000 words, top-{k}; {n_loc} entries per GPU, "
+                        f"per-rank top-{k} all-gathered and merged",
+            "ms_per_query": round(dt * 1e3, 4), "scan_kernel_ms": round(scan_ms, 4),
+            "roofline": {"bound": "hbm", "kernel": "k_bow_scan", "achieved": round(alg / (scan_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                         "unit": "GB/s", "frac": round(alg / (scan_ms * 1e-3) / 1e9 / 8000.0, 4),
+                         "note": "per GPU; algorithmic bytes = 12 B per (word, weight) pair of the shard (SURVEY 8d); the kernel streams only "
+                                 "the 4-B word ids and touches weights on hits"},
+            "top1": int(ids[0]), "top1_score": float(sc[0]), "top1_is_query_entry": bool(int(ids[0]) == query_entry)}
