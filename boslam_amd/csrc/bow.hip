@@ -201,8 +201,44 @@ __global__ __launch_bounds__(BOW_T) void k_bow_scan(const long long* __restrict_
     }
 }
 
-// single workgroup: k rounds of argmin (ties -> smaller id), results best first
-__global__ __launch_bounds__(1024) void k_bow_topk(double* __restrict__ acc, long long n_entries, int k,
+// Stage 1 of the top-k for large databases: workgroup b finds the k best of its slice of TOPK_SLICE accumulators (8 per thread, in
+// registers) and writes them as candidates (value, entry id; value = +inf when the slice runs out).  Ties -> smaller id throughout.
+#define TOPK_SLICE 8192
+#define TOPK_MAXK 64
+__global__ __launch_bounds__(1024) void k_bow_topk_slices(const double* __restrict__ acc, long long n_entries, int k,
+                                                          double* __restrict__ cand_v, long long* __restrict__ cand_i)
+{
+    __shared__ double s_v[16];
+    __shared__ long long s_i[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long base = (long long)blockIdx.x * TOPK_SLICE;
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const long long e = base + tid + 1024 * j; v[j] = e < n_entries ? acc[e] : INFINITY; }
+    for (int r = 0; r < k; r++) {
+        double bv = INFINITY; long long bi = -1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const long long e = base + tid + 1024 * j; if (v[j] < bv) { bv = v[j]; bi = e; } }    // ascending e: first minimum
+        for (int m = 32; m > 0; m >>= 1) {
+            int lo = __double2loint(bv), hi = __double2hiint(bv);
+            const double ov = __hiloint2double(__shfl_xor(hi, m, 64), __shfl_xor(lo, m, 64));
+            const long long oi = ((long long)__shfl_xor((int)(bi >> 32), m, 64) << 32) | (unsigned)__shfl_xor((int)(bi & 0xffffffff), m, 64);
+            if (oi >= 0 && (ov < bv || (ov == bv && (bi < 0 || oi < bi)))) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { s_v[wv] = bv; s_i[wv] = bi; }
+        __syncthreads();
+        bv = INFINITY; bi = -1;
+        for (int w = 0; w < 16; w++) { const double ov = s_v[w]; const long long oi = s_i[w]; if (oi >= 0 && (ov < bv || (ov == bv && (bi < 0 || oi < bi)))) { bv = ov; bi = oi; } }
+        if (tid == 0) { cand_v[(size_t)blockIdx.x * k + r] = bi >= 0 ? bv : INFINITY; cand_i[(size_t)blockIdx.x * k + r] = bi; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (base + tid + 1024 * j == bi) v[j] = INFINITY;          // taken
+    }
+}
+
+// single workgroup: k rounds of argmin (ties -> smaller id), results best first.  cand_i == NULL: over the accumulators themselves
+// (entry id = index); else over stage-1 candidates (entry id = cand_i[index], -1 = empty).
+__global__ __launch_bounds__(1024) void k_bow_topk(double* __restrict__ acc, long long n_entries, int k, const long long* __restrict__ cand_i,
                                                    int* __restrict__ ids, double* __restrict__ scores, int* __restrict__ n_res)
 {
     __shared__ double s_v[16];
@@ -211,7 +247,11 @@ __global__ __launch_bounds__(1024) void k_bow_topk(double* __restrict__ acc, lon
     int found = 0;
     for (int r = 0; r < k; r++) {
         double bv = INFINITY; long long bi = -1;
-        for (long long e = tid; e < n_entries; e += 1024) { const double v = acc[e]; if (v < bv) { bv = v; bi = e; } }
+        for (long long e = tid; e < n_entries; e += 1024) {
+            const double v = acc[e];
+            const long long id = cand_i ? cand_i[e] : e;
+            if (id >= 0 && (v < bv || (v == bv && bi >= 0 && id < bi))) { bv = v; bi = id; }
+        }
         for (int m = 32; m > 0; m >>= 1) {
             int lo = __double2loint(bv), hi = __double2hiint(bv);
             const double ov = __hiloint2double(__shfl_xor(hi, m, 64), __shfl_xor(lo, m, 64));
@@ -224,7 +264,8 @@ __global__ __launch_bounds__(1024) void k_bow_topk(double* __restrict__ acc, lon
         bv = INFINITY; bi = -1;
         for (int w = 0; w < 16; w++) { const double ov = s_v[w]; const long long oi = s_i[w]; if (oi >= 0 && (ov < bv || (ov == bv && (bi < 0 || oi < bi)))) { bv = ov; bi = oi; } }
         if (bi < 0) break;
-        if (tid == 0) { ids[r] = (int)bi; scores[r] = -bv / 2.0; acc[bi] = INFINITY; }
+        if (cand_i) { for (long long e = tid; e < n_entries; e += 1024) if (cand_i[e] == bi) acc[e] = INFINITY; }      // taken
+        if (tid == 0) { ids[r] = (int)bi; scores[r] = -bv / 2.0; if (!cand_i) acc[bi] = INFINITY; }
         found = r + 1;
         __syncthreads();
     }
@@ -327,7 +368,14 @@ extern "C" int bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const doubl
     hipLaunchKernelGGL(k_bow_scan, dim3(grid), dim3(BOW_T), lds, st, (const long long*)bow->pstart.p, (const uint32_t*)bow->words.p,
                        (const double*)bow->vals.p, bow->n_entries, d_qw, d_qv, nq, (double*)bow->acc.p);
     bh_time_end(ctx);
-    hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, st, (double*)bow->acc.p, bow->n_entries, max_results, d_ids, d_sc, d_n);
+    if (bow->n_entries > 4 * TOPK_SLICE && max_results <= TOPK_MAXK) {           // two stages: per-slice candidates, then the merge
+        const int ns = (int)((bow->n_entries + TOPK_SLICE - 1) / TOPK_SLICE);
+        BH_TRY(bh_reserve(ctx, &ctx->st_f, (sizeof(double) + sizeof(long long)) * (size_t)ns * max_results));
+        double* cv = (double*)ctx->st_f.p; long long* ci = (long long*)(cv + (size_t)ns * max_results);
+        hipLaunchKernelGGL(k_bow_topk_slices, dim3(ns), dim3(1024), 0, st, (const double*)bow->acc.p, bow->n_entries, max_results, cv, ci);
+        hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, st, cv, (long long)ns * max_results, max_results, (const long long*)ci, d_ids, d_sc, d_n);
+    } else
+        hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, st, (double*)bow->acc.p, bow->n_entries, max_results, (const long long*)nullptr, d_ids, d_sc, d_n);
     BH_HIP(ctx, hipGetLastError());
     if (mem == BH_MEM_HOST) {
         BH_HIP(ctx, hipMemcpyAsync(scores, d_sc, sizeof(double) * max_results, hipMemcpyDeviceToHost, st));
