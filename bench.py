@@ -209,6 +209,8 @@ def main():
                     "avg_launch_ms": round(dom_ms / dom_n, 4), "alg_bytes_per_launch": int(alg_bytes),
                     "measured_in": f"second timed region of {args.steps} steps with one chunk pipeline ({round(dt_serial / args.steps * 1e3, 3)} "
                                    f"ms/step, {round(fps_serial, 1)} frames/s): with several pipelines in flight a launch shares the chip",
+                    "note": "every front-end kernel except k_gray_mask is VALU-issue- or latency-bound rather than HBM-bound (DESIGN.md section 4, "
+                            "profiles/r01_final_pmc_summary.json); the HBM fraction is what the measurement contract asks for",
                     "path_achieved": round(fps / world * ALG_BYTES_PER_FRAME / 1e9, 2),
                     "path_frac": round(fps / world * ALG_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 5),
                     "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(ktimes.items())}}
