@@ -469,6 +469,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 #define SEL_T    512
 #define SEL_W    8             // waves
 #define CAND_CAP 4096
+#define VL_CAP   768           // recorded non-empty score-map vectors per wave
 
 __device__ __forceinline__ int wave_excl_scan(int v, int lane)
 {
@@ -525,6 +526,7 @@ __global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ py
     __shared__ uint32_t s_hs[256];
     __shared__ int s_wcnt[SEL_W];
     __shared__ int s_thr;
+    __shared__ uint32_t s_vl[SEL_W * VL_CAP];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int level = blockIdx.x;
@@ -544,49 +546,58 @@ __global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ py
     }
     __syncthreads();
     const uint32_t thr = n2 > 0 ? (uint32_t)s_thr : 256u;
-    // (b) pass A: per-wave count of kept candidates over its contiguous slice of the score map
+    // (b) pass A: each wave scans its contiguous slice of the score map ONCE, 8 independent 16-B loads in flight per lane; it counts
+    // the kept candidates and records, in raster order, which 16-B vectors hold any (the map is mostly zeros: a level has a few
+    // hundred non-empty vectors out of up to 19 200)
     const uint4* map = reinterpret_cast<const uint4*>(nms + fb + L.off);
     const int nvec = (L.pitch * L.h) >> 4;
     const int seg = (nvec + SEL_W - 1) / SEL_W;
     const int v0 = wv * seg, v1 = min(v0 + seg, nvec);
-    int cnt = 0;
-    for (int vb = v0; vb < v1; vb += 256) {                   // 4 independent 16-B loads in flight per lane
-        uint4 q[4];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t* vl = s_vl + wv * VL_CAP;
+    int cnt = 0, nl = 0;
+    for (int vb = v0; vb < v1; vb += 512) {
+        uint4 q[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int v = vb + u * 64 + lane; q[u] = v < v1 ? map[v] : make_uint4(0, 0, 0, 0); }
+        for (int u = 0; u < 8; u++) { const int v = vb + u * 64 + lane; q[u] = v < v1 ? map[v] : make_uint4(0, 0, 0, 0); }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (q[u].x | q[u].y | q[u].z | q[u].w)
-                cnt += count_ge(q[u].x, thr) + count_ge(q[u].y, thr) + count_ge(q[u].z, thr) + count_ge(q[u].w, thr);
+        for (int u = 0; u < 8; u++) {
+            int c = 0;
+            if (q[u].x | q[u].y | q[u].z | q[u].w) c = count_ge(q[u].x, thr) + count_ge(q[u].y, thr) + count_ge(q[u].z, thr) + count_ge(q[u].w, thr);
+            const unsigned long long m = __ballot(c != 0);
+            if (m == 0ull) continue;
+            const int pos = nl + __popcll(m & lt_mask);
+            if (c && pos < VL_CAP) vl[pos] = (uint32_t)(vb + u * 64 + lane);
+            nl += __popcll(m);
+            cnt += c;
+        }
     }
     cnt = wave_sum(cnt);
     if (lane == 0) s_wcnt[wv] = cnt;
     __syncthreads();
     int base = 0, total = 0;
     for (int i = 0; i < SEL_W; i++) { const int c = s_wcnt[i]; if (i < wv) base += c; total += c; }
-    // (c) pass B: emit (x,y) in raster order
-    for (int vb4 = v0; vb4 < v1; vb4 += 256) {
-        uint4 q4[4];
+    // (c) pass B: emit (x,y) in raster order - from the recorded vectors, or by a second scan if a wave's record overflowed
+    const bool listed = nl <= VL_CAP;
+    const int nb = listed ? (nl + 63) & ~63 : ((v1 - v0 + 63) & ~63);
+    for (int i = 0; i < nb; i += 64) {
+        int v = -1;
+        if (listed) { if (i + lane < nl) v = (int)vl[i + lane]; }
+        else if (v0 + i + lane < v1) v = v0 + i + lane;
+        const uint4 q = v >= 0 ? map[v] : make_uint4(0, 0, 0, 0);
+        const uint32_t wds[4] = { q.x, q.y, q.z, q.w };
+        int c = 0;
+        if (q.x | q.y | q.z | q.w) c = count_ge(q.x, thr) + count_ge(q.y, thr) + count_ge(q.z, thr) + count_ge(q.w, thr);
+        if (__ballot(c != 0) == 0ull) continue;
+        int pos = base + wave_excl_scan(c, lane);
+        base += wave_sum(c);
+        if (c) {
+            const int byte0 = v << 4;
+            const int y = byte0 / L.pitch, xb = byte0 - y * L.pitch;
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int v = vb4 + u * 64 + lane; q4[u] = v < v1 ? map[v] : make_uint4(0, 0, 0, 0); }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int v = vb4 + u * 64 + lane;
-            const uint4 q = q4[u];
-            const uint32_t wds[4] = { q.x, q.y, q.z, q.w };
-            int c = 0;
-            if (q.x | q.y | q.z | q.w) c = count_ge(q.x, thr) + count_ge(q.y, thr) + count_ge(q.z, thr) + count_ge(q.w, thr);
-            if (__ballot(c != 0) == 0ull) continue;
-            int pos = base + wave_excl_scan(c, lane);
-            base += wave_sum(c);
-            if (c) {
-                const int byte0 = v << 4;
-                const int y = byte0 / L.pitch, xb = byte0 - y * L.pitch;
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const uint32_t sc = (wds[k >> 2] >> (8 * (k & 3))) & 255u;
-                    if (sc >= thr) { if (pos < CAND_CAP) s_xy[pos] = ((uint32_t)y << 16) | (uint32_t)(xb + k); pos++; }
-                }
+            for (int k = 0; k < 16; k++) {
+                const uint32_t sc = (wds[k >> 2] >> (8 * (k & 3))) & 255u;
+                if (sc >= thr) { if (pos < CAND_CAP) s_xy[pos] = ((uint32_t)y << 16) | (uint32_t)(xb + k); pos++; }
             }
         }
     }

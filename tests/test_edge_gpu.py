@@ -168,3 +168,19 @@ def test_new_entry_points_reject_bad_arguments(ctx):
     d = torch.zeros(100, dtype=torch.float64, device="cuda")
     assert L.bh_ctx_copy(ctx.h, C.c_void_p(d.data_ptr()), _lib.ptr(a), 800, 1) == 0
     assert L.bh_ctx_copy(ctx.h, _lib.ptr(b), C.c_void_p(d.data_ptr()), 800, 0) == 0 and np.array_equal(a, b)
+
+
+def test_dense_corner_frame_takes_the_rescan_path(ctx):
+    """White noise: thousands of NMS survivors per level, far more non-empty score-map vectors than k_select records per wave, so the
+    compaction falls back to its second full scan; results must still equal the oracle bit for bit."""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (2, 480, 640), dtype=np.uint8)
+    img[1, :, :320] = 128                                            # half flat, half noise
+    params = frontend.make_params(nfeatures=1000)
+    kps, desc, n = frontend.orb_detect_describe(ctx, img, params=params)
+    P = oracle.orb_params(nfeatures=1000)
+    for f in range(2):
+        okp, odesc, rc = oracle.orb_detect_describe(img[f], None, P)
+        assert rc == 0 and n[f] == len(okp) and np.array_equal(desc[f, :n[f]], odesc)
+        for fld in ("x", "y", "angle", "response", "octave"):
+            assert np.array_equal(kps[fld][f, :n[f]].view(np.uint32), okp[fld].view(np.uint32)), fld
