@@ -175,6 +175,34 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, uin
     unsigned long long MA = 0, MB = 0;
     if (mpyr) { MA = pyr_load8(mpyr + s0); MB = pyr_load8(mpyr + s1); }
     uint32_t o4 = 0, mo4 = 0;
+    if (mpyr) {
+        // image and mask ride in the two 16-bit halves of one register through the horizontal pass: (p0 << 8) + c1*(p1 - p0) stays
+        // below 2^16, so modular 16-bit arithmetic (v_pk_sub/mul/add_u16) is exact; v_perm_b32 builds the (image, mask) byte pairs
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (x + i < D.w) {
+                const uint32_t tx = txs[i];
+                const int sh = ((int)(tx >> 16) - base) << 3;
+                const uint32_t c1 = tx & 0xffffu;
+                const uint32_t pa = (uint32_t)(A >> sh), pb = (uint32_t)(Bv >> sh), ma = (uint32_t)(MA >> sh), mb = (uint32_t)(MB >> sh);
+                const uint32_t P0 = __builtin_amdgcn_perm(ma, pa, 0x0c040c00u), P1 = __builtin_amdgcn_perm(ma, pa, 0x0c050c01u);
+                const uint32_t Q0 = __builtin_amdgcn_perm(mb, pb, 0x0c040c00u), Q1 = __builtin_amdgcn_perm(mb, pb, 0x0c050c01u);
+                const us2 C1 = { (unsigned short)c1, (unsigned short)c1 };
+                const us2 p0v = __builtin_bit_cast(us2, P0), p1v = __builtin_bit_cast(us2, P1), q0v = __builtin_bit_cast(us2, Q0), q1v = __builtin_bit_cast(us2, Q1);
+                const us2 h0v = (us2)(p0v << (us2){ 8, 8 }) + C1 * (p1v - p0v);
+                const us2 h1v = (us2)(q0v << (us2){ 8, 8 }) + C1 * (q1v - q0v);
+                const int h0 = h0v.x, h1 = h1v.x, g0 = h0v.y, g1 = h1v.y;
+                const uint32_t v = (uint32_t)((h0 << 8) + (int)yc1 * (h1 - h0) + 32768) >> 16;
+                const uint32_t w = (uint32_t)((g0 << 8) + (int)yc1 * (g1 - g0) + 32768) >> 16;
+                o4 |= v << (8 * i);
+                mo4 |= (w > 254u ? w : 0u) << (8 * i);                 // THRESH_TOZERO at 254
+            }
+        }
+        *reinterpret_cast<uint32_t*>(pyr + o) = o4;
+        *reinterpret_cast<uint32_t*>(mpyr + o) = mo4;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         if (x + i < D.w) {
