@@ -163,3 +163,22 @@ def test_two_rank_gloo_sharded_matching_equals_single_process(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_committed_bench_line_meets_the_contract():
+    """profiles/r01_final_bench.json is the JSON line bench.py printed on the MI355X; check the measurement contract's fields."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_final_bench.json")))
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
+                 ("cpu_baseline", dict)):
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["dtype"] == "u8" and d["data"] == "synthetic" and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "configs[1]" in d["config"]["workload"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["traffic"] is None or r["traffic"] >= r["alg_bytes_per_launch"]          # PMC traffic cannot be below the compulsory bytes
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "frames/s" and c["value"] > 0 and "sample" in c
+    assert d["parity_sample_ok"] is True
+    assert abs(d["value"] - 1000 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-3
