@@ -3,22 +3,31 @@
 
 A step = one pass of the front-end hot path over one HBM-resident batch: B synthetic 640x480 RGB-D frames ->
 ORB (nfeatures=1000, the reference's other parameters, camera.py:49-56) -> match frame i against frame i-1
-(direction of slam/tracking.py:56).  N>1: one process per GPU, each with its own B frames (frames are independent:
-weak scaling, no data-path collective); rank 0 prints ONE JSON line.
+(direction of slam/tracking.py:56).  N>1: one process per GPU, rank g holds frames [g*B, (g+1)*B) of ONE continuous sequence
+(weak scaling); frames are independent for ORB, and the pair across a shard boundary (query = first frame of rank g, train =
+last frame of rank g-1) is matched by rank g after a point-to-point copy of that one descriptor row (<= 38 KB) from rank g-1:
+N*B - 1 pairs in all, no data-path collective.  Rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N` creates the N ranks itself (N child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+started before this process has touched the GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+the launcher's environment is used as is.  `--gpus` that disagrees with WORLD_SIZE is an error.  Any failure (exception, watchdog,
+parity_sample_ok false) still prints the JSON line, with the reason, and exits non-zero.
 
 The JSON line also carries
-  roofline      the dominant kernel's algorithmic bytes / its hipEvent-measured duration vs the 8 TB/s HBM peak
-  cpu_baseline  the CPU oracle (OpenMP over frames) timed on the host cores on a bounded sample of the same frames
-  local_ba      secondary metric of BASELINE.json: LM iterations/s of the local BA on config 3 (N=1)
-  tracking      pose-only BA and solvePnPRansac problems/s at the reference's live problem size (N=1)
-  bow_query     configs[3] (1 query vs 100 k entries x 1000 words): queries/s, entries sharded over the N ranks, per-rank top-k
-                all-gathered and merged (every N)
-  global_ba     configs[4] (5 000 keyframes x 500 k landmarks): LM iterations/s, landmark-sharded over the N ranks with
-                RCCL all-reduce of the reduced camera system (strong scaling; every N)
+  roofline      dominant kernel: SURVEY 8(d)'s 1 592 000 algorithmic B/frame x frames per launch / its hipEvent-measured duration
+                vs the 8 TB/s HBM peak (`frac`); the same kernel priced on its own compulsory bytes is `kernel_frac`
+  cpu_baseline  the CPU oracle (OpenMP over frames) timed on the host cores on a bounded sample of the same frames; plus a probe
+                for the real reference libraries (cv2 / g2o): timed and diffed when importable, "absent" otherwise
+  inputs        the same step on a low-texture and on a high-corner-density scene (N=1)
+  local_ba      LM iterations/s of the local BA on configs[2] (does not shard: replicas, one per rank, summed)
+  tracking      pose-only BA and solvePnPRansac problems/s at the reference's live problem size (replicas, summed)
+  bow_query     configs[3] (1 query vs 100 k entries x 1000 words): entries sharded over the ranks, per-rank top-k all-gathered
+  global_ba     configs[4] (5 000 keyframes x 500 k landmarks): LM iterations/s, sharded over the ranks, RCCL all-reduce
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,10 +39,76 @@ sys.path.insert(0, ROOT)
 ALG_BYTES_PER_FRAME = 921600 + 614400 + 32 * 1000 + 24 * 1000        # 1 592 000 B/frame at N=1000
 HBM_PEAK_GBS = 8000.0                                                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
+SCENES = {                                                             # zoom (texture px per metre), contrast about 128, noise sigma
+    "default": (370.0, 1.0, 4.0),
+    "low_texture": (370.0, 0.22, 1.5),
+    "high_corner_density": (1500.0, 1.0, 4.0),
+}
 
-def gen_frames_device(torch, B, dev, start=0, chunk=50):
-    """Synthetic frames rendered on the GPU (data generation, not timed): same scene as boslam_amd.synth."""
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (BASELINE config 2: 1000)")
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--cpu-sample", type=int, default=1000, help="frames in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--pipelines", type=int, default=0, help="chunk pipelines (streams) inside the library; 0 = library default")
+    ap.add_argument("--no-ba", action="store_true", help="skip local BA and the tracking stages")
+    ap.add_argument("--no-inputs", action="store_true", help="skip the low-texture / high-corner-density input variants")
+    ap.add_argument("--no-global-ba", action="store_true", help="skip the configs[4] global BA")
+    ap.add_argument("--no-bow", action="store_true", help="skip the configs[3] BoW L1 query")
+    ap.add_argument("--global-ba-timeout", type=float, default=240.0, help="watchdog for the sharded extras (BoW query, global BA), seconds")
+    ap.add_argument("--timeout", type=float, default=1500.0, help="watchdog for the whole run, seconds")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ rank creation (GPU-free parent)
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes.  This parent never imports torch or touches
+    the GPU; rank 0's stdout (the JSON line) is this process's stdout; the exit code is the first non-zero rank code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                c = procs[r].poll()
+                if c is not None:
+                    pending.discard(r)
+                    if c != 0 and rc == 0:
+                        rc = c if c > 0 else 1
+            if rc != 0 and pending:                      # a rank failed: give the others a moment to leave by themselves, then end them
+                t_end = time.time() + 20
+                while time.time() < t_end and any(procs[r].poll() is None for r in pending):
+                    time.sleep(0.2)
+                for r in pending:
+                    if procs[r].poll() is None:
+                        procs[r].kill()
+                break
+            time.sleep(0.1)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ synthetic input (not timed)
+def gen_frames_device(torch, B, dev, start=0, chunk=50, scene="default"):
+    """Synthetic frames rendered on the GPU (data generation, not timed): same scene as boslam_amd.synth for "default"."""
     from boslam_amd import synth
+    ppm, contrast, noise = SCENES[scene]
     tex = torch.from_numpy(synth._texture()).to(dev)
     bgr = torch.empty((B, synth.HEIGHT, synth.WIDTH, 3), dtype=torch.uint8, device=dev)
     depth = torch.empty((B, synth.HEIGHT, synth.WIDTH), dtype=torch.int16, device=dev)
@@ -45,8 +120,9 @@ def gen_frames_device(torch, B, dev, start=0, chunk=50):
     for c0 in range(0, B, chunk):
         n = min(chunk, B - c0)
         k = torch.arange(start + c0, start + c0 + n, dtype=torch.float64, device=dev)
-        sx = (2.0 * (u[None, :] - synth.CX) / synth.FX + 0.002 * k[:, None]) * 370.0 + 640.0      # [n][W]
-        sy = (2.0 * (v[None, :] - synth.CY) / synth.FY + 0.001 * k[:, None]) * 370.0 + 480.0      # [n][H]
+        sx = (2.0 * (u[None, :] - synth.CX) / synth.FX + 0.002 * k[:, None]) * ppm + 640.0      # [n][W]
+        sy = (2.0 * (v[None, :] - synth.CY) / synth.FY + 0.001 * k[:, None]) * ppm + 480.0      # [n][H]
+        sx = sx.remainder(2046.0); sy = sy.remainder(2046.0)                                    # long sequences wrap around the texture
         x0 = sx.floor().clamp(0, 2046).long(); fx = (sx - sx.floor()).float()
         y0 = sy.floor().clamp(0, 2046).long(); fy = (sy - sy.floor()).float()
         yy = y0[:, :, None]; xx = x0[:, None, :]
@@ -54,7 +130,9 @@ def gen_frames_device(torch, B, dev, start=0, chunk=50):
         top = t00 * (1 - fx)[:, None, :] + t01 * fx[:, None, :]
         bot = t10 * (1 - fx)[:, None, :] + t11 * fx[:, None, :]
         img = top * (1 - fy)[:, :, None] + bot * fy[:, :, None]
-        img = img + 4.0 * torch.randn(img.shape, generator=g, device=dev, dtype=torch.float32)
+        if contrast != 1.0:
+            img = 128.0 + (img - 128.0) * contrast
+        img = img + noise * torch.randn(img.shape, generator=g, device=dev, dtype=torch.float32)
         bgr[c0:c0 + n] = (img[..., None] * gains).round().clamp(0, 255).to(torch.uint8)
         d = torch.full((n, synth.HEIGHT, synth.WIDTH), 2000, dtype=torch.int16, device=dev)
         X = torch.arange(synth.WIDTH, device=dev)[None, None, :]; Y = torch.arange(synth.HEIGHT, device=dev)[None, :, None]
@@ -68,9 +146,13 @@ def gen_frames_device(torch, B, dev, start=0, chunk=50):
     return bgr, depth
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline (checker side)
 def cpu_baseline(bgr_host, depth_host, nfeatures, max_kp):
-    """Oracle (OpenMP over frames) on the host cores, bounded sample; returns dict for the JSON line."""
+    """Oracle (OpenMP over frames) on the host cores, bounded sample; returns dict for the JSON line.  Also probes for the real
+    reference libraries: when cv2 / g2o import, the reference's own calls are timed on a slice of the same frames and
+    diffed against the oracle; otherwise the line says they are absent."""
     import oracle
+    from oracle import refprobe
     P = oracle.orb_params(nfeatures=nfeatures)
     cores = min(len(os.sched_getaffinity(0)), 16)      # the box's CPU share for one GPU is 16 cores
     oracle.set_num_threads(cores)
@@ -81,42 +163,52 @@ def cpu_baseline(bgr_host, depth_host, nfeatures, max_kp):
         kps, desc, nk, rc = oracle.orb_batch(bgr_host, depth_host, P, max_kp)
         oracle.match_consecutive(desc, nk, max_kp)
     dt = time.perf_counter() - t0
-    return {"value": n * reps / dt, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": f"{reps} passes over {n} of the benchmark's own frames: ORB(nfeatures={nfeatures}) + {n - 1} consecutive-frame "
-                      f"cross-check matches per pass, CPU oracle (C, -O3, OpenMP over frames), {dt:.1f} s wall"}, (kps, desc, nk)
+    out = {"value": n * reps / dt, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
+           "sample": f"{reps} passes over {n} of the benchmark's own frames: ORB(nfeatures={nfeatures}) + {n - 1} consecutive-frame "
+                     f"cross-check matches per pass, CPU oracle (C, -O3, OpenMP over frames), {dt:.1f} s wall"}
+    try:
+        out["reference_libs"] = refprobe.run(bgr_host[:min(n, 60)], depth_host[:min(n, 60)], nfeatures, kps, desc, nk)
+    except Exception as e:                              # noqa: BLE001 - the probe must never cost the run its headline
+        out["reference_libs"] = {"error": f"{type(e).__name__}: {e}"}
+    return out, (kps, desc, nk)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (BASELINE config 2: 1000)")
-    ap.add_argument("--nfeatures", type=int, default=1000)
-    ap.add_argument("--cpu-sample", type=int, default=1000, help="frames in the cpu_baseline sample (0 = skip)")
-    ap.add_argument("--pipelines", type=int, default=0, help="chunk pipelines (streams) inside the library; 0 = library default (4)")
-    ap.add_argument("--no-ba", action="store_true")
-    ap.add_argument("--no-global-ba", action="store_true", help="skip the configs[4] global BA (landmark-sharded over the ranks)")
-    ap.add_argument("--global-ba-timeout", type=float, default=240.0, help="watchdog for the sharded extras (BoW query, global BA), seconds")
-    ap.add_argument("--no-bow", action="store_true", help="skip the configs[3] BoW L1 query (entries sharded over the ranks)")
-    args = ap.parse_args()
-
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
     # stdout carries exactly ONE line, the JSON result: anything native libraries print there (RCCL / gloo banners) goes to stderr
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    out = {"metric": "rgbd_frames_per_sec_orb_match_640x480", "value": None, "unit": "frames/s", "n_gpus": world}
+    failed = []
 
     def emit(obj):
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(obj), flush=True)
+        os.dup2(2, 1)
+
+    import threading
+    stage = {"name": "front-end headline"}
+
+    def bail():                                          # a stall (hung collective / kernel) must not end as a green run
+        if rank == 0:
+            out.setdefault("errors", []).append(f"{stage['name']}: no result within the watchdog limit")
+            emit(out)
+        os._exit(3)
+
+    whole = threading.Timer(args.timeout, bail)
+    whole.daemon = True
+    whole.start()
 
     import torch
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("BH_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # BH_BENCH_DEVICE: rehearsals of N ranks on one GPU
-    backend = os.environ.get("BH_BENCH_BACKEND", "nccl")                               # "gloo" for such rehearsals (RCCL refuses two ranks per GPU)
+    backend = os.environ.get("BH_BENCH_BACKEND", "nccl")            # "gloo": rehearsal of N ranks on fewer GPUs (RCCL wants one GPU per rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
+    local = int(os.environ.get("BH_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     dist = None
@@ -133,7 +225,7 @@ def main():
     params = frontend.make_params(nfeatures=args.nfeatures)
     B = args.frames
     bgr, depth = gen_frames_device(torch, B, dev, start=rank * B)
-    fe = frontend.DeviceFrontEnd(ctx, B, 480, 640, params, torch_device=dev)
+    fe = frontend.DeviceFrontEnd(ctx, B, 480, 640, params, torch_device=dev, dist=dist, backend=backend)
     torch.cuda.synchronize()
 
     def barrier():
@@ -141,19 +233,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(); ctx.synchronize()
 
+    def sum_over_ranks(v):
+        if dist is None:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        return float(t.item())
+
+    def timed(front, frames_b, frames_d, steps, warm):
+        for _ in range(warm):
+            front.run(frames_b, frames_d)
+        barrier()
+        ctx.status()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            front.run(frames_b, frames_d)
+        barrier()
+        el = time.perf_counter() - t0
+        ctx.status()
+        return el
+
     if args.pipelines > 0:
         os.environ["BH_ORB_PIPELINES"] = str(args.pipelines)
-    for _ in range(args.warmup):
-        fe.run(bgr, depth)
-    barrier()
-    ctx.status()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fe.run(bgr, depth)
-    barrier()
-    dt = time.perf_counter() - t0
-    ctx.status()
+    dt = timed(fe, bgr, depth, args.steps, args.warmup)
     # Roofline pass: the library overlaps several chunk pipelines on separate streams, which makes single-launch durations
     # non-additive (a launch shares the chip with other pipelines' kernels).  Per-kernel durations are therefore taken in a
     # second timed region of the same K steps with ONE pipeline, hipEvents around every launch on the launch stream.
@@ -177,55 +280,58 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    out = None
+    n_kp = fe.n_kp.cpu().numpy(); n_match = fe.n_match.cpu().numpy()
+    pairs_local = B - 1 + (1 if rank > 0 else 0)
+    pairs_total = int(sum_over_ranks(pairs_local if B > 1 or rank > 0 else 0))
     if rank == 0:
-        n_kp = fe.n_kp.cpu().numpy(); n_match = fe.n_match.cpu().numpy()
         fps = world * B * args.steps / dt
         fps_serial = B * args.steps / dt_serial
-        # dominant kernel by summed hipEvent time; its own compulsory traffic per frame (DESIGN.md §kernels)
+        # dominant kernel by summed hipEvent time; its own compulsory traffic per frame (DESIGN.md section 4)
+        nf = args.nfeatures
         per_frame_bytes = {"k_gray_mask": 921600 + 614400 + 2 * 307200, "k_pyr_down": 2 * (926546 + 643332),
-                           "k_fast": 3 * 950532, "k_blur": 2 * 950532, "k_select": 950532 + 56 * args.nfeatures,
-                           "k_describe": 56 * args.nfeatures + 2 * 950532, "k_match": 2 * 32 * args.nfeatures + 12 * args.nfeatures}
+                           "k_fast": 3 * 950532, "k_blur": 2 * 950532, "k_select": 950532 + 56 * nf,
+                           "k_describe": 56 * nf + 2 * 950532, "k_match": 2 * 32 * nf + 12 * nf}
         dom = max(ktimes, key=lambda k: ktimes[k][0])
         dom_ms, dom_n = ktimes[dom]
         launches_per_step = dom_n / args.steps
-        frames_per_launch = B / launches_per_step if dom != "k_pyr_down" else B / (launches_per_step / (params.nlevels - 1))
-        if dom == "k_pyr_down":
-            alg_bytes = per_frame_bytes[dom] * frames_per_launch / (params.nlevels - 1)
-        else:
-            alg_bytes = per_frame_bytes[dom] * frames_per_launch
+        per_level = (params.nlevels - 1) if dom == "k_pyr_down" else 1          # k_pyr_down: one launch per level transition
+        frames_per_launch = B / (launches_per_step / per_level)
         avg_s = dom_ms / dom_n / 1e3
+        alg_bytes = ALG_BYTES_PER_FRAME * frames_per_launch / per_level          # 1 592 000 B per frame
         achieved = alg_bytes / avg_s / 1e9
+        k_bytes = per_frame_bytes.get(dom, ALG_BYTES_PER_FRAME) * frames_per_launch / per_level
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 per_frame = json.load(open(pmc)).get(dom)          # HBM bytes per frame from the PMC passes (tools/pmc_traffic.py)
-                traffic = int(per_frame * frames_per_launch / ((params.nlevels - 1) if dom == "k_pyr_down" else 1)) if per_frame else None
-            except Exception:
+                traffic = int(per_frame * frames_per_launch / per_level) if per_frame else None
+            except Exception:                                       # noqa: BLE001
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "avg_launch_ms": round(dom_ms / dom_n, 4), "alg_bytes_per_launch": int(alg_bytes),
+                    "byte_model": "SURVEY 8(d): 1 592 000 B/frame (BGR + depth in, descriptors + keypoints out) x frames per launch",
+                    "kernel_achieved": round(k_bytes / avg_s / 1e9, 2), "kernel_frac": round(k_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 5),
+                    "kernel_bytes_per_launch": int(k_bytes),
+                    "kernel_byte_model": "the dominant kernel's own compulsory reads + writes per frame (DESIGN.md section 4) x frames per launch",
                     "measured_in": f"second timed region of {args.steps} steps with one chunk pipeline ({round(dt_serial / args.steps * 1e3, 3)} "
                                    f"ms/step, {round(fps_serial, 1)} frames/s): with several pipelines in flight a launch shares the chip",
-                    "note": "every front-end kernel except k_gray_mask is VALU-issue- or latency-bound rather than HBM-bound (DESIGN.md section 4, "
-                            "profiles/r01_final_pmc_summary.json); the HBM fraction is what the measurement contract asks for",
                     "path_achieved": round(fps / world * ALG_BYTES_PER_FRAME / 1e9, 2),
                     "path_frac": round(fps / world * ALG_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 5),
                     "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(ktimes.items())}}
-        out = {"metric": "rgbd_frames_per_sec_orb_match_640x480", "value": round(fps, 1), "unit": "frames/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
-               "data": "synthetic",
-               "config": {"workload": "configs[1]: batched ORB detect+describe + BF-Hamming cross-check match, "
-                                      f"{B} frames 640x480 RGB-D per GPU per step, nfeatures={args.nfeatures}",
-                          "frames_per_gpu": B, "mean_kp_per_frame": float(n_kp.mean()),
-                          "mean_matches_per_pair": float(n_match[1:].mean()) if B > 1 else 0.0,
-                          "pipelines_per_gpu": args.pipelines or 4,
-                          "parallelism": f"frames sharded x{world}, no collective"},
-               "roofline": roofline}
+        out.update({"value": round(fps, 1), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                    "config": {"workload": "configs[1]: batched ORB detect+describe + BF-Hamming cross-check match, "
+                                           f"{B} frames 640x480 RGB-D per GPU per step, nfeatures={args.nfeatures}",
+                               "frames_per_gpu": B, "mean_kp_per_frame": float(n_kp.mean()),
+                               "mean_matches_per_pair": float(n_match[1:].mean()) if B > 1 else 0.0,
+                               "pairs_matched_per_step": pairs_total,
+                               "pipelines_per_gpu": args.pipelines or int(os.environ.get("BH_ORB_PIPELINES", "4")),
+                               "parallelism": f"frames sharded x{world}, one-descriptor-row halo to the next rank, no collective"},
+                    "roofline": roofline})
         if args.cpu_sample > 0 and world == 1:                # cpu_baseline: rank 0 at N=1 only
+            stage["name"] = "cpu_baseline"
             ns = min(args.cpu_sample, B)
             bh = bgr[:ns].cpu().numpy(); dh = depth[:ns].cpu().numpy().view(np.uint16)
             cb, (okps, odesc, onk) = cpu_baseline(bh, dh, args.nfeatures, fe.max_kp)
@@ -235,30 +341,52 @@ def main():
             same = bool(np.array_equal(onk, n_kp[:ns])) and all(
                 np.array_equal(ddesc[f, :onk[f]], odesc[f, :onk[f]]) for f in range(ns))
             out["parity_sample_ok"] = same
-        if not args.no_ba and world == 1:                     # local BA does not shard (replicas only): N=1 figure
-            from boslam_amd import ba_bench
-            out["local_ba"] = ba_bench.run(ctx, dev)
-        if not args.no_ba and world == 1:                     # tracking stages (pose-only BA, PnP-RANSAC): N=1 figures
-            from boslam_amd import track_bench
-            out["tracking"] = track_bench.run(ctx)
+            if not same:
+                failed.append("parity_sample_ok is false: the timed descriptors differ from the oracle's")
 
-    # Sharded extras, every N: configs[3] BoW query (entries sharded, per-rank top-k all-gathered) and configs[4] global BA (landmarks
-    # sharded, RCCL all-reduce hook).  They run after the headline measurement is complete and under a watchdog: should a multi-GPU
-    # collective path stall or a rank fail, rank 0 still prints the JSON line (with the reason) and every rank leaves, instead of
-    # losing the run to a time-out.
+    if not args.no_inputs and world == 1:                     # the data-dependent paths (survivor lists, rescan) on two other scenes
+        stage["name"] = "inputs"
+        res = {}
+        for scene in ("low_texture", "high_corner_density"):
+            nb = min(B, 250)
+            sb, sd = gen_frames_device(torch, nb, dev, scene=scene)
+            f2 = frontend.DeviceFrontEnd(ctx, nb, 480, 640, params, torch_device=dev)
+            el = timed(f2, sb, sd, 5, 1)
+            res[scene] = {"frames_per_s": round(nb * 5 / el, 1), "frames": nb, "mean_kp_per_frame": float(f2.n_kp.float().mean().item()),
+                          "mean_matches_per_pair": float(f2.n_match[1:].float().mean().item())}
+            del f2, sb, sd
+        out["inputs"] = res
+
+    if not args.no_ba:                                        # local BA / tracking do not shard: one replica per rank, values summed
+        from boslam_amd import ba_bench, track_bench
+        for name, fn in (("local_ba", lambda: ba_bench.run(ctx, dev)), ("tracking", lambda: track_bench.run(ctx))):
+            stage["name"] = name
+            try:
+                res = fn()
+            except Exception as e:                              # noqa: BLE001
+                res = {"error": f"{type(e).__name__}: {e}"}
+            if "error" in res:
+                failed.append(f"{name}: {res['error']}")
+                if world > 1:                                   # the other ranks are on their way into a collective: leave now
+                    if rank == 0:
+                        out[name] = res; out["errors"] = failed; emit(out)
+                    os._exit(3)
+            elif name == "local_ba":
+                res["replicas"] = world
+                res["value_all_replicas"] = round(sum_over_ranks(res["value"]), 1)
+            else:
+                res["replicas"] = world
+                for k in ("pose_only_ba", "pnp_ransac"):
+                    res[k]["problems_per_s_all_replicas"] = round(sum_over_ranks(res[k]["problems_per_s"]), 1)
+            if rank == 0:
+                out[name] = res
+
+    # Sharded extras, every N: configs[3] BoW query (entries sharded, per-rank top-k all-gathered) and configs[4] global BA.
+    # They run after the headline measurement is complete and under their own watchdog.
     extras = [] if args.no_bow else ["bow_query"]
     if not args.no_global_ba:
         extras.append("global_ba")
     if extras:
-        import threading
-        stage = {"name": extras[0]}
-
-        def bail():
-            if rank == 0:
-                out[stage["name"]] = {"error": f"no result within {args.global_ba_timeout} s (watchdog)"}
-                emit(out)
-            os._exit(0)
-
         dog = threading.Timer(args.global_ba_timeout, bail)
         dog.daemon = True
         dog.start()
@@ -271,23 +399,38 @@ def main():
                 else:
                     from boslam_amd import ba_bench
                     res = ba_bench.run_global(ctx, dist=dist, device=dev)
-            except Exception as e:                              # noqa: BLE001 - reported in the line, the headline stands
+            except Exception as e:                              # noqa: BLE001 - reported in the line and in the exit code
                 res = {"error": f"{type(e).__name__}: {e}"}
+                failed.append(f"{name}: {res['error']}")
                 if world > 1:                                   # the other ranks may be inside a collective: do not join them again
                     dog.cancel()
                     if rank == 0:
-                        out[name] = res
-                        emit(out)
-                    os._exit(0)
+                        out[name] = res; out["errors"] = failed; emit(out)
+                    os._exit(3)
             if rank == 0:
                 out[name] = res
         dog.cancel()
+    whole.cancel()
     if rank == 0:
+        if failed:
+            out["errors"] = failed
         emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    return 1 if failed else 0
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}; launch one rank per GPU or drop the launcher\n")
+        sys.exit(2)
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -59,6 +59,8 @@ _SIGS = {
     "bh_ba_get_comm": (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_longlong)]),
     "bh_solve_pnp_ransac": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i]),
     "bh_rodrigues": (_i, [_vp, _i, _vp]),
+    "bh_debug_pnp_trace": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bh_debug_f64_ops": (_i, [_vp, _vp, _vp, _i, _vp]),
     "bh_visibility_gate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _d, _d, _d, _i, _i, _d, _vp, _vp, _i]),
     "bh_bow_create": (_i, [_vp, C.POINTER(_vp)]),
     "bh_bow_destroy": (None, [_vp]),
@@ -76,7 +78,7 @@ MISSING = []
 
 
 def exported_symbols():
-    """Names include/boslam_hip.h declares (kept in sync by tests/test_abi.py)."""
+    """Names include/boslam_hip.h declares (kept in sync by tests/test_host_cpu.py)."""
     return sorted(_SIGS)
 
 
@@ -111,7 +113,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name, None)
-            if fn is None:                     # tests/test_abi.py asserts this never happens
+            if fn is None:                     # tests/test_host_cpu.py asserts this never happens
                 MISSING.append(name)
                 continue
             fn.restype, fn.argtypes = res, args

@@ -15,9 +15,12 @@
 #include "bh_internal.h"
 #include <math.h>
 #include <float.h>
+#include "detmath.h"
 
 #define PNP_T 64            // one wave per problem: RANSAC iterations in sequence (as OpenCV runs them), each one wave-parallel
 #define PNP_MAX_HYP 256
+#define PNP_TRACE_HYP 32       // test hook: hypotheses traced per problem
+#define PNP_TRACE_STRIDE 512   // doubles per traced hypothesis
 
 struct pnp_K { double fu, fv, uc, vc; };
 
@@ -231,6 +234,43 @@ __host__ __device__ void p_rodrigues_m2v(const double* R, double* r)
     r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
 }
 
+
+// The same two conversions for the device code of solvePnPRansac, with detmath.h's sin/cos/acos: the CPU restatement uses the same
+// statements, so the refinement and the final rvec agree with it bit for bit (bh_rodrigues above stays on libm, like cv2.Rodrigues).
+__device__ void pd_rodrigues_v2m(const double* r, double* R)
+{
+    const double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (th < DBL_EPSILON) { for (int i = 0; i < 9; i++) R[i] = (i % 4) == 0; return; }
+    double c, s; dm_sincos(th, &s, &c);
+    const double c1 = 1.0 - c, it = 1.0 / th;
+    const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
+    R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
+    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
+    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+}
+
+__device__ void pd_rodrigues_m2v(const double* R, double* r)
+{
+    const double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    const double th = dm_acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
+        double t;
+        t = (R[0] + 1) * 0.5; r[0] = sqrt(t > 0 ? t : 0);
+        t = (R[4] + 1) * 0.5; r[1] = sqrt(t > 0 ? t : 0) * (R[1] < 0 ? -1. : 1.);
+        t = (R[8] + 1) * 0.5; r[2] = sqrt(t > 0 ? t : 0) * (R[2] < 0 ? -1. : 1.);
+        if (fabs(r[0]) < fabs(r[1]) && fabs(r[0]) < fabs(r[2]) && (R[5] > 0) != (r[1] * r[2] > 0)) r[2] = -r[2];
+        const double nr = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        const double k = th / nr; r[0] *= k; r[1] *= k; r[2] *= k;
+        return;
+    }
+    const double vth = 1.0 / (2 * s) * th;
+    r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
+}
+
 extern "C" int bh_rodrigues(const double* in, int in_len, double* out)
 {
     if (!in || !out) return BH_ERR_INVALID;
@@ -298,7 +338,9 @@ __device__ void p_gauss_newton(const double* L, const double* rho, double* betas
 }
 
 // Called by every lane of the wave with the same arguments (wave-uniform); ws = LDS workspace of 3*144 + 12 doubles
-__device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rbest, double* tbest, double* ws)
+// trace (test hook, may be NULL): lane 0 writes the intermediates of this hypothesis (layout: tools/pnp_trace.py)
+#define PTR(off, val) do { if (trace && (threadIdx.x & 63) == 0) trace[(off)] = (val); } while (0)
+__device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rbest, double* tbest, double* ws, double* trace)
 {
     double cws[4][3];
     for (int i = 0; i < 4; i++) cws[i][0] = cws[i][1] = cws[i][2] = 0;
@@ -323,6 +365,8 @@ __device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rb
             a[1 + j] = CCi[3 * j] * (pws[3 * i] - cws[0][0]) + CCi[3 * j + 1] * (pws[3 * i + 1] - cws[0][1]) + CCi[3 * j + 2] * (pws[3 * i + 2] - cws[0][2]);
         a[0] = 1.0 - a[1] - a[2] - a[3];
     }
+    for (int i = 0; i < 12; i++) PTR(8 + i, cws[i / 3][i % 3]);
+    for (int i = 0; i < 20; i++) PTR(20 + i, alphas[i]);
     // MtM (12x12) straight into LDS: lane e accumulates element e over the 5 points in point order (the per-lane loop's order)
     double* sA = ws; double* sV = ws + 144; double* ut = ws + 288; double* dm = ws + 432;
     {
@@ -340,10 +384,13 @@ __device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rb
             double acc = 0;
             for (int i = 0; i < NS; i++) acc += m1[i][pp] * m1[i][qq] + m2[i][pp] * m2[i][qq];
             sA[e] = acc;
+            if (trace) trace[40 + e] = acc;
         }
         __syncthreads();
     }
     pj_eig12_wave(sA, sV, dm, ut);
+    for (int i = 0; i < 12; i++) PTR(184 + i, dm[i]);
+    for (int i = 0; i < 144; i++) PTR(196 + i, ut[i]);
     double L[60], rho[6], dv[4][6][3];
     for (int i = 0; i < 4; i++) {
         const double* v = ut + 12 * (11 - i);
@@ -362,6 +409,8 @@ __device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rb
     }
     rho[0] = p_dist2(cws[0], cws[1]); rho[1] = p_dist2(cws[0], cws[2]); rho[2] = p_dist2(cws[0], cws[3]);
     rho[3] = p_dist2(cws[1], cws[2]); rho[4] = p_dist2(cws[1], cws[3]); rho[5] = p_dist2(cws[2], cws[3]);
+    for (int i = 0; i < 60; i++) PTR(340 + i, L[i]);
+    for (int i = 0; i < 6; i++) PTR(400 + i, rho[i]);
     double best = DBL_MAX;
     for (int N = 1; N <= 3; N++) {
         double betas[4] = {0, 0, 0, 0}, A[30], x[5];
@@ -384,9 +433,14 @@ __device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rb
             if (x[1] < 0) betas[0] = -betas[0];
             betas[2] = x[3] / betas[0];
         }
+        for (int i = 0; i < 4; i++) PTR(406 + 21 * (N - 1) + i, betas[i]);
         p_gauss_newton(L, rho, betas);
         double R[9], t[3];
         const double err = p_epnp_R_t(pws, us, alphas, K, ut, betas, R, t);
+        for (int i = 0; i < 4; i++) PTR(406 + 21 * (N - 1) + 4 + i, betas[i]);
+        for (int i = 0; i < 9; i++) PTR(406 + 21 * (N - 1) + 8 + i, R[i]);
+        for (int i = 0; i < 3; i++) PTR(406 + 21 * (N - 1) + 17 + i, t[i]);
+        PTR(406 + 21 * (N - 1) + 20, err);
         if (err < best || N == 1) { best = err; for (int i = 0; i < 9; i++) Rbest[i] = R[i]; for (int i = 0; i < 3; i++) tbest[i] = t[i]; }
     }
 }
@@ -402,30 +456,11 @@ __device__ int p_update_iters(double p, double ep, int model_points, int max_ite
 {
     p = p < 0 ? 0 : p > 1 ? 1 : p; ep = ep < 0 ? 0 : ep > 1 ? 1 : ep;
     double num = 1. - p; if (num < DBL_MIN) num = DBL_MIN;
-    double denom = 1. - pow(1. - ep, (double)model_points);
+    (void)model_points;                                   // 5: the only minimal-set size of this path
+    double denom = 1. - dm_pow5(1. - ep);
     if (denom < DBL_MIN) return 0;
-    num = log(num); denom = log(denom);
+    num = dm_log(num); denom = dm_log(denom);
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
-}
-
-__device__ __forceinline__ double p_shfl_xor(double v, int m)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);
-    return __hiloint2double(hi, lo);
-}
-
-template <int NV>
-__device__ void p_block_sum(double* v, double* s_red)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < NV; i++) for (int m = 32; m > 0; m >>= 1) v[i] += p_shfl_xor(v[i], m);
-    __syncthreads();
-    if (lane == 0) for (int i = 0; i < NV; i++) s_red[wv * NV + i] = v[i];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NV; i++) { double s = 0; for (int w = 0; w < PNP_T / 64; w++) s += s_red[w * NV + i]; v[i] = s; }
 }
 
 __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__ obj_in, const double* __restrict__ img_in,
@@ -433,11 +468,13 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
                                                       double reproj_error, double confidence, double* __restrict__ rvec,
                                                       double* __restrict__ tvec, int* __restrict__ inliers,
                                                       int* __restrict__ n_inliers, int* __restrict__ ok_out,
-                                                      uint8_t* __restrict__ mask_ws, int lm_max)
+                                                      uint8_t* __restrict__ mask_ws, int lm_max, double* trace_all)
 {
     __shared__ int s_idx[PNP_MAX_HYP * 5];
     __shared__ double s_ws[3 * 144 + 12];
-    __shared__ double s_red[28 * (PNP_T / 64)];
+    __shared__ double s_red[28];
+    __shared__ double s_j[14][PNP_T];                         // one 64-point chunk of the refinement: J0[6], J1[6], e0, e1 per point
+    __shared__ unsigned char s_m[PNP_T];
     __shared__ double s_pose[12], s_try[12];
     __shared__ int s_best, s_flag, s_w[PNP_T / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -477,7 +514,8 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
                 for (int k = 0; k < 3; k++) so[3 * i + k] = (double)(float)obj[3 * p + k];
                 for (int k = 0; k < 2; k++) si[2 * i + k] = (double)(float)img[2 * p + k];
             }
-            p_epnp5(so, si, K, R, t, s_ws);
+            double* trace = trace_all && it < PNP_TRACE_HYP ? trace_all + (b * PNP_TRACE_HYP + it) * PNP_TRACE_STRIDE : nullptr;
+            p_epnp5(so, si, K, R, t, s_ws, trace);
             int good;
             if (n == 5) good = 5;
             else {
@@ -493,6 +531,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
                 for (int m = 32; m > 0; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
                 good = cnt;
             }
+            if (trace && tid == 0) { trace[0] = it; for (int i = 0; i < 5; i++) trace[1 + i] = s_idx[5 * it + i]; for (int i = 0; i < 9; i++) trace[469 + i] = R[i]; for (int i = 0; i < 3; i++) trace[478 + i] = t[i]; trace[481] = good; }
             if (n == 5 || good > (max_good > 4 ? max_good : 4)) {
                 best = it; max_good = good;
                 for (int k = 0; k < 9; k++) bR[k] = R[k];
@@ -521,37 +560,53 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
         mask[i] = m;
     }
     __syncthreads();
-    // phase 4: Levenberg-Marquardt on the inliers
+    // phase 4: Levenberg-Marquardt on the inliers.  The normal equations are summed in POINT ORDER, like the sequential CPU
+    // restatement (a tree reduction would differ in the last bits, and this pose feeds the next frame's float32-rounded input):
+    // per 64-point chunk every lane writes its point's two Jacobian rows and residuals to LDS, then lane k < 28 walks the chunk
+    // in order for accumulator k (21 upper-triangle entries of H, 6 of g, the cost).
+    int r0, r1, r2, r3;                                       // accumulator k: acc += s_j[r0][j] * s_j[r1][j] + s_j[r2][j] * s_j[r3][j]
+    {
+        int k = lane, a = 0;
+        if (k < 21) { while (k >= 6 - a) { k -= 6 - a; a++; } r0 = a; r1 = a + k; r2 = 6 + a; r3 = 6 + a + k; }
+        else if (k < 27) { r0 = k - 21; r1 = 12; r2 = 6 + (k - 21); r3 = 13; }
+        else { r0 = 12; r1 = 12; r2 = 13; r3 = 13; }
+    }
     double lambda = 1e-3;
     for (int it = 0; it < lm_max; it++) {
-        double acc[28];
+        double acc = 0;
+        for (int c0 = 0; c0 < n; c0 += PNP_T) {
+            const int i = c0 + tid;
+            const bool valid = i < n && mask[i];
+            double J0[6] = {0, 0, 0, 0, 0, 0}, J1[6] = {0, 0, 0, 0, 0, 0}, e0 = 0, e1 = 0;
+            if (valid) {
+                const double X[3] = { (double)(float)obj[3 * i], (double)(float)obj[3 * i + 1], (double)(float)obj[3 * i + 2] };
+                const double rx[3] = { p_dot(s_pose, X), p_dot(s_pose + 3, X), p_dot(s_pose + 6, X) };
+                const double x = rx[0] + s_pose[9], y = rx[1] + s_pose[10], z = rx[2] + s_pose[11], iz = 1.0 / z;
+                e0 = K.fu * x * iz + K.uc - (double)(float)img[2 * i]; e1 = K.fv * y * iz + K.vc - (double)(float)img[2 * i + 1];
+                const double du[3] = { K.fu * iz, 0, -K.fu * x * iz * iz }, dv[3] = { 0, K.fv * iz, -K.fv * y * iz * iz };
+                J0[0] = du[1] * (-rx[2]) + du[2] * rx[1]; J0[1] = du[0] * rx[2] + du[2] * (-rx[0]); J0[2] = du[0] * (-rx[1]) + du[1] * rx[0];
+                J0[3] = du[0]; J0[4] = du[1]; J0[5] = du[2];
+                J1[0] = dv[1] * (-rx[2]) + dv[2] * rx[1]; J1[1] = dv[0] * rx[2] + dv[2] * (-rx[0]); J1[2] = dv[0] * (-rx[1]) + dv[1] * rx[0];
+                J1[3] = dv[0]; J1[4] = dv[1]; J1[5] = dv[2];
+            }
+            __syncthreads();                                  // the previous chunk's readers are done
 #pragma unroll
-        for (int i = 0; i < 28; i++) acc[i] = 0;
-        for (int i = tid; i < n; i += PNP_T) if (mask[i]) {
-            const double X[3] = { (double)(float)obj[3 * i], (double)(float)obj[3 * i + 1], (double)(float)obj[3 * i + 2] };
-            const double rx[3] = { p_dot(s_pose, X), p_dot(s_pose + 3, X), p_dot(s_pose + 6, X) };
-            const double x = rx[0] + s_pose[9], y = rx[1] + s_pose[10], z = rx[2] + s_pose[11], iz = 1.0 / z;
-            const double e0 = K.fu * x * iz + K.uc - (double)(float)img[2 * i], e1 = K.fv * y * iz + K.vc - (double)(float)img[2 * i + 1];
-            const double du[3] = { K.fu * iz, 0, -K.fu * x * iz * iz }, dv[3] = { 0, K.fv * iz, -K.fv * y * iz * iz };
-            double J0[6], J1[6];
-            J0[0] = du[1] * (-rx[2]) + du[2] * rx[1]; J0[1] = du[0] * rx[2] + du[2] * (-rx[0]); J0[2] = du[0] * (-rx[1]) + du[1] * rx[0];
-            J0[3] = du[0]; J0[4] = du[1]; J0[5] = du[2];
-            J1[0] = dv[1] * (-rx[2]) + dv[2] * rx[1]; J1[1] = dv[0] * rx[2] + dv[2] * (-rx[0]); J1[2] = dv[0] * (-rx[1]) + dv[1] * rx[0];
-            J1[3] = dv[0]; J1[4] = dv[1]; J1[5] = dv[2];
-            int k = 0;
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int c = a; c < 6; c++) acc[k++] += J0[a] * J0[c] + J1[a] * J1[c];
-#pragma unroll
-            for (int a = 0; a < 6; a++) acc[21 + a] += J0[a] * e0 + J1[a] * e1;
-            acc[27] += e0 * e0 + e1 * e1;
+            for (int a = 0; a < 6; a++) { s_j[a][tid] = J0[a]; s_j[6 + a][tid] = J1[a]; }
+            s_j[12][tid] = e0; s_j[13][tid] = e1; s_m[tid] = valid;
+            __syncthreads();
+            if (lane < 28) {
+                const int cnt = min(PNP_T, n - c0);
+                for (int j = 0; j < cnt; j++)
+                    if (s_m[j]) acc += s_j[r0][j] * s_j[r1][j] + s_j[r2][j] * s_j[r3][j];
+            }
         }
-        p_block_sum<28>(acc, s_red);
+        __syncthreads();
+        if (lane < 28) s_red[lane] = acc;
+        __syncthreads();
         double H[36], g[6];
-        { int k = 0; for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { H[6 * a + c] = acc[k]; H[6 * c + a] = acc[k]; k++; } }
-        for (int a = 0; a < 6; a++) g[a] = acc[21 + a];
-        const double c0 = acc[27];
+        { int k = 0; for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { H[6 * a + c] = s_red[k]; H[6 * c + a] = s_red[k]; k++; } }
+        for (int a = 0; a < 6; a++) g[a] = s_red[21 + a];
+        const double c0 = s_red[27];
         bool improved = false, tiny = false;
         for (int trial = 0; trial < 10 && !improved; trial++) {
             if (tid == 0) {
@@ -561,24 +616,38 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
                 pj_eig<6>(A, d, Vt);
                 for (int e = 0; e < 6; e++) if (d[e] > 0) { double c = 0; for (int a = 0; a < 6; a++) c += Vt[6 * e + a] * g[a]; c /= d[e]; for (int a = 0; a < 6; a++) dx[a] -= c * Vt[6 * e + a]; }
                 double dR[9];
-                p_rodrigues_v2m(dx, dR);
+                pd_rodrigues_v2m(dx, dR);
                 for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) s_try[3 * a + c] = dR[3 * a] * s_pose[c] + dR[3 * a + 1] * s_pose[3 + c] + dR[3 * a + 2] * s_pose[6 + c];
                 for (int a = 0; a < 3; a++) s_try[9 + a] = s_pose[9 + a] + dx[3 + a];
                 double step = 0; for (int a = 0; a < 6; a++) step += dx[a] * dx[a];
                 s_flag = step < 1e-26 ? 1 : 0;
             }
             __syncthreads();
-            double c1[1] = { 0 };
-            for (int i = tid; i < n; i += PNP_T) if (mask[i]) {
-                const double X[3] = { (double)(float)obj[3 * i], (double)(float)obj[3 * i + 1], (double)(float)obj[3 * i + 2] };
-                const double x = p_dot(s_try, X) + s_try[9], y = p_dot(s_try + 3, X) + s_try[10], z = p_dot(s_try + 6, X) + s_try[11];
-                const double e0 = K.fu * x / z + K.uc - (double)(float)img[2 * i], e1 = K.fv * y / z + K.vc - (double)(float)img[2 * i + 1];
-                c1[0] += e0 * e0 + e1 * e1;
-            }
-            p_block_sum<1>(c1, s_red);
-            if (c1[0] < c0 && isfinite(c1[0])) {
-                improved = true; tiny = s_flag != 0; lambda *= 0.2;
+            double c1 = 0;                                    // lane 0 sums the trial cost in point order
+            for (int cb = 0; cb < n; cb += PNP_T) {
+                const int i = cb + tid;
+                const bool valid = i < n && mask[i];
+                double e2 = 0;
+                if (valid) {
+                    const double X[3] = { (double)(float)obj[3 * i], (double)(float)obj[3 * i + 1], (double)(float)obj[3 * i + 2] };
+                    const double x = p_dot(s_try, X) + s_try[9], y = p_dot(s_try + 3, X) + s_try[10], z = p_dot(s_try + 6, X) + s_try[11];
+                    const double e0 = K.fu * x / z + K.uc - (double)(float)img[2 * i], e1 = K.fv * y / z + K.vc - (double)(float)img[2 * i + 1];
+                    e2 = e0 * e0 + e1 * e1;
+                }
                 __syncthreads();
+                s_j[0][tid] = e2; s_m[tid] = valid;
+                __syncthreads();
+                if (tid == 0) {
+                    const int cnt = min(PNP_T, n - cb);
+                    for (int j = 0; j < cnt; j++) if (s_m[j]) c1 += s_j[0][j];
+                }
+            }
+            if (tid == 0) s_red[0] = c1;
+            __syncthreads();
+            c1 = s_red[0];
+            __syncthreads();
+            if (c1 < c0 && isfinite(c1)) {
+                improved = true; tiny = s_flag != 0; lambda *= 0.2;
                 if (tid < 12) s_pose[tid] = s_try[tid];
             } else lambda *= 5.0;
             __syncthreads();
@@ -602,7 +671,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
     }
     if (tid == 0) {
         double r[3];
-        p_rodrigues_m2v(s_pose, r);
+        pd_rodrigues_m2v(s_pose, r);
         for (int k = 0; k < 3; k++) { rvec[3 * b + k] = r[k]; tvec[3 * b + k] = s_pose[9 + k]; }
         n_inliers[b] = base; ok_out[b] = 1;
     }
@@ -637,7 +706,7 @@ extern "C" int bh_solve_pnp_ransac(bh_ctx* ctx, const double* obj, const double*
     }
     pnp_K Kd = { K[0], K[1], K[2], K[3] };
     BH_LAUNCH(ctx, BH_K_PNP, k_pnp_ransac, dim3(B), dim3(PNP_T), st, d_obj, d_img, d_n, stride, Kd, iterations, reproj_error,
-              confidence, d_r, d_t, d_in, d_ni, d_ok, (uint8_t*)ctx->st_h.p, 60);
+              confidence, d_r, d_t, d_in, d_ni, d_ok, (uint8_t*)ctx->st_h.p, 60, (double*)nullptr);
     BH_HIP(ctx, hipGetLastError());
     if (mem == BH_MEM_HOST) {
         BH_HIP(ctx, hipMemcpyAsync(rvec, d_r, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
@@ -647,5 +716,78 @@ extern "C" int bh_solve_pnp_ransac(bh_ctx* ctx, const double* obj, const double*
         BH_HIP(ctx, hipMemcpyAsync(ok, d_ok, sizeof(int) * B, hipMemcpyDeviceToHost, st));
         BH_HIP(ctx, hipStreamSynchronize(st));
     }
+    return BH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ test hooks
+// bh_debug_pnp_trace: bh_solve_pnp_ransac on host arrays that also returns, per problem, the intermediates of its first
+// PNP_TRACE_HYP hypotheses (trace f64[B][32][512]; layout in tests/pnp_trace_layout.py) — used to locate the first differing
+// operation against the oracle's own trace.
+extern "C" int bh_debug_pnp_trace(bh_ctx* ctx, const double* obj, const double* img, const int* n, int B, int stride,
+                                  const double K[4], int iterations, double reproj_error, double confidence,
+                                  double* rvec, double* tvec, int* inliers, int* n_inliers, int* ok, double* trace)
+{
+    if (!ctx || !obj || !img || !n || !K || !rvec || !tvec || !inliers || !n_inliers || !ok || !trace || B < 1 || stride < 1)
+        return BH_ERR_INVALID;
+    for (int b = 0; b < B; b++) if (n[b] < 0 || n[b] > stride) return bh_set_err(ctx, BH_ERR_INVALID, "bh_debug_pnp_trace: n[b] outside [0, stride]");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t np = (size_t)B * stride, ntr = (size_t)B * PNP_TRACE_HYP * PNP_TRACE_STRIDE;
+    BH_TRY(bh_reserve(ctx, &ctx->st_h, np));
+    BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(double) * 3 * np)); BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(double) * 2 * np));
+    BH_TRY(bh_reserve(ctx, &ctx->st_c, sizeof(int) * 3 * (size_t)B)); BH_TRY(bh_reserve(ctx, &ctx->st_d, sizeof(double) * 6 * (size_t)B));
+    BH_TRY(bh_reserve(ctx, &ctx->st_e, sizeof(int) * np));
+    BH_TRY(bh_reserve(ctx, &ctx->st_f, sizeof(double) * ntr));
+    BH_HIP(ctx, hipMemcpyAsync(ctx->st_a.p, obj, sizeof(double) * 3 * np, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipMemcpyAsync(ctx->st_b.p, img, sizeof(double) * 2 * np, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipMemcpyAsync(ctx->st_c.p, n, sizeof(int) * B, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipMemsetAsync(ctx->st_f.p, 0, sizeof(double) * ntr, st));
+    int* d_ni = (int*)ctx->st_c.p + B; int* d_ok = (int*)ctx->st_c.p + 2 * (size_t)B;
+    double* d_r = (double*)ctx->st_d.p; double* d_t = d_r + 3 * (size_t)B;
+    pnp_K Kd = { K[0], K[1], K[2], K[3] };
+    hipLaunchKernelGGL(k_pnp_ransac, dim3(B), dim3(PNP_T), 0, st, (const double*)ctx->st_a.p, (const double*)ctx->st_b.p,
+                       (const int*)ctx->st_c.p, stride, Kd, iterations, reproj_error, confidence, d_r, d_t, (int*)ctx->st_e.p,
+                       d_ni, d_ok, (uint8_t*)ctx->st_h.p, 60, (double*)ctx->st_f.p);
+    BH_HIP(ctx, hipGetLastError());
+    BH_HIP(ctx, hipMemcpyAsync(rvec, d_r, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
+    BH_HIP(ctx, hipMemcpyAsync(tvec, d_t, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
+    BH_HIP(ctx, hipMemcpyAsync(inliers, ctx->st_e.p, sizeof(int) * np, hipMemcpyDeviceToHost, st));
+    BH_HIP(ctx, hipMemcpyAsync(n_inliers, d_ni, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    BH_HIP(ctx, hipMemcpyAsync(ok, d_ok, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    BH_HIP(ctx, hipMemcpyAsync(trace, ctx->st_f.p, sizeof(double) * ntr, hipMemcpyDeviceToHost, st));
+    BH_HIP(ctx, hipStreamSynchronize(st));
+    return BH_OK;
+}
+
+// bh_debug_f64_ops: the f64 primitives the pose kernels lean on, evaluated on the device for n operand pairs, so a test can
+// compare them bit for bit with the host's libm: out f64[8][n] = a/b, sqrt|a|, sin a, cos a, acos(clamp a), log|a|, pow(|a|,5), rint(a).
+__global__ void k_debug_f64_ops(const double* a, const double* b, int n, double* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i], y = b[i];
+    out[0 * (size_t)n + i] = x / y;
+    out[1 * (size_t)n + i] = sqrt(fabs(x));
+    out[2 * (size_t)n + i] = sin(x);
+    out[3 * (size_t)n + i] = cos(x);
+    out[4 * (size_t)n + i] = acos(x > 1 ? 1 : x < -1 ? -1 : x);
+    out[5 * (size_t)n + i] = log(fabs(x));
+    out[6 * (size_t)n + i] = pow(fabs(x), 5.0);
+    out[7 * (size_t)n + i] = rint(x);
+}
+
+extern "C" int bh_debug_f64_ops(bh_ctx* ctx, const double* a, const double* b, int n, double* out)
+{
+    if (!ctx || !a || !b || !out || n < 1) return BH_ERR_INVALID;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(double) * n)); BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(double) * n));
+    BH_TRY(bh_reserve(ctx, &ctx->st_f, sizeof(double) * 8 * (size_t)n));
+    BH_HIP(ctx, hipMemcpyAsync(ctx->st_a.p, a, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipMemcpyAsync(ctx->st_b.p, b, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_debug_f64_ops, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)ctx->st_a.p, (const double*)ctx->st_b.p, n, (double*)ctx->st_f.p);
+    BH_HIP(ctx, hipGetLastError());
+    BH_HIP(ctx, hipMemcpyAsync(out, ctx->st_f.p, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+    BH_HIP(ctx, hipStreamSynchronize(st));
     return BH_OK;
 }

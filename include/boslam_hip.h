@@ -207,6 +207,15 @@ int bh_solve_pnp_ransac(bh_ctx* ctx, const double* obj, const double* img, const
                         const double K[4], int iterations, double reproj_error, double confidence,
                         double* rvec, double* tvec, int* inliers, int* n_inliers, int* ok, int mem);
 int bh_rodrigues(const double* in, int in_len, double* out);
+/* Test hooks (host arrays).  bh_debug_pnp_trace = bh_solve_pnp_ransac that also returns the intermediates of the first 32
+ * RANSAC hypotheses of every problem (trace f64[B][32][512]: sample, control points, barycentric coordinates, M'M, its
+ * eigen-decomposition, L, rho, betas / R / t / error for N = 1..3, chosen R t, inlier count), for locating the first operation
+ * that differs from the CPU oracle's trace.  bh_debug_f64_ops evaluates the f64 primitives the pose kernels rely on for n operand
+ * pairs: out f64[8][n] = a/b, sqrt|a|, sin a, cos a, acos(clamp a), log|a|, pow(|a|, 5), rint a. */
+int bh_debug_pnp_trace(bh_ctx* ctx, const double* obj, const double* img, const int* n, int B, int stride,
+                       const double K[4], int iterations, double reproj_error, double confidence,
+                       double* rvec, double* tvec, int* inliers, int* n_inliers, int* ok, double* trace);
+int bh_debug_f64_ops(bh_ctx* ctx, const double* a, const double* b, int n, double* out);
 
 /* ---- local-map visibility gate ------------------------------------------------------------------------------------
  * Replaces the per-map-point loop of Tracker._track_local_map — slam/tracking.py:97-111 — for B frames:

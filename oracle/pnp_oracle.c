@@ -19,12 +19,17 @@
  * Linear-algebra kernels inside (symmetric Jacobi eigen-solver, one-sided Jacobi SVD of 3x3) are this restatement's own:
  * OpenCV's cvSVD leaves eigenvector signs / orders unspecified, which EPnP is invariant to.
  * n == 4 (OpenCV switches to P3P) is not restated: needs n >= 5.
+ * Inside orc_solve_pnp_ransac the five libm calls OpenCV makes (sin/cos of the refinement's rotation update, acos of the final
+ * Rodrigues, pow and log of RANSACUpdateNumIters) go through detmath.h: fixed-operation-order routines within 2 ulp of libm, so
+ * that the HIP kernel can reproduce this function bit for bit (the result feeds hard thresholds and the next frame's input).
+ * The public orc_rodrigues_* keep libm, like cv2.Rodrigues.
  */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <float.h>
+#include "detmath.h"
 
 /* ---------- small linear algebra ---------- */
 /* cyclic Jacobi for symmetric A (n<=12), eigenvalues descending in d, eigenvectors in ROWS of Vt */
@@ -171,8 +176,49 @@ void orc_rodrigues_mat2vec(const double* R, double* r)
     r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
 }
 
+
+/* the same two conversions with detmath.h's sin/cos/acos (used inside orc_solve_pnp_ransac only) */
+static void det_rodrigues_vec2mat(const double* r, double* R)
+{
+    double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (th < DBL_EPSILON) { for (int i = 0; i < 9; i++) R[i] = (i % 4) == 0; return; }
+    double c, s; dm_sincos(th, &s, &c);
+    double c1 = 1.0 - c, it = 1.0 / th;
+    double x = r[0] * it, y = r[1] * it, z = r[2] * it;
+    R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
+    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
+    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+}
+
+static void det_rodrigues_mat2vec(const double* R, double* r)
+{
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double th = dm_acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
+        double t;
+        t = (R[0] + 1) * 0.5; r[0] = sqrt(t > 0 ? t : 0);
+        t = (R[4] + 1) * 0.5; r[1] = sqrt(t > 0 ? t : 0) * (R[1] < 0 ? -1. : 1.);
+        t = (R[8] + 1) * 0.5; r[2] = sqrt(t > 0 ? t : 0) * (R[2] < 0 ? -1. : 1.);
+        if (fabs(r[0]) < fabs(r[1]) && fabs(r[0]) < fabs(r[2]) && (R[5] > 0) != (r[1] * r[2] > 0)) r[2] = -r[2];
+        double nr = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        double k = th / nr; r[0] *= k; r[1] *= k; r[2] *= k;
+        return;
+    }
+    double vth = 1.0 / (2 * s) * th;
+    r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
+}
+
 /* ---------- EPnP ---------- */
 typedef struct { double fu, fv, uc, vc; } epnp_K;
+
+/* optional trace of the intermediates of every RANSAC hypothesis (tests: first differing operation vs the HIP kernel's trace,
+ * same layout as bh_debug_pnp_trace: 512 doubles per hypothesis).  Not thread-safe; tests set it around one call. */
+static double* g_trace = 0;     /* current hypothesis' slot, or NULL */
+#define OTR(off, val) do { if (g_trace) g_trace[(off)] = (val); } while (0)
 
 static double epnp_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 static double epnp_dist2(const double* a, const double* b) { double d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2]; return d0 * d0 + d1 * d1 + d2 * d2; }
@@ -268,6 +314,8 @@ static void epnp_solve(const double* pws, const double* us, int n, epnp_K K, dou
             a[1 + j] = CCi[3 * j] * (pws[3 * i] - cws[0][0]) + CCi[3 * j + 1] * (pws[3 * i + 1] - cws[0][1]) + CCi[3 * j + 2] * (pws[3 * i + 2] - cws[0][2]);
         a[0] = 1.0 - a[1] - a[2] - a[3];
     }
+    for (int i = 0; i < 12; i++) OTR(8 + i, cws[i / 3][i % 3]);
+    if (n == 5) for (int i = 0; i < 20; i++) OTR(20 + i, alphas[i]);
     double MtM[144] = {0};
     for (int i = 0; i < n; i++) {
         double m1[12], m2[12];
@@ -278,8 +326,11 @@ static void epnp_solve(const double* pws, const double* us, int n, epnp_K K, dou
         }
         for (int p = 0; p < 12; p++) for (int q = 0; q < 12; q++) MtM[12 * p + q] += m1[p] * m1[q] + m2[p] * m2[q];
     }
+    for (int i = 0; i < 144; i++) OTR(40 + i, MtM[i]);
     double dm[12], ut[144];
     jacobi_eig(MtM, 12, dm, ut);
+    for (int i = 0; i < 12; i++) OTR(184 + i, dm[i]);
+    for (int i = 0; i < 144; i++) OTR(196 + i, ut[i]);
     /* L_6x10 and rho */
     double L[60], rho[6], dv[4][6][3];
     const double* v[4] = { ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8 };
@@ -299,6 +350,8 @@ static void epnp_solve(const double* pws, const double* us, int n, epnp_K K, dou
     }
     rho[0] = epnp_dist2(cws[0], cws[1]); rho[1] = epnp_dist2(cws[0], cws[2]); rho[2] = epnp_dist2(cws[0], cws[3]);
     rho[3] = epnp_dist2(cws[1], cws[2]); rho[4] = epnp_dist2(cws[1], cws[3]); rho[5] = epnp_dist2(cws[2], cws[3]);
+    for (int i = 0; i < 60; i++) OTR(340 + i, L[i]);
+    for (int i = 0; i < 6; i++) OTR(400 + i, rho[i]);
     double best = DBL_MAX;
     for (int N = 1; N <= 3; N++) {
         double betas[4] = {0, 0, 0, 0}, A[30], x[5];
@@ -321,9 +374,14 @@ static void epnp_solve(const double* pws, const double* us, int n, epnp_K K, dou
             if (x[1] < 0) betas[0] = -betas[0];
             betas[2] = x[3] / betas[0];
         }
+        for (int i = 0; i < 4; i++) OTR(406 + 21 * (N - 1) + i, betas[i]);
         epnp_gauss_newton(L, rho, betas);
         double R[9], t[3];
         double err = epnp_R_t(pws, us, alphas, n, K, ut, betas, R, t);
+        for (int i = 0; i < 4; i++) OTR(406 + 21 * (N - 1) + 4 + i, betas[i]);
+        for (int i = 0; i < 9; i++) OTR(406 + 21 * (N - 1) + 8 + i, R[i]);
+        for (int i = 0; i < 3; i++) OTR(406 + 21 * (N - 1) + 17 + i, t[i]);
+        OTR(406 + 21 * (N - 1) + 20, err);
         if (err < best || N == 1) { best = err; memcpy(Rbest, R, sizeof(R)); memcpy(tbest, t, sizeof(t)); }
     }
 }
@@ -363,7 +421,7 @@ static void pnp_refine(const double* obj, const double* img, const uint8_t* sel,
             jacobi_eig(A, 6, d, Vt);
             for (int e = 0; e < 6; e++) if (d[e] > 0) { double c = 0; for (int a = 0; a < 6; a++) c += Vt[6 * e + a] * g[a]; c /= d[e]; for (int a = 0; a < 6; a++) dx[a] -= c * Vt[6 * e + a]; }
             double dR[9], Rn[9], tn[3] = { t[0] + dx[3], t[1] + dx[4], t[2] + dx[5] };
-            orc_rodrigues_vec2mat(dx, dR);
+            det_rodrigues_vec2mat(dx, dR);
             for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rn[3 * a + b] = dR[3 * a] * R[b] + dR[3 * a + 1] * R[3 + b] + dR[3 * a + 2] * R[6 + b];
             double c1 = 0;
             for (int i = 0; i < n; i++) if (sel[i]) {
@@ -387,11 +445,15 @@ static int ransac_update_iters(double p, double ep, int model_points, int max_it
 {
     p = p < 0 ? 0 : p > 1 ? 1 : p; ep = ep < 0 ? 0 : ep > 1 ? 1 : ep;
     double num = 1. - p; if (num < DBL_MIN) num = DBL_MIN;
-    double denom = 1. - pow(1. - ep, model_points);
+    (void)model_points;                                   /* 5: the only minimal-set size of this path */
+    double denom = 1. - dm_pow5(1. - ep);
     if (denom < DBL_MIN) return 0;
-    num = log(num); denom = log(denom);
+    num = dm_log(num); denom = dm_log(denom);
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)lrint(num / denom);
 }
+
+static double* g_trace_all = 0; static int g_trace_hyp = 0;
+void orc_pnp_set_trace(double* trace, int max_hyp) { g_trace_all = trace; g_trace_hyp = max_hyp; g_trace = 0; }
 
 /* returns 1 on success.  K = {fx, fy, cx, cy}.  inlier_idx capacity n. */
 int orc_solve_pnp_ransac(const double* obj_in, const double* img_in, int n, const double* Kin, int iterations_count,
@@ -421,6 +483,7 @@ int orc_solve_pnp_ransac(const double* obj_in, const double* img_in, int n, cons
             }
             double so[15], si[10], R[9], t[3];
             for (int i = 0; i < 5; i++) { memcpy(so + 3 * i, obj + 3 * idx[i], 24); memcpy(si + 2 * i, img + 2 * idx[i], 16); }
+            g_trace = g_trace_all && iter < g_trace_hyp ? g_trace_all + 512 * (size_t)iter : 0;
             epnp_solve(so, si, 5, K, R, t);
             int good = 0;
             for (int i = 0; i < n; i++) {
@@ -432,6 +495,7 @@ int orc_solve_pnp_ransac(const double* obj_in, const double* img_in, int n, cons
                 mask[i] = e <= thr2;
                 good += mask[i];
             }
+            if (g_trace) { g_trace[0] = iter; for (int i = 0; i < 5; i++) g_trace[1 + i] = idx[i]; for (int i = 0; i < 9; i++) g_trace[469 + i] = R[i]; for (int i = 0; i < 3; i++) g_trace[478 + i] = t[i]; g_trace[481] = good; g_trace = 0; }
             if (good > (max_good > 4 ? max_good : 4)) {
                 memcpy(best_mask, mask, n); memcpy(bestR, R, sizeof(R)); memcpy(bestt, t, sizeof(t));
                 max_good = good;
@@ -442,7 +506,7 @@ int orc_solve_pnp_ransac(const double* obj_in, const double* img_in, int n, cons
     if (max_good > 0) {
         /* final pose on the inliers, from the original float32-rounded points widened to double (opoints.convertTo(CV_64F)) */
         pnp_refine(obj, img, best_mask, n, K, bestR, bestt);
-        orc_rodrigues_mat2vec(bestR, rvec);
+        det_rodrigues_mat2vec(bestR, rvec);
         memcpy(tvec, bestt, sizeof(bestt));
         int k = 0;
         for (int i = 0; i < n; i++) if (best_mask[i]) inlier_idx[k++] = i;
@@ -450,4 +514,16 @@ int orc_solve_pnp_ransac(const double* obj_in, const double* img_in, int n, cons
     }
     free(obj); free(img); free(mask); free(best_mask);
     return ok;
+}
+
+/* test access to detmath.h: out[0..4][n] = sin, cos, acos(clamped), log|x|, pow5 of x[i] */
+void orc_detmath_eval(const double* x, int n, double* out)
+{
+    for (int i = 0; i < n; i++) {
+        double s, c; dm_sincos(x[i], &s, &c);
+        out[i] = s; out[n + i] = c;
+        out[2 * n + i] = dm_acos(x[i] > 1 ? 1 : x[i] < -1 ? -1 : x[i]);
+        out[3 * n + i] = x[i] != 0 ? dm_log(fabs(x[i])) : 0.0;
+        out[4 * n + i] = dm_pow5(x[i]);
+    }
 }

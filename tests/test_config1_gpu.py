@@ -1,11 +1,11 @@
 """BASELINE configs[0]: the 100-frame two-way PnP tracking sequence (counterpart of experiments/pnp_two_way_tracking.py).
 
-The script feeds every frame's fused (R, t) back into the next frame's PnP input (camera.py:32-43), and RANSAC's inlier test is
-a hard threshold, so a 1e-12 difference can flip one inlier a few frames later and the two trajectories then drift apart by
-design of the reference algorithm.  Parity is therefore checked with teacher forcing: at every frame the GPU library gets
-exactly the oracle's inputs (the oracle replay is pinned by tests/golden/config1_golden.npz in tests/test_oracle_cpu.py) and
-must return the oracle's outputs; the free-running GPU replay is checked on the quantities that do not depend on the feedback
-(keypoints, match counts) exactly and on the trajectory loosely."""
+The script feeds every frame's fused (R, t) back into the next frame's PnP input (camera.py:32-43) and RANSAC's inlier test is a
+hard threshold, so anything short of bit-identical poses would eventually flip an inlier and let the two trajectories drift
+apart.  The HIP solvePnPRansac therefore reproduces the oracle bit for bit (point-order sums, detmath.h), and both checks are
+exact: (1) teacher-forced, every one of the 198 problems of the oracle's replay (pinned by tests/golden/config1_golden.npz in
+tests/test_oracle_cpu.py) returns the oracle's inliers, rvec and tvec; (2) the free-running GPU replay equals the golden log
+for all 100 frames."""
 import os
 import numpy as np
 import pytest
@@ -32,7 +32,7 @@ def seq(ctx):
 def test_teacher_forced_every_frame_matches_the_oracle(ctx, seq):
     g, desc, n, xy, cloud = seq["g"], seq["desc"], seq["n"], seq["xy"], seq["cloud"]
     assert np.array_equal(n, g["n_kp"])
-    stats = dict(frames=0, inlier_sets_equal=0, worst=0.0)
+    stats = dict(frames=0, problems=0)
 
     def match_fn(p, f):
         qi, ti, d, nm = frontend.match_pairs(ctx, desc[p:p + 1], n[p:p + 1], desc[f:f + 1], n[f:f + 1])
@@ -48,13 +48,10 @@ def test_teacher_forced_every_frame_matches_the_oracle(ctx, seq):
         for k in range(2):
             o_ok, o_r, o_t, o_in = out[k]
             assert bool(ok[k]) == o_ok
-            same = np.array_equal(inl[k][:ni[k]], o_in)
-            stats["inlier_sets_equal"] += int(same)
-            assert same or len(np.setxor1d(inl[k][:ni[k]], o_in)) <= 2          # a point sitting on the 8-px threshold
-            err = max(np.abs(rv[k] - o_r).max(), np.abs(tv[k] - o_t).max())
-            stats["worst"] = max(stats["worst"], err)
-            assert err < (1e-6 if same else 1e-3)
-            assert np.allclose(cv2_shim.Rodrigues(rv[k])[0], oracle.rodrigues(rv[k]), atol=1e-14)
+            assert np.array_equal(inl[k][:ni[k]], o_in)
+            assert np.array_equal(rv[k], o_r) and np.array_equal(tv[k], o_t), (rv[k] - o_r, tv[k] - o_t)     # bit for bit
+            assert np.array_equal(cv2_shim.Rodrigues(rv[k])[0], oracle.rodrigues(rv[k]))
+            stats["problems"] += 1
         stats["frames"] += 1
         return out                                                               # continue on the oracle's state
 
@@ -62,14 +59,14 @@ def test_teacher_forced_every_frame_matches_the_oracle(ctx, seq):
     for k in ("state", "num_matches", "num_inliers", "num_union"):
         assert np.array_equal(log[k], g[k]), k
     assert np.abs(log["R"] - g["R"]).max() < 1e-12 and np.abs(log["t"] - g["t"]).max() < 1e-12
-    assert stats["frames"] == 99 and stats["inlier_sets_equal"] >= 2 * 99 - 4, stats
+    assert stats["frames"] == 99 and stats["problems"] == 198, stats
 
 
-def test_free_running_gpu_replay(ctx, seq):
+def test_free_running_gpu_replay_equals_the_golden_log(ctx, seq):
     g = seq["g"]
     log = two_way_tracking.run(ctx, seq["bgr"], seq["depth"], K4)
-    assert (log["state"][1:] == 1).all() and np.array_equal(log["num_matches"], g["num_matches"])
-    first = int(np.argmax(log["num_inliers"] != g["num_inliers"])) if (log["num_inliers"] != g["num_inliers"]).any() else len(g["state"])
-    assert first >= 5                                                            # identical until the first threshold flip ...
-    assert np.abs(log["t"][:first] - g["t"][:first]).max() < 1e-6
-    assert abs(np.median(log["t"][1:, 0]) - np.median(g["t"][1:, 0])) < 2e-3     # ... and the same motion estimate afterwards
+    assert (log["state"][1:] == 1).all()
+    for k in ("state", "num_matches", "num_inliers", "num_union"):
+        assert np.array_equal(log[k], g[k]), k
+    for k in ("R", "t", "point_diff", "norm_tvec", "cam_R", "cam_t_norm"):
+        assert np.array_equal(log[k], g[k]), (k, np.abs(log[k] - g[k]).max())                                  # all 100 frames, bit for bit

@@ -331,3 +331,18 @@ def test_config1_replay_is_pinned_by_the_golden_fixture():
     for k in ("state", "num_matches", "num_inliers", "num_union", "n_kp"):
         assert np.array_equal(log[k], g[k][:12]), k
     assert np.array_equal(log["R"], g["R"][:12]) and np.array_equal(log["t"], g["t"][:12]) and np.array_equal(log["point_diff"], g["point_diff"][:12])
+
+
+def test_detmath_tracks_libm():
+    """oracle/detmath.h (fixed-operation-order sin/cos/acos/log/pow5 shared, as text, with the HIP kernels) stays within 2 ulp of
+    libm where solvePnPRansac uses it."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-1, 1, 200000), rng.uniform(-50, 50, 200000), 1 - rng.uniform(0, 1e-6, 50000), [0.5, -0.5, 1.0, -1.0, 0.25]])
+    out = np.zeros((5, len(x)))
+    oracle.lib().orc_detmath_eval(x.ctypes.data_as(__import__("ctypes").c_void_p), len(x), out.ctypes.data_as(__import__("ctypes").c_void_p))
+    ref = [np.sin(x), np.cos(x), np.arccos(np.clip(x, -1, 1)), np.log(np.abs(x)), x ** 5]
+    for name, got, want in zip(("sin", "cos", "acos", "log", "pow5"), out, ref):
+        big = np.abs(want) > 1e-3                                      # relative ulps are meaningless next to a zero of the function
+        d = np.abs(got[big].view(np.int64) - want[big].view(np.int64))
+        assert d.max() <= (3 if name == "pow5" else 2), (name, int(d.max()))
+        assert np.allclose(got, want, rtol=1e-15, atol=1e-16), name
