@@ -88,6 +88,7 @@ void bh_time_end(bh_ctx* ctx);
 
 int  bh_set_err(bh_ctx* ctx, int code, const char* fmt, ...);
 int  bh_reserve(bh_ctx* ctx, bh_buf* b, size_t bytes);
+int  bh_status_ready(bh_ctx* ctx);      // allocates + zeroes the sticky device status word on first use
 
 #define BH_HIP(ctx, call)                                                                          \
     do {                                                                                           \

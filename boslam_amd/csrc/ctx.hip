@@ -16,11 +16,26 @@ int bh_reserve(bh_ctx* ctx, bh_buf* b, size_t bytes)
 {
     if (bytes <= b->cap) return BH_OK;
     // a grow frees the old block: make sure nothing enqueued still uses it
-    if (b->p) { BH_HIP(ctx, hipStreamSynchronize(ctx->stream)); BH_HIP(ctx, hipFree(b->p)); b->p = nullptr; b->cap = 0; }
+    if (b->p) {
+        BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int p = 0; p < BH_MAX_PIPES - 1; p++)                // chunk pipelines of an earlier call that returned early (error path) may still run
+            if (ctx->aux_stream[p]) BH_HIP(ctx, hipStreamSynchronize(ctx->aux_stream[p]));
+        BH_HIP(ctx, hipFree(b->p)); b->p = nullptr; b->cap = 0;
+    }
     size_t want = (bytes + 255) & ~(size_t)255;
     hipError_t e = hipMalloc(&b->p, want);
     if (e != hipSuccess) { b->p = nullptr; return bh_set_err(ctx, BH_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
     b->cap = want;
+    return BH_OK;
+}
+
+// The device status word is STICKY: kernels OR capacity flags into it, nothing clears it except bh_ctx_status after reading it, so
+// a BH_MEM_DEVICE caller that checks once after many enqueued steps sees every flag raised in between.
+int bh_status_ready(bh_ctx* ctx)
+{
+    if (ctx->status.p) return BH_OK;
+    BH_TRY(bh_reserve(ctx, &ctx->status, 256));
+    BH_HIP(ctx, hipMemsetAsync(ctx->status.p, 0, 256, ctx->stream));
     return BH_OK;
 }
 
@@ -100,6 +115,7 @@ extern "C" int bh_ctx_status(bh_ctx* ctx)
     if (!ctx->status.p) return BH_OK;
     uint32_t st = 0;
     BH_HIP(ctx, hipMemcpyAsync(&st, ctx->status.p, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    BH_HIP(ctx, hipMemsetAsync(ctx->status.p, 0, 256, ctx->stream));           // read-and-clear, in stream order
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (st & BH_ST_KP_OVERFLOW) return bh_set_err(ctx, BH_ERR_CAPACITY, "more keypoints than max_kp (ties at the retainBest cut); output truncated");
     if (st & 4u) return bh_set_err(ctx, BH_ERR_INVALID, "matcher: descriptor count above the supported maximum (nq <= 8192, nt <= 2^20)");

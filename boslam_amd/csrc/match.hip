@@ -104,7 +104,7 @@ extern "C" int bh_match_hamming_crosscheck(bh_ctx* ctx, const uint8_t* q, const 
     if (B == 0) return BH_OK;
     BH_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    BH_TRY(bh_reserve(ctx, &ctx->status, 256));
+    BH_TRY(bh_status_ready(ctx));
     const uint8_t* d_q = q; const uint8_t* d_t = t; const int* d_nq = nq; const int* d_nt = nt;
     int *d_qi = qidx, *d_ti = tidx, *d_d = dist, *d_nm = n_match;
     if (mem == BH_MEM_HOST) {
@@ -130,7 +130,6 @@ extern "C" int bh_match_hamming_crosscheck(bh_ctx* ctx, const uint8_t* q, const 
         d_nq = (const int*)ctx->st_c.p; d_nt = d_nq + B;
         d_qi = (int*)ctx->st_d.p; d_ti = d_qi + (size_t)B * out_stride; d_d = d_ti + (size_t)B * out_stride;
         d_nm = d_d + (size_t)B * out_stride;
-        BH_HIP(ctx, hipMemsetAsync(ctx->status.p, 0, 256, st));
     }
     BH_LAUNCH(ctx, BH_K_MATCH, k_match, dim3(B), dim3(MT), st, d_q, d_nq, q_stride, d_t, d_nt, t_stride, d_qi, d_ti, d_d, d_nm,
                        out_stride, (uint32_t*)ctx->status.p);
@@ -141,10 +140,7 @@ extern "C" int bh_match_hamming_crosscheck(bh_ctx* ctx, const uint8_t* q, const 
         BH_HIP(ctx, hipMemcpyAsync(tidx, d_ti, ob, hipMemcpyDeviceToHost, st));
         BH_HIP(ctx, hipMemcpyAsync(dist, d_d, ob, hipMemcpyDeviceToHost, st));
         BH_HIP(ctx, hipMemcpyAsync(n_match, d_nm, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-        uint32_t stw = 0;
-        BH_HIP(ctx, hipMemcpyAsync(&stw, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
-        BH_HIP(ctx, hipStreamSynchronize(st));
-        if (stw & 8u) return bh_set_err(ctx, BH_ERR_CAPACITY, "more matches than out_stride");
+        return bh_ctx_status(ctx);                                 // synchronises; reads and clears the sticky status word
     }
     return BH_OK;
 }

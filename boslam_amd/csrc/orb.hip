@@ -933,7 +933,7 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         BH_TRY(bh_reserve(ctx, &Wk.sel_resp, sizeof(float) * (size_t)sel_cap * g.nlevels * chunk));
         BH_TRY(bh_reserve(ctx, &Wk.sel_cnt, sizeof(int) * (size_t)g.nlevels * chunk));
     }
-    BH_TRY(bh_reserve(ctx, &ctx->status, 256));
+    BH_TRY(bh_status_ready(ctx));
     ctx->ws_frames = chunk;
 
     const size_t fpx = (size_t)H * W;
@@ -945,7 +945,6 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         BH_TRY(bh_reserve(ctx, &ctx->st_desc, (size_t)32 * max_kp * chunk));
         BH_TRY(bh_reserve(ctx, &ctx->st_nkp, sizeof(int) * chunk));
     }
-    BH_HIP(ctx, hipMemsetAsync(ctx->status.p, 0, 256, st));
     if (npipe > 1) {                                             // fork: the aux streams start after everything queued so far
         BH_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         for (int p = 1; p < npipe; p++) BH_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream[p - 1], ctx->ev_fork, 0));

@@ -685,6 +685,7 @@ extern "C" int bh_solve_pnp_ransac(bh_ctx* ctx, const double* obj, const double*
     if (!obj || !img || !n || !K || !rvec || !tvec || !inliers || !n_inliers || !ok || B < 0 || stride < 1 ||
         (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE) || !(confidence > 0 && confidence < 1))
         return bh_set_err(ctx, BH_ERR_INVALID, "bh_solve_pnp_ransac: bad argument");
+    if (iterations > PNP_MAX_HYP) return bh_set_err(ctx, BH_ERR_INVALID, "bh_solve_pnp_ransac: iterations > %d not supported", PNP_MAX_HYP);
     if (B == 0) return BH_OK;
     BH_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;

@@ -97,9 +97,15 @@ def match_pairs(ctx, q, nq, t, nt, out_stride=None):
 class DeviceFrontEnd:
     """HBM-resident batch pipeline used by bench.py: inputs and outputs are device buffers (torch tensors are used
     only as the allocator); ORB on B frames then consecutive-frame matching (query = frame i, train = frame i-1,
-    the direction of slam/tracking.py:56)."""
+    the direction of slam/tracking.py:56).
 
-    def __init__(self, ctx, B, H, W, params, max_kp=None, torch_device="cuda:0"):
+    With `dist` (torch.distributed, one rank per GPU) the ranks hold consecutive shards of ONE frame sequence: rank g's frame 0
+    follows rank g-1's frame B-1.  ORB needs nothing from the neighbours; the pair across the shard boundary needs the previous
+    rank's last descriptor row (max_kp x 32 B) and its keypoint count, which travel point to point (RCCL send/recv over xGMI on the
+    library's stream; staged through host memory for gloo rehearsals) - no collective.  Pair 0 of rank g > 0 is then matched like
+    every other pair: n_match[0] / qidx[0] ... hold it (rank 0 has no pair 0)."""
+
+    def __init__(self, ctx, B, H, W, params, max_kp=None, torch_device="cuda:0", dist=None, backend="nccl"):
         import torch
         self.torch = torch
         self.ctx, self.B, self.H, self.W, self.params = ctx, B, H, W, params
@@ -112,6 +118,44 @@ class DeviceFrontEnd:
         self.tidx = torch.zeros_like(self.qidx)
         self.dist = torch.zeros_like(self.qidx)
         self.n_match = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.pg, self.backend = dist, backend
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.stream = None
+        if self.world > 1:
+            self.halo_desc = torch.zeros((self.max_kp, 32), dtype=torch.uint8, device=dev)
+            self.halo_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+            if backend == "nccl":
+                # one stream orders the library's kernels and RCCL's send/recv: the library adopts a torch stream
+                self.stream = torch.cuda.Stream(device=dev)
+                ctx.set_stream(self.stream.cuda_stream)
+
+    def _halo_exchange(self):
+        """Last descriptor row + count of this rank -> rank+1; the same from rank-1 into halo_desc / halo_n."""
+        torch, pg = self.torch, self.pg
+        last_d, last_n = self.desc[self.B - 1], self.n_kp[self.B - 1:self.B]
+        if self.backend == "nccl":
+            with torch.cuda.stream(self.stream):
+                ops = []
+                if self.rank + 1 < self.world:
+                    ops += [pg.P2POp(pg.isend, last_d, self.rank + 1), pg.P2POp(pg.isend, last_n, self.rank + 1)]
+                if self.rank > 0:
+                    ops += [pg.P2POp(pg.irecv, self.halo_desc, self.rank - 1), pg.P2POp(pg.irecv, self.halo_n, self.rank - 1)]
+                for w in pg.batch_isend_irecv(ops):
+                    w.wait()                                                   # orders the stream, does not block the host
+        else:                                                                  # gloo rehearsal: host staging
+            self.ctx.synchronize()
+            reqs, rd, rn = [], None, None
+            if self.rank + 1 < self.world:
+                reqs += [pg.isend(last_d.cpu(), self.rank + 1, tag=0), pg.isend(last_n.cpu(), self.rank + 1, tag=1)]
+            if self.rank > 0:
+                rd = torch.empty((self.max_kp, 32), dtype=torch.uint8); rn = torch.empty((1,), dtype=torch.int32)
+                reqs += [pg.irecv(rd, self.rank - 1, tag=0), pg.irecv(rn, self.rank - 1, tag=1)]
+            for r in reqs:
+                r.wait()
+            if rd is not None:
+                self.halo_desc.copy_(rd); self.halo_n.copy_(rn)
+                torch.cuda.synchronize()
 
     def run(self, bgr, depth):
         """bgr u8[B][H][W][3], depth u16-as-int16 [B][H][W] device tensors.  Enqueues; does not synchronise."""
@@ -128,6 +172,14 @@ class DeviceFrontEnd:
                 self.desc.data_ptr(), self.n_kp.data_ptr(), self.max_kp, self.B - 1,
                 self.qidx.data_ptr() + 4 * self.max_kp, self.tidx.data_ptr() + 4 * self.max_kp,
                 self.dist.data_ptr() + 4 * self.max_kp, self.n_match.data_ptr() + 4, self.max_kp, BH_MEM_DEVICE))
+        if self.world > 1:
+            self._halo_exchange()
+            if self.rank > 0:                                                  # the pair across the shard boundary
+                c.check(L.bh_match_hamming_crosscheck(
+                    c.h, self.desc.data_ptr(), self.n_kp.data_ptr(), self.max_kp,
+                    self.halo_desc.data_ptr(), self.halo_n.data_ptr(), self.max_kp, 1,
+                    self.qidx.data_ptr(), self.tidx.data_ptr(), self.dist.data_ptr(), self.n_match.data_ptr(),
+                    self.max_kp, BH_MEM_DEVICE))
 
 
 def medoid_descriptors(ctx, desc, k):

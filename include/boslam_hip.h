@@ -70,7 +70,9 @@ int         bh_ctx_synchronize(bh_ctx* ctx);
 /* Blocking copy between host and device memory on the context's device (to_device != 0: host -> device).  For callers
  * without a HIP runtime binding of their own, e.g. an all-reduce hook that stages through host memory. */
 int         bh_ctx_copy(bh_ctx* ctx, void* dst, const void* src, size_t bytes, int to_device);
-/* Deferred status of BH_MEM_DEVICE work (capacity flags raised on the device); synchronises the stream. */
+/* Deferred status of BH_MEM_DEVICE work: capacity flags raised on the device are STICKY (every enqueued call ORs into one status
+ * word; nothing clears it but this function), so one check after many enqueued steps reports a flag raised by any of them.
+ * Synchronises the stream, returns the first error (or BH_OK) and clears the word. */
 int         bh_ctx_status(bh_ctx* ctx);
 const char* bh_version(void);
 /* Optional per-kernel timing with hipEvents recorded on the context's stream around every kernel launch
@@ -200,7 +202,10 @@ int bh_ba_window_problem(bh_ctx* ctx, int K, const int* nbr_start, const int* nb
  * experiments/pnp_two_way_tracking.py:57-61,68-69 (slam/tracking.py:68-71 is dead code) — for B problems.
  *   obj f64[B][stride][3], img f64[B][stride][2], n int[B] (n >= 5; n == 4, where OpenCV switches to P3P, reports ok = 0)
  *   K = {fx, fy, cx, cy}; distortion is zero in the reference (camera.py:82, config.py:34)
- *   defaults of the reference call: iterations 100, reproj_error 8.0, confidence 0.99
+ *   defaults of the reference call: iterations 100, reproj_error 8.0, confidence 0.99; iterations > 256 is BH_ERR_INVALID (the
+ *   kernel pre-draws the sample stream of cv::RNG for at most 256 hypotheses)
+ *   the final pose is the Levenberg-Marquardt minimiser of the reprojection error over the RANSAC inliers, started from the RANSAC
+ *   model (OpenCV: solvePnP(ITERATIVE) from a DLT guess, CvLevMarq 20 iterations / FLT_EPSILON): same minimum, poses agree to ~1e-6
  *   rvec/tvec f64[B][3] (world -> camera), inliers int[B][stride] ascending, n_inliers int[B], ok int[B] (1/0)
  * bh_rodrigues is plain host math (3-vector <-> 3x3 row-major matrix; in_len 3 or 9). */
 int bh_solve_pnp_ransac(bh_ctx* ctx, const double* obj, const double* img, const int* n, int B, int stride,
