@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libboslam_hip.so")
+LIB_PATH = os.environ.get("BH_LIB_PATH") or os.path.join(_HERE, "csrc", "libboslam_hip.so")    # BH_LIB_PATH: A/B builds of the library
 
 BH_OK, BH_ERR_INVALID, BH_ERR_HIP, BH_ERR_CAPACITY, BH_ERR_NOMEM, BH_ERR_NUMERIC = 0, -1, -2, -3, -4, -5
 BH_MEM_HOST, BH_MEM_DEVICE = 0, 1

@@ -26,6 +26,7 @@ struct bh_level_geom {
     int   tabx_off, taby_off;        // offsets (in u32) into the resize coefficient table
     int   nsx_in, n_edge, nrb;       // blur: interior / edge 4-px strips per row, 16-row blocks
     int   bblk_base, eblk_base;      // blur: first workgroup of the level in the interior / edge launch
+    int   list_off, list_cap;        // corner list of the level inside one frame's list block (entries of 8 B)
 };
 
 struct bh_orb_geom {
@@ -35,6 +36,7 @@ struct bh_orb_geom {
     int fast_thr, edge_thr;
     int tab_len;
     int bblk_total, eblk_total;
+    int list_stride;                 // corner-list entries per frame (all levels)
     bh_level_geom lv[BH_MAX_LEVELS];
 };
 
@@ -44,7 +46,7 @@ enum bh_kid { BH_K_GRAY = 0, BH_K_PYR, BH_K_FAST, BH_K_BLUR, BH_K_SELECT, BH_K_B
 
 struct bh_time_rec { int kid; hipEvent_t e0, e1; };
 
-struct bh_orb_ws { bh_buf pyr, mpyr, nms, blur, hist, sel_xy, sel_resp, sel_cnt; };   // one chunk pipeline's workspace
+struct bh_orb_ws { bh_buf pyr, mpyr, clist, blur, hist, sel_xy, sel_resp, sel_cnt; };   // one chunk pipeline's workspace
 
 struct bh_ctx {
     int         device = 0;

@@ -17,7 +17,9 @@
 #include <math.h>
 #include <float.h>
 
-#define TILE_W 64
+#ifndef TILE_W
+#define TILE_W 128
+#endif
 #define TILE_H 32
 
 // ------------------------------------------------------------------------------------------------ geometry (host)
@@ -40,7 +42,7 @@ static int build_geom(const bh_orb_params* p, int H, int W, bh_orb_geom* g)
     float factor = (float)(1.0 / p->scaleFactor);
     float nd = p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)p->nlevels));
     int sum = 0;
-    int off = 0, tiles = 0, tab = 0, bblk = 0, eblk = 0;
+    int off = 0, tiles = 0, tab = 0, bblk = 0, eblk = 0, lst = 0;
     for (int l = 0; l < p->nlevels; l++) {
         bh_level_geom& L = g->lv[l];
         L.scale = (float)pow((double)p->scaleFactor, (double)l);
@@ -58,11 +60,14 @@ static int build_geom(const bh_orb_params* p, int H, int W, bh_orb_geom* g)
         L.nrb = (L.h + 15) / 16;
         L.bblk_base = bblk; bblk += (L.nsx_in * L.nrb + 255) / 256;
         L.eblk_base = eblk; eblk += (L.n_edge * L.nrb + 255) / 256;
+        // strict 3x3 maxima: at most one per 2x2 block in theory; w*h/8 entries leave a wide margin over any real image (overflow is flagged)
+        L.list_off = lst; L.list_cap = align_up((L.w * L.h + 7) / 8, 8); lst += L.list_cap;
         L.tabx_off = tab; tab += align_up(L.w, 4);
         L.taby_off = tab; tab += align_up(L.h, 4);
         if (l < p->nlevels - 1) { L.nfeat = round_even_f(nd); sum += L.nfeat; nd *= factor; }
         else L.nfeat = p->nfeatures - sum > 0 ? p->nfeatures - sum : 0;
     }
+    g->list_stride = lst;
     g->pyr_stride = off; g->ntiles = tiles; g->tab_len = tab; g->bblk_total = bblk; g->eblk_total = eblk;
     return BH_OK;
 }
@@ -239,115 +244,146 @@ __device__ __forceinline__ int tile_level(const bh_orb_geom& g, int tile)
 }
 
 // ------------------------------------------------------------------------------------------------ FAST-9/16 + NMS
-#define FPX_W (TILE_W + 8)      // pixel tile: x0-4 .. x0+67  (18 words)
-#define FPX_H (TILE_H + 8)      //             y0-4 .. y0+35
-#define FSC_W (TILE_W + 2)      // score tile: x0-1 .. x0+64
+// Tile = 128 x 32 pixels.  LDS pixel tile: rows y0-4 .. y0+35, pixels x0-4 .. x0+131 as 34 aligned words per row, stored with a
+// pitch of 36 words (one pad word on either side, so word+-1 never leaves the row).  The score tile (rows y0-1 .. y0+32) has the
+// same word geometry, so one index serves both: item i = score row * 36 + word, its pixel row starts 3 rows further down.
+#define FPX_H (TILE_H + 8)
+#define FRW   (TILE_W / 4 + 2)  // real words per row (34)
+#define FPW   (FRW + 2)         // LDS pitch in words (36)
 #define FSC_H (TILE_H + 2)
-#define FSC_P 72                // score-tile row pitch; tile column sx lives at byte sx+3 so output words are aligned
-#define FRG   12                // rows per lane in the sliding column pass (3 row groups x 66 columns)
+#define FROW  (4 * FPW)         // bytes per LDS row (144)
+#define FITEMS (FSC_H * FPW)    // 1224 (item, word) pairs of the score tile
 
 typedef short fs2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ fs2 fswap(fs2 a) { return fs2{ a.y, a.x }; }
-
-__device__ __forceinline__ uint32_t contig9(uint32_t m)
+__device__ __forceinline__ fs2 fmn(fs2 a, fs2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ fs2 fmx(fs2 a, fs2 b) { return __builtin_elementwise_max(a, b); }
+// LDS fetch-add issued as ONE ds_add_rtn_u32 for all active lanes (the hardware serialises lanes that hit the same address).  The
+// compiler's atomic optimiser would turn a divergent-value atomicAdd into a scalar loop over the active lanes (~8 SALU each).
+__device__ __forceinline__ int lds_add_rtn(int* p, int v)
 {
-    m |= m << 16;
-    uint32_t a = m & (m >> 1);
-    a &= a >> 2;
-    a &= a >> 4;
-    a &= m >> 8;
-    return a & 0xffffu;
+    int old;
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int*)p;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(a), "v"(v) : "memory");
+    return old;
 }
+__device__ __forceinline__ fs2 fpk(uint32_t hi_src, uint32_t lo_src, uint32_t sel) { return __builtin_bit_cast(fs2, __builtin_amdgcn_perm(hi_src, lo_src, sel)); }
 
-// One workgroup per 64x32 tile.  Each lane issues its 3 pixel-word loads and its 2 mask-word loads up front (the mask
-// words belong to the two output words the lane stores in phase 3), so no phase waits on a second global round trip.
+// One workgroup per 128x32 tile of one pyramid level of one frame.
+//   phase 1  the reference detector's opposite-pair pretest (a 9-arc contains ring pixel k or k+8, so both pairs (0,8) and (4,12)
+//            must hold a darker -- or both a brighter -- pixel) on FOUR adjacent pixels per lane: the five operands (centre, up, down,
+//            left, right) come from aligned LDS words through v_perm into packed 16-bit lanes, v_pk_min/max/add/sub_i16 do two pixels
+//            per instruction, the sign bits are the verdict.  All 256 lanes; survivors (a few %) go to an LDS list.
+//   phase 2  full 16-pixel ring on the survivors: score = largest threshold at which the pixel is still a corner, by a packed
+//            doubling min/max tree over the 16 arcs; corners write their score into a sparse LDS score tile.
+//   phase 3  the same list again: strict 3x3 NMS against the score tile, border and mask filter; kept corners are appended to the
+//            level's corner list in HBM (one reservation per tile) and counted in the score histogram.  No dense score map exists.
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ mpyr,
-                                              uint8_t* __restrict__ nms, uint32_t* __restrict__ hist, bh_orb_geom g)
+                                              uint2* __restrict__ clist, int* __restrict__ ccnt, uint32_t* __restrict__ hist,
+                                              bh_orb_geom g, const uint32_t* __restrict__ tile_tab, uint32_t* __restrict__ status)
 {
-    __shared__ uint32_t s_px[(FPX_H + 2) * (FPX_W / 4)];        // +2 rows: the last row group reads past the tile (results unused)
-    __shared__ uint32_t s_scw[FSC_H * (FSC_P / 4)];
-    __shared__ uint16_t s_list[FSC_H * FSC_W];
+    __shared__ uint32_t s_px[FPX_H * FPW];
+    __shared__ uint32_t s_scw[FITEMS];
+    __shared__ uint16_t s_list[4 * FITEMS];
     __shared__ uint32_t s_hist[256];
-    __shared__ int s_n;
+    __shared__ uint32_t s_vm[FPW];
+    __shared__ int s_n, s_k, s_base;
 
     const int tid = threadIdx.x;
-    const int level = tile_level(g, blockIdx.x);
+    const uint32_t tt = tile_tab[blockIdx.x];                   // level | tile column << 4 | tile row << 16 (host-built: no per-wave level search / division)
+    const int level = tt & 15;
     const bh_level_geom L = g.lv[level];
-    const int t = blockIdx.x - L.tile_base;
-    const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
-    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
+    const int x0 = (int)((tt >> 4) & 0xfffu) * TILE_W, y0 = (int)(tt >> 16) * TILE_H;
     const int frame = blockIdx.y;
     const size_t fbase = (size_t)frame * g.pyr_stride + L.off;
     const uint8_t* img = pyr + fbase;
 
-    uint32_t pw[3], cm[2];
+    constexpr int NLD = (FPX_H * FRW + 255) / 256;
+    uint32_t pw[NLD];
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
+    for (int j = 0; j < NLD; j++) {
         const int i = tid + 256 * j;
-        const int r = i / (FPX_W / 4), c = i - r * (FPX_W / 4);
+        const int r = i / FRW, c = i - r * FRW;
         const int y = y0 - 4 + r, x = x0 - 4 + c * 4;
-        uint32_t v = 0;                                          // outside the image -> 0 (never used by a valid pixel)
-        if (i < FPX_H * (FPX_W / 4) && y >= 0 && y < L.h && x >= 0 && x < L.pitch)
+        uint32_t v = 0;                                          // outside the image -> 0 (never used by a scored pixel)
+        if (i < FPX_H * FRW && y >= 0 && y < L.h && x >= 0 && x < L.pitch)
             v = *reinterpret_cast<const uint32_t*>(img + (size_t)y * L.pitch + x);
         pw[j] = v;
     }
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int wd = tid + 256 * j;
-        const int y = y0 + (wd >> 4), x = x0 + ((wd & 15) << 2);
-        uint32_t m = 0xffffffffu;
-        if (mpyr) m = y < L.h ? *reinterpret_cast<const uint32_t*>(mpyr + fbase + (size_t)y * L.pitch + x) : 0u;
-        cm[j] = m;
-    }
+    const int thr = g.fast_thr, et = g.edge_thr;
+    // Only pixels that can survive the border filter, or suppress a survivor in the 3x3 NMS, need a score:
+    // [et-1, dim-et] intersected with the detector's own scan range [3, dim-4], and the tile's score columns x0-1 .. x0+128.
+    const int xlo = max(max(3, et - 1), x0 - 1), xhi = min(min(L.w - 4, L.w - et), x0 + TILE_W);
+    const int ylo = max(3, et - 1), yhi = min(L.h - 4, L.h - et);
     s_hist[tid] = 0;
-    if (tid == 0) s_n = 0;
-    for (int i = tid; i < FSC_H * (FSC_P / 4); i += 256) s_scw[i] = 0;
+    if (tid == 0) { s_n = 0; s_k = 0; }
+    if (tid < FPW) {                                             // per tile word: 0x80 in the bytes whose pixel is in [xlo, xhi]; pads 0
+        const int xb = x0 - 8 + 4 * tid;
+        const int lo = min(max(xlo - xb, 0), 4), hi = min(max(xhi - xb + 1, 0), 4);
+        s_vm[tid] = (tid >= 1 && tid <= FRW) ? (uint32_t)((0x80808080ull << (8 * lo)) & (0x80808080ull >> (8 * (4 - hi)))) : 0u;
+    }
+    for (int i = tid; i < FITEMS; i += 256) s_scw[i] = 0;
 #pragma unroll
-    for (int j = 0; j < 3; j++) { const int i = tid + 256 * j; if (i < FPX_H * (FPX_W / 4)) s_px[i] = pw[j]; }
-    const uint32_t cm0 = cm[0], cm1 = cm[1];
+    for (int j = 0; j < NLD; j++) {
+        const int i = tid + 256 * j;
+        const int r = i / FRW, c = i - r * FRW;
+        if (i < FPX_H * FRW) s_px[r * FPW + 1 + c] = pw[j];
+    }
     __syncthreads();
 
     const uint8_t* px = reinterpret_cast<const uint8_t*>(s_px);
     uint8_t* s_sc = reinterpret_cast<uint8_t*>(s_scw);
-    const int thr = g.fast_thr, et = g.edge_thr;
-    // Only pixels that can survive the border filter, or suppress a survivor in the 3x3 NMS, need a score:
-    // [et-1, dim-et] intersected with the detector's own scan range [3, dim-4].
-    const int xlo = max(3, et - 1), xhi = min(L.w - 4, L.w - et), ylo = max(3, et - 1), yhi = min(L.h - 4, L.h - et);
-    // phase 1: cheap necessary test (opposite-pair rule of the reference detector: a 9-arc contains ring pixel k or k+8,
-    // so both pairs (0,8) and (4,12) must hold a darker -- or both a brighter -- pixel).  Branch-free, one lane walks
-    // 12 rows of one column with a 7-deep register window; survivors (a few %) go to an LDS list.
-    if (tid < 3 * FSC_W) {
-        const int rg = tid / FSC_W, col = tid - rg * FSC_W;
-        const int x = x0 - 1 + col;
-        const bool xok = x >= xlo && x <= xhi;
-        const uint8_t* cp = px + (rg * FRG) * FPX_W + (col + 3);        // px row of score row sy, ring row -3
-        int a0 = cp[0], a1 = cp[FPX_W], a2 = cp[2 * FPX_W], a3 = cp[3 * FPX_W], a4 = cp[4 * FPX_W], a5 = cp[5 * FPX_W];
+    // ---- phase 1
+    {
+        const fs2 T = fs2{ (short)thr, (short)thr };
 #pragma unroll
-        for (int r = 0; r < FRG; r++) {
-            const int sy = rg * FRG + r, y = y0 - 1 + sy;
-            const int a6 = cp[(r + 6) * FPX_W];
-            const int p4 = cp[(r + 3) * FPX_W + 3], p12 = cp[(r + 3) * FPX_W - 3];
-            const int v = a3, lo = v - thr, hi = v + thr;
-            const int dk = max(min(a6, a0), min(p4, p12)), br = min(max(a6, a0), max(p4, p12));
-            const bool pass = xok && sy < FSC_H && y >= ylo && y <= yhi && ((dk < lo) | (br > hi));
-            if (pass) s_list[atomicAdd(&s_n, 1)] = (uint16_t)(sy * FSC_W + col);
-            a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = a5; a5 = a6;
+        for (int it = 0; it < (FITEMS + 255) / 256; it++) {
+            const int i = tid + 256 * it;
+            const int sy = i / FPW, w = i - sy * FPW;
+            const int y = y0 - 1 + sy;
+            const uint32_t vm = (sy < FSC_H && y >= ylo && y <= yhi) ? s_vm[w] : 0u;
+            const uint32_t* cw = s_px + min(i, FITEMS - 1) + 3 * FPW;
+            const uint32_t W0 = cw[0], Wm = cw[-1], Wp = cw[1], U = cw[-3 * FPW], D = cw[3 * FPW];
+            // packed 16-bit operand pairs: pixels (0,1) and (2,3) of the word; left = pixel - 3, right = pixel + 3
+            const fs2 C0 = fpk(0, W0, 0x0c010c00u), C1 = fpk(0, W0, 0x0c030c02u);
+            const fs2 U0 = fpk(0, U, 0x0c010c00u), U1 = fpk(0, U, 0x0c030c02u);
+            const fs2 D0 = fpk(0, D, 0x0c010c00u), D1 = fpk(0, D, 0x0c030c02u);
+            const fs2 L0 = fpk(0, Wm, 0x0c020c01u), L1 = fpk(W0, Wm, 0x0c040c03u);
+            const fs2 R0 = fpk(Wp, W0, 0x0c040c03u), R1 = fpk(0, Wp, 0x0c020c01u);
+            const fs2 dk0 = fmx(fmn(D0, U0), fmn(R0, L0)), br0 = fmn(fmx(D0, U0), fmx(R0, L0));
+            const fs2 dk1 = fmx(fmn(D1, U1), fmn(R1, L1)), br1 = fmn(fmx(D1, U1), fmx(R1, L1));
+            const fs2 m0 = ((dk0 + T) - C0) | ((C0 + T) - br0);    // negative <=> darker pair below v - thr, or brighter pair above v + thr
+            const fs2 m1 = ((dk1 + T) - C1) | ((C1 + T) - br1);
+            uint32_t P = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, m1), __builtin_bit_cast(uint32_t, m0), 0x07050301u) & vm;
+            if (P) {
+                int pos = lds_add_rtn(&s_n, __popc(P));              // same-address LDS atomic from the few lanes that have survivors
+#ifdef FAST_APPEND_LOOP
+                do {                                                 // 1.1 survivors per non-empty word on average
+                    const int k = (__ffs(P) - 1) >> 3;
+                    s_list[pos++] = (uint16_t)(4 * i + k);           // byte index into the score tile
+                    P &= P - 1;
+                } while (P);
+#else
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (P & (0x80u << (8 * k))) s_list[pos++] = (uint16_t)(4 * i + k);   // byte index into the score tile
+#endif
+            }
         }
     }
     __syncthreads();
-    // phase 2: full 16-pixel ring test on the survivors; corners get their score (largest threshold at which the pixel
-    // is still a corner) by a doubling min/max tree over the 16 arcs
+    // ---- phase 2
     const int n = s_n;
-    for (int j = tid; j < n; j += 256) {
-        const int i = s_list[j];
-        const int sy = i / FSC_W, sx = i - sy * FSC_W;
-        const uint8_t* c = px + (sy + 3) * FPX_W + (sx + 3);
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + tid;
+        if (j >= n) continue;
+        const int b = s_list[j];
+        const uint8_t* c = px + b + 3 * FROW;
         const int v = c[0];
         int d[16];
-        d[0] = v - c[3 * FPX_W];       d[1] = v - c[3 * FPX_W + 1];   d[2] = v - c[2 * FPX_W + 2];   d[3] = v - c[FPX_W + 3];
-        d[4] = v - c[3];               d[5] = v - c[-FPX_W + 3];      d[6] = v - c[-2 * FPX_W + 2];  d[7] = v - c[-3 * FPX_W + 1];
-        d[8] = v - c[-3 * FPX_W];      d[9] = v - c[-3 * FPX_W - 1];  d[10] = v - c[-2 * FPX_W - 2]; d[11] = v - c[-FPX_W - 3];
-        d[12] = v - c[-3];             d[13] = v - c[FPX_W - 3];      d[14] = v - c[2 * FPX_W - 2];  d[15] = v - c[3 * FPX_W - 1];
+        d[0] = v - c[3 * FROW];       d[1] = v - c[3 * FROW + 1];   d[2] = v - c[2 * FROW + 2];   d[3] = v - c[FROW + 3];
+        d[4] = v - c[3];              d[5] = v - c[-FROW + 3];      d[6] = v - c[-2 * FROW + 2];  d[7] = v - c[-3 * FROW + 1];
+        d[8] = v - c[-3 * FROW];      d[9] = v - c[-3 * FROW - 1];  d[10] = v - c[-2 * FROW - 2]; d[11] = v - c[-FROW - 3];
+        d[12] = v - c[-3];            d[13] = v - c[FROW - 3];      d[14] = v - c[2 * FROW - 2];  d[15] = v - c[3 * FROW - 1];
         // Packed 16-bit lanes: P[k] = (d[k], d[k+8]); the ring rotated by j is P[k+j], with P[8+i] = swap(P[i]).
         // A = max over the 16 arcs of min(d over 9 ring pixels), Bn = min over arcs of max(d): the pixel is a corner iff
         // A > thr or -Bn > thr, and its score (cornerScore<16>) is max(thr, A, -Bn) - 1.
@@ -355,55 +391,63 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
 #pragma unroll
         for (int k = 0; k < 8; k++) P[k] = fs2{ (short)d[k], (short)d[k + 8] };
 #pragma unroll
-        for (int k = 0; k < 8; k++) { const fs2 nx = k < 7 ? P[k + 1] : fswap(P[0]); mn[k] = __builtin_elementwise_min(P[k], nx); mx[k] = __builtin_elementwise_max(P[k], nx); }
+        for (int k = 0; k < 8; k++) { const fs2 nx = k < 7 ? P[k + 1] : fswap(P[0]); mn[k] = fmn(P[k], nx); mx[k] = fmx(P[k], nx); }
 #pragma unroll
-        for (int k = 0; k < 8; k++) { t0[k] = __builtin_elementwise_min(mn[k], k < 6 ? mn[k + 2] : fswap(mn[k - 6])); t1[k] = __builtin_elementwise_max(mx[k], k < 6 ? mx[k + 2] : fswap(mx[k - 6])); }
+        for (int k = 0; k < 8; k++) { t0[k] = fmn(mn[k], k < 6 ? mn[k + 2] : fswap(mn[k - 6])); t1[k] = fmx(mx[k], k < 6 ? mx[k + 2] : fswap(mx[k - 6])); }
 #pragma unroll
-        for (int k = 0; k < 8; k++) { mn[k] = __builtin_elementwise_min(t0[k], k < 4 ? t0[k + 4] : fswap(t0[k - 4])); mx[k] = __builtin_elementwise_max(t1[k], k < 4 ? t1[k + 4] : fswap(t1[k - 4])); }
+        for (int k = 0; k < 8; k++) { mn[k] = fmn(t0[k], k < 4 ? t0[k + 4] : fswap(t0[k - 4])); mx[k] = fmx(t1[k], k < 4 ? t1[k + 4] : fswap(t1[k - 4])); }
         fs2 am = fs2{ -32768, -32768 }, bm2 = fs2{ 32767, 32767 };
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const fs2 ninth = fswap(P[k]);                       // (d[k+8], d[k+16]) closes the 9-arc
-            am = __builtin_elementwise_max(am, __builtin_elementwise_min(mn[k], ninth));
-            bm2 = __builtin_elementwise_min(bm2, __builtin_elementwise_max(mx[k], ninth));
+            am = fmx(am, fmn(mn[k], ninth));
+            bm2 = fmn(bm2, fmx(mx[k], ninth));
         }
         const int A = max((int)am.x, (int)am.y), Bn = min((int)bm2.x, (int)bm2.y);
         if (!(A > thr || -Bn > thr)) continue;
         const int a0 = max(thr, A);
         const int b0 = min(Bn, -a0);
-        s_sc[sy * FSC_P + sx + 3] = (uint8_t)(-b0 - 1);
+        s_sc[b] = (uint8_t)(-b0 - 1);
     }
     __syncthreads();
-    // phase 3: strict 3x3 NMS, mask and border filter, dense score-map store (4 px per lane) + histogram
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int wd = tid + 256 * j;
-        const int oy = wd >> 4, ox = (wd & 15) << 2;
-        const int y = y0 + oy;
-        if (y >= L.h) continue;
-        const uint32_t cm = j == 0 ? cm0 : cm1;
-        uint32_t out = 0;
-        const uint32_t sc4 = s_scw[(oy + 1) * (FSC_P / 4) + (ox >> 2) + 1];        // tile columns ox+1 .. ox+4
-        if (sc4) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int sc = (sc4 >> (8 * i)) & 255;
-                if (sc == 0) continue;
-                const int x = x0 + ox + i;
-                const uint8_t* q = s_sc + (oy + 1) * FSC_P + (ox + i + 4);
-                const bool keep = sc > q[-1] && sc > q[1] && sc > q[-FSC_P - 1] && sc > q[-FSC_P] && sc > q[-FSC_P + 1] &&
-                                  sc > q[FSC_P - 1] && sc > q[FSC_P] && sc > q[FSC_P + 1];
-                if (!keep) continue;
-                if (!(x >= et && x < L.w - et && y >= et && y < L.h - et)) continue;
-                if (((cm >> (8 * i)) & 255u) == 0) continue;
-                out |= (uint32_t)sc << (8 * i);
-                atomicAdd(&s_hist[sc], 1u);
-            }
+    // ---- phase 3: kept corners are staged in LDS (the pixel tile is dead by now and lends its space), then the tile reserves its
+    // range of the level's corner list with ONE global atomic (a returning atomic per wave was measured 35 % slower: every wave
+    // then waits out an L2 round trip on a counter all tiles of the level contend for)
+    uint32_t* s_out = s_px;                                      // (score << 24) | (score-tile byte index): up to TILE_W * TILE_H / 4 entries
+    for (int j = tid; j < n; j += 256) {
+        const int b = s_list[j];
+        const int sc = s_sc[b];
+        if (sc == 0) continue;
+        const int sy = b / FROW, xb = b - sy * FROW;
+        if (sy < 1 || sy > TILE_H || xb < 8 || xb >= 8 + TILE_W) continue;            // halo positions belong to the neighbour tiles
+        const int x = x0 - 8 + xb, y = y0 - 1 + sy;
+        if (!(x >= et && x < L.w - et && y >= et && y < L.h - et)) continue;
+        const uint8_t* q = s_sc + b;
+        const bool keep = sc > q[-1] && sc > q[1] && sc > q[-FROW - 1] && sc > q[-FROW] && sc > q[-FROW + 1] &&
+                          sc > q[FROW - 1] && sc > q[FROW] && sc > q[FROW + 1];
+        if (!keep) continue;
+        if (mpyr && mpyr[fbase + (size_t)y * L.pitch + x] == 0) continue;
+        const int k = atomicAdd(&s_k, 1);
+        s_out[k] = ((uint32_t)sc << 24) | (uint32_t)b;
+        atomicAdd(&s_hist[sc], 1u);
+    }
+    __syncthreads();
+    const int kk = s_k;
+    const size_t lv = (size_t)frame * g.nlevels + level;
+    if (tid == 0 && kk) s_base = atomicAdd(&ccnt[lv], kk);
+    if (s_hist[tid]) atomicAdd(&hist[lv * 256 + tid], s_hist[tid]);
+    __syncthreads();
+    if (kk) {
+        const int base = s_base;
+        uint2* dst = clist + (size_t)frame * g.list_stride + L.list_off;
+        for (int i = tid; i < kk; i += 256) {
+            const uint32_t e = s_out[i];
+            const int b = e & 0xffffffu, sy = b / FROW, xb = b - sy * FROW;
+            const uint32_t x = (uint32_t)(x0 - 8 + xb), y = (uint32_t)(y0 - 1 + sy);
+            if (base + i < L.list_cap) dst[base + i] = make_uint2((y << 16) | x, e >> 24);
+            else atomicOr(status, BH_ST_CAND_OVERFLOW);
         }
-        *reinterpret_cast<uint32_t*>(nms + fbase + (size_t)y * L.pitch + x0 + ox) = out;
     }
-    __syncthreads();
-    if (s_hist[tid]) atomicAdd(&hist[((size_t)frame * g.nlevels + level) * 256 + tid], s_hist[tid]);
 }
 
 // ------------------------------------------------------------------------------------------------ 7x7 Gaussian blur
@@ -542,21 +586,20 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
-// One workgroup per (level, frame).  Output: the level's kept candidates in raster order in a staging slot
-// sel_xy/sel_resp[frame][level][sel_cap] + sel_cnt[frame][level]; k_describe turns slots into final keypoints.
-__global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ nms,
-                                                  const uint32_t* __restrict__ hist, bh_orb_geom g, int sel_cap,
-                                                  uint32_t* __restrict__ sel_xy, float* __restrict__ sel_resp,
+// One workgroup per (level, frame).  Input: the level's corner list written by k_fast (unordered) and its score histogram.
+// Output: the level's kept keypoints in raster order in a staging slot sel_xy/sel_resp[frame][level][sel_cap] + sel_cnt[frame][level];
+// k_describe turns slots into final keypoints.
+__global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ pyr, const uint2* __restrict__ clist,
+                                                  const int* __restrict__ ccnt, const uint32_t* __restrict__ hist, bh_orb_geom g,
+                                                  int sel_cap, uint32_t* __restrict__ sel_xy, float* __restrict__ sel_resp,
                                                   int* __restrict__ sel_cnt, uint32_t* __restrict__ status)
 {
-    __shared__ uint32_t s_xy[CAND_CAP];
-    __shared__ float    s_resp[CAND_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_xy[CAND_CAP];
+    __shared__ __attribute__((aligned(16))) float    s_resp[CAND_CAP];
     __shared__ uint32_t s_hs[256];
-    __shared__ int s_wcnt[SEL_W];
-    __shared__ int s_thr;
-    __shared__ uint32_t s_vl[SEL_W * VL_CAP];
+    __shared__ int s_thr, s_m, s_kept;
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
     const int level = blockIdx.x;
     const size_t f = blockIdx.y;
     const size_t fb = f * g.pyr_stride;
@@ -564,7 +607,7 @@ __global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ py
     const int n2 = 2 * L.nfeat;
     // (a) retainBest(2 n_l) threshold on the u8 FAST score: largest s with #(score >= s) >= 2 n_l
     if (tid < 256) s_hs[tid] = hist[(f * g.nlevels + level) * 256 + tid];
-    if (tid == 0) s_thr = 1;
+    if (tid == 0) { s_thr = 1; s_m = 0; s_kept = 0; }
     __syncthreads();
     if (tid >= 1 && tid < 256) {
         uint32_t suf = 0;
@@ -574,65 +617,17 @@ __global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ py
     }
     __syncthreads();
     const uint32_t thr = n2 > 0 ? (uint32_t)s_thr : 256u;
-    // (b) pass A: each wave scans its contiguous slice of the score map ONCE, 8 independent 16-B loads in flight per lane; it counts
-    // the kept candidates and records, in raster order, which 16-B vectors hold any (the map is mostly zeros: a level has a few
-    // hundred non-empty vectors out of up to 19 200)
-    const uint4* map = reinterpret_cast<const uint4*>(nms + fb + L.off);
-    const int nvec = (L.pitch * L.h) >> 4;
-    const int seg = (nvec + SEL_W - 1) / SEL_W;
-    const int v0 = wv * seg, v1 = min(v0 + seg, nvec);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t* vl = s_vl + wv * VL_CAP;
-    int cnt = 0, nl = 0;
-    for (int vb = v0; vb < v1; vb += 512) {
-        uint4 q[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const int v = vb + u * 64 + lane; q[u] = v < v1 ? map[v] : make_uint4(0, 0, 0, 0); }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            int c = 0;
-            if (q[u].x | q[u].y | q[u].z | q[u].w) c = count_ge(q[u].x, thr) + count_ge(q[u].y, thr) + count_ge(q[u].z, thr) + count_ge(q[u].w, thr);
-            const unsigned long long m = __ballot(c != 0);
-            if (m == 0ull) continue;
-            const int pos = nl + __popcll(m & lt_mask);
-            if (c && pos < VL_CAP) vl[pos] = (uint32_t)(vb + u * 64 + lane);
-            nl += __popcll(m);
-            cnt += c;
-        }
+    // (b) the corners at or above the threshold (ties at the cut all kept), in whatever order the list has them
+    const uint2* lst = clist + f * (size_t)g.list_stride + L.list_off;
+    const int nc = min(ccnt[f * g.nlevels + level], L.list_cap);
+    for (int i = tid; i < nc; i += SEL_T) {
+        const uint2 r = lst[i];
+        if (r.y >= thr) { const int pos = atomicAdd(&s_m, 1); if (pos < CAND_CAP) s_xy[pos] = r.x; }
     }
-    cnt = wave_sum(cnt);
-    if (lane == 0) s_wcnt[wv] = cnt;
     __syncthreads();
-    int base = 0, total = 0;
-    for (int i = 0; i < SEL_W; i++) { const int c = s_wcnt[i]; if (i < wv) base += c; total += c; }
-    // (c) pass B: emit (x,y) in raster order - from the recorded vectors, or by a second scan if a wave's record overflowed
-    const bool listed = nl <= VL_CAP;
-    const int nb = listed ? (nl + 63) & ~63 : ((v1 - v0 + 63) & ~63);
-    for (int i = 0; i < nb; i += 64) {
-        int v = -1;
-        if (listed) { if (i + lane < nl) v = (int)vl[i + lane]; }
-        else if (v0 + i + lane < v1) v = v0 + i + lane;
-        const uint4 q = v >= 0 ? map[v] : make_uint4(0, 0, 0, 0);
-        const uint32_t wds[4] = { q.x, q.y, q.z, q.w };
-        int c = 0;
-        if (q.x | q.y | q.z | q.w) c = count_ge(q.x, thr) + count_ge(q.y, thr) + count_ge(q.z, thr) + count_ge(q.w, thr);
-        if (__ballot(c != 0) == 0ull) continue;
-        int pos = base + wave_excl_scan(c, lane);
-        base += wave_sum(c);
-        if (c) {
-            const int byte0 = v << 4;
-            const int y = byte0 / L.pitch, xb = byte0 - y * L.pitch;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t sc = (wds[k >> 2] >> (8 * (k & 3))) & 255u;
-                if (sc >= thr) { if (pos < CAND_CAP) s_xy[pos] = ((uint32_t)y << 16) | (uint32_t)(xb + k); pos++; }
-            }
-        }
-    }
-    if (total > CAND_CAP) { if (tid == 0) atomicOr(status, BH_ST_CAND_OVERFLOW); total = CAND_CAP; }
-    __syncthreads();
-    const int m = total;
-    // (d) Harris response, 7x7 block of 3x3 Sobel products
+    int m = s_m;
+    if (m > CAND_CAP) { if (tid == 0) atomicOr(status, BH_ST_CAND_OVERFLOW); m = CAND_CAP; }
+    // (c) Harris response, 7x7 block of 3x3 Sobel products
     const uint8_t* img = pyr + fb + L.off;
     for (int i = tid; i < m; i += SEL_T) {
         const uint32_t xy = s_xy[i];
@@ -664,39 +659,42 @@ __global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ py
         s_resp[i] = ((t1 - t2) - t3) * scale_sq_sq;
     }
     __syncthreads();
-    // (e) retainBest(n_l): keep i iff fewer than n_l responses are strictly greater (ties at the cut all kept)
-    const int per = (m + SEL_T - 1) / SEL_T;          // consecutive entries per thread
-    const int i0 = tid * per;
-    int keep_mask = 0, kcnt = 0;
-    for (int e = 0; e < per; e++) {
-        const int i = i0 + e;
-        if (i >= m) break;
+    // (d) retainBest(n_l): keep i iff fewer than n_l responses are strictly greater (ties at the cut all kept).  The O(m^2) scans
+    // read the shared arrays four entries per ds_read_b128; the tail up to a multiple of 4 is padded so that it never counts.
+    const int m4 = (m + 3) & ~3;
+    for (int i = m + tid; i < m4; i += SEL_T) { s_resp[i] = -INFINITY; s_xy[i] = 0xffffffffu; }
+    __syncthreads();
+    for (int i = tid; i < m; i += SEL_T) {
         bool keep = true;
         if (m > L.nfeat) {
             const float r = s_resp[i];
             int rank = 0;
-            for (int j = 0; j < m; j++) rank += (s_resp[j] > r);
+            for (int j = 0; j < m4; j += 4) {
+                const float4 q = *reinterpret_cast<const float4*>(s_resp + j);
+                rank += (q.x > r) + (q.y > r) + (q.z > r) + (q.w > r);
+            }
             keep = rank < L.nfeat;
         }
-        if (keep) { keep_mask |= 1 << e; kcnt++; }
+        if (!keep) s_xy[i] = 0xffffffffu;                         // dropped entries sort behind every kept one (nobody else reads s_xy here)
+        if (keep) atomicAdd(&s_kept, 1);
     }
-    const int wpre = wave_excl_scan(kcnt, lane);
-    const int wtot = wave_sum(kcnt);
-    __syncthreads();                                   // s_wcnt reuse
-    if (lane == 0) s_wcnt[wv] = wtot;
     __syncthreads();
-    int kbase = 0, ktotal = 0;
-    for (int i = 0; i < SEL_W; i++) { const int c = s_wcnt[i]; if (i < wv) kbase += c; ktotal += c; }
-    int pos = kbase + wpre;
+    // (e) canonical order: a kept keypoint's slot is the number of kept keypoints before it in raster order ((y << 16) | x is the key)
     const size_t slot = (f * g.nlevels + level) * (size_t)sel_cap;
-    for (int e = 0; e < per; e++) {
-        if (!(keep_mask & (1 << e))) continue;
-        if (pos < sel_cap) { sel_xy[slot + pos] = s_xy[i0 + e]; sel_resp[slot + pos] = s_resp[i0 + e]; }
-        pos++;
+    for (int i = tid; i < m; i += SEL_T) {
+        const uint32_t key = s_xy[i];
+        if (key == 0xffffffffu) continue;
+        int pos = 0;
+        for (int j = 0; j < m4; j += 4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(s_xy + j);
+            pos += (q.x < key) + (q.y < key) + (q.z < key) + (q.w < key);
+        }
+        if (pos < sel_cap) { sel_xy[slot + pos] = key; sel_resp[slot + pos] = s_resp[i]; }
     }
     if (tid == 0) {
-        if (ktotal > sel_cap) { atomicOr(status, BH_ST_KP_OVERFLOW); ktotal = sel_cap; }
-        sel_cnt[f * g.nlevels + level] = ktotal;
+        int kt = s_kept;
+        if (kt > sel_cap) { atomicOr(status, BH_ST_KP_OVERFLOW); kt = sel_cap; }
+        sel_cnt[f * g.nlevels + level] = kt;
     }
 }
 
@@ -857,15 +855,18 @@ static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
         return BH_OK;
     bh_orb_geom g;
     if (build_geom(p, H, W, &g) != BH_OK) return bh_set_err(ctx, BH_ERR_INVALID, "unsupported ORB parameters / image size");
-    uint32_t* tab = (uint32_t*)calloc(g.tab_len + 4, sizeof(uint32_t));
+    uint32_t* tab = (uint32_t*)calloc(g.tab_len + 4 + g.ntiles, sizeof(uint32_t));
+    for (int l = 0; l < g.nlevels; l++)                          // tile table, after the coefficient table (offset tab_len + 4)
+        for (int t = 0; t < g.lv[l].tiles_x * g.lv[l].tiles_y; t++)
+            tab[g.tab_len + 4 + g.lv[l].tile_base + t] = (uint32_t)l | ((uint32_t)(t % g.lv[l].tiles_x) << 4) | ((uint32_t)(t / g.lv[l].tiles_x) << 16);
     for (int l = 1; l < g.nlevels; l++) {
         lin_coeffs(g.lv[l - 1].w, g.lv[l].w, tab + g.lv[l].tabx_off);
         for (int x = g.lv[l].w; x < align_up(g.lv[l].w, 4); x++) tab[g.lv[l].tabx_off + x] = tab[g.lv[l].tabx_off + g.lv[l].w - 1];
         lin_coeffs(g.lv[l - 1].h, g.lv[l].h, tab + g.lv[l].taby_off);
     }
-    int rc = bh_reserve(ctx, &ctx->tab, sizeof(uint32_t) * (g.tab_len + 4));
+    int rc = bh_reserve(ctx, &ctx->tab, sizeof(uint32_t) * (g.tab_len + 4 + g.ntiles));
     if (rc == BH_OK) {
-        hipError_t e = hipMemcpyAsync(ctx->tab.p, tab, sizeof(uint32_t) * g.tab_len, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = hipMemcpyAsync(ctx->tab.p, tab, sizeof(uint32_t) * (g.tab_len + 4 + g.ntiles), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = bh_set_err(ctx, BH_ERR_HIP, "coefficient table upload failed: %s", hipGetErrorString(e));
     }
@@ -926,9 +927,9 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         bh_orb_ws& Wk = ctx->ows[p];
         BH_TRY(bh_reserve(ctx, &Wk.pyr, ws + 256));             // +256: the 12-byte resize windows may read past the last row
         if (has_mask) BH_TRY(bh_reserve(ctx, &Wk.mpyr, ws + 256));
-        BH_TRY(bh_reserve(ctx, &Wk.nms, ws));
+        BH_TRY(bh_reserve(ctx, &Wk.clist, sizeof(uint2) * (size_t)g.list_stride * chunk));
         BH_TRY(bh_reserve(ctx, &Wk.blur, ws));
-        BH_TRY(bh_reserve(ctx, &Wk.hist, sizeof(uint32_t) * 256 * g.nlevels * chunk));
+        BH_TRY(bh_reserve(ctx, &Wk.hist, sizeof(uint32_t) * 257 * g.nlevels * chunk));      // histograms, then the corner counts
         BH_TRY(bh_reserve(ctx, &Wk.sel_xy, sizeof(uint32_t) * (size_t)sel_cap * g.nlevels * chunk));
         BH_TRY(bh_reserve(ctx, &Wk.sel_resp, sizeof(float) * (size_t)sel_cap * g.nlevels * chunk));
         BH_TRY(bh_reserve(ctx, &Wk.sel_cnt, sizeof(int) * (size_t)g.nlevels * chunk));
@@ -973,10 +974,11 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
             d_kps = kps + (size_t)f0 * max_kp; d_desc = desc + (size_t)f0 * max_kp * 32; d_nkp = n_kp + f0;
         }
         uint8_t* pyr = (uint8_t*)Wk.pyr.p; uint8_t* mpyr = has_mask ? (uint8_t*)Wk.mpyr.p : nullptr;
-        uint8_t* nms = (uint8_t*)Wk.nms.p; uint8_t* blur = (uint8_t*)Wk.blur.p;
+        uint2* clist = (uint2*)Wk.clist.p; uint8_t* blur = (uint8_t*)Wk.blur.p;
         uint32_t* hist = (uint32_t*)Wk.hist.p;
+        int* ccnt = (int*)(hist + (size_t)256 * g.nlevels * chunk);
 
-        BH_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * g.nlevels * nb, st));
+        BH_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(uint32_t) * 257 * g.nlevels * chunk, st));
         {
             const int n = (g.lv[0].pitch >> 2) * g.lv[0].h;
             BH_LAUNCH(ctx, BH_K_GRAY, k_gray_mask, dim3((n + 255) / 256, nb), dim3(256), st, d_img, channels, d_mask, d_depth,
@@ -986,10 +988,11 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
             const int n = (g.lv[l].pitch >> 2) * g.lv[l].h;
             BH_LAUNCH(ctx, BH_K_PYR, k_pyr_down, dim3((n + 255) / 256, nb), dim3(256), st, pyr, mpyr, g, l, (const uint32_t*)ctx->tab.p);
         }
-        BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, nms, hist, g);
+        BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, clist, ccnt, hist, g,
+                  (const uint32_t*)ctx->tab.p + g.tab_len + 4, (uint32_t*)ctx->status.p);
         BH_LAUNCH(ctx, BH_K_BLUR, k_blur<false>, dim3(g.bblk_total, nb), dim3(256), st, pyr, blur, g, G);
         BH_LAUNCH(ctx, BH_K_BLUR, k_blur<true>, dim3(g.eblk_total, nb), dim3(256), st, pyr, blur, g, G);
-        BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, nms, hist, g, sel_cap, (uint32_t*)Wk.sel_xy.p,
+        BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, clist, ccnt, hist, g, sel_cap, (uint32_t*)Wk.sel_xy.p,
                   (float*)Wk.sel_resp.p, (int*)Wk.sel_cnt.p, (uint32_t*)ctx->status.p);
         BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3((max_kp + 3) / 4, nb), dim3(256), st, pyr, blur, g, UM,
                   (float)params->patchSize, sel_cap, max_kp, (const uint32_t*)Wk.sel_xy.p, (const float*)Wk.sel_resp.p,
@@ -1021,7 +1024,25 @@ extern "C" int bh_orb_debug_fetch(bh_ctx* ctx, int frame, uint8_t* pyr, uint8_t*
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (pyr)  BH_HIP(ctx, hipMemcpy(pyr, (uint8_t*)Wk.pyr.p + o, n, hipMemcpyDeviceToHost));
     if (mask_pyr && ctx->last_has_mask) BH_HIP(ctx, hipMemcpy(mask_pyr, (uint8_t*)Wk.mpyr.p + o, n, hipMemcpyDeviceToHost));
-    if (nms)  BH_HIP(ctx, hipMemcpy(nms, (uint8_t*)Wk.nms.p + o, n, hipMemcpyDeviceToHost));
+    if (nms) {                                                   // the dense NMS score map no longer exists on the device: rebuild it from the corner lists
+        const bh_orb_geom& g = ctx->geom;
+        memset(nms, 0, n);
+        uint2* lst = (uint2*)malloc(sizeof(uint2) * (size_t)g.list_stride);
+        int cnt[BH_MAX_LEVELS];
+        const int* ccnt = (const int*)((const uint32_t*)Wk.hist.p + (size_t)256 * g.nlevels * ctx->ws_frames);
+        hipError_t e = hipMemcpy(lst, (uint2*)Wk.clist.p + (size_t)frame * g.list_stride, sizeof(uint2) * (size_t)g.list_stride, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(cnt, ccnt + (size_t)frame * g.nlevels, sizeof(int) * g.nlevels, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (int l = 0; l < g.nlevels; l++) {
+                const bh_level_geom& L = g.lv[l];
+                for (int i = 0; i < cnt[l] && i < L.list_cap; i++) {
+                    const uint2 r = lst[L.list_off + i];
+                    nms[L.off + (size_t)(r.x >> 16) * L.pitch + (r.x & 0xffffu)] = (uint8_t)r.y;
+                }
+            }
+        free(lst);
+        if (e != hipSuccess) return bh_set_err(ctx, BH_ERR_HIP, "bh_orb_debug_fetch: %s", hipGetErrorString(e));
+    }
     if (blur) BH_HIP(ctx, hipMemcpy(blur, (uint8_t*)Wk.blur.p + o, n, hipMemcpyDeviceToHost));
     return BH_OK;
 }

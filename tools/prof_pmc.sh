@@ -4,7 +4,7 @@
 #   bash tools/prof_pmc.sh <outdir-under-gpurun_out> [bench args...]
 set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
-ARGS=${@:---frames 256 --steps 2 --warmup 1 --no-ba --no-global-ba --cpu-sample 0 --pipelines 1}
+ARGS=${@:---frames 256 --steps 2 --warmup 1 --no-ba --no-global-ba --no-bow --no-inputs --cpu-sample 0 --pipelines 1}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
