@@ -289,7 +289,8 @@ def run_rank(args):
         # dominant kernel by summed hipEvent time; its own compulsory traffic per frame
         nf = args.nfeatures
         per_frame_bytes = {"k_gray_mask": 921600 + 614400 + 2 * 307200, "k_pyr_down": 2 * (926546 + 643332),
-                           "k_fast": 3 * 950532, "k_blur": 2 * 950532, "k_select": 950532 + 56 * nf,
+                           "k_fast": 2 * 950532 + 16 * nf,           # pyramid pixels in, blurred pyramid out, ~2 n corner records of 8 B
+                           "k_select": 16 * nf + 81 * 2 * nf + 8 * nf,   # corner records, the 9x9 Harris windows of ~2 n candidates, staging slots
                            "k_describe": 56 * nf + 2 * 950532, "k_match": 2 * 32 * nf + 12 * nf}
         dom = max(ktimes, key=lambda k: ktimes[k][0])
         dom_ms, dom_n = ktimes[dom]

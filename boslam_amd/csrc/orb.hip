@@ -146,11 +146,14 @@ __global__ __launch_bounds__(256) void k_gray_mask(const uint8_t* __restrict__ i
 // reference fit one 8-byte window starting at the first column, so each of the two source rows is ONE (unaligned) 8-byte
 // load per plane (image, mask) — 6 loads per lane, all issued before the first use — and the byte pairs are picked with a
 // 64-bit shift instead of 16 single-byte loads per plane.
-__device__ __forceinline__ unsigned long long pyr_load8(const uint8_t* p)
-{   // 8 bytes from a byte-aligned address (global memory tolerates unaligned dword accesses on gfx9)
-    unsigned long long v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
+__device__ __forceinline__ unsigned long long pyr_load8(const uint8_t* __restrict__ base, size_t off)
+{   // 8 bytes from byte offset `off` of a 4-byte-aligned buffer as ONE aligned 12-byte load (global_load_dwordx3) + a funnel shift:
+    // an unaligned 8-byte request is split by the memory pipeline, which is what bounded this kernel (measured)
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(base + (off & ~(size_t)3));
+    const uint32_t sh = ((uint32_t)off & 3u) << 3;
+    const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, uint8_t* __restrict__ mpyr,
@@ -176,9 +179,9 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, uin
     // the 4 outputs reference source columns a0 .. a0+5 (scale <= 1.3): one 8-byte window per source row and plane
     const int base = (int)(tx4.x >> 16);
     const size_t s0 = fb + S.off + (size_t)r0 * S.pitch + base, s1 = fb + S.off + (size_t)r1 * S.pitch + base;
-    const unsigned long long A = pyr_load8(pyr + s0), Bv = pyr_load8(pyr + s1);
+    const unsigned long long A = pyr_load8(pyr, s0), Bv = pyr_load8(pyr, s1);
     unsigned long long MA = 0, MB = 0;
-    if (mpyr) { MA = pyr_load8(mpyr + s0); MB = pyr_load8(mpyr + s1); }
+    if (mpyr) { MA = pyr_load8(mpyr, s0); MB = pyr_load8(mpyr, s1); }
     uint32_t o4 = 0, mo4 = 0;
     if (mpyr) {
         // image and mask ride in the two 16-bit halves of one register through the horizontal pass: (p0 << 8) + c1*(p1 - p0) stays
@@ -243,7 +246,15 @@ __device__ __forceinline__ int tile_level(const bh_orb_geom& g, int tile)
     return l;
 }
 
-// ------------------------------------------------------------------------------------------------ FAST-9/16 + NMS
+// ------------------------------------------------------------------------------------------------ FAST-9/16 + NMS + 7x7 blur
+struct bh_gauss7 { int k[7]; };
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (i < 0) i = -i; else if (i >= n) i = 2 * (n - 1) - i;
+    return min(max(i, 0), n - 1);
+}
+
 // Tile = 128 x 32 pixels.  LDS pixel tile: rows y0-4 .. y0+35, pixels x0-4 .. x0+131 as 34 aligned words per row, stored with a
 // pitch of 36 words (one pad word on either side, so word+-1 never leaves the row).  The score tile (rows y0-1 .. y0+32) has the
 // same word geometry, so one index serves both: item i = score row * 36 + word, its pixel row starts 3 rows further down.
@@ -280,6 +291,7 @@ __device__ __forceinline__ fs2 fpk(uint32_t hi_src, uint32_t lo_src, uint32_t se
 //            level's corner list in HBM (one reservation per tile) and counted in the score histogram.  No dense score map exists.
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ mpyr,
                                               uint2* __restrict__ clist, int* __restrict__ ccnt, uint32_t* __restrict__ hist,
+                                              uint8_t* __restrict__ blur, bh_gauss7 G,
                                               bh_orb_geom g, const uint32_t* __restrict__ tile_tab, uint32_t* __restrict__ status)
 {
     __shared__ uint32_t s_px[FPX_H * FPW];
@@ -287,6 +299,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
     __shared__ uint16_t s_list[4 * FITEMS];
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_vm[FPW];
+    __shared__ uint32_t s_out[TILE_W * TILE_H / 4];            // kept corners: strict 3x3 maxima, at most one per 2x2 block
     __shared__ int s_n, s_k, s_base;
 
     const int tid = threadIdx.x;
@@ -298,6 +311,9 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
     const size_t fbase = (size_t)frame * g.pyr_stride + L.off;
     const uint8_t* img = pyr + fbase;
 
+    // The tile's halo outside the level image is filled by reflection (BORDER_REFLECT_101, what the 7x7 blur below needs; FAST never
+    // scores a pixel whose ring leaves the image).  Words inside the image are one aligned load; the few that straddle or lie
+    // just beyond the left / right border gather their 4 bytes; anything further than 8 px beyond the border is never read.
     constexpr int NLD = (FPX_H * FRW + 255) / 256;
     uint32_t pw[NLD];
 #pragma unroll
@@ -305,9 +321,15 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
         const int i = tid + 256 * j;
         const int r = i / FRW, c = i - r * FRW;
         const int y = y0 - 4 + r, x = x0 - 4 + c * 4;
-        uint32_t v = 0;                                          // outside the image -> 0 (never used by a scored pixel)
-        if (i < FPX_H * FRW && y >= 0 && y < L.h && x >= 0 && x < L.pitch)
-            v = *reinterpret_cast<const uint32_t*>(img + (size_t)y * L.pitch + x);
+        uint32_t v = 0;
+        if (i < FPX_H * FRW && y < L.h + 8 && x < L.w + 8) {
+            const uint8_t* row = img + (size_t)reflect101(y, L.h) * L.pitch;
+            if (x >= 0 && x + 3 < L.w) v = *reinterpret_cast<const uint32_t*>(row + x);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) v |= (uint32_t)row[reflect101(x + k, L.w)] << (8 * k);
+            }
+        }
         pw[j] = v;
     }
     const int thr = g.fast_thr, et = g.edge_thr;
@@ -410,10 +432,9 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
         s_sc[b] = (uint8_t)(-b0 - 1);
     }
     __syncthreads();
-    // ---- phase 3: kept corners are staged in LDS (the pixel tile is dead by now and lends its space), then the tile reserves its
+    // ---- phase 3: kept corners are staged in LDS as (score << 24) | (score-tile byte index), then the tile reserves its
     // range of the level's corner list with ONE global atomic (a returning atomic per wave was measured 35 % slower: every wave
     // then waits out an L2 round trip on a counter all tiles of the level contend for)
-    uint32_t* s_out = s_px;                                      // (score << 24) | (score-tile byte index): up to TILE_W * TILE_H / 4 entries
     for (int j = tid; j < n; j += 256) {
         const int b = s_list[j];
         const int sc = s_sc[b];
@@ -448,92 +469,54 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
             else atomicOr(status, BH_ST_CAND_OVERFLOW);
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------ 7x7 Gaussian blur
-struct bh_gauss7 { int k[7]; };
-
-__device__ __forceinline__ int reflect101(int i, int n)
-{
-    if (i < 0) i = -i; else if (i >= n) i = 2 * (n - 1) - i;
-    return min(max(i, 0), n - 1);
-}
-
-// Register-sliding strip kernel, no LDS: one lane owns a 4-px wide column strip and BL_R output rows.  Per input row it
-// loads the three aligned words covering x0-4 .. x0+7, forms the 4 horizontal sums with v_alignbyte + v_dot4_u32_u8
-// (taps {k0..k3} and {k4,k5,k6,0}), keeps the last 7 rows of sums in registers and emits one packed u32 per output row.
-// Interior strips (all 12 px inside the level) take aligned word loads; the 2-3 strips per row that touch the left/right
-// border run the same body with reflect-101 byte gathers in a separate small launch (EDGE) so that no wave diverges.
-#define BL_R 16
-
-template <bool EDGE>
-__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
-                                              bh_orb_geom g, bh_gauss7 G)
-{
-    int level = 0;
-    for (int i = 1; i < g.nlevels; i++) if ((int)blockIdx.x >= (EDGE ? g.lv[i].eblk_base : g.lv[i].bblk_base)) level = i;
-    const bh_level_geom L = g.lv[level];
-    const int nsx = EDGE ? L.n_edge : L.nsx_in;
-    const int idx = ((int)blockIdx.x - (EDGE ? L.eblk_base : L.bblk_base)) * 256 + threadIdx.x;
-    const int rb = idx / nsx, si = idx - rb * nsx;
-    if (rb >= L.nrb) return;
-    // interior strips are 1 .. nsx_in; edge strips are 0 and nsx_in+1 .. nsx_in+n_edge-1
-    const int sx = EDGE ? (si == 0 ? 0 : L.nsx_in + si) : si + 1;
-    const int x0 = sx * 4, y0 = rb * BL_R;
-    const size_t fbase = (size_t)blockIdx.y * g.pyr_stride + L.off;
-    const uint8_t* img = pyr + fbase;
-    const uint32_t K03 = (uint32_t)G.k[0] | ((uint32_t)G.k[1] << 8) | ((uint32_t)G.k[2] << 16) | ((uint32_t)G.k[3] << 24);
-    const uint32_t K46 = (uint32_t)G.k[4] | ((uint32_t)G.k[5] << 8) | ((uint32_t)G.k[6] << 16);
-    // column pass with v_dot2_u32_u16: consecutive row sums are kept as 16-bit pairs P[q] = (h_q, h_q+1); the 7 taps of
-    // output row y are dot2(P[y-3],(k0,k1)) + dot2(P[y-1],(k2,k3)) + dot2(P[y+1],(k4,k5)) + k6*h[y+3]  (20 ops per strip row
-    // instead of 28 multiply-adds)
-    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    const us2 K01 = { (unsigned short)G.k[0], (unsigned short)G.k[1] }, K23 = { (unsigned short)G.k[2], (unsigned short)G.k[3] },
-              K45 = { (unsigned short)G.k[4], (unsigned short)G.k[5] };
-    uint32_t pr[6][4];                      // pr[q % 6] = P[q]
-    uint32_t hprev[4] = { 0, 0, 0, 0 };
+    // ---- 7x7 sigma-2 Gaussian of the tile from the same LDS pixels (integer kernel, (sum + 32768) >> 16; the descriptor's input).
+    // A lane owns a 4-pixel column strip and 4 output rows: per input row three aligned LDS words, the 4 horizontal sums with
+    // v_alignbyte + v_dot4_u32_u8 (taps {k0..k3} and {k4,k5,k6,0}); consecutive row sums are kept as 16-bit pairs P[q] = (h_q, h_q+1)
+    // and the column pass of output row y is dot2(P[y-3],(k0,k1)) + dot2(P[y-1],(k2,k3)) + dot2(P[y+1],(k4,k5)) + k6*h[y+3].
+    {
+        const int strip = tid & (TILE_W / 4 - 1), grp = tid / (TILE_W / 4);
+        const int xs = x0 + 4 * strip;
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        const uint32_t K03 = (uint32_t)G.k[0] | ((uint32_t)G.k[1] << 8) | ((uint32_t)G.k[2] << 16) | ((uint32_t)G.k[3] << 24);
+        const uint32_t K46 = (uint32_t)G.k[4] | ((uint32_t)G.k[5] << 8) | ((uint32_t)G.k[6] << 16);
+        const us2 K01 = { (unsigned short)G.k[0], (unsigned short)G.k[1] }, K23 = { (unsigned short)G.k[2], (unsigned short)G.k[3] },
+                  K45 = { (unsigned short)G.k[4], (unsigned short)G.k[5] };
+        constexpr int BR = TILE_H * (TILE_W / 4) / 256;           // output rows per lane (4)
+        for (int yb = grp * BR; yb < TILE_H; yb += BR * (256 / (TILE_W / 4))) {
+            if (xs >= L.w || y0 + yb >= L.h) continue;
+            const uint32_t* col = s_px + (yb + 1) * FPW + strip + 1;      // LDS row of y0 + yb - 3, word of pixels xs-4 .. xs-1
+            uint32_t pr[6][4];
+            uint32_t hprev[4] = { 0, 0, 0, 0 };
 #pragma unroll
-    for (int r = 0; r < BL_R + 6; r++) {
-        const int yr = reflect101(y0 - 3 + r, L.h);
-        const uint8_t* row = img + (size_t)yr * L.pitch;
-        uint32_t W0, W1, W2;
-        if (!EDGE) {
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(row + x0 - 4);
-            W0 = p[0]; W1 = p[1]; W2 = p[2];
-        } else {
-            W0 = W1 = W2 = 0;
+            for (int r = 0; r < BR + 6; r++) {
+                const uint32_t W0 = col[r * FPW], W1 = col[r * FPW + 1], W2 = col[r * FPW + 2];
+                uint32_t h[4];
+                h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 1), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 1), K46, 0u, false), false);
+                h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 2), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 2), K46, 0u, false), false);
+                h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 3), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 3), K46, 0u, false), false);
+                h[3] = __builtin_amdgcn_udot4(W1, K03, __builtin_amdgcn_udot4(W2, K46, 0u, false), false);
+                if (r >= 1) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                W0 |= (uint32_t)row[reflect101(x0 - 4 + k, L.w)] << (8 * k);
-                W1 |= (uint32_t)row[reflect101(x0 + k, L.w)] << (8 * k);
-                W2 |= (uint32_t)row[reflect101(x0 + 4 + k, L.w)] << (8 * k);
+                    for (int i = 0; i < 4; i++) pr[(r - 1) % 6][i] = hprev[i] | (h[i] << 16);       // P[r-1] = (h_{r-1}, h_r)
+                }
+                if (r >= 6) {
+                    const int y = y0 + yb + r - 6;
+                    uint32_t out = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        uint32_t sm = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pr[(r - 6) % 6][i]), K01, 32768u, false);
+                        sm = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pr[(r - 4) % 6][i]), K23, sm, false);
+                        sm = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pr[(r - 2) % 6][i]), K45, sm, false);
+                        sm += __umul24(h[i], (uint32_t)G.k[6]);
+                        sm >>= 16;
+                        out |= min(sm, 255u) << (8 * i);
+                    }
+                    if (y < L.h) *reinterpret_cast<uint32_t*>(blur + fbase + (size_t)y * L.pitch + xs) = out;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) hprev[i] = h[i];
             }
         }
-        uint32_t h[4];
-        h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 1), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 1), K46, 0u, false), false);
-        h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 2), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 2), K46, 0u, false), false);
-        h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 3), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 3), K46, 0u, false), false);
-        h[3] = __builtin_amdgcn_udot4(W1, K03, __builtin_amdgcn_udot4(W2, K46, 0u, false), false);
-        if (r >= 1) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) pr[(r - 1) % 6][i] = hprev[i] | (h[i] << 16);       // P[r-1] = (h_{r-1}, h_r)
-        }
-        if (r >= 6) {
-            const int y = y0 + r - 6;
-            uint32_t out = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                uint32_t s = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pr[(r - 6) % 6][i]), K01, 32768u, false);
-                s = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pr[(r - 4) % 6][i]), K23, s, false);
-                s = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pr[(r - 2) % 6][i]), K45, s, false);
-                s += __umul24(h[i], (uint32_t)G.k[6]);
-                s >>= 16;
-                out |= min(s, 255u) << (8 * i);
-            }
-            if (y < L.h) *reinterpret_cast<uint32_t*>(blur + fbase + (size_t)y * L.pitch + x0) = out;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) hprev[i] = h[i];
     }
 }
 
@@ -557,12 +540,24 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
+// Wave-wide integer sum on the DPP network (row shifts inside the four 16-lane rows, then row_bcast:15 / row_bcast:31 into the
+// following rows): no LDS crossbar round trips.  The total arrives in lane 63 and is handed to every lane.
+__device__ __forceinline__ int wave_sum_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ int count_ge(uint32_t w, uint32_t thr)
 {
     return (int)(((w & 255u) >= thr) + (((w >> 8) & 255u) >= thr) + (((w >> 16) & 255u) >= thr) + ((w >> 24) >= thr));
 }
 
-struct bh_umax { int u[16]; unsigned long long packed; };   // packed: 4 bits per row half-width
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
@@ -725,7 +720,7 @@ __device__ __forceinline__ void sincos_small(double x, double* sn, double* cs)
     *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
-__constant__ signed char c_pattern[1024] = {
+__constant__ __attribute__((aligned(4))) signed char c_pattern[1024] = {
 #include "brief_pattern.h"
 };
 
@@ -738,7 +733,7 @@ __constant__ signed char c_pattern[1024] = {
 // the 31x31 patch per step, integer wave reduction, fastAtan2.  Steered BRIEF: lane l evaluates tests l, 64+l, 128+l,
 // 192+l; four ballots give the 32 descriptor bytes.
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                  bh_orb_geom g, bh_umax UM, float patch_size, int sel_cap, int max_kp,
+                                                  bh_orb_geom g, const uint32_t* __restrict__ ic_mask, float patch_size, int sel_cap, int max_kp,
                                                   const uint32_t* __restrict__ sel_xy, const float* __restrict__ sel_resp,
                                                   const int* __restrict__ sel_cnt, bh_kp* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int* __restrict__ n_kp,
@@ -762,20 +757,21 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     const uint32_t xy = sel_xy[si];
     const int cx = xy & 0xffffu, cy = xy >> 16;
     const size_t lbase = f * g.pyr_stride + L.off;
-    // ---- intensity-centroid angle
+    // ---- intensity-centroid angle.  Lane = (row parity, column u): step `it` visits row v = 2 it + (lane >> 5) - 15.  Which steps fall
+    // inside the 749-pixel disc is a per-lane constant (ic_mask, built on the host from the reference's umax table), and with
+    // S = sum I, T = sum it*I over a lane's in-disc pixels: m10 = u S, m01 = 2 T + ((lane >> 5) - 15) S (integers, exact).
+    const int u = (lane & 31) - 15, vb = (lane >> 5) - 15;
+    const uint32_t msk = ic_mask[lane];
     const uint8_t* c = pyr + lbase + (size_t)cy * L.pitch + cx;
-    const int u = (lane & 31) - 15;
-    int m10 = 0, m01 = 0;
+    const uint8_t* p = c + vb * L.pitch + u;
+    int S = 0, T = 0;
 #pragma unroll
     for (int it = 0; it < 16; it++) {
-        const int v = it * 2 + (lane >> 5) - 15;             // v <= 16, u <= 16: always inside the level (31-px border)
-        const int av = min(v < 0 ? -v : v, 15);
-        const int I = c[v * L.pitch + u];                     // unconditional: all 16 loads are issued back to back
-        const int um = (int)((UM.packed >> (4 * av)) & 15ull);
-        const bool in = v <= 15 && u >= -um && u <= um;
-        m10 += in ? u * I : 0; m01 += in ? v * I : 0;
+        int I = p[it * 2 * L.pitch];                           // unconditional (v <= 16, |u| <= 16: inside the level's 31-px border); 16 loads in flight
+        I = (msk >> it) & 1u ? I : 0;
+        S += I; T += it * I;
     }
-    m10 = wave_sum(m10); m01 = wave_sum(m01);
+    const int m10 = wave_sum_dpp(u * S), m01 = wave_sum_dpp(2 * T + vb * S);
     const float angle_deg = fast_atan2_deg((float)m01, (float)m10);
     bh_kp kp;
     kp.x = (float)cx * L.scale; kp.y = (float)cy * L.scale;
@@ -793,8 +789,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     unsigned long long bits[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        const signed char* q = c_pattern + (t * 64 + lane) * 4;
-        const float qx0 = (float)q[0], qy0 = (float)q[1], qx1 = (float)q[2], qy1 = (float)q[3];
+        const int q4 = *reinterpret_cast<const int*>(c_pattern + (t * 64 + lane) * 4);       // the four signed bytes of test 64 t + lane
+        const float qx0 = (float)(signed char)q4, qy0 = (float)(signed char)(q4 >> 8), qx1 = (float)(signed char)(q4 >> 16), qy1 = (float)(q4 >> 24);
         const float x0 = qx0 * a - qy0 * b, y0 = qx0 * b + qy0 * a;
         const float x1 = qx1 * a - qy1 * b, y1 = qx1 * b + qy1 * a;
         const int t0 = center[__float2int_rn(y0) * L.pitch + __float2int_rn(x0)];
@@ -855,7 +851,20 @@ static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
         return BH_OK;
     bh_orb_geom g;
     if (build_geom(p, H, W, &g) != BH_OK) return bh_set_err(ctx, BH_ERR_INVALID, "unsupported ORB parameters / image size");
-    uint32_t* tab = (uint32_t*)calloc(g.tab_len + 4 + g.ntiles, sizeof(uint32_t));
+    uint32_t* tab = (uint32_t*)calloc(g.tab_len + 4 + g.ntiles + 64, sizeof(uint32_t));
+    {   // k_describe's per-lane disc masks (after the tile table): bit `it` set iff pixel (u, v) = ((lane & 31) - 15, 2 it + (lane >> 5) - 15)
+        // lies in the intensity-centroid disc of the reference (|v| <= 15, |u| <= umax[|v|])
+        int um[17]; umax_table(um);
+        for (int lane = 0; lane < 64; lane++) {
+            const int u = (lane & 31) - 15;
+            uint32_t m = 0;
+            for (int it = 0; it < 16; it++) {
+                const int v = it * 2 + (lane >> 5) - 15, av = v < 0 ? -v : v;
+                if (av <= 15 && u >= -um[av] && u <= um[av]) m |= 1u << it;
+            }
+            tab[g.tab_len + 4 + g.ntiles + lane] = m;
+        }
+    }
     for (int l = 0; l < g.nlevels; l++)                          // tile table, after the coefficient table (offset tab_len + 4)
         for (int t = 0; t < g.lv[l].tiles_x * g.lv[l].tiles_y; t++)
             tab[g.tab_len + 4 + g.lv[l].tile_base + t] = (uint32_t)l | ((uint32_t)(t % g.lv[l].tiles_x) << 4) | ((uint32_t)(t / g.lv[l].tiles_x) << 16);
@@ -864,9 +873,9 @@ static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
         for (int x = g.lv[l].w; x < align_up(g.lv[l].w, 4); x++) tab[g.lv[l].tabx_off + x] = tab[g.lv[l].tabx_off + g.lv[l].w - 1];
         lin_coeffs(g.lv[l - 1].h, g.lv[l].h, tab + g.lv[l].taby_off);
     }
-    int rc = bh_reserve(ctx, &ctx->tab, sizeof(uint32_t) * (g.tab_len + 4 + g.ntiles));
+    int rc = bh_reserve(ctx, &ctx->tab, sizeof(uint32_t) * (g.tab_len + 4 + g.ntiles + 64));
     if (rc == BH_OK) {
-        hipError_t e = hipMemcpyAsync(ctx->tab.p, tab, sizeof(uint32_t) * (g.tab_len + 4 + g.ntiles), hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = hipMemcpyAsync(ctx->tab.p, tab, sizeof(uint32_t) * (g.tab_len + 4 + g.ntiles + 64), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = bh_set_err(ctx, BH_ERR_HIP, "coefficient table upload failed: %s", hipGetErrorString(e));
     }
@@ -951,7 +960,6 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         for (int p = 1; p < npipe; p++) BH_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream[p - 1], ctx->ev_fork, 0));
     }
 
-    bh_umax UM; { int um[17]; umax_table(um); UM.packed = 0; for (int i = 0; i < 16; i++) { UM.u[i] = um[i]; UM.packed |= (unsigned long long)(um[i] & 15) << (4 * i); } }
     bh_gauss7 G; gauss7_coeffs(G.k);
 
     for (int f0 = 0, ci = 0; f0 < B; f0 += chunk, ci++) {
@@ -988,13 +996,11 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
             const int n = (g.lv[l].pitch >> 2) * g.lv[l].h;
             BH_LAUNCH(ctx, BH_K_PYR, k_pyr_down, dim3((n + 255) / 256, nb), dim3(256), st, pyr, mpyr, g, l, (const uint32_t*)ctx->tab.p);
         }
-        BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, clist, ccnt, hist, g,
+        BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, clist, ccnt, hist, blur, G, g,
                   (const uint32_t*)ctx->tab.p + g.tab_len + 4, (uint32_t*)ctx->status.p);
-        BH_LAUNCH(ctx, BH_K_BLUR, k_blur<false>, dim3(g.bblk_total, nb), dim3(256), st, pyr, blur, g, G);
-        BH_LAUNCH(ctx, BH_K_BLUR, k_blur<true>, dim3(g.eblk_total, nb), dim3(256), st, pyr, blur, g, G);
         BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, clist, ccnt, hist, g, sel_cap, (uint32_t*)Wk.sel_xy.p,
                   (float*)Wk.sel_resp.p, (int*)Wk.sel_cnt.p, (uint32_t*)ctx->status.p);
-        BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3((max_kp + 3) / 4, nb), dim3(256), st, pyr, blur, g, UM,
+        BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3((max_kp + 3) / 4, nb), dim3(256), st, pyr, blur, g, (const uint32_t*)ctx->tab.p + g.tab_len + 4 + g.ntiles,
                   (float)params->patchSize, sel_cap, max_kp, (const uint32_t*)Wk.sel_xy.p, (const float*)Wk.sel_resp.p,
                   (const int*)Wk.sel_cnt.p, d_kps, d_desc, d_nkp, (uint32_t*)ctx->status.p);
         BH_HIP(ctx, hipGetLastError());
