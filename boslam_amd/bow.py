@@ -61,12 +61,24 @@ class BowDatabase:
     def erase(self, entry_id):
         self.ctx.check(_lib.lib().bh_bow_erase_entry(self.h, int(entry_id)))
 
-    def query(self, q_words, q_vals, max_results=1):
+    def query(self, q_words, q_vals, max_results=1, subset=None):
+        """Top `max_results` (entry id, score).  `subset` = the fork's target_inds: only these entries may be returned (empty = all)."""
         q_words = np.ascontiguousarray(q_words, dtype=np.uint32); q_vals = np.ascontiguousarray(q_vals, dtype=np.float64)
         ids = np.zeros(max_results, np.int32); sc = np.zeros(max_results, np.float64); n = C.c_int(0)
-        self.ctx.check(_lib.lib().bh_bow_query_l1(self.h, _lib.ptr(q_words), _lib.ptr(q_vals), len(q_words), int(max_results),
-                                                  _lib.ptr(ids), _lib.ptr(sc), C.byref(n), BH_MEM_HOST))
+        if subset is not None and len(subset):
+            sub = np.ascontiguousarray(subset, dtype=np.int32)
+            self.ctx.check(_lib.lib().bh_bow_query_l1_subset(self.h, _lib.ptr(q_words), _lib.ptr(q_vals), len(q_words), _lib.ptr(sub), len(sub),
+                                                             int(max_results), _lib.ptr(ids), _lib.ptr(sc), C.byref(n)))
+        else:
+            self.ctx.check(_lib.lib().bh_bow_query_l1(self.h, _lib.ptr(q_words), _lib.ptr(q_vals), len(q_words), int(max_results),
+                                                      _lib.ptr(ids), _lib.ptr(sc), C.byref(n), BH_MEM_HOST))
         return ids[:n.value].copy(), sc[:n.value].copy()
+
+    def compare(self, i, j):
+        """compareBowsL1 of two stored entries -> (number of common words, L1 score)."""
+        cnt = C.c_int(0); score = C.c_double(0.0)
+        self.ctx.check(_lib.lib().bh_bow_compare_l1(self.h, int(i), int(j), C.byref(cnt), C.byref(score)))
+        return cnt.value, score.value
 
     def close(self):
         if getattr(self, "h", None):
@@ -154,11 +166,18 @@ class Vocabulary:
 
 
 class Dbow:
-    """Mirror of the reference's slam/bow_db.py Dbow (add / erase / query / distance) over the HIP vocabulary + database.
-    `voc` is the flat tree dict (the reference loads /DBow3/orbvoc.dbow3, which is not in its repo)."""
+    """Mirror of the reference's slam/bow_db.py Dbow (add / erase / query / distance / compareFrames) over the HIP vocabulary +
+    database.  `voc` is a vocabulary file (the reference's default is "/DBow3/orbvoc.dbow3", slam/bow_db.py:17; DBoW3 binary or
+    YAML, see dbow3_io) or an already flat tree dict.  The reference's `setVocabulary(voc, True, 2)` also switches on DBoW3's direct
+    index, which none of the reference's calls read; it is not kept."""
 
-    def __init__(self, voc, ctx=None):
+    DEFAULT_VOCABULARY = "/DBow3/orbvoc.dbow3"
+
+    def __init__(self, voc=DEFAULT_VOCABULARY, ctx=None):
         self.ctx = ctx or _lib.default_context()
+        if not isinstance(voc, dict):
+            from . import dbow3_io
+            voc = dbow3_io.load_vocabulary(voc)
         self.voc = Vocabulary(self.ctx, voc)
         self.db = BowDatabase(self.ctx)
         self.entry2frame = {}
@@ -178,13 +197,71 @@ class Dbow:
         del self.entry2frame[j]
 
     def query(self, frame, subset_inds=()):
-        if len(subset_inds):
-            raise NotImplementedError("target_inds restriction of the DBoW3 fork is not supported")
+        """slam/bow_db.py:37-42: best (frame id, score) among the entries in subset_inds (empty: all), or (None, None)."""
         w, v = self.voc.transform(frame.des)
-        ids, sc = self.db.query(w, v, 1)
+        ids, sc = self.db.query(w, v, 1, subset=list(subset_inds))
         if len(ids) > 0:
             return self.entry2frame[int(ids[0])], float(sc[0])
         return None, None
 
     def distance(self, f1, f2):
         return self.voc.distance(f1, f2)
+
+    def compareFrames(self, frame1, frame2):
+        """slam/bow_db.py:47-57: float32 (2, 1) array [number of common words, L1 score], as compare_bows returns its cv::Mat."""
+        if frame1.id not in self.frame2entry:
+            self.add(frame1)
+        if frame2.id not in self.frame2entry:
+            self.add(frame2)
+        cnt, score = self.db.compare(self.frame2entry[frame1.id], self.frame2entry[frame2.id])
+        return np.array([[cnt], [score]], dtype=np.float32)
+
+
+class Result:
+    """DBoW3::Result as pyDBoW3 exposes it (slam/bow_db.py:41 reads .Id and .Score)."""
+    __slots__ = ("Id", "Score")
+
+    def __init__(self, Id, Score):
+        self.Id = int(Id); self.Score = float(Score)
+
+    def __repr__(self):
+        return f"Result(Id={self.Id}, Score={self.Score})"
+
+
+class Database:
+    """Call-compatible stand-in for pyDBoW3.Database (docker/pydbow3/src/dbow3.cpp:121-193) for the calls the reference makes:
+    setVocabulary (slam/bow_db.py:18), add (:26), erase (:33), query(des, target_inds, max_results, max_id) (:39 and
+    slam/loop_closing.py:15), compare_bows (:57)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or _lib.default_context()
+        self.voc = None
+        self.db = BowDatabase(self.ctx)
+
+    def setVocabulary(self, vocabulary, use_di=False, di_levels=0):
+        self.voc = vocabulary if isinstance(vocabulary, Vocabulary) else Vocabulary(self.ctx, vocabulary)
+
+    def loadVocabulary(self, filename, use_di=False, di_levels=0):
+        from . import dbow3_io
+        self.setVocabulary(dbow3_io.load_vocabulary(filename), use_di, di_levels)
+
+    def add(self, features):
+        w, v = self.voc.transform(features)
+        return self.db.add(w, v)
+
+    def erase(self, i):
+        self.db.erase(i)
+
+    def query(self, features, target_inds=(), max_results=1, max_id=-1):
+        w, v = self.voc.transform(features)
+        subset = list(target_inds)
+        if max_id >= 0:                                            # DBoW3: only entries with id <= max_id
+            subset = [i for i in (subset or range(self.db.n_entries)) if i <= max_id]
+            if not subset:
+                return []
+        ids, sc = self.db.query(w, v, max_results, subset=subset)
+        return [Result(i, s) for i, s in zip(ids, sc)]
+
+    def compare_bows(self, i, j):
+        cnt, score = self.db.compare(i, j)
+        return np.array([[cnt], [score]], dtype=np.float32)

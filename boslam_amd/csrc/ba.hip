@@ -877,7 +877,7 @@ __device__ __forceinline__ int sw_slot(int d, int J)      // ring slot of LDS ti
 //            NB2 = NBLK-split-16 block columns of the REVERSED matrix (the stored matrix bottom-up).  The 16 block columns in
 //            between (>= the bandwidth) separate the two eliminations completely; each side stops with its trailing window =
 //            A22 minus its own Schur update, and writes window + rhs rows to xch;
-//   k_sw_separator + k_ba_chol<32>: the 256 x 256 separator system  W_top + W_bottom - A22  is assembled and solved;
+//   k_sw_separator + k_ba_chol<16>: the 256 x 256 separator system  W_top + W_bottom - A22  is assembled and solved;
 //   phase 2, grid 2: both sides back-substitute their own part with the separator's solution in place.
 // No extra flops, two CUs instead of one.  phase 0 = everything in one workgroup.
 #define SW_XCH_TILE(side, q, d) (65536 * (side) + 256 * (16 * (q) + (d)))       // window tile (column q, distance d), row-major 16x16
@@ -1269,7 +1269,7 @@ static int sw_solve(bh_ctx* ctx, hipStream_t st, double* S, const double* bs, in
     hipLaunchKernelGGL(k_sw_reverse, dim3(n1), dim3(256), 0, st, (const double*)S, bs, n, bw, npad, n1, S1, bs1);
     hipLaunchKernelGGL(k_ba_chol_sw, dim3(2), dim3(SW_NT), lds, st, S, bs, n, bw, x, state, 1, split, S1, (const double*)bs1, n1, x1, nb2, xch);
     hipLaunchKernelGGL(k_sw_separator, dim3(256), dim3(256), 0, st, (const double*)S, bs, bw, split, (const double*)xch, Ssep, bsep);
-    hipLaunchKernelGGL(k_ba_chol<32>, dim3(1), dim3(1024), sizeof(double) * ((size_t)256 * 33 + 1100), st, Ssep, (const double*)bsep, 256, 255,
+    hipLaunchKernelGGL(k_ba_chol<16>, dim3(1), dim3(1024), sizeof(double) * ((size_t)256 * 17 + 1100), st, Ssep, (const double*)bsep, 256, 255,
                        x + 16 * (size_t)split, state);
     hipLaunchKernelGGL(k_sw_rev_vec, dim3(1), dim3(256), 0, st, x, x1, n, npad, n1, 0);
     hipLaunchKernelGGL(k_ba_chol_sw, dim3(2), dim3(SW_NT), lds, st, S, bs, n, bw, x, state, 2, split, S1, (const double*)bs1, n1, x1, nb2, xch);
@@ -1576,10 +1576,11 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     }
     BH_TRY(bh_reserve(ctx, &ba->xch, sizeof(double) * SW_SCRATCH_DOUBLES(n6i, ba->bw)));
     if (!ba->chol_window) {   // panel width by LDS budget: min(n, NB+bw) x (NB+1) panel + 1024 partial sums, f64, <= 150 KB
-        int nb = 32;
+        int nb = 16;                                              // 16 measured fastest (0.37 vs 0.47 ms at n = 288: <32> spills 152 VGPRs)
         while (nb >= 8 && sizeof(double) * ((size_t)std::min(n6i, nb + ba->bw) * (nb + 1) + 1100) > 150 * 1024) nb >>= 1;
         if (nb < 8) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: reduced camera system too wide for the single-workgroup banded solver "
                                       "(%d free keyframes, covisibility half-bandwidth %d keyframes)", Cf, bwb);
+        if (const char* e = getenv("BH_BA_CHOL_NB")) { const int v = atoi(e); if ((v == 8 || v == 16 || v == 32) && v <= nb) nb = v; }      // A/B switch
         ba->chol_nb = nb;
     }
 
@@ -1742,7 +1743,7 @@ extern "C" int bh_ba_debug_band_solve(bh_ctx* ctx, const double* band, const dou
         (void)hipFuncSetAttribute((const void*)k_ba_chol<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         BH_TRY(sw_solve(ctx, st, dA, (const double*)db, n, bw, dx, dS, mode == 3 ? (nblk - 16) / 2 : 0, (double*)ctx->st_c.p));
     } else {
-        int nbsel = 32;
+        int nbsel = 16;
         while (nbsel >= 8 && sizeof(double) * ((size_t)std::min(n, nbsel + bw) * (nbsel + 1) + 1100) > 150 * 1024) nbsel >>= 1;
         if (nbsel < 8) return bh_set_err(ctx, BH_ERR_INVALID, "band solve: band too wide");
         const size_t lds = sizeof(double) * ((size_t)std::min(n, nbsel + bw) * (nbsel + 1) + 1100);

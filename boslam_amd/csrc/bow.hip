@@ -333,10 +333,33 @@ extern "C" int bh_bow_set_db(bh_bow* bow, long long n_entries, const int64_t* st
     return BH_OK;
 }
 
+// ---- query restricted to a subset of entries (the fork's Database::query(features, target_inds, ...), slam/bow_db.py:37-39):
+// accumulators of entries outside target_inds are set to +inf (= absent from the results) between the scan and the top-k.
+__global__ void k_bow_flag_set(const int* __restrict__ subset, int n_subset, long long n_entries, uint8_t* __restrict__ flag)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_subset) { const int e = subset[i]; if (e >= 0 && e < n_entries) flag[e] = 1; }
+}
+__global__ void k_bow_flag_apply(const uint8_t* __restrict__ flag, long long n_entries, double* __restrict__ acc)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e < n_entries && !flag[e]) acc[e] = INFINITY;
+}
+
+static int bow_query_impl(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, const int* subset, int n_subset,
+                          int max_results, int* ids, double* scores, int* n_results, int mem);
+
+
 extern "C" int bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, int max_results,
                                int* ids, double* scores, int* n_results, int mem)
 {
     if (!bow) return BH_ERR_INVALID;
+    return bow_query_impl(bow, q_words, q_vals, nq, nullptr, 0, max_results, ids, scores, n_results, mem);
+}
+
+static int bow_query_impl(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, const int* subset, int n_subset,
+                          int max_results, int* ids, double* scores, int* n_results, int mem)
+{
     bh_ctx* ctx = bow->ctx;
     if (!q_words || !q_vals || !ids || !scores || !n_results || nq < 0 || max_results < 1 || max_results > 1024 ||
         (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE))
@@ -368,6 +391,14 @@ extern "C" int bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const doubl
     hipLaunchKernelGGL(k_bow_scan, dim3(grid), dim3(BOW_T), lds, st, (const long long*)bow->pstart.p, (const uint32_t*)bow->words.p,
                        (const double*)bow->vals.p, bow->n_entries, d_qw, d_qv, nq, (double*)bow->acc.p);
     bh_time_end(ctx);
+    if (n_subset > 0) {                                        // restrict to target_inds: everything else becomes "no common word"
+        BH_TRY(bh_reserve(ctx, &ctx->st_g, (size_t)bow->n_entries + sizeof(int) * (size_t)n_subset + 16));
+        uint8_t* flag = (uint8_t*)ctx->st_g.p; int* d_sub = (int*)(flag + (((size_t)bow->n_entries + 15) & ~(size_t)15));
+        BH_HIP(ctx, hipMemsetAsync(flag, 0, (size_t)bow->n_entries, st));
+        BH_HIP(ctx, hipMemcpyAsync(d_sub, subset, sizeof(int) * (size_t)n_subset, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_bow_flag_set, dim3((n_subset + 255) / 256), dim3(256), 0, st, (const int*)d_sub, n_subset, bow->n_entries, flag);
+        hipLaunchKernelGGL(k_bow_flag_apply, dim3((unsigned)((bow->n_entries + 255) / 256)), dim3(256), 0, st, (const uint8_t*)flag, bow->n_entries, (double*)bow->acc.p);
+    }
     if (bow->n_entries > 4 * TOPK_SLICE && max_results <= TOPK_MAXK) {           // two stages: per-slice candidates, then the merge
         const int ns = (int)((bow->n_entries + TOPK_SLICE - 1) / TOPK_SLICE);
         BH_TRY(bh_reserve(ctx, &ctx->st_f, (sizeof(double) + sizeof(long long)) * (size_t)ns * max_results));
@@ -383,6 +414,54 @@ extern "C" int bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const doubl
         BH_HIP(ctx, hipMemcpyAsync(n_results, d_n, sizeof(int), hipMemcpyDeviceToHost, st));
         BH_HIP(ctx, hipStreamSynchronize(st));
     }
+    return BH_OK;
+}
+
+extern "C" int bh_bow_query_l1_subset(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, const int* subset,
+                                      int n_subset, int max_results, int* ids, double* scores, int* n_results)
+{
+    if (!bow) return BH_ERR_INVALID;
+    if (n_subset < 0 || (n_subset && !subset)) return bh_set_err(bow->ctx, BH_ERR_INVALID, "bh_bow_query_l1_subset: bad subset");
+    return bow_query_impl(bow, q_words, q_vals, nq, subset, n_subset, max_results, ids, scores, n_results, BH_MEM_HOST);
+}
+
+// ---- L1 comparison of two stored entries (the fork's Database::compareBowsL1 behind Dbow.compareFrames, slam/bow_db.py:47-57 ->
+// dbow3.cpp:154-162): number of common words and Score = -sum(|a - b| - |a| - |b|) / 2 over them.  One wave: lane l takes words
+// l, l + 64, ... of entry i and binary-searches entry j; the partial sums are added in lane order.
+__global__ __launch_bounds__(64) void k_bow_compare(const long long* __restrict__ pstart, const uint32_t* __restrict__ words,
+                                                    const double* __restrict__ vals, int ei, int ej, double* __restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const long long a0 = pstart[ei], a1 = pstart[ei + 1], b0 = pstart[ej], b1 = pstart[ej + 1];
+    double acc = 0; int cnt = 0;
+    for (long long a = a0 + lane; a < a1; a += 64) {
+        const uint32_t w = words[a];
+        if (w == BOW_PAD_WORD) continue;
+        long long lo = b0, hi = b1;
+        while (lo < hi) { const long long mid = (lo + hi) >> 1; if (words[mid] < w) lo = mid + 1; else hi = mid; }
+        if (lo < b1 && words[lo] == w) { const double x = vals[a], y = vals[lo]; acc += fabs(x - y) - fabs(x) - fabs(y); cnt++; }
+    }
+    __shared__ double s_a[64]; __shared__ int s_c[64];
+    s_a[lane] = acc; s_c[lane] = cnt;
+    __syncthreads();
+    if (lane == 0) { double t = 0; int c = 0; for (int i = 0; i < 64; i++) { t += s_a[i]; c += s_c[i]; } out[0] = (double)c; out[1] = -t / 2.0; }
+}
+
+extern "C" int bh_bow_compare_l1(bh_bow* bow, int entry_i, int entry_j, int* n_common, double* score)
+{
+    if (!bow) return BH_ERR_INVALID;
+    bh_ctx* ctx = bow->ctx;
+    if (!n_common || !score || entry_i < 0 || entry_j < 0 || entry_i >= bow->n_entries || entry_j >= bow->n_entries)
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_compare_l1: bad argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    BH_TRY(bh_reserve(ctx, &bow->res, 64));
+    hipLaunchKernelGGL(k_bow_compare, dim3(1), dim3(64), 0, ctx->stream, (const long long*)bow->pstart.p, (const uint32_t*)bow->words.p,
+                       (const double*)bow->vals.p, entry_i, entry_j, (double*)bow->res.p);
+    BH_HIP(ctx, hipGetLastError());
+    double h[2];
+    BH_HIP(ctx, hipMemcpyAsync(h, bow->res.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_common = (int)h[0]; *score = h[1];
     return BH_OK;
 }
 

@@ -248,6 +248,14 @@ int  bh_bow_set_db(bh_bow* bow, long long n_entries, const int64_t* start, const
 int  bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, int max_results,
                      int* ids, double* scores, int* n_results, int mem);
 
+/* The fork's Database::query(features, target_inds, max_results, max_id) with a non-empty target_inds — slam/bow_db.py:37-39 ->
+ * dbow3.cpp:147-152: only the entries listed in `subset` can appear in the result (host arrays). */
+int  bh_bow_query_l1_subset(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, const int* subset, int n_subset,
+                            int max_results, int* ids, double* scores, int* n_results);
+/* The fork's Database::compareBowsL1(i, j, cnt, score) behind Dbow.compareFrames — slam/bow_db.py:47-57 -> dbow3.cpp:154-162:
+ * number of words the two stored entries share and their L1 score -sum(|a - b| - |a| - |b|) / 2 over those words. */
+int  bh_bow_compare_l1(bh_bow* bow, int entry_i, int entry_j, int* n_common, double* score);
+
 /* Database::add at the BoW-vector level — slam/bow_db.py:26 -> dbow3.cpp:138-140: appends one entry (host arrays, words
  * strictly ascending), returns its entry id. */
 int  bh_bow_add_entry(bh_bow* bow, const uint32_t* words, const double* vals, int n, int* entry_id);

@@ -261,6 +261,25 @@ def bow_query_l1(q_words, q_vals, start, words, vals, max_results=1):
     return ids[:n].copy(), sc[:n].copy()
 
 
+def bow_query_l1_subset(q_words, q_vals, start, words, vals, subset, max_results):
+    q_words = np.ascontiguousarray(q_words, dtype=np.uint32); q_vals = np.ascontiguousarray(q_vals, dtype=np.float64)
+    start = np.ascontiguousarray(start, dtype=np.int64); words = np.ascontiguousarray(words, dtype=np.uint32)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    allowed = np.zeros(len(start) - 1, np.uint8); allowed[np.asarray(subset, dtype=np.int64)] = 1
+    ids = np.zeros(max(max_results, 1), np.int32); sc = np.zeros(max(max_results, 1), np.float64)
+    n = lib().orc_bow_query_l1_subset(_p(q_words), _p(q_vals), len(q_words), _p(start), _p(words), _p(vals), len(start) - 1,
+                                      _p(allowed), int(max_results), _p(ids), _p(sc))
+    return ids[:n].copy(), sc[:n].copy()
+
+
+def bow_compare_l1(start, words, vals, i, j):
+    start = np.ascontiguousarray(start, dtype=np.int64); words = np.ascontiguousarray(words, dtype=np.uint32)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    cnt = C.c_int(0); score = C.c_double(0.0)
+    lib().orc_bow_compare_l1(_p(start), _p(words), _p(vals), int(i), int(j), C.byref(cnt), C.byref(score))
+    return cnt.value, score.value
+
+
 def rodrigues(v):
     """cv2.Rodrigues semantics: 3-vector -> 3x3 matrix, or 3x3 matrix -> 3-vector."""
     v = np.ascontiguousarray(v, dtype=np.float64)

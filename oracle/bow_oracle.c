@@ -47,14 +47,40 @@ static int orc_res_cmp(const void* a, const void* b)
     return (x->id > y->id) - (x->id < y->id);
 }
 
-/* returns the number of results written (<= max_results); ids/scores sorted best first */
+/* returns the number of results written (<= max_results); ids/scores sorted best first.  allowed (may be NULL): u8[n_entries], the
+ * fork's target_inds restriction (slam/bow_db.py:37-39): only entries with allowed[e] != 0 are considered. */
+int orc_bow_query_l1_subset(const uint32_t* q_words, const double* q_vals, int nq,
+                            const int64_t* start, const uint32_t* words, const double* vals, int n_entries,
+                            const uint8_t* allowed, int max_results, int* ids, double* scores);
 int orc_bow_query_l1(const uint32_t* q_words, const double* q_vals, int nq,
                      const int64_t* start, const uint32_t* words, const double* vals, int n_entries,
                      int max_results, int* ids, double* scores)
 {
+    return orc_bow_query_l1_subset(q_words, q_vals, nq, start, words, vals, n_entries, 0, max_results, ids, scores);
+}
+
+/* the fork's compareBowsL1(i, j, cnt, score) behind Dbow.compareFrames (slam/bow_db.py:47-57 -> dbow3.cpp:154-162) [fork, unpinned]:
+ * number of common words and -sum(|a - b| - |a| - |b|) / 2 over them, summed in ascending word order */
+void orc_bow_compare_l1(const int64_t* start, const uint32_t* words, const double* vals, int ei, int ej, int* n_common, double* score)
+{
+    int64_t a = start[ei], a1 = start[ei + 1], b = start[ej], b1 = start[ej + 1];
+    double acc = 0; int cnt = 0;
+    while (a < a1 && b < b1) {
+        if (words[a] < words[b]) a++;
+        else if (words[a] > words[b]) b++;
+        else { acc += fabs(vals[a] - vals[b]) - fabs(vals[a]) - fabs(vals[b]); cnt++; a++; b++; }
+    }
+    *n_common = cnt; *score = -acc / 2.0;
+}
+
+int orc_bow_query_l1_subset(const uint32_t* q_words, const double* q_vals, int nq,
+                            const int64_t* start, const uint32_t* words, const double* vals, int n_entries,
+                            const uint8_t* allowed, int max_results, int* ids, double* scores)
+{
     orc_res* r = malloc(sizeof(orc_res) * (size_t)(n_entries > 0 ? n_entries : 1));
     int nr = 0;
     for (int e = 0; e < n_entries; e++) {
+        if (allowed && !allowed[e]) continue;
         /* merge-join: both lists ascending; accumulation order = ascending word id, as in DBoW3's outer loop */
         int64_t a = start[e], b = start[e + 1];
         int i = 0; int hit = 0; double acc = 0;

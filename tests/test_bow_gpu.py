@@ -121,3 +121,72 @@ def test_dbow_shim_end_to_end_relocalisation(ctx):
     oi2, os2 = oracle.bow_query_l1(qw, qv, start, words, vals, 2)
     assert fid2 == frames[int(oi2[1])].id and score2 == os2[1]
     assert db.distance(frames[0].des[0], frames[0].des[0]) == 0 and db.distance(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+
+
+def test_real_shape_vocabulary_k10_L6_from_a_dbow3_file(ctx, tmp_path):
+    """The shape of the reference's /DBow3/orbvoc.dbow3 (slam/bow_db.py:17-18): k = 10, L = 6, 10^6 words, read back from a DBoW3
+    binary file; quantisation on the GPU is bit-identical to the oracle's walk of the same tree."""
+    from boslam_amd import dbow3_io
+    voc = dbow3_io.renumber_words_in_file_order(synth.vocabulary(k=10, L=6, seed=3))
+    p = tmp_path / "orbvoc.dbow3"
+    dbow3_io.save_binary(p, voc)
+    loaded = dbow3_io.load_vocabulary(p)
+    v = bow.Vocabulary(ctx, loaded)
+    d = synth.random_descriptors(77, 1000)
+    d[::9] = loaded["node_desc"][np.flatnonzero(loaded["node_word"] >= 0)[:len(d[::9])]]
+    w, x = v.transform(d)
+    ow, ox = oracle.voc_transform(loaded, d)
+    assert len(ow) > 900 and np.array_equal(w, ow) and np.array_equal(x.view(np.uint64), ox.view(np.uint64))
+    ow2, ox2 = oracle.voc_transform(voc, d)                      # and equal to the tree the file was written from
+    assert np.array_equal(w, ow2) and np.array_equal(x, ox2)
+    v.close()
+
+
+def test_dbow_from_file_subset_query_and_compare_frames(ctx, tmp_path):
+    """slam/bow_db.py end to end from a vocabulary FILE: Dbow(path), query(frame, subset_inds) (the fork's target_inds), compareFrames
+    (the fork's compareBowsL1), and the live call of slam/loop_closing.py:15 with the local window excluded."""
+    from boslam_amd import dbow3_io, loop_closing
+    voc = dbow3_io.renumber_words_in_file_order(synth.vocabulary(k=10, L=3, seed=8))
+    p = tmp_path / "voc.yml.gz"
+    dbow3_io.save_yaml(p, voc)
+
+    class Frame:
+        def __init__(self, i, des): self.id = 500 + i; self.des = des
+    frames = [Frame(i, synth.random_descriptors(70 + i, 300 + 7 * i)) for i in range(10)]
+    frames[6].des[:200] = frames[2].des[:200]                         # 6 revisits 2
+    db = bow.Dbow(str(p), ctx=ctx)
+    for f in frames:
+        db.add(f)
+    rows = [oracle.voc_transform(voc, f.des) for f in frames]
+    start = np.concatenate([[0], np.cumsum([len(r[0]) for r in rows])]).astype(np.int64)
+    words = np.concatenate([r[0] for r in rows]); vals = np.concatenate([r[1] for r in rows])
+    qw, qv = rows[6]
+    # unrestricted: the frame itself wins
+    assert db.query(frames[6])[0] == 506
+    # restricted to a subset that excludes itself: the revisited frame wins; scores equal the oracle's bit for bit
+    sub = [0, 1, 2, 3, 9]
+    fid, sc = db.query(frames[6], subset_inds=sub)
+    oi, os_ = oracle.bow_query_l1_subset(qw, qv, start, words, vals, sub, 1)
+    assert fid == 500 + int(oi[0]) == 502 and sc == os_[0]
+    ids, scs = db.db.query(qw, qv, 4, subset=sub)
+    oi4, os4 = oracle.bow_query_l1_subset(qw, qv, start, words, vals, sub, 4)
+    assert np.array_equal(ids, oi4) and np.array_equal(scs, os4)
+    # compareFrames: (common words, score) as a float32 (2, 1) array
+    c = db.compareFrames(frames[6], frames[2])
+    oc, osc = oracle.bow_compare_l1(start, words, vals, 6, 2)
+    assert c.shape == (2, 1) and c.dtype == np.float32 and int(c[0, 0]) == oc and abs(float(c[1, 0]) - osc) < 1e-6 and oc > 50
+    c2 = db.compareFrames(frames[0], frames[1])
+    oc2, osc2 = oracle.bow_compare_l1(start, words, vals, 0, 1)
+    assert int(c2[0, 0]) == oc2 and abs(float(c2[1, 0]) - osc2) < 1e-6
+    # loop-closure candidate (slam/loop_closing.py:15) with the local window {5, 6, 7} excluded
+    fid, sc = loop_closing.loop_candidate_detection(db, frames[6], exclude_frame_ids=[505, 507])
+    keep = [e for e in range(10) if e not in (5, 6, 7)]
+    oi, os_ = oracle.bow_query_l1_subset(qw, qv, start, words, vals, keep, 1)
+    assert fid == 502 == 500 + int(oi[0]) and sc == os_[0]
+    # pyDBoW3.Database-shaped access (the object slam/loop_closing.py holds)
+    D = bow.Database(ctx); D.loadVocabulary(str(p), True, 2)
+    for f in frames:
+        D.add(f.des)
+    res = D.query(frames[6].des, [], 1, -1)
+    assert len(res) == 1 and res[0].Id == 6 and abs(res[0].Score - 1.0) < 1e-12
+    assert [r.Id for r in D.query(frames[6].des, [], 3, 5)] == [int(i) for i in oracle.bow_query_l1_subset(qw, qv, start, words, vals, range(6), 3)[0]]
