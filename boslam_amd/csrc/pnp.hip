@@ -90,13 +90,15 @@ __device__ void pj_eig(const double* Ain, double* d, double* Vt)      // symmetr
     }
 }
 
-// 12x12 symmetric cyclic Jacobi, the same rotation sequence and per-element arithmetic as pj_eig<12>, executed by one wave with
-// the matrices in LDS: lanes 0..11 rotate the column pair, then the row pair; lanes 16..27 rotate the eigenvector columns.
-// (The per-lane version keeps two 144-element arrays in scratch memory and walks them ~600 rotations x 36 elements long.)
-// Every lane must call it with the same arguments (one-wave workgroup: __syncthreads is a wave barrier).
-__device__ void pj_eig12_wave(double* sA, double* sV, double* sd, double* sVt)
+// Symmetric cyclic Jacobi of an N x N matrix (N <= 12) held in LDS, executed by one wave: the same rotation sequence and per-element
+// arithmetic as the sequential pj_eig<N> (and as the CPU restatement), with lanes 0..N-1 rotating the column pair, then the row
+// pair, and lanes 16..16+N-1 the eigenvector columns.  Eigenvalues descending in sd, eigenvectors in the rows of sVt.
+// (A per-lane version keeps A and V in registers / scratch: at N = 4..6 that is what made the kernel spill 260 VGPRs, at N = 12 it
+// walks two 144-element scratch arrays.)  Every lane must call it with the same arguments (one-wave workgroup: __syncthreads is a
+// wave barrier).
+template <int N>
+__device__ void pj_eig_wave(double* sA, double* sV, double* sd, double* sVt)
 {
-    constexpr int N = 12;
     const int lane = threadIdx.x & 63;
     for (int i = lane; i < N * N; i += 64) sV[i] = (i / N) == (i % N) ? 1.0 : 0.0;
     __syncthreads();
@@ -123,29 +125,54 @@ __device__ void pj_eig12_wave(double* sA, double* sV, double* sd, double* sVt)
         if (!rot) break;
     }
     int order[N];
+#pragma unroll
     for (int i = 0; i < N; i++) order[i] = i;
-    for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) if (sA[order[j] * N + order[j]] > sA[order[i] * N + order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = i + 1; j < N; j++) {                      // the reference's exchange sort (descending, strict '>'), on compile-time positions
+            const bool sw = sA[order[j] * N + order[j]] > sA[order[i] * N + order[i]];
+            const int oi = order[i], oj = order[j];
+            order[i] = sw ? oj : oi; order[j] = sw ? oi : oj;
+        }
     __syncthreads();
-    for (int e = lane; e < N * N; e += 64) { const int i = e / N, k = e % N; sVt[e] = sV[k * N + order[i]]; }
-    if (lane < N) sd[lane] = sA[order[lane] * N + order[lane]];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (lane < N) sVt[i * N + lane] = sV[lane * N + order[i]];
+        if (lane == 0) sd[i] = sA[order[i] * N + order[i]];
+    }
     __syncthreads();
 }
 
+// min |A x - b| (m x N, N <= 6) through the eigen-decomposition of A'A (pseudo-inverse, tiny modes dropped).  A, b and the result are
+// wave-uniform registers; A'A, its eigen-decomposition and nothing else live in the LDS workspace ws (>= 3 N^2 + N doubles).
 template <int N>
-__device__ void p_lsq(const double* A, const double* b, int m, double* x)     // min |Ax-b| via eigen-decomposition of A'A
+__device__ void p_lsq(const double* A, const double* b, int m, double* x, double* ws)
 {
-    double AtA[N * N], Atb[N], d[N], Vt[N * N];
+    double* sA = ws; double* sV = ws + N * N; double* sVt = ws + 2 * N * N; double* sd = ws + 3 * N * N;
+    double Atb[N];
+    __syncthreads();                                            // earlier readers of ws are done
+#pragma unroll
     for (int i = 0; i < N; i++) {
         Atb[i] = 0; for (int k = 0; k < m; k++) Atb[i] += A[k * N + i] * b[k];
-        for (int j = 0; j < N; j++) { double s = 0; for (int k = 0; k < m; k++) s += A[k * N + i] * A[k * N + j]; AtA[i * N + j] = s; }
+#pragma unroll
+        for (int j = 0; j < N; j++) { double s = 0; for (int k = 0; k < m; k++) s += A[k * N + i] * A[k * N + j]; sA[i * N + j] = s; }      // every lane writes the same value
     }
-    pj_eig<N>(AtA, d, Vt);
+    __syncthreads();
+    pj_eig_wave<N>(sA, sV, sd, sVt);
+#pragma unroll
     for (int i = 0; i < N; i++) x[i] = 0;
+    const double d0 = sd[0];
+#pragma unroll
     for (int e = 0; e < N; e++) {
-        if (d[e] <= d[0] * 1e-14 || d[e] <= 0) continue;
-        double c = 0; for (int i = 0; i < N; i++) c += Vt[e * N + i] * Atb[i];
-        c /= d[e];
-        for (int i = 0; i < N; i++) x[i] += c * Vt[e * N + i];
+        const double de = sd[e];
+        if (de <= d0 * 1e-14 || de <= 0) continue;
+        double c = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) c += sVt[e * N + i] * Atb[i];
+        c /= de;
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] += c * sVt[e * N + i];
     }
 }
 
@@ -317,7 +344,7 @@ __device__ double p_epnp_R_t(const double* pws, const double* us, const double* 
     return sum2 / NS;
 }
 
-__device__ void p_gauss_newton(const double* L, const double* rho, double* betas)
+__device__ void p_gauss_newton(const double* L, const double* rho, double* betas, double* ws2)
 {
     for (int it = 0; it < 5; it++) {
         double A[24], b[6], x[4];
@@ -332,15 +359,16 @@ __device__ void p_gauss_newton(const double* L, const double* rho, double* betas
                              r[6] * betas[0] * betas[3] + r[7] * betas[1] * betas[3] + r[8] * betas[2] * betas[3] +
                              r[9] * betas[3] * betas[3]);
         }
-        p_lsq<4>(A, b, 6, x);
+        p_lsq<4>(A, b, 6, x, ws2);
         for (int i = 0; i < 4; i++) betas[i] += x[i];
     }
 }
 
-// Called by every lane of the wave with the same arguments (wave-uniform); ws = LDS workspace of 3*144 + 12 doubles
+// Called by every lane of the wave with the same arguments (wave-uniform); ws = LDS workspace of 3*144 + 12 doubles for the 12x12
+// problem (its eigenvectors stay live to the end), ws2 = 3*36 + 6 doubles for the small least-squares solves + 66 for L and rho
 // trace (test hook, may be NULL): lane 0 writes the intermediates of this hypothesis (layout: tools/pnp_trace.py)
 #define PTR(off, val) do { if (trace && (threadIdx.x & 63) == 0) trace[(off)] = (val); } while (0)
-__device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rbest, double* tbest, double* ws, double* trace)
+__device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rbest, double* tbest, double* ws, double* ws2, double* trace)
 {
     double cws[4][3];
     for (int i = 0; i < 4; i++) cws[i][0] = cws[i][1] = cws[i][2] = 0;
@@ -370,28 +398,37 @@ __device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rb
     // MtM (12x12) straight into LDS: lane e accumulates element e over the 5 points in point order (the per-lane loop's order)
     double* sA = ws; double* sV = ws + 144; double* ut = ws + 288; double* dm = ws + 432;
     {
-        double m1[NS][12], m2[NS][12];
+        // the two rows each point contributes to M go through LDS (the eigenvector scratch sV is free until the decomposition
+        // starts): lane e then reads its operands by index - a lane-indexed register array would live in scratch memory
+        double* m1 = sV; double* m2 = sV + 12 * NS;
+        __syncthreads();                              // the previous hypothesis' readers of ws are done
         for (int i = 0; i < NS; i++) {
             const double* a = alphas + 4 * i;
             for (int j = 0; j < 4; j++) {
-                m1[i][3 * j] = a[j] * K.fu; m1[i][3 * j + 1] = 0.0;          m1[i][3 * j + 2] = a[j] * (K.uc - us[2 * i]);
-                m2[i][3 * j] = 0.0;         m2[i][3 * j + 1] = a[j] * K.fv;  m2[i][3 * j + 2] = a[j] * (K.vc - us[2 * i + 1]);
+                m1[12 * i + 3 * j] = a[j] * K.fu; m1[12 * i + 3 * j + 1] = 0.0;          m1[12 * i + 3 * j + 2] = a[j] * (K.uc - us[2 * i]);
+                m2[12 * i + 3 * j] = 0.0;         m2[12 * i + 3 * j + 1] = a[j] * K.fv;  m2[12 * i + 3 * j + 2] = a[j] * (K.vc - us[2 * i + 1]);
             }
         }
-        __syncthreads();                              // the previous hypothesis' readers of ws are done
-        for (int e = (int)(threadIdx.x & 63); e < 144; e += 64) {
-            const int pp = e / 12, qq = e % 12;
+        __syncthreads();
+        double accs[3];
+        for (int u = 0; u < 3; u++) {
+            const int e = (int)(threadIdx.x & 63) + 64 * u;
+            const int pp = min(e, 143) / 12, qq = min(e, 143) % 12;
             double acc = 0;
-            for (int i = 0; i < NS; i++) acc += m1[i][pp] * m1[i][qq] + m2[i][pp] * m2[i][qq];
-            sA[e] = acc;
-            if (trace) trace[40 + e] = acc;
+            for (int i = 0; i < NS; i++) acc += m1[12 * i + pp] * m1[12 * i + qq] + m2[12 * i + pp] * m2[12 * i + qq];
+            accs[u] = acc;
+        }
+        for (int u = 0; u < 3; u++) {
+            const int e = (int)(threadIdx.x & 63) + 64 * u;
+            if (e < 144) { sA[e] = accs[u]; if (trace) trace[40 + e] = accs[u]; }
         }
         __syncthreads();
     }
-    pj_eig12_wave(sA, sV, dm, ut);
+    pj_eig_wave<12>(sA, sV, dm, ut);
     for (int i = 0; i < 12; i++) PTR(184 + i, dm[i]);
     for (int i = 0; i < 144; i++) PTR(196 + i, ut[i]);
-    double L[60], rho[6], dv[4][6][3];
+    double* L = ws2 + 3 * 36 + 6; double* rho = L + 60;      // in LDS: read many times by the three beta solves and Gauss-Newton
+    double dv[4][6][3];
     for (int i = 0; i < 4; i++) {
         const double* v = ut + 12 * (11 - i);
         int a = 0, b = 1;
@@ -416,25 +453,25 @@ __device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rb
         double betas[4] = {0, 0, 0, 0}, A[30], x[5];
         if (N == 1) {
             for (int i = 0; i < 6; i++) { A[4 * i] = L[10 * i]; A[4 * i + 1] = L[10 * i + 1]; A[4 * i + 2] = L[10 * i + 3]; A[4 * i + 3] = L[10 * i + 6]; }
-            p_lsq<4>(A, rho, 6, x);
+            p_lsq<4>(A, rho, 6, x, ws2);
             if (x[0] < 0) { betas[0] = sqrt(-x[0]); betas[1] = -x[1] / betas[0]; betas[2] = -x[2] / betas[0]; betas[3] = -x[3] / betas[0]; }
             else { betas[0] = sqrt(x[0]); betas[1] = x[1] / betas[0]; betas[2] = x[2] / betas[0]; betas[3] = x[3] / betas[0]; }
         } else if (N == 2) {
             for (int i = 0; i < 6; i++) { A[3 * i] = L[10 * i]; A[3 * i + 1] = L[10 * i + 1]; A[3 * i + 2] = L[10 * i + 2]; }
-            p_lsq<3>(A, rho, 6, x);
+            p_lsq<3>(A, rho, 6, x, ws2);
             if (x[0] < 0) { betas[0] = sqrt(-x[0]); betas[1] = (x[2] < 0) ? sqrt(-x[2]) : 0.0; }
             else { betas[0] = sqrt(x[0]); betas[1] = (x[2] > 0) ? sqrt(x[2]) : 0.0; }
             if (x[1] < 0) betas[0] = -betas[0];
         } else {
             for (int i = 0; i < 6; i++) for (int k = 0; k < 5; k++) A[5 * i + k] = L[10 * i + k];
-            p_lsq<5>(A, rho, 6, x);
+            p_lsq<5>(A, rho, 6, x, ws2);
             if (x[0] < 0) { betas[0] = sqrt(-x[0]); betas[1] = (x[2] < 0) ? sqrt(-x[2]) : 0.0; }
             else { betas[0] = sqrt(x[0]); betas[1] = (x[2] > 0) ? sqrt(x[2]) : 0.0; }
             if (x[1] < 0) betas[0] = -betas[0];
             betas[2] = x[3] / betas[0];
         }
         for (int i = 0; i < 4; i++) PTR(406 + 21 * (N - 1) + i, betas[i]);
-        p_gauss_newton(L, rho, betas);
+        p_gauss_newton(L, rho, betas, ws2);
         double R[9], t[3];
         const double err = p_epnp_R_t(pws, us, alphas, K, ut, betas, R, t);
         for (int i = 0; i < 4; i++) PTR(406 + 21 * (N - 1) + 4 + i, betas[i]);
@@ -472,6 +509,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
 {
     __shared__ int s_idx[PNP_MAX_HYP * 5];
     __shared__ double s_ws[3 * 144 + 12];
+    __shared__ double s_ws2[3 * 36 + 6 + 60 + 6];
     __shared__ double s_red[28];
     __shared__ double s_j[14][PNP_T];                         // one 64-point chunk of the refinement: J0[6], J1[6], e0, e1 per point
     __shared__ unsigned char s_m[PNP_T];
@@ -515,7 +553,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
                 for (int k = 0; k < 2; k++) si[2 * i + k] = (double)(float)img[2 * p + k];
             }
             double* trace = trace_all && it < PNP_TRACE_HYP ? trace_all + (b * PNP_TRACE_HYP + it) * PNP_TRACE_STRIDE : nullptr;
-            p_epnp5(so, si, K, R, t, s_ws, trace);
+            p_epnp5(so, si, K, R, t, s_ws, s_ws2, trace);
             int good;
             if (n == 5) good = 5;
             else {
@@ -609,18 +647,36 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
         const double c0 = s_red[27];
         bool improved = false, tiny = false;
         for (int trial = 0; trial < 10 && !improved; trial++) {
-            if (tid == 0) {
-                double A[36], d[6], Vt[36], dx[6] = {0, 0, 0, 0, 0, 0};
-                for (int i = 0; i < 36; i++) A[i] = H[i];
-                for (int a = 0; a < 6; a++) A[7 * a] += lambda * (H[7 * a] > 1e-12 ? H[7 * a] : 1e-12);
-                pj_eig<6>(A, d, Vt);
-                for (int e = 0; e < 6; e++) if (d[e] > 0) { double c = 0; for (int a = 0; a < 6; a++) c += Vt[6 * e + a] * g[a]; c /= d[e]; for (int a = 0; a < 6; a++) dx[a] -= c * Vt[6 * e + a]; }
-                double dR[9];
-                pd_rodrigues_v2m(dx, dR);
-                for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) s_try[3 * a + c] = dR[3 * a] * s_pose[c] + dR[3 * a + 1] * s_pose[3 + c] + dR[3 * a + 2] * s_pose[6 + c];
-                for (int a = 0; a < 3; a++) s_try[9 + a] = s_pose[9 + a] + dx[3 + a];
-                double step = 0; for (int a = 0; a < 6; a++) step += dx[a] * dx[a];
-                s_flag = step < 1e-26 ? 1 : 0;
+            {   // damped normal equations: eigen-decomposition in LDS by the whole wave, the step on every lane
+                double* sA = s_ws2; double* sV = s_ws2 + 36; double* sVt = s_ws2 + 72; double* sd = s_ws2 + 108;
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 36; i++) sA[i] = H[i];
+#pragma unroll
+                for (int a = 0; a < 6; a++) sA[7 * a] = H[7 * a] + lambda * (H[7 * a] > 1e-12 ? H[7 * a] : 1e-12);
+                __syncthreads();
+                pj_eig_wave<6>(sA, sV, sd, sVt);
+                double dx[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 6; e++) {
+                    const double de = sd[e];
+                    if (de > 0) {
+                        double c = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; a++) c += sVt[6 * e + a] * g[a];
+                        c /= de;
+#pragma unroll
+                        for (int a = 0; a < 6; a++) dx[a] -= c * sVt[6 * e + a];
+                    }
+                }
+                if (tid == 0) {
+                    double dR[9];
+                    pd_rodrigues_v2m(dx, dR);
+                    for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) s_try[3 * a + c] = dR[3 * a] * s_pose[c] + dR[3 * a + 1] * s_pose[3 + c] + dR[3 * a + 2] * s_pose[6 + c];
+                    for (int a = 0; a < 3; a++) s_try[9 + a] = s_pose[9 + a] + dx[3 + a];
+                    double step = 0; for (int a = 0; a < 6; a++) step += dx[a] * dx[a];
+                    s_flag = step < 1e-26 ? 1 : 0;
+                }
             }
             __syncthreads();
             double c1 = 0;                                    // lane 0 sums the trial cost in point order
