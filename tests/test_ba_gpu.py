@@ -211,3 +211,29 @@ def test_global_ba_config5_full_size(ctx):
     assert np.array_equal(lg[:, 2:], res["0"][2][:, 2:]) and np.allclose(lg[:, 0], res["0"][2][:, 0], rtol=1e-10)
     assert np.abs(t - res["0"][0]).max() < 1e-8 and np.abs(pts - res["0"][1]).max() < 1e-8
     assert np.abs(t - pr["tgt"]).mean() < 0.2 * np.abs(pr["t"] - pr["tgt"]).mean()
+
+
+def test_device_built_problem_equals_host_built(ctx, monkeypatch):
+    """bh_ba_set_problem builds the graph structure (slots, edges by point / by camera, camera pairs, band) on the device; the
+    former host loops stay selectable (BH_BA_BUILD=host).  Same problem, both builds: poses, landmarks, per-edge chi2 and the LM
+    log must agree bit for bit - they can only do so if every structural array is identical."""
+    probs = [synth.ba_problem(n_kf=12, n_pts=500, seed=4), synth.ba_problem(n_kf=50, n_pts=10000, seed=7),
+             synth.ba_problem_sequence(n_kf=300, n_pts=9000, window=6, seed=3)]
+    pr = synth.ba_problem(n_kf=9, n_pts=200, seed=2)                       # unused point, unused camera, fixed camera with edges
+    keep = (pr["ecam"] != 4) & (pr["ept"] != 17)
+    probs.append(dict(pr, ecam=pr["ecam"][keep], ept=pr["ept"][keep], meas=pr["meas"][keep]))
+    for pr in probs:
+        res = []
+        for mode in ("device", "host"):
+            if mode == "host":
+                monkeypatch.setenv("BH_BA_BUILD", "host")
+            else:
+                monkeypatch.delenv("BH_BA_BUILD", raising=False)
+            s = ba.LocalBA(ctx, pr["K"])
+            s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+            done = s.optimize(4)
+            res.append((s.poses(), s.points(), s.chi2(), s.log()[:done]))
+            s.close()
+        (Rd, td), pd, cd, ld = res[0]; (Rh, th), ph, ch, lh = res[1]
+        assert np.array_equal(ld, lh) and np.array_equal(Rd, Rh) and np.array_equal(td, th)
+        assert np.array_equal(pd, ph, equal_nan=True) and np.array_equal(cd, ch)
