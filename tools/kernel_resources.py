@@ -16,5 +16,7 @@ for f in sorted(os.listdir(src)):
         name = re.search(r"\.name:\s+(\S+)", blk).group(1)
         g = lambda k: int(re.search(rf"\.{k}:\s+(\d+)", blk).group(1))
         m = re.match(r"_Z\d+(k_[a-z_0-9]+)", name)
+        if not m:
+            continue                                   # library kernels (hipcub sorts / scans inside ba.hip)
         short = (m.group(1) if m else name) + ("<" + ",".join(re.findall(r"L[ib](\d+)E", name)) + ">" if "IL" in name else "")
         print(f"{base:6s} {short:28s} vgpr {g('vgpr_count'):4d} spill {g('vgpr_spill_count'):4d} scratch {g('private_segment_fixed_size'):5d} B  lds {g('group_segment_fixed_size'):6d} B")

@@ -8,10 +8,11 @@ import json, subprocess, sys, os
 root, fpl = sys.argv[1], int(sys.argv[2])
 here = os.path.dirname(os.path.abspath(__file__))
 d = json.loads(subprocess.run([sys.executable, os.path.join(here, "pmc_summary.py"), root], capture_output=True, text=True, check=True).stdout)
-WIDE = {"k_gray_mask": 2, "k_pyr_down": 2, "k_select": 2}
+WIDE = {"k_gray_mask": 2, "k_pyr_down": 2, "k_select": 2, "k_bow_scan": 2}      # >= 8 B per lane loads (12 B + 8 B, 12 B, 8 B records, 16 B)
+PER_LAUNCH = {"k_bow_scan", "k_bow_topk", "k_bow_topk_slices", "k_bow_pack"}                # reported per launch (= per query), not per frame
 out = {"_note": "HBM bytes per FRAME = (FETCH_SIZE x factor + WRITE_SIZE) KiB per launch / frames per launch; rocprofv3 --pmc, FETCH_SIZE and "
                 "WRITE_SIZE in separate passes, bench.py --frames 256 --pipelines 1 (launches of %d frames); k_pyr_down and k_blur are "
-                "summed over their launches per frame batch.  factor 2 = kernels with >= 8 B/lane loads (gfx950 FETCH_SIZE correction, "
+                "summed over their launches per frame batch; k_bow_* entries are bytes per launch (one query of configs[3] on one GPU).  factor 2 = kernels with >= 8 B/lane loads (gfx950 FETCH_SIZE correction, "
                 "calibrated on k_gray_mask), 1 otherwise." % fpl, "_factors": WIDE}
 agg = {}
 for k, v in d.items():
@@ -20,7 +21,7 @@ for k, v in d.items():
         continue
     per_launch = (v["FETCH_SIZE"] * WIDE.get(base, 1) + v.get("WRITE_SIZE", 0.0)) * 1024.0
     launches_per_batch = 7 if base == "k_pyr_down" else 1
-    agg[base] = agg.get(base, 0.0) + per_launch * launches_per_batch / fpl
+    agg[base] = agg.get(base, 0.0) + per_launch * launches_per_batch / (1 if base in PER_LAUNCH else fpl)
 for k, v in sorted(agg.items()):
     out[k] = int(round(v))
 print(json.dumps(out, indent=1))
