@@ -139,6 +139,13 @@ __device__ __forceinline__ double d_shfl_idx(double v, int src)
     lo = __shfl(lo, src, 64); hi = __shfl(hi, src, 64);
     return __hiloint2double(hi, lo);
 }
+template <int SH> __device__ __forceinline__ double d_row_shr(double v)          // value of lane - SH inside the 16-lane DPP row, 0 at the row's start
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + SH, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + SH, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double d_readlane(double v, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
@@ -371,6 +378,7 @@ struct bh_ba {
     int bw = 0;                        // scalar half-bandwidth of the reduced camera system (6*max|s1-s2| + 5)
     int chol_nb = 32;                  // panel width chosen for the LDS budget
     int chol_window = 0;               // on-chip sliding-window banded Cholesky (k_ba_chol_sw) instead of the panel kernel
+    int chol_dense = 0;                // whole factor on chip (k_ba_chol_dense): 6 Cf <= 288, the local-BA window
     int schur_wave = 0;                // one wave per camera pair (many short edge lists) instead of a 256-thread workgroup
     int last_err_sel = 0;              // which err buffer holds "the last computeActiveErrors"
     // landmark-sharded multi-GPU mode (bh_ba_set_allreduce)
@@ -796,6 +804,235 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
 }
 #undef AB
 
+
+// ---- k_ba_chol_dense: dense SPD solve S x = b with the WHOLE factor on chip (local-BA windows: n <= 288, the case bw = n - 1;
+// also the 256 x 256 separator system of the two-way window solve).  The panel kernel above streams the trailing matrix through
+// L2 once per panel and spends most of a panel in one wave's triangular solves; here the strictly lower tiles (16x16, MFMA
+// accumulator layout) live in the registers of one 1024-thread workgroup, the diagonal tiles in LDS, and every O(n^3) and O(n^2)
+// step is a matrix-core instruction.  Wave 0 is the panel wave (no tiles: its registers hold the 16x16 factor and its inverse);
+// waves 1..15 own the tiles, at most 11 each: tile t of the column-major enumeration of the strict lower triangle belongs to wave
+// 1 + t mod 15 and never moves; the diagonal tiles are updated in LDS by the panel wave while the tile waves update theirs.
+//   per block column J:  [2] wave 0 factors diagonal tile J (row per lane, v_readlane broadcasts), inverts the 16x16 triangle
+//        (column per lane) and finishes y_J = Linv y_J;  [3] the tile waves turn their tiles of column J into
+//        L(i,J) = T(i,J) Linv' with 4 MFMAs (operands via LDS), publish them and take L(i,J) y_J out of y_i;  [4] they update
+//        their tiles T(i,j) -= L(i,J) L(j,J)' with 4 MFMAs each, operands from the published column.  Three barriers per column.
+//   backward substitution: the factor is still in the registers; per block column the owners form L(i,J)' x_i (lane sums), wave 0
+//        adds the partials in row order and applies Linv'.  Fixed summation order throughout (bitwise reproducible).
+// Lanes of one wave exchanging data through LDS: the hardware executes a wave's LDS operations in order, but the compiler reasons
+// per thread and may move a lane's read above another lane's (non-aliasing, for that thread) write: this keeps them apart.
+#define CD_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define CD_MAXT 18                                   // tile rows: n <= 288 (153 strict-lower tiles on 15 waves x 11)
+#define CD_NTW 11
+#define CD_P 17                                      // LDS tile pitch in doubles
+#define CD_TILE (16 * CD_P)
+#define CD_LDS_DOUBLES (3 * CD_MAXT * CD_TILE /*Lc, Linv, diagonal tiles*/ + 3 * CD_MAXT * 16 /*y, x, partials*/ + 16)
+
+__global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict__ A, const double* __restrict__ bs, int n, int bw,
+                                                        double* __restrict__ x, ba_state* __restrict__ St)
+{
+    extern __shared__ double sm[];
+    double* Lc = sm;                                  // [NT][16][17] the factored block column J (operands of [4])
+    double* Li = Lc + CD_MAXT * CD_TILE;              // [NT][16][17] inverses of the diagonal tiles' factors
+    double* Dg = Li + CD_MAXT * CD_TILE;              // [NT][16][17] diagonal tiles (lower part; updated in place until factored)
+    double* sy = Dg + CD_MAXT * CD_TILE;              // [NT*16] right-hand side -> y
+    double* sx = sy + CD_MAXT * 16;                   // [NT*16] solution
+    double* spart = sx + CD_MAXT * 16;                // [NT][16] partial L' x of the backward pass
+    double* sz = spart + CD_MAXT * 16;                // [16]
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int NT = (n + 15) >> 4, T = NT * (NT - 1) / 2, LD = bw + 1;
+    if (tid == 0) s_fail = St->chol_ok ? 0 : 1;
+    for (int i = tid; i < NT * 16; i += 1024) sy[i] = i < n ? bs[i] : 0.0;
+    for (int e = tid; e < NT * 256; e += 1024) {      // diagonal tiles: lower part, identity padding
+        const int j = e >> 8, rr = (e >> 4) & 15, cc = e & 15, r = 16 * j + rr, c = 16 * j + cc;
+        double v = 0.0;
+        if (r < n && c < n) { if (c <= r && r - c <= bw) v = A[(size_t)r * LD + (c - r + bw)]; }
+        else if (r == c) v = 1.0;
+        Dg[j * CD_TILE + rr * CD_P + cc] = v;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        // ================================================================ panel wave
+        const int rl = lane & 15;                     // lanes 16..63 mirror lanes 0..15 (duplicates keep every v_readlane source defined)
+        for (int J = 0; J < NT; J++) {
+            __syncthreads();                          // B1: diagonal tile J has received its last update
+            double row[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) row[k] = Dg[J * CD_TILE + rl * CD_P + k];
+            bool bad = false;
+            double myinv = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const double dg = d_readlane(row[c], c);
+                bad = bad | (!(dg > 0) | !(dg < 1.0e300));
+                const double y0 = __builtin_amdgcn_rsq(dg);
+                double g = dg * y0, h = 0.5 * y0;
+                double rr = __builtin_fma(-g, h, 0.5); g = __builtin_fma(g, rr, g); h = __builtin_fma(h, rr, h);
+                rr = __builtin_fma(-g, h, 0.5); g = __builtin_fma(g, rr, g); h = __builtin_fma(h, rr, h);
+                const double id = h + h;
+                myinv = rl == c ? id : myinv;
+                const double lc = rl == c ? g : row[c] * id;
+                row[c] = rl >= c ? lc : row[c];
+#pragma unroll
+                for (int c2 = c + 1; c2 < 16; c2++) {
+                    const double l2 = d_readlane(lc, c2);
+                    row[c2] = rl >= c2 ? __builtin_fma(-lc, l2, row[c2]) : row[c2];
+                }
+            }
+            // inverse of the lower-triangular factor, column rl per lane: X[i] = (delta_i,rl - sum_{k<i} L[i][k] X[k]) / L[i][i]
+            double X[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double s2 = i == rl ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; k++) s2 = __builtin_fma(-d_readlane(row[k], i), X[k], s2);
+                X[i] = i >= rl ? s2 * d_readlane(myinv, i) : 0.0;
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) Li[J * CD_TILE + i * CD_P + rl] = X[i];
+            }
+            if (bad && lane == 0) s_fail = 1;
+            CD_WAVE_SYNC();
+            // y_J = Linv y_J (row rl of Linv through LDS)
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) acc = __builtin_fma(Li[J * CD_TILE + rl * CD_P + c], sy[16 * J + c], acc);
+            CD_WAVE_SYNC();                           // every lane has read all 16 old values
+            if (lane < 16) sy[16 * J + rl] = acc;
+            __syncthreads();                          // B2: Linv_J and y_J are ready
+            if (s_fail) break;
+            __syncthreads();                          // B3: column J published, y updated
+            // [4] (panel wave's share): the diagonal tiles j > J, in LDS: D_j -= L(j,J) L(j,J)'
+            {
+                const int col = lane & 15, r0 = lane >> 4;
+                for (int j = J + 1; j < NT; j++) {
+                    ba_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) {
+                        const double o = Lc[j * CD_TILE + col * CD_P + 4 * ks + r0];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o, o, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) Dg[j * CD_TILE + (r0 + 4 * rg) * CD_P + col] -= acc[rg];
+                }
+            }
+        }
+        if (!s_fail)
+            for (int J = NT - 1; J >= 0; J--) {
+                __syncthreads();                      // the partials of column J are in spart
+                double z = sy[16 * J + rl];
+                for (int i = J + 1; i < NT; i++) z -= spart[i * 16 + rl];
+                if (lane < 16) sz[rl] = z;
+                CD_WAVE_SYNC();
+                double acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc = __builtin_fma(Li[J * CD_TILE + r * CD_P + rl], sz[r], acc);      // (Linv')[rl][r] = Linv[r][rl]
+                if (lane < 16) sx[16 * J + rl] = acc;
+                __syncthreads();                      // x_J is ready
+            }
+    } else {
+        // ================================================================ tile waves
+        const int colq = lane & 15, r0q = lane >> 4;
+        uint32_t tq[6] = { 0, 0, 0, 0, 0, 0 };        // (i | j << 8) of my tiles, two per register; 0xffff = no tile
+#define CD_TIJ(k) ((int)((tq[(k) >> 1] >> (16 * ((k) & 1))) & 0xffffu))
+        ba_d4 Tl[CD_NTW];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int t = (wv - 1) + 15 * k;
+            int j = 0, rem = t;
+            const bool have = k < CD_NTW && t < T;
+            if (have) { while (rem >= NT - 1 - j) { rem -= NT - 1 - j; j++; } }
+            const int i = j + 1 + rem;
+            tq[k >> 1] |= (uint32_t)(have ? (i | (j << 8)) : 0xffff) << (16 * (k & 1));
+            if (k < CD_NTW) {
+                ba_d4 v = { 0.0, 0.0, 0.0, 0.0 };
+                if (have) {
+                    const int c = 16 * j + colq;
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) {
+                        const int r = 16 * i + r0q + 4 * rg;
+                        v[rg] = (r < n && c < n && r - c <= bw) ? A[(size_t)r * LD + (c - r + bw)] : 0.0;      // strictly below the diagonal tiles: r > c
+                    }
+                }
+                Tl[k] = v;
+            }
+        }
+        bool failed = false;
+        for (int J = 0; J < NT; J++) {
+            // per-lane LDS addresses are recomputed inside the step: left alone, LICM hoists the loop-invariant tile addresses out of
+            // the J loop and the tiles spill (same cure as in k_ba_chol_sw)
+            int col = colq, r0 = r0q;
+            asm volatile("" : "+v"(col), "+v"(r0), "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]));
+            __syncthreads();                          // B1
+            __syncthreads();                          // B2
+            if (s_fail) { failed = true; break; }
+            // [3] column J: L(i,J) = T(i,J) Linv'.  The raw tile goes to its Lc slot, is read back as the A operand, and the slot is
+            // then overwritten with the result (same wave, LDS operations in order).
+            const double yj = sy[16 * J + col];
+#pragma unroll
+            for (int k = 0; k < CD_NTW; k++) {
+                const int id = CD_TIJ(k);
+                if (id == 0xffff || (id >> 8) != J) continue;
+                const int i = id & 255;
+                double* slot = Lc + i * CD_TILE;
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) slot[(r0 + 4 * rg) * CD_P + col] = Tl[k][rg];
+                CD_WAVE_SYNC();
+                ba_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(slot[col * CD_P + 4 * ks + r0], Li[J * CD_TILE + col * CD_P + 4 * ks + r0], acc, 0, 0, 0);
+                Tl[k] = acc;
+                CD_WAVE_SYNC();                       // the operand reads above precede the overwrite below in every lane
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    slot[(r0 + 4 * rg) * CD_P + col] = acc[rg];
+                    // y_i -= L(i,J) y_J : the sum over the 16 columns is a sum over the 16 lanes of a DPP row
+                    double v = acc[rg] * yj;
+                    v += d_row_shr<1>(v); v += d_row_shr<2>(v); v += d_row_shr<4>(v); v += d_row_shr<8>(v);      // lane 15 of the row holds the sum
+                    if (col == 15) sy[16 * i + r0 + 4 * rg] -= v;
+                }
+            }
+            __syncthreads();                          // B3
+            // [4] trailing update T(i,j) -= L(i,J) L(j,J)' of my register tiles
+#pragma unroll
+            for (int k = 0; k < CD_NTW; k++) {
+                const int id = CD_TIJ(k);
+                if (id == 0xffff || (id >> 8) <= J) continue;
+                const int i = id & 255, j = id >> 8;
+                ba_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[i * CD_TILE + col * CD_P + 4 * ks + r0], Lc[j * CD_TILE + col * CD_P + 4 * ks + r0], acc, 0, 0, 0);
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) Tl[k][rg] -= acc[rg];
+            }
+        }
+        if (!failed)
+            for (int J = NT - 1; J >= 0; J--) {
+                int col = colq, r0 = r0q;
+                asm volatile("" : "+v"(col), "+v"(r0), "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]));
+#pragma unroll
+                for (int k = 0; k < CD_NTW; k++) {
+                    const int id = CD_TIJ(k);
+                    if (id == 0xffff || (id >> 8) != J) continue;
+                    const int i = id & 255;
+                    double v = 0.0;
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) v = __builtin_fma(Tl[k][rg], sx[16 * i + r0 + 4 * rg], v);      // column `col`, my 4 rows
+                    v += d_shfl_xor(v, 16); v += d_shfl_xor(v, 32);                                               // the other 12 rows
+                    if (lane < 16) spart[i * 16 + col] = v;
+                }
+                __syncthreads();
+                __syncthreads();
+            }
+#undef CD_TIJ
+    }
+    if (s_fail) { if (tid == 0) St->chol_ok = 0; for (int i = tid; i < n; i += 1024) x[i] = 0; return; }
+    for (int i = tid; i < n; i += 1024) x[i] = sx[i];
+}
+
 // ---- k_ba_chol_sw: banded Cholesky with the whole trailing window ON CHIP (global-BA sizes: n >> bw, bw <= 256).
 // The panel kernel above streams the bw x bw trailing window through global memory once per panel; here it never leaves
 // the CU.  16x16 tiles; block column J is owned by wave J mod 16.  Tile (J+d, J), d = 0..D (D = ceil-band in blocks <= 16):
@@ -878,7 +1115,7 @@ __device__ __forceinline__ int sw_slot(int d, int J)      // ring slot of LDS ti
 //            NB2 = NBLK-split-16 block columns of the REVERSED matrix (the stored matrix bottom-up).  The 16 block columns in
 //            between (>= the bandwidth) separate the two eliminations completely; each side stops with its trailing window =
 //            A22 minus its own Schur update, and writes window + rhs rows to xch;
-//   k_sw_separator + k_ba_chol<16>: the 256 x 256 separator system  W_top + W_bottom - A22  is assembled and solved;
+//   k_sw_separator + k_ba_chol_dense: the 256 x 256 separator system  W_top + W_bottom - A22  is assembled and solved;
 //   phase 2, grid 2: both sides back-substitute their own part with the separator's solution in place.
 // No extra flops, two CUs instead of one.  phase 0 = everything in one workgroup.
 #define SW_XCH_TILE(side, q, d) (65536 * (side) + 256 * (16 * (q) + (d)))       // window tile (column q, distance d), row-major 16x16
@@ -1270,7 +1507,7 @@ static int sw_solve(bh_ctx* ctx, hipStream_t st, double* S, const double* bs, in
     hipLaunchKernelGGL(k_sw_reverse, dim3(n1), dim3(256), 0, st, (const double*)S, bs, n, bw, npad, n1, S1, bs1);
     hipLaunchKernelGGL(k_ba_chol_sw, dim3(2), dim3(SW_NT), lds, st, S, bs, n, bw, x, state, 1, split, S1, (const double*)bs1, n1, x1, nb2, xch);
     hipLaunchKernelGGL(k_sw_separator, dim3(256), dim3(256), 0, st, (const double*)S, bs, bw, split, (const double*)xch, Ssep, bsep);
-    hipLaunchKernelGGL(k_ba_chol<16>, dim3(1), dim3(1024), sizeof(double) * ((size_t)256 * 17 + 1100), st, Ssep, (const double*)bsep, 256, 255,
+    hipLaunchKernelGGL(k_ba_chol_dense, dim3(1), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)Ssep, (const double*)bsep, 256, 255,
                        x + 16 * (size_t)split, state);
     hipLaunchKernelGGL(k_sw_rev_vec, dim3(1), dim3(256), 0, st, x, x1, n, npad, n1, 0);
     hipLaunchKernelGGL(k_ba_chol_sw, dim3(2), dim3(SW_NT), lds, st, S, bs, n, bw, x, state, 2, split, S1, (const double*)bs1, n1, x1, nb2, xch);
@@ -1425,6 +1662,7 @@ extern "C" int bh_ba_create(bh_ctx* ctx, const double K[5], bh_ba** out)
     (void)hipFuncSetAttribute((const void*)k_ba_chol<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute((const void*)k_ba_chol<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute((const void*)k_ba_chol<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_ba_chol_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
     (void)hipFuncSetAttribute((const void*)k_ba_chol_sw, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     bh_ba* ba = new bh_ba();
     ba->ctx = ctx; ba->K = { K[0], K[1], K[2], K[3] };
@@ -1820,6 +2058,10 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
         ba->chol_split = (ba->chol_window && (ba->bw + 15) / 16 == 16 && nblk >= 96 && !(tw && !strcmp(tw, "0"))) ? (nblk - 16) / 2 : 0;
     }
     BH_TRY(bh_reserve(ctx, &ba->xch, sizeof(double) * SW_SCRATCH_DOUBLES(n6i, ba->bw)));
+    {
+        const char* ev = getenv("BH_BA_CHOL");
+        ba->chol_dense = (!ba->chol_window && n6i >= 1 && n6i <= 16 * CD_MAXT && !(ev && !strcmp(ev, "panel"))) ? 1 : 0;
+    }
     if (!ba->chol_window) {   // panel width by LDS budget: min(n, NB+bw) x (NB+1) panel + 1024 partial sums, f64, <= 150 KB
         int nb = 16;                                              // 16 measured fastest (0.37 vs 0.47 ms at n = 288: <32> spills 152 VGPRs)
         while (nb >= 8 && sizeof(double) * ((size_t)std::min(n6i, nb + ba->bw) * (nb + 1) + 1100) > 150 * 1024) nb >>= 1;
@@ -1924,6 +2166,7 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                     const size_t lds = sizeof(double) * ((size_t)std::min(n6, nbsel + bw) * (nbsel + 1) + 1100);
                     bh_time_begin(ctx, BH_K_BA_SOLVE);
                     if (ba->chol_window) (void)sw_solve(ctx, st, S, (const double*)bs, n6, bw, dxp, state, ba->chol_split, (double*)ba->xch.p);
+                    else if (ba->chol_dense) hipLaunchKernelGGL(k_ba_chol_dense, dim3(1), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)S, (const double*)bs, n6, bw, dxp, state);
                     else if (nbsel == 32) hipLaunchKernelGGL(k_ba_chol<32>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     else if (nbsel == 16) hipLaunchKernelGGL(k_ba_chol<16>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     else hipLaunchKernelGGL(k_ba_chol<8>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
@@ -1974,7 +2217,11 @@ extern "C" int bh_ba_debug_band_solve(bh_ctx* ctx, const double* band, const dou
     BH_HIP(ctx, hipMemcpyAsync(dA, band, nb, hipMemcpyHostToDevice, st));
     BH_HIP(ctx, hipMemcpyAsync(db, rhs, sizeof(double) * n, hipMemcpyHostToDevice, st));
     BH_HIP(ctx, hipMemcpyAsync(dS, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
-    if (mode >= 1) {
+    (void)hipFuncSetAttribute((const void*)k_ba_chol_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
+    if (mode == 4) {
+        if (n > 16 * CD_MAXT) return bh_set_err(ctx, BH_ERR_INVALID, "band solve: the on-chip dense kernel needs n <= %d", 16 * CD_MAXT);
+        hipLaunchKernelGGL(k_ba_chol_dense, dim3(1), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)dA, (const double*)db, n, bw, dx, dS);
+    } else if (mode >= 1) {
         if ((bw + 15) / 16 > 16 || bw < 15) return bh_set_err(ctx, BH_ERR_INVALID, "band solve: the window kernel needs 15 <= bw <= 256");
         const int nblk = (n + 15) / 16;
         if (mode == 3 && ((bw + 15) / 16 != 16 || nblk < 40)) return bh_set_err(ctx, BH_ERR_INVALID, "band solve: two-way mode needs a 16-tile band and >= 40 block columns");

@@ -66,3 +66,24 @@ def test_not_positive_definite_is_reported(ctx):
         x = np.zeros(n)
         rc = _lib.lib().bh_ba_debug_band_solve(ctx.h, _lib.ptr(low), _lib.ptr(rhs), n, bw, 3, _lib.ptr(x), None)
         assert rc == -5, bad_row
+
+
+@pytest.mark.parametrize("n,bw", [(288, 287), (256, 255), (16, 15), (17, 16), (100, 99), (271, 270), (288, 40), (5, 4), (1, 0)])
+def test_on_chip_dense_kernel_matches_scipy(ctx, n, bw):
+    """k_ba_chol_dense (mode 4): the whole factor in registers / LDS - the local-BA window (n = 288 at configs[2]) and the 256 x 256
+    separator system of the two-way solve; sizes that are not multiples of the tile, a banded matrix, the 1 x 1 case."""
+    low, rhs = band_system(n, bw, seed=3 * n + bw)
+    ref = scipy_solve(low, rhs, bw) if bw > 0 else rhs / low[:, 0]
+    x, _ = gpu_solve(ctx, low, rhs, bw, 4)
+    assert np.abs(x - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), np.abs(x - ref).max()
+    x2, _ = gpu_solve(ctx, low, rhs, bw, 4)
+    assert np.array_equal(x, x2)                                        # fixed summation order: bitwise reproducible
+
+
+def test_on_chip_dense_kernel_reports_a_bad_pivot(ctx):
+    for bad in (0, 100, 287):
+        low, rhs = band_system(288, 287, seed=9)
+        low[bad, 287] = -5.0
+        x = np.ones(288)
+        rc = _lib.lib().bh_ba_debug_band_solve(ctx.h, _lib.ptr(low), _lib.ptr(rhs), 288, 287, 4, _lib.ptr(x), None)
+        assert rc == -5 and not x.any()
