@@ -16,6 +16,7 @@
 #include <math.h>
 #include <float.h>
 #include "detmath.h"
+#include "pnp_small.h"
 
 #define PNP_T 64            // one wave per problem: RANSAC iterations in sequence (as OpenCV runs them), each one wave-parallel
 #define PNP_MAX_HYP 256
@@ -359,13 +360,13 @@ __device__ void p_gauss_newton(const double* L, const double* rho, double* betas
                              r[6] * betas[0] * betas[3] + r[7] * betas[1] * betas[3] + r[8] * betas[2] * betas[3] +
                              r[9] * betas[3] * betas[3]);
         }
-        p_lsq<4>(A, b, 6, x, ws2);
+        ps_qr_solve_6x4(A, b, x);                       // Householder QR in registers (wave-uniform), as the published EPnP code
         for (int i = 0; i < 4; i++) betas[i] += x[i];
     }
 }
 
 // Called by every lane of the wave with the same arguments (wave-uniform); ws = LDS workspace of 3*144 + 12 doubles for the 12x12
-// problem (its eigenvectors stay live to the end), ws2 = 3*36 + 6 doubles for the small least-squares solves + 66 for L and rho
+// problem (its eigenvectors stay live to the end), ws2 = 3*36 + 6 doubles for the small least-squares solves + 66 for L and rho + 20 for the barycentric coordinates
 // trace (test hook, may be NULL): lane 0 writes the intermediates of this hypothesis (layout: tools/pnp_trace.py)
 #define PTR(off, val) do { if (trace && (threadIdx.x & 63) == 0) trace[(off)] = (val); } while (0)
 __device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rbest, double* tbest, double* ws, double* ws2, double* trace)
@@ -386,7 +387,7 @@ __device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rb
     double CC[9], CCi[9];
     for (int i = 0; i < 3; i++) for (int j = 1; j < 4; j++) CC[3 * i + j - 1] = cws[j][i] - cws[0][i];
     if (!p_inv3(CC, CCi)) { for (int i = 0; i < 9; i++) Rbest[i] = (i % 4) == 0; tbest[0] = tbest[1] = tbest[2] = 0; return; }
-    double alphas[4 * NS];
+    double* alphas = ws2 + 3 * 36 + 6 + 66;          // [4 * NS] in LDS as well
     for (int i = 0; i < NS; i++) {
         double* a = alphas + 4 * i;
         for (int j = 0; j < 3; j++)
@@ -509,11 +510,12 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
 {
     __shared__ int s_idx[PNP_MAX_HYP * 5];
     __shared__ double s_ws[3 * 144 + 12];
-    __shared__ double s_ws2[3 * 36 + 6 + 60 + 6];
+    __shared__ double s_ws2[3 * 36 + 6 + 60 + 6 + 20];
+    __shared__ double s_samp[25];
     __shared__ double s_red[28];
     __shared__ double s_j[14][PNP_T];                         // one 64-point chunk of the refinement: J0[6], J1[6], e0, e1 per point
     __shared__ unsigned char s_m[PNP_T];
-    __shared__ double s_pose[12], s_try[12];
+    __shared__ double s_pose[12], s_try[12], s_c1;
     __shared__ int s_best, s_flag, s_w[PNP_T / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t b = blockIdx.x;
@@ -546,7 +548,8 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
         int best = -1, max_good = 0, niters = niter0;
         double bR[9], bt[3];
         for (int it = 0; it < niters; it++) {
-            double so[15], si[10], R[9], t[3];
+            double* so = s_samp; double* si = s_samp + 15;      // the sample, in LDS (every lane writes and reads the same values)
+            double R[9], t[3];
             for (int i = 0; i < 5; i++) {
                 const int p = s_idx[5 * it + i];
                 for (int k = 0; k < 3; k++) so[3 * i + k] = (double)(float)obj[3 * p + k];
@@ -641,34 +644,21 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
         __syncthreads();
         if (lane < 28) s_red[lane] = acc;
         __syncthreads();
-        double H[36], g[6];
-        { int k = 0; for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { H[6 * a + c] = s_red[k]; H[6 * c + a] = s_red[k]; k++; } }
-        for (int a = 0; a < 6; a++) g[a] = s_red[21 + a];
-        const double c0 = s_red[27];
+        const double c0 = s_red[27];                          // H (21 upper-triangle entries), g (6) and the cost stay in s_red for the trials
         bool improved = false, tiny = false;
         for (int trial = 0; trial < 10 && !improved; trial++) {
-            {   // damped normal equations: eigen-decomposition in LDS by the whole wave, the step on every lane
-                double* sA = s_ws2; double* sV = s_ws2 + 36; double* sVt = s_ws2 + 72; double* sd = s_ws2 + 108;
-                __syncthreads();
+            {   // damped normal equations (SPD): Cholesky in registers, the same statements as the CPU restatement (pnp_small.h)
+                double A[36], ng[6], dx[6];
+                {
+                    int k = 0;
 #pragma unroll
-                for (int i = 0; i < 36; i++) sA[i] = H[i];
+                    for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int a = 0; a < 6; a++) sA[7 * a] = H[7 * a] + lambda * (H[7 * a] > 1e-12 ? H[7 * a] : 1e-12);
-                __syncthreads();
-                pj_eig_wave<6>(sA, sV, sd, sVt);
-                double dx[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int e = 0; e < 6; e++) {
-                    const double de = sd[e];
-                    if (de > 0) {
-                        double c = 0;
-#pragma unroll
-                        for (int a = 0; a < 6; a++) c += sVt[6 * e + a] * g[a];
-                        c /= de;
-#pragma unroll
-                        for (int a = 0; a < 6; a++) dx[a] -= c * sVt[6 * e + a];
-                    }
+                        for (int c = a; c < 6; c++) { const double h = s_red[k]; A[6 * a + c] = h; A[6 * c + a] = h; k++; }
                 }
+#pragma unroll
+                for (int a = 0; a < 6; a++) { const double h = A[7 * a]; A[7 * a] = h + lambda * (h > 1e-12 ? h : 1e-12); ng[a] = -s_red[21 + a]; }
+                ps_chol6_solve(A, ng, dx);
                 if (tid == 0) {
                     double dR[9];
                     pd_rodrigues_v2m(dx, dR);
@@ -698,9 +688,9 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
                     for (int j = 0; j < cnt; j++) if (s_m[j]) c1 += s_j[0][j];
                 }
             }
-            if (tid == 0) s_red[0] = c1;
+            if (tid == 0) s_c1 = c1;
             __syncthreads();
-            c1 = s_red[0];
+            c1 = s_c1;
             __syncthreads();
             if (c1 < c0 && isfinite(c1)) {
                 improved = true; tiny = s_flag != 0; lambda *= 0.2;

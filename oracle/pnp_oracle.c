@@ -13,6 +13,9 @@
  *     is repeated until it differs from the earlier members of the subset;
  *   - scoring: squared reprojection error in float32 <= reprojErr^2; a model replaces the best when its inlier count is
  *     greater than max(best count, 4); after every improvement niters = RANSACUpdateNumIters(conf, outlier ratio, 5, niters);
+ *   - small dense solves: the 6x4 Gauss-Newton systems by Householder QR (as epnp.cpp's qr_solve), the three initial 6xN systems by
+ *     a pseudo-inverse (eigen-decomposition of the normal equations; OpenCV: cvSolve(SVD)), the refinement's 6x6 damped normal equations
+ *     by Cholesky (pnp_small.h; OpenCV: CvLevMarq solves with SVD);
  *   - final pose: minimiser of the reprojection error over the inliers (OpenCV: solvePnP(..., ITERATIVE) = DLT initial guess +
  *     Levenberg-Marquardt; here Levenberg-Marquardt started from the RANSAC model — same minimum whenever both converge);
  *   - Rodrigues: R = cos(th) I + (1-cos(th)) rr' + sin(th) [r]x and its inverse.
@@ -30,6 +33,7 @@
 #include <math.h>
 #include <float.h>
 #include "detmath.h"
+#include "pnp_small.h"
 
 /* ---------- small linear algebra ---------- */
 /* cyclic Jacobi for symmetric A (n<=12), eigenvalues descending in d, eigenvectors in ROWS of Vt */
@@ -284,7 +288,7 @@ static void epnp_gauss_newton(const double* L, const double* rho, double* betas)
                              r[6] * betas[0] * betas[3] + r[7] * betas[1] * betas[3] + r[8] * betas[2] * betas[3] +
                              r[9] * betas[3] * betas[3]);
         }
-        lsq_solve(A, b, 6, 4, x);
+        ps_qr_solve_6x4(A, b, x);                       /* Householder QR, as the published EPnP code (epnp.cpp qr_solve) */
         for (int i = 0; i < 4; i++) betas[i] += x[i];
     }
 }
@@ -415,11 +419,10 @@ static void pnp_refine(const double* obj, const double* img, const uint8_t* sel,
         if (cost < 0) cost = c0;
         int improved = 0;
         for (int trial = 0; trial < 10 && !improved; trial++) {
-            double A[36], d[6], Vt[36], dx[6] = {0};
+            double A[36], ng[6], dx[6];
             memcpy(A, H, sizeof(A));
-            for (int a = 0; a < 6; a++) A[7 * a] += lambda * (H[7 * a] > 1e-12 ? H[7 * a] : 1e-12);
-            jacobi_eig(A, 6, d, Vt);
-            for (int e = 0; e < 6; e++) if (d[e] > 0) { double c = 0; for (int a = 0; a < 6; a++) c += Vt[6 * e + a] * g[a]; c /= d[e]; for (int a = 0; a < 6; a++) dx[a] -= c * Vt[6 * e + a]; }
+            for (int a = 0; a < 6; a++) { A[7 * a] += lambda * (H[7 * a] > 1e-12 ? H[7 * a] : 1e-12); ng[a] = -g[a]; }
+            ps_chol6_solve(A, ng, dx);                      /* damped normal equations: SPD, Cholesky (a failed pivot gives dx = 0: the trial is rejected) */
             double dR[9], Rn[9], tn[3] = { t[0] + dx[3], t[1] + dx[4], t[2] + dx[5] };
             det_rodrigues_vec2mat(dx, dR);
             for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rn[3 * a + b] = dR[3 * a] * R[b] + dR[3 * a + 1] * R[3 + b] + dR[3 * a + 2] * R[6 + b];

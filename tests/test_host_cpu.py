@@ -61,10 +61,12 @@ def test_brief_pattern_table_digest():
     assert np.array_equal(vals, oracle.pattern())
 
 
-def test_detmath_copies_are_identical():
+@pytest.mark.parametrize("name", ["detmath.h", "pnp_small.h"])
+def test_shared_fixed_order_headers_are_identical(name):
+    """The product and the checker evaluate these routines with the same statements: the two copies must not drift apart."""
     mark = "/* ---- identical from here on ---- */"
-    a = open(os.path.join(ROOT, "boslam_amd", "csrc", "detmath.h")).read()
-    b = open(os.path.join(ROOT, "oracle", "detmath.h")).read()
+    a = open(os.path.join(ROOT, "boslam_amd", "csrc", name)).read()
+    b = open(os.path.join(ROOT, "oracle", name)).read()
     assert mark in a and mark in b and a[a.index(mark):] == b[b.index(mark):]
 
 
