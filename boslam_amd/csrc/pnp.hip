@@ -91,16 +91,18 @@ __device__ void pj_eig(const double* Ain, double* d, double* Vt)      // symmetr
     }
 }
 
-// Symmetric cyclic Jacobi of an N x N matrix (N <= 12) held in LDS, executed by one wave: the same rotation sequence and per-element
-// arithmetic as the sequential pj_eig<N> (and as the CPU restatement), with lanes 0..N-1 rotating the column pair, then the row
-// pair, and lanes 16..16+N-1 the eigenvector columns.  Eigenvalues descending in sd, eigenvectors in the rows of sVt.
-// (A per-lane version keeps A and V in registers / scratch: at N = 4..6 that is what made the kernel spill 260 VGPRs, at N = 12 it
-// walks two 144-element scratch arrays.)  Every lane must call it with the same arguments (one-wave workgroup: __syncthreads is a
-// wave barrier).
+// Symmetric Jacobi eigen-decomposition of an N x N matrix (N <= 12) held in LDS, executed by one wave, with the rotations of a sweep
+// arranged in ROUNDS of disjoint pairs (round-robin ordering; the CPU restatement's jacobi_eig_rr fixes the same operation order):
+// per round lane i < N/2 derives the rotation of pair i from the matrix as it stands (a chain of 3 divisions and 2 square roots -
+// once per round instead of once per rotation), then all column rotations of the round are applied (lane = pair x row, A and V),
+// then all row rotations.  Eigenvalues descending in sd, eigenvectors in the rows of sVt.  srot: 6 x {c, s} + flags (>= 24 doubles).
+// Every lane must call it with the same arguments (one-wave workgroup: __syncthreads is a wave barrier).
 template <int N>
-__device__ void pj_eig_wave(double* sA, double* sV, double* sd, double* sVt)
+__device__ void pj_eig_wave(double* sA, double* sV, double* sd, double* sVt, double* srot)
 {
+    constexpr int M = (N + 1) & ~1, NP = M / 2;
     const int lane = threadIdx.x & 63;
+    int* sact = reinterpret_cast<int*>(srot + 12);            // act[6], P[6], Q[6]
     for (int i = lane; i < N * N; i += 64) sV[i] = (i / N) == (i % N) ? 1.0 : 0.0;
     __syncthreads();
     for (int sweep = 0; sweep < 30; sweep++) {
@@ -108,23 +110,51 @@ __device__ void pj_eig_wave(double* sA, double* sV, double* sd, double* sVt)
         for (int p = 0; p < N; p++) for (int q = p + 1; q < N; q++) off += sA[p * N + q] * sA[p * N + q];
         if (off < 1e-300) break;
         bool rot = false;
-        for (int p = 0; p < N - 1; p++)
-            for (int q = p + 1; q < N; q++) {
-                const double apq = sA[p * N + q];
-                if (fabs(apq) < 1e-300 || fabs(apq) <= 1e-17 * sqrt(fabs(sA[p * N + p] * sA[q * N + q]))) continue;
-                rot = true;
-                const double tau = (sA[q * N + q] - sA[p * N + p]) / (2.0 * apq);
-                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-                __syncthreads();
-                if (lane < N) { const int k = lane; const double akp = sA[k * N + p], akq = sA[k * N + q]; sA[k * N + p] = c * akp - s * akq; sA[k * N + q] = s * akp + c * akq; }
-                else if (lane >= 16 && lane < 16 + N) { const int k = lane - 16; const double vkp = sV[k * N + p], vkq = sV[k * N + q]; sV[k * N + p] = c * vkp - s * vkq; sV[k * N + q] = s * vkp + c * vkq; }
-                __syncthreads();
-                if (lane < N) { const int k = lane; const double apk = sA[p * N + k], aqk = sA[q * N + k]; sA[p * N + k] = c * apk - s * aqk; sA[q * N + k] = s * apk + c * aqk; }
-                __syncthreads();
+        for (int r = 0; r < M - 1; r++) {
+            __syncthreads();
+            if (lane < NP) {
+                const int i = lane;
+                const int a = i == 0 ? M - 1 : (r + i) % (M - 1), b = i == 0 ? r : (r - i + (M - 1)) % (M - 1);
+                const int p = a < b ? a : b, q = a < b ? b : a;
+                double c = 1.0, s = 0.0; int act = 0;
+                if (q < N) {
+                    const double apq = sA[p * N + q];
+                    if (!(fabs(apq) < 1e-300 || fabs(apq) <= 1e-17 * sqrt(fabs(sA[p * N + p] * sA[q * N + q])))) {
+                        const double tau = (sA[q * N + q] - sA[p * N + p]) / (2.0 * apq);
+                        const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + t * t); s = t * c; act = 1;
+                    }
+                }
+                srot[2 * i] = c; srot[2 * i + 1] = s; sact[i] = act; sact[6 + i] = p; sact[12 + i] = q;
             }
+            __syncthreads();
+            // column rotations: work item w = pair * N + k for A, NP * N + the same for V
+            for (int w = lane; w < 2 * NP * N; w += 64) {
+                const bool isV = w >= NP * N;
+                const int ww = isV ? w - NP * N : w;
+                const int i = ww / N, k = ww - i * N;
+                if (!sact[i]) continue;
+                const int p = sact[6 + i], q = sact[12 + i];
+                const double c = srot[2 * i], s = srot[2 * i + 1];
+                double* Mx = isV ? sV : sA;
+                const double xp = Mx[k * N + p], xq = Mx[k * N + q];
+                Mx[k * N + p] = c * xp - s * xq; Mx[k * N + q] = s * xp + c * xq;
+            }
+            __syncthreads();
+            for (int w = lane; w < NP * N; w += 64) {
+                const int i = w / N, k = w - i * N;
+                if (!sact[i]) continue;
+                const int p = sact[6 + i], q = sact[12 + i];
+                const double c = srot[2 * i], s = srot[2 * i + 1];
+                const double apk = sA[p * N + k], aqk = sA[q * N + k];
+                sA[p * N + k] = c * apk - s * aqk; sA[q * N + k] = s * apk + c * aqk;
+            }
+            for (int i = 0; i < NP; i++) rot = rot | (sact[i] != 0);
+        }
+        __syncthreads();
         if (!rot) break;
     }
+    __syncthreads();
     int order[N];
 #pragma unroll
     for (int i = 0; i < N; i++) order[i] = i;
@@ -160,7 +190,7 @@ __device__ void p_lsq(const double* A, const double* b, int m, double* x, double
         for (int j = 0; j < N; j++) { double s = 0; for (int k = 0; k < m; k++) s += A[k * N + i] * A[k * N + j]; sA[i * N + j] = s; }      // every lane writes the same value
     }
     __syncthreads();
-    pj_eig_wave<N>(sA, sV, sd, sVt);
+    pj_eig_wave<N>(sA, sV, sd, sVt, ws + 3 * 36 + 6 + 66 + 20);
 #pragma unroll
     for (int i = 0; i < N; i++) x[i] = 0;
     const double d0 = sd[0];
@@ -425,7 +455,7 @@ __device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rb
         }
         __syncthreads();
     }
-    pj_eig_wave<12>(sA, sV, dm, ut);
+    pj_eig_wave<12>(sA, sV, dm, ut, ws2 + 3 * 36 + 6 + 66 + 20);
     for (int i = 0; i < 12; i++) PTR(184 + i, dm[i]);
     for (int i = 0; i < 144; i++) PTR(196 + i, ut[i]);
     double* L = ws2 + 3 * 36 + 6; double* rho = L + 60;      // in LDS: read many times by the three beta solves and Gauss-Newton
@@ -510,11 +540,10 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
 {
     __shared__ int s_idx[PNP_MAX_HYP * 5];
     __shared__ double s_ws[3 * 144 + 12];
-    __shared__ double s_ws2[3 * 36 + 6 + 60 + 6 + 20];
+    __shared__ double s_ws2[3 * 36 + 6 + 60 + 6 + 20 + 24];   // + rotation scratch of pj_eig_wave
     __shared__ double s_samp[25];
     __shared__ double s_red[28];
     __shared__ double s_j[14][PNP_T];                         // one 64-point chunk of the refinement: J0[6], J1[6], e0, e1 per point
-    __shared__ unsigned char s_m[PNP_T];
     __shared__ double s_pose[12], s_try[12], s_c1;
     __shared__ int s_best, s_flag, s_w[PNP_T / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -633,12 +662,13 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
             __syncthreads();                                  // the previous chunk's readers are done
 #pragma unroll
             for (int a = 0; a < 6; a++) { s_j[a][tid] = J0[a]; s_j[6 + a][tid] = J1[a]; }
-            s_j[12][tid] = e0; s_j[13][tid] = e1; s_m[tid] = valid;
+            s_j[12][tid] = e0; s_j[13][tid] = e1;
             __syncthreads();
             if (lane < 28) {
-                const int cnt = min(PNP_T, n - c0);
-                for (int j = 0; j < cnt; j++)
-                    if (s_m[j]) acc += s_j[r0][j] * s_j[r1][j] + s_j[r2][j] * s_j[r3][j];
+                // points that are not inliers (or beyond n) have zero rows: adding their +0.0 leaves the sum bit for bit what the
+                // CPU restatement gets by skipping them, and the loop can be unrolled (loads in flight, only the adds are a chain)
+#pragma unroll 16
+                for (int j = 0; j < PNP_T; j++) acc += s_j[r0][j] * s_j[r1][j] + s_j[r2][j] * s_j[r3][j];
             }
         }
         __syncthreads();
@@ -665,7 +695,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
                     for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) s_try[3 * a + c] = dR[3 * a] * s_pose[c] + dR[3 * a + 1] * s_pose[3 + c] + dR[3 * a + 2] * s_pose[6 + c];
                     for (int a = 0; a < 3; a++) s_try[9 + a] = s_pose[9 + a] + dx[3 + a];
                     double step = 0; for (int a = 0; a < 6; a++) step += dx[a] * dx[a];
-                    s_flag = step < 1e-26 ? 1 : 0;
+                    s_flag = step < 1e-18 ? 1 : 0;
                 }
             }
             __syncthreads();
@@ -681,11 +711,11 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
                     e2 = e0 * e0 + e1 * e1;
                 }
                 __syncthreads();
-                s_j[0][tid] = e2; s_m[tid] = valid;
+                s_j[0][tid] = e2;
                 __syncthreads();
                 if (tid == 0) {
-                    const int cnt = min(PNP_T, n - cb);
-                    for (int j = 0; j < cnt; j++) if (s_m[j]) c1 += s_j[0][j];
+#pragma unroll 16
+                    for (int j = 0; j < PNP_T; j++) c1 += s_j[0][j];          // zeros for the points that do not count
                 }
             }
             if (tid == 0) s_c1 = c1;
@@ -753,7 +783,7 @@ extern "C" int bh_solve_pnp_ransac(bh_ctx* ctx, const double* obj, const double*
     }
     pnp_K Kd = { K[0], K[1], K[2], K[3] };
     BH_LAUNCH(ctx, BH_K_PNP, k_pnp_ransac, dim3(B), dim3(PNP_T), st, d_obj, d_img, d_n, stride, Kd, iterations, reproj_error,
-              confidence, d_r, d_t, d_in, d_ni, d_ok, (uint8_t*)ctx->st_h.p, 60, (double*)nullptr);
+              confidence, d_r, d_t, d_in, d_ni, d_ok, (uint8_t*)ctx->st_h.p, 20, (double*)nullptr);
     BH_HIP(ctx, hipGetLastError());
     if (mem == BH_MEM_HOST) {
         BH_HIP(ctx, hipMemcpyAsync(rvec, d_r, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
@@ -794,7 +824,7 @@ extern "C" int bh_debug_pnp_trace(bh_ctx* ctx, const double* obj, const double* 
     pnp_K Kd = { K[0], K[1], K[2], K[3] };
     hipLaunchKernelGGL(k_pnp_ransac, dim3(B), dim3(PNP_T), 0, st, (const double*)ctx->st_a.p, (const double*)ctx->st_b.p,
                        (const int*)ctx->st_c.p, stride, Kd, iterations, reproj_error, confidence, d_r, d_t, (int*)ctx->st_e.p,
-                       d_ni, d_ok, (uint8_t*)ctx->st_h.p, 60, (double*)ctx->st_f.p);
+                       d_ni, d_ok, (uint8_t*)ctx->st_h.p, 20, (double*)ctx->st_f.p);
     BH_HIP(ctx, hipGetLastError());
     BH_HIP(ctx, hipMemcpyAsync(rvec, d_r, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
     BH_HIP(ctx, hipMemcpyAsync(tvec, d_t, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));

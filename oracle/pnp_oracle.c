@@ -77,6 +77,63 @@ static void jacobi_eig(const double* Ain, int n, double* d, double* Vt)
     for (int i = 0; i < n; i++) { d[i] = A[order[i] * n + order[i]]; for (int k = 0; k < n; k++) Vt[i * n + k] = V[k * n + order[i]]; }
 }
 
+
+/* The same eigen-problem with the rotations of a sweep arranged in ROUNDS of disjoint pairs (round-robin tournament ordering: with
+ * M = n rounded up to even, round r pairs the fixed player M-1 with r and (r+k) mod (M-1) with (r-k) mod (M-1), k = 1 .. M/2-1; a pair
+ * with the dummy player of an odd n is a bye).  All rotation angles of a round are taken from the matrix as it stands at the start of
+ * the round (the diagonal and the pivot element of one pair are not touched by the others), then every column rotation of the round is
+ * applied, then every row rotation.  Mathematically the classical Jacobi method with another pivot order; on the GPU a round is one
+ * step of one wave instead of up to six dependent rotations, and this restatement fixes the operation order the kernel reproduces.
+ * Used for the 12x12 M'M of EPnP and the small normal equations of lsq_solve. */
+static void jacobi_eig_rr(const double* Ain, int n, double* d, double* Vt)
+{
+    double A[144], V[144];
+    const int M = (n + 1) & ~1, NP = M / 2;
+    for (int i = 0; i < n * n; i++) A[i] = Ain[i];
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = i == j;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0;
+        int rot = 0;
+        for (int p = 0; p < n; p++) for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
+        if (off < 1e-300) break;
+        for (int r = 0; r < M - 1; r++) {
+            int P[6], Q[6], act[6]; double C[6], S[6];
+            for (int i = 0; i < NP; i++) {
+                int a = i == 0 ? M - 1 : (r + i) % (M - 1), b = i == 0 ? r : (r - i + (M - 1)) % (M - 1);
+                int p = a < b ? a : b, q = a < b ? b : a;
+                P[i] = p; Q[i] = q; act[i] = 0; C[i] = 1.0; S[i] = 0.0;
+                if (q >= n) continue;                                   /* bye */
+                double apq = A[p * n + q];
+                if (fabs(apq) < 1e-300 || fabs(apq) <= 1e-17 * sqrt(fabs(A[p * n + p] * A[q * n + q]))) continue;
+                double tau = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                C[i] = 1.0 / sqrt(1.0 + t * t); S[i] = t * C[i]; act[i] = 1; rot = 1;
+            }
+            for (int i = 0; i < NP; i++) if (act[i]) {
+                const int p = P[i], q = Q[i]; const double c = C[i], s = S[i];
+                for (int k = 0; k < n; k++) {
+                    double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq;
+                    double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+            for (int i = 0; i < NP; i++) if (act[i]) {
+                const int p = P[i], q = Q[i]; const double c = C[i], s = S[i];
+                for (int k = 0; k < n; k++) {
+                    double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk;
+                }
+            }
+        }
+        if (!rot) break;
+    }
+    int order[12];
+    for (int i = 0; i < n; i++) order[i] = i;
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) if (A[order[j] * n + order[j]] > A[order[i] * n + order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+    for (int i = 0; i < n; i++) { d[i] = A[order[i] * n + order[i]]; for (int k = 0; k < n; k++) Vt[i * n + k] = V[k * n + order[i]]; }
+}
+
 /* least squares min |A x - b| (m x n, n <= 5) through the eigen-decomposition of A'A (pseudo-inverse, tiny modes dropped) */
 static void lsq_solve(const double* A, const double* b, int m, int n, double* x)
 {
@@ -85,7 +142,7 @@ static void lsq_solve(const double* A, const double* b, int m, int n, double* x)
         Atb[i] = 0; for (int k = 0; k < m; k++) Atb[i] += A[k * n + i] * b[k];
         for (int j = 0; j < n; j++) { double s = 0; for (int k = 0; k < m; k++) s += A[k * n + i] * A[k * n + j]; AtA[i * n + j] = s; }
     }
-    jacobi_eig(AtA, n, d, Vt);
+    jacobi_eig_rr(AtA, n, d, Vt);
     for (int i = 0; i < n; i++) x[i] = 0;
     for (int e = 0; e < n; e++) {
         if (d[e] <= d[0] * 1e-14 || d[e] <= 0) continue;
@@ -332,7 +389,7 @@ static void epnp_solve(const double* pws, const double* us, int n, epnp_K K, dou
     }
     for (int i = 0; i < 144; i++) OTR(40 + i, MtM[i]);
     double dm[12], ut[144];
-    jacobi_eig(MtM, 12, dm, ut);
+    jacobi_eig_rr(MtM, 12, dm, ut);
     for (int i = 0; i < 12; i++) OTR(184 + i, dm[i]);
     for (int i = 0; i < 144; i++) OTR(196 + i, ut[i]);
     /* L_6x10 and rho */
@@ -395,7 +452,7 @@ static void pnp_refine(const double* obj, const double* img, const uint8_t* sel,
 {
     double lambda = 1e-3;
     double cost = -1;
-    for (int it = 0; it < 60; it++) {
+    for (int it = 0; it < 20; it++) {                       /* CvLevMarq: at most 20 iterations */
         double H[36] = {0}, g[6] = {0}, c0 = 0;
         for (int i = 0; i < n; i++) if (sel[i]) {
             const double* X = obj + 3 * i;
@@ -434,7 +491,7 @@ static void pnp_refine(const double* obj, const double* img, const uint8_t* sel,
                 c1 += e0 * e0 + e1 * e1;
             }
             if (c1 < c0 && isfinite(c1)) { memcpy(R, Rn, sizeof(Rn)); memcpy(t, tn, sizeof(tn)); lambda *= 0.2; improved = 1; cost = c1;
-                double step = 0; for (int a = 0; a < 6; a++) step += dx[a] * dx[a]; if (step < 1e-26) it = 1000; }
+                double step = 0; for (int a = 0; a < 6; a++) step += dx[a] * dx[a]; if (step < 1e-18) it = 1000; }          /* |step| < 1e-9: OpenCV stops at a relative parameter change of FLT_EPSILON */
             else lambda *= 5.0;
         }
         if (!improved) break;
