@@ -175,9 +175,9 @@ def test_two_rank_gloo_sharded_matching_equals_single_process(tmp_path):
 
 
 def test_committed_bench_line_meets_the_contract():
-    """profiles/r01_final_bench.json is the JSON line bench.py printed on the MI355X; check the measurement contract's fields."""
+    """profiles/r02_bench.json is the JSON line bench.py printed on the MI355X; check the measurement contract's fields."""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_final_bench.json")))
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench.json")).read().strip().splitlines()[-1])
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                  ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
                  ("cpu_baseline", dict)):
@@ -187,7 +187,13 @@ def test_committed_bench_line_meets_the_contract():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["traffic"] is None or r["traffic"] >= r["alg_bytes_per_launch"]          # PMC traffic cannot be below the compulsory bytes
+    assert r["alg_bytes_per_launch"] == 1592000 * 125                                  # 1 592 000 B per frame x frames per launch
+    assert abs(r["kernel_frac"] - r["kernel_achieved"] / r["peak"]) < 1e-4 and "byte_model" in r and "kernel_byte_model" in r
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "frames/s" and c["value"] > 0 and "sample" in c
-    assert d["parity_sample_ok"] is True
+    assert c["reference_libs"]["cv2"] == "absent" and c["reference_libs"]["g2o"] == "absent"      # the probe ran; the box has neither
+    assert d["parity_sample_ok"] is True and "errors" not in d
+    assert set(d["inputs"]) == {"low_texture", "high_corner_density"}
+    b = d["bow_query"]["roofline"]
+    assert b["frac"] < 0.79 and b["survey_bytes_per_query"] == 3 * (b["bytes_per_query"] - 16 * 100000)   # streamed-bytes fraction stays physical
     assert abs(d["value"] - 1000 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-3
