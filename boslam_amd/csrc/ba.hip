@@ -373,6 +373,7 @@ struct bh_ba {
     bh_buf err[2], chi_e[2];           // [0] at the current state (iteration start), [1] at the trial state
     bh_buf Hpl, Hll, bl, Hpp, bp, pdiag, cdiag;
     bh_buf Dinv, db, S, bs, dxp, dxl, state, pairs, part, xch;
+    bh_buf join, j_start;              // per camera pair: the (edge, edge) pairs that share a landmark (Schur complement's work list)
     int chol_split = 0;                // two-way window solve: first block column of the separator (0 = one workgroup)
     int npairs = 0;
     int bw = 0;                        // scalar half-bandwidth of the reduced camera system (6*max|s1-s2| + 5)
@@ -557,48 +558,37 @@ __global__ __launch_bounds__(256) void k_ba_dinv(const double* __restrict__ Hll,
     for (int a = 0; a < 3; a++) db[3 * j + a] = Di[3 * a] * bl[3 * j] + Di[3 * a + 1] * bl[3 * j + 1] + Di[3 * a + 2] * bl[3 * j + 2];
 }
 
-#define SCH_LDS 6144
 // ---- k_ba_schur_S: workgroup per camera pair (s1 <= s2): S[s1][s2] = [s1==s2](Hpp + lambda I) - sum_j Hpl_1j Dinv_j Hpl_2j'
-template <int NT, int NLDS>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_ba_schur_S(const int2* __restrict__ pairs, const int* __restrict__ c_start,
-                                                    const int* __restrict__ c_edges, const int* __restrict__ e_pt,
+template <int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_ba_schur_S(const int2* __restrict__ pairs, const int* __restrict__ j_start,
+                                                    const int2* __restrict__ join, const int* __restrict__ e_pt,
                                                     const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                                                     const double* __restrict__ Hpp, const ba_state* __restrict__ St,
                                                     int bw, int add_diag, double* __restrict__ Sm)
 {
-    // NT = 256 for a few long edge lists (local BA), one wave per pair for many short ones (global BA)
+    // NT = 256 for a few long lists (local BA), one wave per pair for many short ones (global BA).  join[j_start[p] .. j_start[p+1])
+    // lists the (edge of s1, edge of s2) pairs that observe the same landmark, in landmark order: built once per problem
+    // (ba_build_device); round 1 re-derived it in every trial by a binary search per edge, 90 % of which found nothing.
     __shared__ double s_red[36 * (NT / 64)];
-    __shared__ int s_pt2[NLDS];                            // camera s2's point ids (ascending): the join searches LDS
     const int tid = threadIdx.x;
     const int s1 = pairs[blockIdx.x].x, s2 = pairs[blockIdx.x].y;
-    const int a0 = c_start[s1], a1 = c_start[s1 + 1], b0 = c_start[s2], b1 = c_start[s2 + 1];
-    const int n2 = b1 - b0;
-    const bool in_lds = n2 <= NLDS;
-    if (in_lds) for (int i = tid; i < n2; i += NT) s_pt2[i] = e_pt[c_edges[b0 + i]];
-    __syncthreads();
+    const int t0 = j_start[blockIdx.x], t1 = j_start[blockIdx.x + 1];
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0;
- for (int u = a0 + tid; u < a1; u += NT) {
-        const int e1 = c_edges[u];
-        const int j = e_pt[e1];
-        int lo = 0, hi = n2;                                     // lower_bound of j in camera s2's point-sorted list
-        if (in_lds) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pt2[mid] < j) lo = mid + 1; else hi = mid; } }
-        else { while (lo < hi) { const int mid = (lo + hi) >> 1; if (e_pt[c_edges[b0 + mid]] < j) lo = mid + 1; else hi = mid; } }
-        lo += b0;
-        for (int v = lo; v < b1 && e_pt[c_edges[v]] == j; v++) {
-            const int e2 = c_edges[v];
-            const double* B1 = Hpl + 18 * (size_t)e1; const double* B2 = Hpl + 18 * (size_t)e2; const double* Di = Dinv + 9 * (size_t)j;
-            double BD[18];
+    for (int t = t0 + tid; t < t1; t += NT) {
+        const int2 ee = join[t];
+        const int e1 = ee.x, e2 = ee.y, j = e_pt[e1];
+        const double* B1 = Hpl + 18 * (size_t)e1; const double* B2 = Hpl + 18 * (size_t)e2; const double* Di = Dinv + 9 * (size_t)j;
+        double BD[18];
 #pragma unroll
-            for (int a = 0; a < 6; a++)
+        for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int bb = 0; bb < 3; bb++) BD[3 * a + bb] = B1[3 * a] * Di[bb] + B1[3 * a + 1] * Di[3 + bb] + B1[3 * a + 2] * Di[6 + bb];
+            for (int bb = 0; bb < 3; bb++) BD[3 * a + bb] = B1[3 * a] * Di[bb] + B1[3 * a + 1] * Di[3 + bb] + B1[3 * a + 2] * Di[6 + bb];
 #pragma unroll
-            for (int a = 0; a < 6; a++)
+        for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int bb = 0; bb < 6; bb++) acc[6 * a + bb] += BD[3 * a] * B2[3 * bb] + BD[3 * a + 1] * B2[3 * bb + 1] + BD[3 * a + 2] * B2[3 * bb + 2];
-        }
+            for (int bb = 0; bb < 6; bb++) acc[6 * a + bb] += BD[3 * a] * B2[3 * bb] + BD[3 * a + 1] * B2[3 * bb + 1] + BD[3 * a + 2] * B2[3 * bb + 2];
     }
     // wave sums, then thread e < 36 adds the waves' partials of element e in wave order (same order as d_block_sum; reading the
     // result as acc[tid] would index the accumulator array dynamically and move all 36 accumulators to scratch memory)
@@ -1678,7 +1668,7 @@ extern "C" void bh_ba_destroy(bh_ba* ba)
     bh_buf* all[] = { &ba->cams[0], &ba->cams[1], &ba->pts[0], &ba->pts[1], &ba->e_cam, &ba->e_pt, &ba->e_meas, &ba->cslot,
                       &ba->p_start, &ba->p_edges, &ba->c_start, &ba->c_edges, &ba->err[0], &ba->err[1], &ba->chi_e[0],
                       &ba->chi_e[1], &ba->Hpl, &ba->Hll, &ba->bl, &ba->Hpp, &ba->bp, &ba->pdiag, &ba->cdiag, &ba->Dinv,
-                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch };
+                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch, &ba->join, &ba->j_start };
     for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     delete ba;
 }
@@ -1814,6 +1804,51 @@ __global__ void k_bld_gather_pts(const double* __restrict__ points, const int* _
     if (s >= 0) { pts[3 * (size_t)s] = points[3 * (size_t)j]; pts[3 * (size_t)s + 1] = points[3 * (size_t)j + 1]; pts[3 * (size_t)s + 2] = points[3 * (size_t)j + 2]; }
 }
 
+// join list of the Schur complement: for every landmark every pair (u <= v) of its free-camera edges, keyed by the camera pair
+__global__ void k_bld_join_count(const int* __restrict__ p_start, const int* __restrict__ p_edges, const int* __restrict__ ep,
+                                 const int* __restrict__ cam_slot, int Pa, int* __restrict__ cnt)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Pa) return;
+    int f = 0;
+    for (int u = p_start[j]; u < p_start[j + 1]; u++) f += cam_slot[ep[p_edges[u]]] >= 0;
+    cnt[j] = f * (f + 1) / 2;
+}
+__global__ void k_bld_join_emit(const int* __restrict__ p_start, const int* __restrict__ p_edges, const int* __restrict__ ep,
+                                const int* __restrict__ cam_slot, int Pa, int Cf, const long long* __restrict__ off,
+                                unsigned long long* __restrict__ key, unsigned long long* __restrict__ val)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Pa) return;
+    long long o = off[j];
+    const int a0 = p_start[j], a1 = p_start[j + 1];
+    for (int u = a0; u < a1; u++) {
+        const int e1 = p_edges[u], s1 = cam_slot[ep[e1]]; if (s1 < 0) continue;
+        for (int v = u; v < a1; v++) {
+            const int e2 = p_edges[v], s2 = cam_slot[ep[e2]]; if (s2 < 0) continue;      // edges of a point are sorted by camera: s1 <= s2
+            key[o] = (unsigned long long)s1 * Cf + s2;
+            val[o] = ((unsigned long long)(unsigned)e1 << 32) | (unsigned)e2;
+            o++;
+        }
+    }
+}
+__global__ void k_bld_join_start(const int2* __restrict__ pairs, int npairs, int Cf, const unsigned long long* __restrict__ key, long long M,
+                                 int* __restrict__ j_start)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p > npairs) return;
+    if (p == npairs) { j_start[p] = (int)M; return; }
+    const unsigned long long k = (unsigned long long)pairs[p].x * Cf + pairs[p].y;
+    long long lo = 0, hi = M;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (key[mid] < k) lo = mid + 1; else hi = mid; }
+    j_start[p] = (int)lo;
+}
+__global__ void k_bld_join_unpack(const unsigned long long* __restrict__ val, long long M, int2* __restrict__ join)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < M) join[t] = make_int2((int)(val[t] >> 32), (int)(val[t] & 0xffffffffu));
+}
+
 struct ba_build_out { int Cf, Pa, c_total, npairs, bwb; };
 
 // Builds every structural array of the problem in ba's device buffers from the uploaded edge list.  scratch: ctx->st_a .. st_g.
@@ -1921,6 +1956,41 @@ static int ba_build_device(bh_ba* ba, int C, const uint8_t* fixed, int P, const 
         npairs = hv[0]; bwb = hv[1]; c_total = hv[2];
         BH_TRY(bh_reserve(ctx, &ba->pairs, sizeof(int2) * ((size_t)npairs + 1)));
         hipLaunchKernelGGL(k_bld_pairs_emit, G(nw), T, 0, st, (const unsigned*)bits, (const int*)woff, nw, Cf, (int2*)ba->pairs.p);
+    }
+    // the Schur complement's work list: (edge, edge) pairs per camera pair, landmarks ascending inside a pair (stable sort of the
+    // per-landmark enumeration by camera-pair key)
+    {
+        BH_TRY(bh_reserve(ctx, &ba->j_start, sizeof(int) * ((size_t)npairs + 2)));
+        long long M = 0;
+        if (Pa && Cf) {
+            int* jc = p_cnt;                                                   // reuse: per-point incidence counts (p_cnt is dead: p_start is built)
+            hipLaunchKernelGGL(k_bld_join_count, G(Pa), T, 0, st, (const int*)ba->p_start.p, (const int*)ba->p_edges.p, (const int*)ep, (const int*)cam_slot, Pa, jc);
+            BH_TRY(bh_reserve(ctx, &ctx->st_g, sizeof(long long) * ((size_t)Pa + 2) + 1024));
+            long long* joff = (long long*)ctx->st_g.p;
+            BH_HIP(ctx, hipMemsetAsync(jc + Pa, 0, sizeof(int), st));
+            size_t need3 = 0;
+            BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, need3, jc, joff, Pa + 1, st));
+            BH_TRY(bh_reserve(ctx, &ctx->st_e, need3 + 256));
+            BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->st_e.p, need3, jc, joff, Pa + 1, st));
+            BH_HIP(ctx, hipMemcpyAsync(&M, joff + Pa, sizeof(long long), hipMemcpyDeviceToHost, st));
+            BH_HIP(ctx, hipStreamSynchronize(st));
+            if (M >= (1ll << 31)) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: %lld landmark / camera-pair incidences (limit 2^31)", M);
+            BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(unsigned long long) * 4 * (size_t)(M + 1)));
+            unsigned long long* jk = (unsigned long long*)ctx->st_b.p; unsigned long long* jk2 = jk + M + 1; unsigned long long* jv = jk2 + M + 1; unsigned long long* jv2 = jv + M + 1;
+            hipLaunchKernelGGL(k_bld_join_emit, G(Pa), T, 0, st, (const int*)ba->p_start.p, (const int*)ba->p_edges.p, (const int*)ep, (const int*)cam_slot, Pa, Cf, (const long long*)joff, jk, jv);
+            int bits_k = 1; while ((1ll << bits_k) < (long long)Cf * Cf) bits_k++;
+            hipcub::DoubleBuffer<unsigned long long> kj(jk, jk2), vj(jv, jv2);
+            size_t need4 = 0;
+            BH_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, need4, kj, vj, (int)M, 0, bits_k, st));
+            BH_TRY(bh_reserve(ctx, &ctx->st_e, need4 + 256));
+            BH_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->st_e.p, need4, kj, vj, (int)M, 0, bits_k, st));
+            BH_TRY(bh_reserve(ctx, &ba->join, sizeof(int2) * (size_t)(M + 1)));
+            hipLaunchKernelGGL(k_bld_join_unpack, G(M), T, 0, st, (const unsigned long long*)vj.Current(), M, (int2*)ba->join.p);
+            hipLaunchKernelGGL(k_bld_join_start, G((long long)npairs + 1), T, 0, st, (const int2*)ba->pairs.p, npairs, Cf, (const unsigned long long*)kj.Current(), M, (int*)ba->j_start.p);
+        } else {
+            BH_TRY(bh_reserve(ctx, &ba->join, sizeof(int2)));
+            BH_HIP(ctx, hipMemsetAsync(ba->j_start.p, 0, sizeof(int) * ((size_t)npairs + 2), st));
+        }
     }
     out->npairs = npairs; out->bwb = bwb; out->c_total = c_total;
     // active points in slot order; host mirrors of the slots (get_points / get_poses map back through them)
@@ -2031,6 +2101,25 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
         BH_TRY(upload(ctx, &ba->p_start, p_start)); BH_TRY(upload(ctx, &ba->p_edges, p_edges));
         BH_TRY(upload(ctx, &ba->c_start, c_start)); BH_TRY(upload(ctx, &ba->c_edges, c_edges));
         BH_TRY(upload(ctx, &ba->pairs, pairs));
+        {   // the join list, as the device build produces it: per camera pair (lexicographic), landmarks ascending
+            std::vector<int> j_start(pairs.size() + 1, 0);
+            std::vector<long long> pair_of((size_t)Cf * Cf, -1);
+            for (size_t q = 0; q < pairs.size(); q++) pair_of[(size_t)pairs[q].x * Cf + pairs[q].y] = (long long)q;
+            for (int j = 0; j < Pa; j++)
+                for (int u = p_start[j]; u < p_start[j + 1]; u++) {
+                    const int s1 = ba->cam_slot[e_cam[p_edges[u]]]; if (s1 < 0) continue;
+                    for (int v = u; v < p_start[j + 1]; v++) { const int s2 = ba->cam_slot[e_cam[p_edges[v]]]; if (s2 >= 0) j_start[pair_of[(size_t)s1 * Cf + s2] + 1]++; }
+                }
+            for (size_t q = 0; q < pairs.size(); q++) j_start[q + 1] += j_start[q];
+            std::vector<int2> join(j_start[pairs.size()] + 1);
+            std::vector<int> fill(j_start.begin(), j_start.end() - 1);
+            for (int j = 0; j < Pa; j++)
+                for (int u = p_start[j]; u < p_start[j + 1]; u++) {
+                    const int e1 = p_edges[u], s1 = ba->cam_slot[e_cam[e1]]; if (s1 < 0) continue;
+                    for (int v = u; v < p_start[j + 1]; v++) { const int e2 = p_edges[v], s2 = ba->cam_slot[e_cam[e2]]; if (s2 >= 0) join[fill[pair_of[(size_t)s1 * Cf + s2]]++] = make_int2(e1, e2); }
+                }
+            BH_TRY(upload(ctx, &ba->join, join)); BH_TRY(upload(ctx, &ba->j_start, j_start));
+        }
         BH_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the host vectors above go out of scope
     }
     ba->schur_wave = (Cf > 0 && ba->npairs >= 4096 && c_total / Cf < 1024) ? 1 : 0;
@@ -2153,10 +2242,10 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
             if (Cf) {
                 BH_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double) * (size_t)n6 * (ba->bw + 1), st));     // blocks without a common point stay zero
                 if (ba->schur_wave)
-                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<64, 1024>), dim3(ba->npairs), dim3(64), st, (const int2*)ba->pairs.p, c_start, c_edges, e_pt,
+                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<64>), dim3(ba->npairs), dim3(64), st, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
                               (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S);
                 else
-                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<256, SCH_LDS>), dim3(ba->npairs), dim3(256), st, (const int2*)ba->pairs.p, c_start, c_edges, e_pt,
+                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<256>), dim3(ba->npairs), dim3(256), st, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
                               (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S);
                 BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_b, dim3(Cf), dim3(256), st, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)db,
                           (const double*)bp, dist ? lead : 1, bs);
