@@ -380,6 +380,8 @@ struct bh_ba {
     int chol_nb = 32;                  // panel width chosen for the LDS budget
     int chol_window = 0;               // on-chip sliding-window banded Cholesky (k_ba_chol_sw) instead of the panel kernel
     int chol_dense = 0;                // whole factor on chip (k_ba_chol_dense): 6 Cf <= 288, the local-BA window
+    int chol_bcr = 0;                  // block cyclic reduction over the whole chip (long narrow systems: global BA)
+    struct bcr_dev* bcr = nullptr;
     int schur_wave = 0;                // one wave per camera pair (many short edge lists) instead of a 256-thread workgroup
     int last_err_sel = 0;              // which err buffer holds "the last computeActiveErrors"
     // landmark-sharded multi-GPU mode (bh_ba_set_allreduce)
@@ -817,9 +819,22 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
 #define CD_TILE (16 * CD_P)
 #define CD_LDS_DOUBLES (3 * CD_MAXT * CD_TILE /*Lc, Linv, diagonal tiles*/ + 3 * CD_MAXT * 16 /*y, x, partials*/ + 16)
 
-__global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict__ A, const double* __restrict__ bs, int n, int bw,
-                                                        double* __restrict__ x, ba_state* __restrict__ St)
+// BCR = true: the batched factor-only form used by the block cyclic reduction below - workgroup b factors the 256 x 256 block
+// el[b].e of Dblk (row-major, lower part) in place (strictly lower tiles -> L, diagonal tiles -> the INVERSES of their factors) and
+// leaves y = L^-1 g in yv; no backward pass.
+struct bcr_elim { int e, l, r, sl, sr; };            // block to eliminate, its chain neighbours (-1: none), the coupling slots (e x l), (e x r)
+template <bool BCR>
+__global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict__ A_, const double* __restrict__ bs_, int n, int bw,
+                                                        double* __restrict__ x, ba_state* __restrict__ St, const bcr_elim* __restrict__ el,
+                                                        double* Dblk, const double* gv, double* yv)
 {
+    const double* A = A_; const double* bs = bs_;
+    double* Aout = nullptr; double* yout = nullptr;
+    if constexpr (BCR) {
+        const int e = el[blockIdx.x].e;
+        Aout = Dblk + (size_t)e * 65536; A = Aout; bs = gv + 256 * (size_t)e; yout = yv + 256 * (size_t)e;
+    }
+#define CD_A(r, c) (BCR ? A[(size_t)(r) * 256 + (c)] : A[(size_t)(r) * LD + ((c) - (r) + bw)])
     extern __shared__ double sm[];
     double* Lc = sm;                                  // [NT][16][17] the factored block column J (operands of [4])
     double* Li = Lc + CD_MAXT * CD_TILE;              // [NT][16][17] inverses of the diagonal tiles' factors
@@ -836,7 +851,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
     for (int e = tid; e < NT * 256; e += 1024) {      // diagonal tiles: lower part, identity padding
         const int j = e >> 8, rr = (e >> 4) & 15, cc = e & 15, r = 16 * j + rr, c = 16 * j + cc;
         double v = 0.0;
-        if (r < n && c < n) { if (c <= r && r - c <= bw) v = A[(size_t)r * LD + (c - r + bw)]; }
+        if (r < n && c < n) { if (c <= r && r - c <= bw) v = CD_A(r, c); }
         else if (r == c) v = 1.0;
         Dg[j * CD_TILE + rr * CD_P + cc] = v;
     }
@@ -908,7 +923,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
                 }
             }
         }
-        if (!s_fail)
+        if (!BCR && !s_fail)
             for (int J = NT - 1; J >= 0; J--) {
                 __syncthreads();                      // the partials of column J are in spart
                 double z = sy[16 * J + rl];
@@ -942,7 +957,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
 #pragma unroll
                     for (int rg = 0; rg < 4; rg++) {
                         const int r = 16 * i + r0q + 4 * rg;
-                        v[rg] = (r < n && c < n && r - c <= bw) ? A[(size_t)r * LD + (c - r + bw)] : 0.0;      // strictly below the diagonal tiles: r > c
+                        v[rg] = (r < n && c < n && r - c <= bw) ? CD_A(r, c) : 0.0;      // strictly below the diagonal tiles: r > c
                     }
                 }
                 Tl[k] = v;
@@ -974,6 +989,10 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
                 for (int ks = 0; ks < 4; ks++)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(slot[col * CD_P + 4 * ks + r0], Li[J * CD_TILE + col * CD_P + 4 * ks + r0], acc, 0, 0, 0);
                 Tl[k] = acc;
+                if constexpr (BCR) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) Aout[(size_t)(16 * i + r0 + 4 * rg) * 256 + 16 * J + col] = acc[rg];
+                }
                 CD_WAVE_SYNC();                       // the operand reads above precede the overwrite below in every lane
 #pragma unroll
                 for (int rg = 0; rg < 4; rg++) {
@@ -999,7 +1018,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
                 for (int rg = 0; rg < 4; rg++) Tl[k][rg] -= acc[rg];
             }
         }
-        if (!failed)
+        if (!BCR && !failed)
             for (int J = NT - 1; J >= 0; J--) {
                 int col = colq, r0 = r0q;
                 asm volatile("" : "+v"(col), "+v"(r0), "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]));
@@ -1019,8 +1038,19 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
             }
 #undef CD_TIJ
     }
+    if constexpr (BCR) {
+        __syncthreads();
+        if (s_fail) { if (tid == 0) St->chol_ok = 0; return; }
+        for (int e = tid; e < NT * 256; e += 1024) {
+            const int j = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
+            Aout[(size_t)(16 * j + rr) * 256 + 16 * j + cc] = Li[j * CD_TILE + rr * CD_P + cc];
+        }
+        for (int i = tid; i < 256; i += 1024) yout[i] = sy[i];
+        return;
+    }
     if (s_fail) { if (tid == 0) St->chol_ok = 0; for (int i = tid; i < n; i += 1024) x[i] = 0; return; }
     for (int i = tid; i < n; i += 1024) x[i] = sx[i];
+#undef CD_A
 }
 
 // ---- k_ba_chol_sw: banded Cholesky with the whole trailing window ON CHIP (global-BA sizes: n >> bw, bw <= 256).
@@ -1497,11 +1527,237 @@ static int sw_solve(bh_ctx* ctx, hipStream_t st, double* S, const double* bs, in
     hipLaunchKernelGGL(k_sw_reverse, dim3(n1), dim3(256), 0, st, (const double*)S, bs, n, bw, npad, n1, S1, bs1);
     hipLaunchKernelGGL(k_ba_chol_sw, dim3(2), dim3(SW_NT), lds, st, S, bs, n, bw, x, state, 1, split, S1, (const double*)bs1, n1, x1, nb2, xch);
     hipLaunchKernelGGL(k_sw_separator, dim3(256), dim3(256), 0, st, (const double*)S, bs, bw, split, (const double*)xch, Ssep, bsep);
-    hipLaunchKernelGGL(k_ba_chol_dense, dim3(1), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)Ssep, (const double*)bsep, 256, 255,
-                       x + 16 * (size_t)split, state);
+    hipLaunchKernelGGL(k_ba_chol_dense<false>, dim3(1), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)Ssep, (const double*)bsep, 256, 255,
+                       x + 16 * (size_t)split, state, (const bcr_elim*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
     hipLaunchKernelGGL(k_sw_rev_vec, dim3(1), dim3(256), 0, st, x, x1, n, npad, n1, 0);
     hipLaunchKernelGGL(k_ba_chol_sw, dim3(2), dim3(SW_NT), lds, st, S, bs, n, bw, x, state, 2, split, S1, (const double*)bs1, n1, x1, nb2, xch);
     hipLaunchKernelGGL(k_sw_rev_vec, dim3((n1 + 255) / 256), dim3(256), 0, st, x, x1, n, npad, n1, 1);
+    return BH_OK;
+}
+
+// ---- block cyclic reduction of the banded reduced camera system (the solve on many CUs).
+// bw <= 256, so in 256 x 256 blocks the matrix is block tridiagonal: a chain of N = ceil(n / 256) diagonal blocks D_i and the
+// couplings between neighbours.  Every other block of the chain (the even positions) is eliminated AT THE SAME TIME - none of them
+// touches another - which leaves a chain of half the length over the odd positions with fill between what were second neighbours;
+// log2 N levels later one block is left.  That is a Cholesky factorisation in nested-dissection order (no pivoting needed: SPD),
+// with every O(m^3) step on the matrix cores and the level's work spread over the chip:
+//   k_ba_chol_dense<true>   one workgroup per eliminated block e: D_e = L L', y_e = L^-1 g_e            (in place)
+//   k_bcr_trsm              U = L^-1 M for both couplings M (e x neighbour), one wave per 16-column strip; the solved tiles stay
+//                           in the accumulator layout, which IS the B-operand layout of v_mfma_f64_16x16x4_f64 (row 4 rg + l/16)
+//   k_bcr_update            survivor s: D_s -= U'U (both eliminated neighbours, lower tiles), g_s -= U'y; and the fill between the
+//                           two survivors either side of e: -U_a' U_b, written with its rows on the block the NEXT level eliminates
+//   k_bcr_back              levels in reverse: x_e = L^-T (y_e - U_l x_l - U_r x_r)
+// Couplings are stored (eliminated block) x (neighbour) at every level, so every product has the form X'Y with X, Y row-major and
+// the reduction index on the rows: both MFMA operands are coalesced 128-B row segments straight from L2.
+#define BCR_BLK 65536
+struct bcr_work { int out, kind, a0, b0, a1, ye0, ye1; };     // kind 0: D[out] -= U[a0]'U[a0] + U[a1]'U[a1], g[out] -= U[a0]'y[ye0] + U[a1]'y[ye1]
+                                                              // kind 1: C[out] = -U[a0]'U[b0]
+struct bcr_plan {
+    int N = 0, nslots = 0, nlev = 0;
+    std::vector<int> e_off, w_off;                            // per level: first entry of elim / work
+    std::vector<bcr_elim> elim;
+    std::vector<bcr_work> work;
+};
+static void bcr_make_plan(int N, bcr_plan* P)
+{
+    P->N = N; P->elim.clear(); P->work.clear(); P->e_off.assign(1, 0); P->w_off.assign(1, 0);
+    std::vector<int> chain(N), next;
+    for (int i = 0; i < N; i++) chain[i] = i;
+    int base = 0, nslots = N - 1;                             // level-0 coupling p joins blocks p and p + 1
+    for (;;) {
+        const int k = (int)chain.size();
+        for (int p = 0; p < k; p += 2)
+            P->elim.push_back({ chain[p], p > 0 ? chain[p - 1] : -1, p + 1 < k ? chain[p + 1] : -1, p > 0 ? base + p - 1 : -1, p + 1 < k ? base + p : -1 });
+        next.clear();
+        for (int p = 1; p < k; p += 2) {
+            next.push_back(chain[p]);
+            P->work.push_back({ chain[p], 0, base + p - 1, -1, p + 1 < k ? base + p : -1, chain[p - 1], p + 1 < k ? chain[p + 1] : -1 });
+        }
+        const int nb = nslots;
+        for (int q = 0; q + 1 < (int)next.size(); q++) {      // fill through the eliminated block at position 2q + 2
+            const int sa = base + 2 * q + 1, sb = base + 2 * q + 2;        // (e x next[q]), (e x next[q + 1])
+            P->work.push_back({ nb + q, 1, (q & 1) ? sb : sa, (q & 1) ? sa : sb, -1, -1, -1 });      // rows on the even position of the new chain
+        }
+        if (next.size() > 1) nslots += (int)next.size() - 1;
+        P->e_off.push_back((int)P->elim.size()); P->w_off.push_back((int)P->work.size());
+        if (k == 1) break;
+        base = nb; chain = next;
+    }
+    P->nslots = nslots; P->nlev = (int)P->e_off.size() - 1;
+}
+
+// band storage -> diagonal blocks (lower part, identity padding), level-0 couplings (rows on the even block), right-hand side
+__global__ __launch_bounds__(256) void k_bcr_extract(const double* __restrict__ A, const double* __restrict__ bs, int n, int bw, int N,
+                                                     double* __restrict__ Dblk, double* __restrict__ Cpl, double* __restrict__ g)
+{
+    const int b = blockIdx.x, r = blockIdx.y, c = threadIdx.x;
+    const size_t LD = (size_t)bw + 1;
+    if (b < N) {
+        const int R = 256 * b + r, C = 256 * b + c;
+        double v = 0.0;
+        if (R < n && C < n) { if (c <= r && r - c <= bw) v = A[R * LD + (C - R + bw)]; }
+        else if (R == C) v = 1.0;
+        Dblk[(size_t)b * BCR_BLK + r * 256 + c] = v;
+        if (c == 0) g[256 * b + r] = R < n ? bs[R] : 0.0;
+    } else {
+        const int p = b - N;
+        const int R = 256 * (p + 1) + r, C = 256 * p + c;     // element (R, C) of the lower triangle, read along the band row
+        const double v = (R < n && R - C <= bw) ? A[R * LD + (C - R + bw)] : 0.0;
+        Cpl[(size_t)p * BCR_BLK + ((p & 1) ? r * 256 + c : c * 256 + r)] = v;      // odd p: rows on block p + 1; even p: rows on block p
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bcr_trsm(const bcr_elim* __restrict__ el, const double* __restrict__ Dblk, double* __restrict__ Cpl)
+{
+    const bcr_elim E = el[blockIdx.z];
+    const int slot = blockIdx.y ? E.sr : E.sl;
+    if (slot < 0) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 15, r0 = lane >> 4;
+    const double* __restrict__ L = Dblk + (size_t)E.e * BCR_BLK + (size_t)col * 256 + r0;      // A operand: row `col` of a tile, k = 4 ks + r0
+    double* __restrict__ M = Cpl + (size_t)slot * BCR_BLK + 16 * (blockIdx.x * 4 + wv) + (size_t)r0 * 256 + col;
+    ba_d4 U[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        ba_d4 acc;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) acc[rg] = M[(size_t)(16 * i + 4 * rg) * 256];
+#pragma unroll
+        for (int k = 0; k < i; k++) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-L[(size_t)(16 * i) * 256 + 16 * k + 4 * ks], U[k][ks], acc, 0, 0, 0);
+        }
+        ba_d4 u = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)                        // the diagonal tile holds the inverse of its factor
+            u = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(size_t)(16 * i) * 256 + 16 * i + 4 * ks], acc[ks], u, 0, 0, 0);
+        U[i] = u;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) M[(size_t)(16 * i + 4 * rg) * 256] = u[rg];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bcr_update(const bcr_work* __restrict__ wk, double* __restrict__ Dblk, double* __restrict__ Cpl,
+                                                    double* __restrict__ g, const double* __restrict__ yv)
+{
+    const bcr_work W = wk[blockIdx.y];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 15, r0 = lane >> 4;
+    const int t = blockIdx.x * 4 + wv, ti = t >> 4, tj = t & 15;
+    if (W.kind == 0 && tj > ti) return;
+    ba_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+    double gacc = 0.0;
+    const bool do_g = W.kind == 0 && ti == tj;
+#pragma unroll 1
+    for (int side = 0; side < 2; side++) {
+        const int sa = side ? W.a1 : W.a0;
+        if (sa < 0) continue;
+        const int sb = W.kind ? W.b0 : sa;
+        const double* __restrict__ Ua = Cpl + (size_t)sa * BCR_BLK + (size_t)r0 * 256 + 16 * ti + col;
+        const double* __restrict__ Ub = Cpl + (size_t)sb * BCR_BLK + (size_t)r0 * 256 + 16 * tj + col;
+        const double* __restrict__ ye = yv + 256 * (size_t)((side ? W.ye1 : W.ye0) < 0 ? 0 : (side ? W.ye1 : W.ye0)) + r0;
+#pragma unroll 8
+        for (int kk = 0; kk < 64; kk++) {
+            const double a = Ua[(size_t)kk * 1024], b = Ub[(size_t)kk * 1024];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            if (do_g) gacc = __builtin_fma(a, ye[4 * kk], gacc);
+        }
+    }
+    if (W.kind == 0) {
+        double* __restrict__ D = Dblk + (size_t)W.out * BCR_BLK + (size_t)(16 * ti + r0) * 256 + 16 * tj + col;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) D[(size_t)rg * 1024] -= acc[rg];
+        if (do_g) {
+            gacc += d_shfl_xor(gacc, 16); gacc += d_shfl_xor(gacc, 32);
+            if (lane < 16) g[256 * (size_t)W.out + 16 * ti + col] -= gacc;
+        }
+    } else {
+        double* __restrict__ C = Cpl + (size_t)W.out * BCR_BLK + (size_t)(16 * ti + r0) * 256 + 16 * tj + col;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) C[(size_t)rg * 1024] = -acc[rg];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bcr_back(const bcr_elim* __restrict__ el, const double* __restrict__ Dblk, const double* __restrict__ Cpl,
+                                                  const double* __restrict__ yv, double* __restrict__ xp, double* __restrict__ x, int n,
+                                                  const ba_state* __restrict__ St)
+{
+    __shared__ double z[256], xi[16];
+    const bcr_elim E = el[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t o = 256 * (size_t)E.e;
+    if (!St->chol_ok) { xp[o + tid] = 0.0; if (o + tid < (size_t)n) x[o + tid] = 0.0; return; }
+    {   // z = y_e - U_l x_l - U_r x_r: a wave takes 64 rows, a lane 4 columns of each row
+        double xl[4] = { 0, 0, 0, 0 }, xr[4] = { 0, 0, 0, 0 };
+        if (E.l >= 0) for (int q = 0; q < 4; q++) xl[q] = xp[256 * (size_t)E.l + 4 * lane + q];
+        if (E.r >= 0) for (int q = 0; q < 4; q++) xr[q] = xp[256 * (size_t)E.r + 4 * lane + q];
+        const double* Ul = Cpl + (size_t)(E.sl < 0 ? 0 : E.sl) * BCR_BLK + 4 * lane;
+        const double* Ur = Cpl + (size_t)(E.sr < 0 ? 0 : E.sr) * BCR_BLK + 4 * lane;
+#pragma unroll 4
+        for (int rr = 0; rr < 64; rr++) {
+            const int row = 64 * wv + rr;
+            double s2 = 0.0;
+            if (E.sl >= 0) { const double4 u = *reinterpret_cast<const double4*>(Ul + (size_t)row * 256); s2 = __builtin_fma(u.x, xl[0], __builtin_fma(u.y, xl[1], __builtin_fma(u.z, xl[2], u.w * xl[3]))); }
+            if (E.sr >= 0) { const double4 u = *reinterpret_cast<const double4*>(Ur + (size_t)row * 256); s2 += __builtin_fma(u.x, xr[0], __builtin_fma(u.y, xr[1], __builtin_fma(u.z, xr[2], u.w * xr[3]))); }
+            for (int m = 32; m > 0; m >>= 1) s2 += d_shfl_xor(s2, m);
+            if (lane == 0) z[row] = yv[o + row] - s2;
+        }
+    }
+    __syncthreads();
+    const double* L = Dblk + (size_t)E.e * BCR_BLK;
+    for (int J = 15; J >= 0; J--) {
+        if (tid < 16) {                                       // x_J = Linv_JJ' z_J
+            double s2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) s2 = __builtin_fma(L[(size_t)(16 * J + r) * 256 + 16 * J + tid], z[16 * J + r], s2);
+            xi[tid] = s2;
+            xp[o + 16 * J + tid] = s2;
+            if (o + 16 * J + tid < (size_t)n) x[o + 16 * J + tid] = s2;
+        }
+        __syncthreads();
+        if (tid < 16 * J) {                                   // z_j -= L(J, j)' x_J for the block rows above
+            double s2 = z[tid];
+#pragma unroll
+            for (int r = 0; r < 16; r++) s2 = __builtin_fma(-L[(size_t)(16 * J + r) * 256 + tid], xi[r], s2);
+            z[tid] = s2;
+        }
+        __syncthreads();
+    }
+}
+
+#define BCR_SCRATCH_BYTES(N) (sizeof(double) * ((size_t)(N) * BCR_BLK + (size_t)(2 * (N) + 2) * BCR_BLK + 3 * (size_t)(N) * 256) + 64 * (size_t)(4 * (N) + 8))
+struct bcr_dev { bcr_plan plan; double *D = nullptr, *C = nullptr, *g = nullptr, *y = nullptr, *xp = nullptr; bcr_elim* elim = nullptr; bcr_work* work = nullptr; };
+// carve the scratch buffer and upload the elimination plan (on the stream; the plan's host vectors live in `dv`)
+static int bcr_prepare(bh_ctx* ctx, hipStream_t st, bcr_dev* dv, int n, void* scratch)
+{
+    const int N = (n + 255) / 256;
+    bcr_make_plan(N, &dv->plan);
+    dv->D = (double*)scratch; dv->C = dv->D + (size_t)N * BCR_BLK; dv->g = dv->C + (size_t)(2 * N + 2) * BCR_BLK;
+    dv->y = dv->g + (size_t)N * 256; dv->xp = dv->y + (size_t)N * 256;
+    dv->elim = (bcr_elim*)(dv->xp + (size_t)N * 256); dv->work = (bcr_work*)(dv->elim + 2 * N + 4);
+    if (dv->plan.nslots > 2 * N + 2 || (int)dv->plan.elim.size() > 2 * N + 4 || (int)dv->plan.work.size() > 2 * N + 4)
+        return bh_set_err(ctx, BH_ERR_CAPACITY, "bcr_prepare: plan larger than its scratch");
+    BH_HIP(ctx, hipMemcpyAsync(dv->elim, dv->plan.elim.data(), sizeof(bcr_elim) * dv->plan.elim.size(), hipMemcpyHostToDevice, st));
+    if (!dv->plan.work.empty())
+        BH_HIP(ctx, hipMemcpyAsync(dv->work, dv->plan.work.data(), sizeof(bcr_work) * dv->plan.work.size(), hipMemcpyHostToDevice, st));
+    return BH_OK;
+}
+static int bcr_solve(bh_ctx* ctx, hipStream_t st, const bcr_dev* dv, const double* S, const double* bs, int n, int bw, double* x, ba_state* state)
+{
+    const bcr_plan& P = dv->plan;
+    hipLaunchKernelGGL(k_bcr_extract, dim3(2 * P.N - 1, 256), dim3(256), 0, st, S, bs, n, bw, P.N, dv->D, dv->C, dv->g);
+    for (int lv = 0; lv < P.nlev; lv++) {
+        const int ne = P.e_off[lv + 1] - P.e_off[lv], nw = P.w_off[lv + 1] - P.w_off[lv];
+        hipLaunchKernelGGL(k_ba_chol_dense<true>, dim3(ne), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)nullptr, (const double*)nullptr, 256, 255,
+                           (double*)nullptr, state, (const bcr_elim*)(dv->elim + P.e_off[lv]), dv->D, (const double*)dv->g, dv->y);
+        if (nw) {
+            hipLaunchKernelGGL(k_bcr_trsm, dim3(4, 2, ne), dim3(256), 0, st, (const bcr_elim*)(dv->elim + P.e_off[lv]), (const double*)dv->D, dv->C);
+            hipLaunchKernelGGL(k_bcr_update, dim3(64, nw), dim3(256), 0, st, (const bcr_work*)(dv->work + P.w_off[lv]), dv->D, dv->C, dv->g, (const double*)dv->y);
+        }
+    }
+    for (int lv = P.nlev - 1; lv >= 0; lv--)
+        hipLaunchKernelGGL(k_bcr_back, dim3(P.e_off[lv + 1] - P.e_off[lv]), dim3(256), 0, st, (const bcr_elim*)(dv->elim + P.e_off[lv]), (const double*)dv->D,
+                           (const double*)dv->C, (const double*)dv->y, dv->xp, x, n, (const ba_state*)state);
+    BH_HIP(ctx, hipGetLastError());
     return BH_OK;
 }
 
@@ -1652,7 +1908,8 @@ extern "C" int bh_ba_create(bh_ctx* ctx, const double K[5], bh_ba** out)
     (void)hipFuncSetAttribute((const void*)k_ba_chol<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute((const void*)k_ba_chol<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute((const void*)k_ba_chol<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_ba_chol_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
+    (void)hipFuncSetAttribute((const void*)k_ba_chol_dense<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
+    (void)hipFuncSetAttribute((const void*)k_ba_chol_dense<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
     (void)hipFuncSetAttribute((const void*)k_ba_chol_sw, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     bh_ba* ba = new bh_ba();
     ba->ctx = ctx; ba->K = { K[0], K[1], K[2], K[3] };
@@ -1670,6 +1927,7 @@ extern "C" void bh_ba_destroy(bh_ba* ba)
                       &ba->chi_e[1], &ba->Hpl, &ba->Hll, &ba->bl, &ba->Hpp, &ba->bp, &ba->pdiag, &ba->cdiag, &ba->Dinv,
                       &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch, &ba->join, &ba->j_start };
     for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    delete ba->bcr;
     delete ba;
 }
 
@@ -2146,7 +2404,15 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
         const char* tw = getenv("BH_BA_CHOL_TWOWAY");
         ba->chol_split = (ba->chol_window && (ba->bw + 15) / 16 == 16 && nblk >= 96 && !(tw && !strcmp(tw, "0"))) ? (nblk - 16) / 2 : 0;
     }
-    BH_TRY(bh_reserve(ctx, &ba->xch, sizeof(double) * SW_SCRATCH_DOUBLES(n6i, ba->bw)));
+    {   // long narrow systems: block cyclic reduction on the whole chip (BH_BA_CHOL_BCR=0 keeps the window kernels)
+        const char* eb = getenv("BH_BA_CHOL_BCR");
+        ba->chol_bcr = (ba->chol_window && n6i >= 8 * 256 && !(eb && !strcmp(eb, "0"))) ? 1 : 0;
+    }
+    BH_TRY(bh_reserve(ctx, &ba->xch, std::max(sizeof(double) * SW_SCRATCH_DOUBLES(n6i, ba->bw), ba->chol_bcr ? BCR_SCRATCH_BYTES((n6i + 255) / 256) : (size_t)0)));
+    if (ba->chol_bcr) {
+        if (!ba->bcr) ba->bcr = new bcr_dev();
+        BH_TRY(bcr_prepare(ctx, ctx->stream, ba->bcr, n6i, ba->xch.p));
+    }
     {
         const char* ev = getenv("BH_BA_CHOL");
         ba->chol_dense = (!ba->chol_window && n6i >= 1 && n6i <= 16 * CD_MAXT && !(ev && !strcmp(ev, "panel"))) ? 1 : 0;
@@ -2254,8 +2520,10 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                     const int nbsel = ba->chol_nb, bw = ba->bw;
                     const size_t lds = sizeof(double) * ((size_t)std::min(n6, nbsel + bw) * (nbsel + 1) + 1100);
                     bh_time_begin(ctx, BH_K_BA_SOLVE);
-                    if (ba->chol_window) (void)sw_solve(ctx, st, S, (const double*)bs, n6, bw, dxp, state, ba->chol_split, (double*)ba->xch.p);
-                    else if (ba->chol_dense) hipLaunchKernelGGL(k_ba_chol_dense, dim3(1), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)S, (const double*)bs, n6, bw, dxp, state);
+                    if (ba->chol_bcr) (void)bcr_solve(ctx, st, ba->bcr, (const double*)S, (const double*)bs, n6, bw, dxp, state);
+                    else if (ba->chol_window) (void)sw_solve(ctx, st, S, (const double*)bs, n6, bw, dxp, state, ba->chol_split, (double*)ba->xch.p);
+                    else if (ba->chol_dense) hipLaunchKernelGGL(k_ba_chol_dense<false>, dim3(1), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)S, (const double*)bs, n6, bw, dxp, state,
+                                                                 (const bcr_elim*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
                     else if (nbsel == 32) hipLaunchKernelGGL(k_ba_chol<32>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     else if (nbsel == 16) hipLaunchKernelGGL(k_ba_chol<16>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     else hipLaunchKernelGGL(k_ba_chol<8>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
@@ -2306,10 +2574,18 @@ extern "C" int bh_ba_debug_band_solve(bh_ctx* ctx, const double* band, const dou
     BH_HIP(ctx, hipMemcpyAsync(dA, band, nb, hipMemcpyHostToDevice, st));
     BH_HIP(ctx, hipMemcpyAsync(db, rhs, sizeof(double) * n, hipMemcpyHostToDevice, st));
     BH_HIP(ctx, hipMemcpyAsync(dS, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
-    (void)hipFuncSetAttribute((const void*)k_ba_chol_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
-    if (mode == 4) {
+    (void)hipFuncSetAttribute((const void*)k_ba_chol_dense<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
+    (void)hipFuncSetAttribute((const void*)k_ba_chol_dense<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
+    bcr_dev bdv;
+    if (mode == 5) {
+        if (bw > 256) return bh_set_err(ctx, BH_ERR_INVALID, "band solve: block cyclic reduction needs bw <= 256");
+        BH_TRY(bh_reserve(ctx, &ctx->st_c, BCR_SCRATCH_BYTES((n + 255) / 256)));
+        BH_TRY(bcr_prepare(ctx, st, &bdv, n, ctx->st_c.p));
+        BH_TRY(bcr_solve(ctx, st, &bdv, (const double*)dA, (const double*)db, n, bw, dx, dS));
+    } else if (mode == 4) {
         if (n > 16 * CD_MAXT) return bh_set_err(ctx, BH_ERR_INVALID, "band solve: the on-chip dense kernel needs n <= %d", 16 * CD_MAXT);
-        hipLaunchKernelGGL(k_ba_chol_dense, dim3(1), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)dA, (const double*)db, n, bw, dx, dS);
+        hipLaunchKernelGGL(k_ba_chol_dense<false>, dim3(1), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)dA, (const double*)db, n, bw, dx, dS,
+                           (const bcr_elim*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
     } else if (mode >= 1) {
         if ((bw + 15) / 16 > 16 || bw < 15) return bh_set_err(ctx, BH_ERR_INVALID, "band solve: the window kernel needs 15 <= bw <= 256");
         const int nblk = (n + 15) / 16;

@@ -264,6 +264,9 @@ __device__ __forceinline__ int reflect101(int i, int n)
 #define FSC_H (TILE_H + 2)
 #define FROW  (4 * FPW)         // bytes per LDS row (144)
 #define FITEMS (FSC_H * FPW)    // 1224 (item, word) pairs of the score tile
+#ifndef FBLUR_ROWS
+#define FBLUR_ROWS 4             // output rows per lane in the blur
+#endif
 
 typedef short fs2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ fs2 fswap(fs2 a) { return fs2{ a.y, a.x }; }
@@ -470,7 +473,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
         }
     }
     // ---- 7x7 sigma-2 Gaussian of the tile from the same LDS pixels (integer kernel, (sum + 32768) >> 16; the descriptor's input).
-    // A lane owns a 4-pixel column strip and 4 output rows: per input row three aligned LDS words, the 4 horizontal sums with
+    // A lane owns a 4-pixel column strip and FBLUR_ROWS output rows (the row sums of FBLUR_ROWS + 6 input rows: taller strips recompute
+    // fewer of them - 16 rows on one wave cost 2/3 of 4 rows on four waves): per input row three aligned LDS words, the 4 horizontal sums with
     // v_alignbyte + v_dot4_u32_u8 (taps {k0..k3} and {k4,k5,k6,0}); consecutive row sums are kept as 16-bit pairs P[q] = (h_q, h_q+1)
     // and the column pass of output row y is dot2(P[y-3],(k0,k1)) + dot2(P[y-1],(k2,k3)) + dot2(P[y+1],(k4,k5)) + k6*h[y+3].
     {
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
         const uint32_t K46 = (uint32_t)G.k[4] | ((uint32_t)G.k[5] << 8) | ((uint32_t)G.k[6] << 16);
         const us2 K01 = { (unsigned short)G.k[0], (unsigned short)G.k[1] }, K23 = { (unsigned short)G.k[2], (unsigned short)G.k[3] },
                   K45 = { (unsigned short)G.k[4], (unsigned short)G.k[5] };
-        constexpr int BR = TILE_H * (TILE_W / 4) / 256;           // output rows per lane (4)
+        constexpr int BR = FBLUR_ROWS;
         for (int yb = grp * BR; yb < TILE_H; yb += BR * (256 / (TILE_W / 4))) {
             if (xs >= L.w || y0 + yb >= L.h) continue;
             const uint32_t* col = s_px + (yb + 1) * FPW + strip + 1;      // LDS row of y0 + yb - 3, word of pixels xs-4 .. xs-1

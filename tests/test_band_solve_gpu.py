@@ -87,3 +87,26 @@ def test_on_chip_dense_kernel_reports_a_bad_pivot(ctx):
         x = np.ones(288)
         rc = _lib.lib().bh_ba_debug_band_solve(ctx.h, _lib.ptr(low), _lib.ptr(rhs), 288, 287, 4, _lib.ptr(x), None)
         assert rc == -5 and not x.any()
+
+
+@pytest.mark.parametrize("n,bw", [(100, 20), (256, 255), (257, 30), (600, 245), (1000, 256), (2500, 245), (4099, 130), (30000, 245)])
+def test_block_cyclic_reduction_matches_scipy(ctx, n, bw):
+    """mode 5: the 256-block cyclic reduction (k_ba_chol_dense<true> / k_bcr_trsm / k_bcr_update / k_bcr_back) - one block, two
+    blocks, chains of odd and even length at several levels, sizes that are not multiples of 256, configs[4]'s 30 000 x 245."""
+    low, rhs = band_system(n, bw, seed=7 * n + bw)
+    ref = scipy_solve(low, rhs, bw)
+    x, _ = gpu_solve(ctx, low, rhs, bw, 5)
+    assert np.abs(x - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), np.abs(x - ref).max()
+    x2, _ = gpu_solve(ctx, low, rhs, bw, 5)
+    assert np.array_equal(x, x2)                                        # fixed summation order: bitwise reproducible
+
+
+def test_block_cyclic_reduction_reports_a_bad_pivot(ctx):
+    n, bw = 3000, 245
+    for bad_row in (100, 700, 2900):                                    # blocks eliminated at different levels
+        low, rhs = band_system(n, bw, seed=11)
+        low[bad_row, bw] = -5.0
+        x = np.ones(n)
+        rc = _lib.lib().bh_ba_debug_band_solve(ctx.h, _lib.ptr(low), _lib.ptr(rhs), n, bw, 5, _lib.ptr(x), None)
+        assert rc == -5, bad_row
+        assert not x.any()
