@@ -94,11 +94,34 @@ def run_global(ctx, n_kf=5000, n_pts=500000, iters=5, window=20, dist=None, devi
     flops = nblk * D * (D + 1) // 2 * 4 * 2048
     ms = out["kernel_ms_per_iter"].get("k_ba_solve", 0.0)
     if ms > 0 and D <= 16:
-        cus = 2 if (D == 16 and nblk >= 96 and os.environ.get("BH_BA_CHOL_TWOWAY") != "0") else 1      # two-way schedule: one CU per end
-        out["solve_roofline"] = {"bound": "mfma", "kernel": "k_ba_chol_sw", "achieved": round(flops / (ms * 1e-3) / 1e12, 5), "unit": "TFLOP/s",
-                                 "peak": 78.6, "frac": round(flops / (ms * 1e-3) / 78.6e12, 6), "cus_used": cus,
-                                 "peak_of_cus_used": round(78.6 * cus / 256, 4), "frac_of_cus_used": round(flops / (ms * 1e-3) / (78.6e12 * cus / 256), 4),
-                                 "mfma_flops_per_solve": int(flops),
-                                 "note": "two dependency chains of ~%d block columns, one CU each; the dense f64 MFMA peak of 78.6 TFLOP/s is for 256 CUs" % (nblk // cus)}
+        bcr = n6 >= 8 * 256 and bw >= 15 and os.environ.get("BH_BA_CHOL_BCR") != "0" and os.environ.get("BH_BA_CHOL") != "panel"
+        if bcr:
+            # block cyclic reduction in 256-blocks: the work it ISSUES (dense blocks: Cholesky + two triangular solves + three
+            # products per eliminated block) next to the band's own flops, which is what `achieved` is priced on
+            N = (n6 + 255) // 256
+            issued, k = 0, N
+            while k >= 1:
+                ne = (k + 1) // 2; ns = k // 2
+                issued += ne * (800 * 4) * 2048                         # on-chip Cholesky of a 256-block: 800 tile products
+                issued += (2 * ns if k > 1 else 0) * 16 * 544 * 2048   # U = L^-1 M, one per (eliminated, survivor) edge of the chain
+                issued += (2 * ns if k > 1 else 0) * 136 * 64 * 2048 + max(ns - 1, 0) * 256 * 64 * 2048
+                if k == 1:
+                    break
+                k = ns
+            out["solve_roofline"] = {"bound": "mfma", "kernel": "k_ba_chol_dense<true> + k_bcr_trsm + k_bcr_update + k_bcr_back",
+                                     "achieved": round(flops / (ms * 1e-3) / 1e12, 5), "unit": "TFLOP/s", "peak": 78.6,
+                                     "frac": round(flops / (ms * 1e-3) / 78.6e12, 6), "cus_used": 256,
+                                     "mfma_flops_per_solve": int(flops), "mfma_flops_issued": int(issued),
+                                     "issued_frac": round(issued / (ms * 1e-3) / 78.6e12, 5),
+                                     "note": "block cyclic reduction: %d blocks of 256, %d levels; the band needs %.2f GFLOP, the nested-dissection "
+                                             "order issues %.1f GFLOP on dense blocks; the chain of on-chip 256-block factorisations (one per level) "
+                                             "bounds the time" % (N, int(np.ceil(np.log2(N))) + 1, flops / 1e9, issued / 1e9)}
+        else:
+            cus = 2 if (D == 16 and nblk >= 96 and os.environ.get("BH_BA_CHOL_TWOWAY") != "0") else 1      # two-way schedule: one CU per end
+            out["solve_roofline"] = {"bound": "mfma", "kernel": "k_ba_chol_sw", "achieved": round(flops / (ms * 1e-3) / 1e12, 5), "unit": "TFLOP/s",
+                                     "peak": 78.6, "frac": round(flops / (ms * 1e-3) / 78.6e12, 6), "cus_used": cus,
+                                     "peak_of_cus_used": round(78.6 * cus / 256, 4), "frac_of_cus_used": round(flops / (ms * 1e-3) / (78.6e12 * cus / 256), 4),
+                                     "mfma_flops_per_solve": int(flops),
+                                     "note": "two dependency chains of ~%d block columns, one CU each; the dense f64 MFMA peak of 78.6 TFLOP/s is for 256 CUs" % (nblk // cus)}
     s.close()
     return out

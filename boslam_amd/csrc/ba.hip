@@ -1593,6 +1593,7 @@ __global__ __launch_bounds__(256) void k_bcr_extract(const double* __restrict__ 
     const int b = blockIdx.x, r = blockIdx.y, c = threadIdx.x;
     const size_t LD = (size_t)bw + 1;
     if (b < N) {
+        if ((c >> 4) > (r >> 4)) return;                      // tiles above the diagonal are never read
         const int R = 256 * b + r, C = 256 * b + c;
         double v = 0.0;
         if (R < n && C < n) { if (c <= r && r - c <= bw) v = A[R * LD + (C - R + bw)]; }
@@ -1607,118 +1608,204 @@ __global__ __launch_bounds__(256) void k_bcr_extract(const double* __restrict__ 
     }
 }
 
+// U = L^-1 M.  A workgroup takes four 16-column strips of one coupling (a wave each); the 16 x 16(i+1) tile row i of L is staged
+// through LDS by all four waves (coalesced 16-B loads, double-buffered: row i + 1 is in flight while row i feeds the matrix cores -
+// read straight from L2, every one of the 544 dependent MFMAs of a strip waited for its own operand load: 101 us per level).
+#define TR_P 262                                     // LDS row pitch in doubles: 16 rows x 4 k-offsets land in 64 distinct banks
 __global__ __launch_bounds__(256) void k_bcr_trsm(const bcr_elim* __restrict__ el, const double* __restrict__ Dblk, double* __restrict__ Cpl)
 {
+    __shared__ double sL[2][16 * TR_P];
     const bcr_elim E = el[blockIdx.z];
     const int slot = blockIdx.y ? E.sr : E.sl;
     if (slot < 0) return;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 15, r0 = lane >> 4;
-    const double* __restrict__ L = Dblk + (size_t)E.e * BCR_BLK + (size_t)col * 256 + r0;      // A operand: row `col` of a tile, k = 4 ks + r0
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, col = lane & 15, r0 = lane >> 4;
+    const int lr = tid >> 4, lc = (tid & 15) * 2;     // staging: row lr of the tile row, columns lc + 32 m
+    const double* __restrict__ Lg = Dblk + (size_t)E.e * BCR_BLK + (size_t)lr * 256 + lc;
     double* __restrict__ M = Cpl + (size_t)slot * BCR_BLK + 16 * (blockIdx.x * 4 + wv) + (size_t)r0 * 256 + col;
     ba_d4 U[16];
+    {
+        const double2 v = *reinterpret_cast<const double2*>(Lg);      // tile row 0 is the first diagonal tile alone
+        if (lc < 16) { sL[0][lr * TR_P + lc] = v.x; sL[0][lr * TR_P + lc + 1] = v.y; }
+    }
 #pragma unroll
     for (int i = 0; i < 16; i++) {
+        __syncthreads();                              // tile row i is in sL[i & 1]; every wave is done with sL[(i + 1) & 1]
+        double2 nx[8];
+        if (i < 15) {
+#pragma unroll
+            for (int m = 0; m < (16 * (i + 2) + 31) / 32; m++)
+                if (lc + 32 * m < 16 * (i + 2)) nx[m] = *reinterpret_cast<const double2*>(Lg + (size_t)(16 * (i + 1)) * 256 + 32 * m);
+        }
         ba_d4 acc;
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) acc[rg] = M[(size_t)(16 * i + 4 * rg) * 256];
+        const double* __restrict__ sa = sL[i & 1] + col * TR_P + r0;
 #pragma unroll
         for (int k = 0; k < i; k++) {
 #pragma unroll
             for (int ks = 0; ks < 4; ks++)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-L[(size_t)(16 * i) * 256 + 16 * k + 4 * ks], U[k][ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sa[16 * k + 4 * ks], U[k][ks], acc, 0, 0, 0);
         }
         ba_d4 u = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
         for (int ks = 0; ks < 4; ks++)                        // the diagonal tile holds the inverse of its factor
-            u = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(size_t)(16 * i) * 256 + 16 * i + 4 * ks], acc[ks], u, 0, 0, 0);
+            u = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[16 * i + 4 * ks], acc[ks], u, 0, 0, 0);
         U[i] = u;
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) M[(size_t)(16 * i + 4 * rg) * 256] = u[rg];
+        if (i < 15) {
+            double* __restrict__ dst = sL[(i + 1) & 1] + lr * TR_P + lc;
+#pragma unroll
+            for (int m = 0; m < (16 * (i + 2) + 31) / 32; m++)
+                if (lc + 32 * m < 16 * (i + 2)) { dst[32 * m] = nx[m].x; dst[32 * m + 1] = nx[m].y; }
+        }
     }
 }
 
+// X'Y products of one level.  A workgroup owns a 32 x 32 block of the result (2 x 2 tiles: two A and two B operand loads feed four
+// MFMAs) and splits the reduction index over its four waves (64 rows each - at the small levels the length of a wave's MFMA chain
+// is what the launch waits for); the four partial blocks meet in LDS and wave w adds up tile w in wave order (fixed summation order).
 __global__ __launch_bounds__(256) void k_bcr_update(const bcr_work* __restrict__ wk, double* __restrict__ Dblk, double* __restrict__ Cpl,
                                                     double* __restrict__ g, const double* __restrict__ yv)
 {
+    __shared__ double red[4 * 4 * 4 * 64];            // [wave][tile][rg][lane]
+    __shared__ double gred[4][2][16];
     const bcr_work W = wk[blockIdx.y];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 15, r0 = lane >> 4;
-    const int t = blockIdx.x * 4 + wv, ti = t >> 4, tj = t & 15;
-    if (W.kind == 0 && tj > ti) return;
-    ba_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
-    double gacc = 0.0;
-    const bool do_g = W.kind == 0 && ti == tj;
+    const int bi = blockIdx.x >> 3, bj = blockIdx.x & 7;
+    if (W.kind == 0 && bj > bi) return;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, col = lane & 15, r0 = lane >> 4;
+    ba_d4 acc[4] = { { 0.0, 0.0, 0.0, 0.0 }, { 0.0, 0.0, 0.0, 0.0 }, { 0.0, 0.0, 0.0, 0.0 }, { 0.0, 0.0, 0.0, 0.0 } };
+    double g0 = 0.0, g1 = 0.0;
+    const bool do_g = W.kind == 0 && bi == bj;
 #pragma unroll 1
     for (int side = 0; side < 2; side++) {
         const int sa = side ? W.a1 : W.a0;
         if (sa < 0) continue;
         const int sb = W.kind ? W.b0 : sa;
-        const double* __restrict__ Ua = Cpl + (size_t)sa * BCR_BLK + (size_t)r0 * 256 + 16 * ti + col;
-        const double* __restrict__ Ub = Cpl + (size_t)sb * BCR_BLK + (size_t)r0 * 256 + 16 * tj + col;
-        const double* __restrict__ ye = yv + 256 * (size_t)((side ? W.ye1 : W.ye0) < 0 ? 0 : (side ? W.ye1 : W.ye0)) + r0;
+        const double* __restrict__ Ua = Cpl + (size_t)sa * BCR_BLK + (size_t)(64 * wv + r0) * 256 + 32 * bi + col;
+        const double* __restrict__ Ub = Cpl + (size_t)sb * BCR_BLK + (size_t)(64 * wv + r0) * 256 + 32 * bj + col;
+        const int yb = side ? W.ye1 : W.ye0;
+        const double* __restrict__ ye = yv + 256 * (size_t)(yb < 0 ? 0 : yb) + 64 * wv + r0;
 #pragma unroll 8
-        for (int kk = 0; kk < 64; kk++) {
-            const double a = Ua[(size_t)kk * 1024], b = Ub[(size_t)kk * 1024];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-            if (do_g) gacc = __builtin_fma(a, ye[4 * kk], gacc);
+        for (int kk = 0; kk < 16; kk++) {
+            const double a0 = Ua[(size_t)kk * 1024], a1 = Ua[(size_t)kk * 1024 + 16], b0 = Ub[(size_t)kk * 1024], b1 = Ub[(size_t)kk * 1024 + 16];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[3], 0, 0, 0);
+            if (do_g) { const double yk = ye[4 * kk]; g0 = __builtin_fma(a0, yk, g0); g1 = __builtin_fma(a1, yk, g1); }
         }
     }
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) red[((wv * 4 + t) * 4 + rg) * 64 + lane] = acc[t][rg];
+    if (do_g) {
+        g0 += d_shfl_xor(g0, 16); g0 += d_shfl_xor(g0, 32); g1 += d_shfl_xor(g1, 16); g1 += d_shfl_xor(g1, 32);
+        if (lane < 16) { gred[wv][0][col] = g0; gred[wv][1][col] = g1; }
+    }
+    __syncthreads();
+    const int ti = 2 * bi + (wv >> 1), tj = 2 * bj + (wv & 1);
+    if (do_g && tid < 32) {
+        const int h = tid >> 4, c = tid & 15;
+        g[256 * (size_t)W.out + 32 * bi + 16 * h + c] -= ((gred[0][h][c] + gred[1][h][c]) + gred[2][h][c]) + gred[3][h][c];
+    }
+    if (W.kind == 0 && tj > ti) return;
+    double v[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++)
+        v[rg] = ((red[((0 * 4 + wv) * 4 + rg) * 64 + lane] + red[((1 * 4 + wv) * 4 + rg) * 64 + lane]) + red[((2 * 4 + wv) * 4 + rg) * 64 + lane]) + red[((3 * 4 + wv) * 4 + rg) * 64 + lane];
+    double* __restrict__ O = (W.kind == 0 ? Dblk : Cpl) + (size_t)W.out * BCR_BLK + (size_t)(16 * ti + r0) * 256 + 16 * tj + col;
     if (W.kind == 0) {
-        double* __restrict__ D = Dblk + (size_t)W.out * BCR_BLK + (size_t)(16 * ti + r0) * 256 + 16 * tj + col;
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++) D[(size_t)rg * 1024] -= acc[rg];
-        if (do_g) {
-            gacc += d_shfl_xor(gacc, 16); gacc += d_shfl_xor(gacc, 32);
-            if (lane < 16) g[256 * (size_t)W.out + 16 * ti + col] -= gacc;
-        }
+        for (int rg = 0; rg < 4; rg++) O[(size_t)rg * 1024] -= v[rg];
     } else {
-        double* __restrict__ C = Cpl + (size_t)W.out * BCR_BLK + (size_t)(16 * ti + r0) * 256 + 16 * tj + col;
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++) C[(size_t)rg * 1024] = -acc[rg];
+        for (int rg = 0; rg < 4; rg++) O[(size_t)rg * 1024] = -v[rg];
     }
 }
 
-__global__ __launch_bounds__(256) void k_bcr_back(const bcr_elim* __restrict__ el, const double* __restrict__ Dblk, const double* __restrict__ Cpl,
-                                                  const double* __restrict__ yv, double* __restrict__ xp, double* __restrict__ x, int n,
-                                                  const ba_state* __restrict__ St)
+// x_e = L^-T (y_e - U_l x_l - U_r x_r).  1024 threads stream the two couplings (16 rows per wave, every load in flight at once:
+// a 256-thread version spent most of its 47 us waiting for 1 MB through four waves); the first 256 then walk the factor upwards,
+// the next block row already in registers when the previous one's barrier falls.
+__global__ __launch_bounds__(1024) void k_bcr_back(const bcr_elim* __restrict__ el, const double* __restrict__ Dblk, const double* __restrict__ Cpl,
+                                                   const double* __restrict__ yv, double* __restrict__ xp, double* __restrict__ x, int n,
+                                                   const ba_state* __restrict__ St)
 {
     __shared__ double z[256], xi[16];
     const bcr_elim E = el[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t o = 256 * (size_t)E.e;
-    if (!St->chol_ok) { xp[o + tid] = 0.0; if (o + tid < (size_t)n) x[o + tid] = 0.0; return; }
-    {   // z = y_e - U_l x_l - U_r x_r: a wave takes 64 rows, a lane 4 columns of each row
-        double xl[4] = { 0, 0, 0, 0 }, xr[4] = { 0, 0, 0, 0 };
-        if (E.l >= 0) for (int q = 0; q < 4; q++) xl[q] = xp[256 * (size_t)E.l + 4 * lane + q];
-        if (E.r >= 0) for (int q = 0; q < 4; q++) xr[q] = xp[256 * (size_t)E.r + 4 * lane + q];
-        const double* Ul = Cpl + (size_t)(E.sl < 0 ? 0 : E.sl) * BCR_BLK + 4 * lane;
-        const double* Ur = Cpl + (size_t)(E.sr < 0 ? 0 : E.sr) * BCR_BLK + 4 * lane;
-#pragma unroll 4
-        for (int rr = 0; rr < 64; rr++) {
-            const int row = 64 * wv + rr;
-            double s2 = 0.0;
-            if (E.sl >= 0) { const double4 u = *reinterpret_cast<const double4*>(Ul + (size_t)row * 256); s2 = __builtin_fma(u.x, xl[0], __builtin_fma(u.y, xl[1], __builtin_fma(u.z, xl[2], u.w * xl[3]))); }
-            if (E.sr >= 0) { const double4 u = *reinterpret_cast<const double4*>(Ur + (size_t)row * 256); s2 += __builtin_fma(u.x, xr[0], __builtin_fma(u.y, xr[1], __builtin_fma(u.z, xr[2], u.w * xr[3]))); }
-            for (int m = 32; m > 0; m >>= 1) s2 += d_shfl_xor(s2, m);
-            if (lane == 0) z[row] = yv[o + row] - s2;
+    if (!St->chol_ok) { if (tid < 256) { xp[o + tid] = 0.0; if (o + tid < (size_t)n) x[o + tid] = 0.0; } return; }
+    const double* L = Dblk + (size_t)E.e * BCR_BLK;
+    const bool walker = tid < 256;
+    double ln[16], ld[16];
+    if (walker) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) { ln[r] = L[(size_t)(240 + r) * 256 + (tid < 240 ? tid : 0)]; ld[r] = L[(size_t)(240 + r) * 256 + 240 + (tid & 15)]; }
+    }
+    {   // z = y_e - U_l x_l - U_r x_r: 16 lanes per row (DPP row sums), 4 rows per wave instruction, 16 rows per wave
+        const int cl = lane & 15, rq = lane >> 4;
+        const double* Ul = Cpl + (size_t)(E.sl < 0 ? 0 : E.sl) * BCR_BLK + 4 * cl;
+        const double* Ur = Cpl + (size_t)(E.sr < 0 ? 0 : E.sr) * BCR_BLK + 4 * cl;
+        const double* xlp = xp + 256 * (size_t)(E.l < 0 ? 0 : E.l) + 4 * cl;
+        const double* xrp = xp + 256 * (size_t)(E.r < 0 ? 0 : E.r) + 4 * cl;
+        double s2[4] = { 0.0, 0.0, 0.0, 0.0 };
+        if (E.sl >= 0) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const double4 xv = *reinterpret_cast<const double4*>(xlp + 64 * m);
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const double4 u = *reinterpret_cast<const double4*>(Ul + (size_t)(16 * wv + 4 * it + rq) * 256 + 64 * m);
+                    s2[it] = __builtin_fma(u.x, xv.x, __builtin_fma(u.y, xv.y, __builtin_fma(u.z, xv.z, __builtin_fma(u.w, xv.w, s2[it]))));
+                }
+            }
+        }
+        if (E.sr >= 0) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const double4 xv = *reinterpret_cast<const double4*>(xrp + 64 * m);
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const double4 u = *reinterpret_cast<const double4*>(Ur + (size_t)(16 * wv + 4 * it + rq) * 256 + 64 * m);
+                    s2[it] = __builtin_fma(u.x, xv.x, __builtin_fma(u.y, xv.y, __builtin_fma(u.z, xv.z, __builtin_fma(u.w, xv.w, s2[it]))));
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            double v = s2[it];
+            v += d_row_shr<1>(v); v += d_row_shr<2>(v); v += d_row_shr<4>(v); v += d_row_shr<8>(v);      // lane 15 of the row holds the sum
+            const int row = 16 * wv + 4 * it + rq;
+            if (cl == 15) z[row] = yv[o + row] - v;
         }
     }
     __syncthreads();
-    const double* L = Dblk + (size_t)E.e * BCR_BLK;
+#pragma unroll
     for (int J = 15; J >= 0; J--) {
         if (tid < 16) {                                       // x_J = Linv_JJ' z_J
-            double s2 = 0.0;
+            double s3 = 0.0;
 #pragma unroll
-            for (int r = 0; r < 16; r++) s2 = __builtin_fma(L[(size_t)(16 * J + r) * 256 + 16 * J + tid], z[16 * J + r], s2);
-            xi[tid] = s2;
-            xp[o + 16 * J + tid] = s2;
-            if (o + 16 * J + tid < (size_t)n) x[o + 16 * J + tid] = s2;
+            for (int r = 0; r < 16; r++) s3 = __builtin_fma(ld[r], z[16 * J + r], s3);
+            xi[tid] = s3;
+            xp[o + 16 * J + tid] = s3;
+            if (o + 16 * J + tid < (size_t)n) x[o + 16 * J + tid] = s3;
+            if (J > 0) {                                      // the next diagonal tile: in flight across both barriers
+#pragma unroll
+                for (int r = 0; r < 16; r++) ld[r] = L[(size_t)(16 * (J - 1) + r) * 256 + 16 * (J - 1) + tid];
+            }
         }
         __syncthreads();
         if (tid < 16 * J) {                                   // z_j -= L(J, j)' x_J for the block rows above
-            double s2 = z[tid];
+            double s3 = z[tid];
 #pragma unroll
-            for (int r = 0; r < 16; r++) s2 = __builtin_fma(-L[(size_t)(16 * J + r) * 256 + tid], xi[r], s2);
-            z[tid] = s2;
+            for (int r = 0; r < 16; r++) s3 = __builtin_fma(-ln[r], xi[r], s3);
+            z[tid] = s3;
+        }
+        if (walker && J > 0) {                                // block row J - 1 of the factor: in flight across the barrier and the next x_J
+#pragma unroll
+            for (int r = 0; r < 16; r++) ln[r] = L[(size_t)(16 * (J - 1) + r) * 256 + (tid < 16 * (J - 1) ? tid : 0)];
         }
         __syncthreads();
     }
@@ -1755,7 +1842,7 @@ static int bcr_solve(bh_ctx* ctx, hipStream_t st, const bcr_dev* dv, const doubl
         }
     }
     for (int lv = P.nlev - 1; lv >= 0; lv--)
-        hipLaunchKernelGGL(k_bcr_back, dim3(P.e_off[lv + 1] - P.e_off[lv]), dim3(256), 0, st, (const bcr_elim*)(dv->elim + P.e_off[lv]), (const double*)dv->D,
+        hipLaunchKernelGGL(k_bcr_back, dim3(P.e_off[lv + 1] - P.e_off[lv]), dim3(1024), 0, st, (const bcr_elim*)(dv->elim + P.e_off[lv]), (const double*)dv->D,
                            (const double*)dv->C, (const double*)dv->y, dv->xp, x, n, (const ba_state*)state);
     BH_HIP(ctx, hipGetLastError());
     return BH_OK;
