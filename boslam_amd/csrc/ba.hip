@@ -566,22 +566,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 8))) void
                                                     const int2* __restrict__ join, const int* __restrict__ e_pt,
                                                     const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                                                     const double* __restrict__ Hpp, const ba_state* __restrict__ St,
-                                                    int bw, int add_diag, double* __restrict__ Sm)
+                                                    int bw, int add_diag, double* __restrict__ Sm, int npairs)
 {
     // NT = 256 for a few long lists (local BA), one wave per pair for many short ones (global BA).  join[j_start[p] .. j_start[p+1])
     // lists the (edge of s1, edge of s2) pairs that observe the same landmark, in landmark order: built once per problem
     // (ba_build_device); round 1 re-derived it in every trial by a binary search per edge, 90 % of which found nothing.
     __shared__ double s_red[36 * (NT / 64)];
     const int tid = threadIdx.x;
-    const int s1 = pairs[blockIdx.x].x, s2 = pairs[blockIdx.x].y;
-    const int t0 = j_start[blockIdx.x], t1 = j_start[blockIdx.x + 1];
+    // workgroups are dealt to the 8 XCDs round-robin; each XCD takes one contiguous eighth of the (s1, s2)-sorted pair list, so that
+    // the blocks of camera s1 (shared by its ~2 x band pairs in a row) and of s2 (met again at (s1 + 1, s2), one band later) are still
+    // in that XCD's own L2 - dealt pair by pair, every reuse was a miss in seven other L2s
+    const int chunk = (gridDim.x + 7) >> 3;
+    const int pid = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (pid >= npairs) return;
+    const int s1 = pairs[pid].x, s2 = pairs[pid].y;
+    const int t0 = j_start[pid], t1 = j_start[pid + 1];
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0;
     for (int t = t0 + tid; t < t1; t += NT) {
         const int2 ee = join[t];
         const int e1 = ee.x, e2 = ee.y, j = e_pt[e1];
-        const double* B1 = Hpl + 18 * (size_t)e1; const double* B2 = Hpl + 18 * (size_t)e2; const double* Di = Dinv + 9 * (size_t)j;
+        // the 144-B blocks are 16-B aligned (hipMalloc base, 18 doubles each): nine 16-B loads per block instead of eighteen 8-B ones -
+        // every lane reads a different block, so the load count is what the texture path is billed for
+        double B1[18], B2[18];
+        {
+            const double2* q1 = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)e1); const double2* q2 = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)e2);
+#pragma unroll
+            for (int q = 0; q < 9; q++) { const double2 u = q1[q], w = q2[q]; B1[2 * q] = u.x; B1[2 * q + 1] = u.y; B2[2 * q] = w.x; B2[2 * q + 1] = w.y; }
+        }
+        const double* Di = Dinv + 9 * (size_t)j;
         double BD[18];
 #pragma unroll
         for (int a = 0; a < 6; a++)
@@ -592,19 +606,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 #pragma unroll
             for (int bb = 0; bb < 6; bb++) acc[6 * a + bb] += BD[3 * a] * B2[3 * bb] + BD[3 * a + 1] * B2[3 * bb + 1] + BD[3 * a + 2] * B2[3 * bb + 2];
     }
-    // wave sums, then thread e < 36 adds the waves' partials of element e in wave order (same order as d_block_sum; reading the
-    // result as acc[tid] would index the accumulator array dynamically and move all 36 accumulators to scratch memory)
+    double v = 0;
+    if constexpr (NT == 64) {
+        // one wave: the 36 x 64 partial sums are transposed through LDS (pitch 65: lanes k read column j of rows k without bank conflicts)
+        // and lane k < 36 adds up element k in lane order, four interleaved chains - 36 butterfly reductions were 432 ds_bpermutes.
+        // (18.7 KB: two workgroups per SIMD, which is also what the 188 VGPRs allow; forcing 3 or 4 spills and was measured slower)
+        __shared__ double s_tr[36 * 65];
 #pragma unroll
-    for (int i = 0; i < 36; i++) acc[i] = d_wave_sum(acc[i]);
-    if ((tid & 63) == 0) {
+        for (int i = 0; i < 36; i++) s_tr[i * 65 + tid] = acc[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tid < 36) {
+            double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
 #pragma unroll
-        for (int i = 0; i < 36; i++) s_red[(tid >> 6) * 36 + i] = acc[i];
+            for (int l = 0; l < 64; l += 4) { p0 += s_tr[tid * 65 + l]; p1 += s_tr[tid * 65 + l + 1]; p2 += s_tr[tid * 65 + l + 2]; p3 += s_tr[tid * 65 + l + 3]; }
+            v = (p0 + p1) + (p2 + p3);
+        }
+    } else {
+        // wave sums, then thread e < 36 adds the waves' partials of element e in wave order (same order as d_block_sum; reading the
+        // result as acc[tid] would index the accumulator array dynamically and move all 36 accumulators to scratch memory)
+#pragma unroll
+        for (int i = 0; i < 36; i++) acc[i] = d_wave_sum(acc[i]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int i = 0; i < 36; i++) s_red[(tid >> 6) * 36 + i] = acc[i];
+        }
+        __syncthreads();
+        if (tid < 36)
+            for (int w = 0; w < NT / 64; w++) v += s_red[w * 36 + tid];
     }
-    __syncthreads();
     if (tid < 36) {
         const int a = tid / 6, bb = tid - a * 6;
-        double v = 0;
-        for (int w = 0; w < NT / 64; w++) v += s_red[w * 36 + tid];
         v = -v;
         if (s1 == s2 && add_diag) { v += Hpp[36 * (size_t)s1 + tid]; if (a == bb) v += St->lambda; }
         // lower band storage: element (row, col), row >= col, at Sm[row*LD + (col - row + bw)]; s1 <= s2
@@ -2595,11 +2626,11 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
             if (Cf) {
                 BH_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double) * (size_t)n6 * (ba->bw + 1), st));     // blocks without a common point stay zero
                 if (ba->schur_wave)
-                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<64>), dim3(ba->npairs), dim3(64), st, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
-                              (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S);
+                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<64>), dim3((ba->npairs + 7) / 8 * 8), dim3(64), st, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
+                              (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S, ba->npairs);
                 else
-                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<256>), dim3(ba->npairs), dim3(256), st, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
-                              (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S);
+                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<256>), dim3((ba->npairs + 7) / 8 * 8), dim3(256), st, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
+                              (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S, ba->npairs);
                 BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_b, dim3(Cf), dim3(256), st, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)db,
                           (const double*)bp, dist ? lead : 1, bs);
                 if (dist) { BH_TRY(ba_allreduce(ba, S, (long long)n6 * (ba->bw + 1), 0)); BH_TRY(ba_allreduce(ba, bs, n6, 0)); }
