@@ -27,6 +27,7 @@ struct bh_level_geom {
     int   nsx_in, n_edge, nrb;       // blur: interior / edge 4-px strips per row, 16-row blocks
     int   bblk_base, eblk_base;      // blur: first workgroup of the level in the interior / edge launch
     int   list_off, list_cap;        // corner list of the level inside one frame's list block (entries of 8 B)
+    int   moff, mpitch;              // bit-packed mask level: first word inside one frame's block, words per row (pitch / 32 + 1 pad word)
 };
 
 struct bh_orb_geom {
@@ -37,6 +38,7 @@ struct bh_orb_geom {
     int tab_len;
     int bblk_total, eblk_total;
     int list_stride;                 // corner-list entries per frame (all levels)
+    int mstride;                     // words per frame of the bit-packed mask pyramid
     bh_level_geom lv[BH_MAX_LEVELS];
 };
 
@@ -67,7 +69,7 @@ struct bh_ctx {
     bh_buf      st_img, st_mask, st_depth, st_kps, st_desc, st_nkp;     // host-mode staging
     bh_buf      st_a, st_b, st_c, st_d, st_e, st_f, st_g, st_h;         // generic staging (match / BA)
     int         last_B = 0;
-    int         last_has_mask = 0;
+    int         last_has_mask = 0, last_mask_bits = 0;
     // ---- per-kernel timing ----
     int         timing_on = 0;
     bh_time_rec* trecs = nullptr;

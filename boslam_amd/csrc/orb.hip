@@ -42,7 +42,7 @@ static int build_geom(const bh_orb_params* p, int H, int W, bh_orb_geom* g)
     float factor = (float)(1.0 / p->scaleFactor);
     float nd = p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)p->nlevels));
     int sum = 0;
-    int off = 0, tiles = 0, tab = 0, bblk = 0, eblk = 0, lst = 0;
+    int off = 0, tiles = 0, tab = 0, bblk = 0, eblk = 0, lst = 0, moff = 0;
     for (int l = 0; l < p->nlevels; l++) {
         bh_level_geom& L = g->lv[l];
         L.scale = (float)pow((double)p->scaleFactor, (double)l);
@@ -51,6 +51,7 @@ static int build_geom(const bh_orb_params* p, int H, int W, bh_orb_geom* g)
         if (L.w < 1 || L.h < 1) return BH_ERR_INVALID;
         L.pitch = align_up(L.w, 64);
         L.off = off; off += L.pitch * L.h;
+        L.mpitch = (L.pitch >> 5) + 1; L.moff = moff; moff += L.mpitch * L.h;
         L.tiles_x = (L.w + TILE_W - 1) / TILE_W;
         L.tiles_y = (L.h + TILE_H - 1) / TILE_H;
         L.tile_base = tiles; tiles += L.tiles_x * L.tiles_y;
@@ -67,7 +68,7 @@ static int build_geom(const bh_orb_params* p, int H, int W, bh_orb_geom* g)
         if (l < p->nlevels - 1) { L.nfeat = round_even_f(nd); sum += L.nfeat; nd *= factor; }
         else L.nfeat = p->nfeatures - sum > 0 ? p->nfeatures - sum : 0;
     }
-    g->list_stride = lst;
+    g->list_stride = lst; g->mstride = align_up(moff + 4, 16);
     g->pyr_stride = off; g->ntiles = tiles; g->tab_len = tab; g->bblk_total = bblk; g->eblk_total = eblk;
     return BH_OK;
 }
@@ -89,12 +90,22 @@ static void lin_coeffs(int src, int dst, uint32_t* out)
     }
 }
 
+// One u32 per 8 lanes from 4 bits each: lane 8k+7 returns the nibbles of lanes 8k .. 8k+7 (lane 8k in bits 0-3).  DPP row shifts,
+// zero fill at the row start; the 16 lanes of a DPP row must all be active.
+template <int CTRL> __device__ __forceinline__ uint32_t u_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t nib_gather8(uint32_t nib, int lane)
+{
+    uint32_t v = nib << (4 * (lane & 7));
+    v |= u_dpp<0x111>(v); v |= u_dpp<0x112>(v); v |= u_dpp<0x114>(v);
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------ gray + mask, level 0
 __global__ __launch_bounds__(256) void k_gray_mask(const uint8_t* __restrict__ img, int channels,
                                                    const uint8_t* __restrict__ mask,
                                                    const uint16_t* __restrict__ depth,
                                                    uint8_t* __restrict__ pyr, uint8_t* __restrict__ mpyr,
-                                                   int W, int H, int pitch, int pyr_stride)
+                                                   int W, int H, int pitch, int pyr_stride, uint32_t* __restrict__ mbits, int mpitch, int mstride)
 {
     const int groups = pitch >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -138,6 +149,11 @@ __global__ __launch_bounds__(256) void k_gray_mask(const uint8_t* __restrict__ i
     const size_t o = f * pyr_stride + (size_t)y * pitch + x;
     *reinterpret_cast<uint32_t*>(pyr + o) = g4;
     if (mpyr) *reinterpret_cast<uint32_t*>(mpyr + o) = m4;
+    if (mbits) {                                               // depth-derived masks are binary: one bit per pixel, 8 lanes make a word
+        const uint32_t nib = ((m4 & 0xffu) ? 1u : 0u) | ((m4 & 0xff00u) ? 2u : 0u) | ((m4 & 0xff0000u) ? 4u : 0u) | ((m4 >> 24) ? 8u : 0u);
+        const uint32_t wd = nib_gather8(nib, threadIdx.x);
+        if ((threadIdx.x & 7) == 7) mbits[f * mstride + (size_t)y * mpitch + (x >> 5)] = wd;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ pyramid level l from l-1
@@ -157,15 +173,66 @@ __device__ __forceinline__ unsigned long long pyr_load8(const uint8_t* __restric
 }
 
 __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, uint8_t* __restrict__ mpyr,
-                                                  bh_orb_geom g, int level, const uint32_t* __restrict__ tab)
+                                                  bh_orb_geom g, int level, const uint32_t* __restrict__ tab, uint32_t* __restrict__ mbits)
 {
     const bh_level_geom S = g.lv[level - 1], D = g.lv[level];
     const int groups = D.pitch >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int y = idx / groups, x = (idx - y * groups) << 2;
-    if (y >= D.h) return;
+    if (y >= D.h) return;                                      // whole rows (pitch / 4 is a multiple of 16 lanes)
     const size_t fb = (size_t)blockIdx.y * g.pyr_stride;
     const size_t o = fb + D.off + (size_t)y * D.pitch + x;
+    if (mbits) {
+        // Bit-packed mask (depth-derived, so binary at every level).  With 0 / 255 inputs the reference arithmetic
+        //   v = ((256-yc1) h0 + yc1 h1 + 32768) >> 16,  h = 255 ((256-c1) b0 + c1 b1),  keep v == 255
+        // is  T = (256-yc1) H0 + yc1 H1 >= 65408,  H = (256-c1) b0 + c1 b1  (checked exhaustively over c1, yc1, the 16 bit patterns).
+        // A lane whose six source columns x two rows are all set / all clear needs none of it.
+        uint32_t o4 = 0, nib = 0;
+        if (x < D.w) {
+            const uint4 tx4 = *reinterpret_cast<const uint4*>(tab + D.tabx_off + x);
+            const uint32_t ty = tab[D.taby_off + y];
+            const int r0 = ty >> 16, r1 = min(r0 + 1, S.h - 1);
+            const uint32_t yc1 = ty & 0xffffu;
+            const uint32_t txs[4] = { tx4.x, tx4.y, tx4.z, tx4.w };
+            const int base = (int)(tx4.x >> 16);
+            const size_t s0 = fb + S.off + (size_t)r0 * S.pitch + base, s1 = fb + S.off + (size_t)r1 * S.pitch + base;
+            const unsigned long long A = pyr_load8(pyr, s0), Bv = pyr_load8(pyr, s1);
+            const uint32_t* ms = mbits + (size_t)blockIdx.y * g.mstride + S.moff + (base >> 5);
+            const uint32_t* q0 = ms + (size_t)r0 * S.mpitch; const uint32_t* q1 = ms + (size_t)r1 * S.mpitch;
+            const uint32_t A8 = __builtin_amdgcn_alignbit(q0[1], q0[0], (uint32_t)base & 31u), B8 = __builtin_amdgcn_alignbit(q1[1], q1[0], (uint32_t)base & 31u);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (x + i < D.w) {
+                    const uint32_t tx = txs[i];
+                    const int sh = ((int)(tx >> 16) - base) << 3;
+                    const uint32_t c1 = tx & 0xffffu;
+                    const uint32_t pa = (uint32_t)(A >> sh), pb = (uint32_t)(Bv >> sh);
+                    const int p0 = (int)(pa & 255u), q0v = (int)(pb & 255u);
+                    const int h0 = (p0 << 8) + (int)c1 * ((int)((pa >> 8) & 255u) - p0);
+                    const int h1 = (q0v << 8) + (int)c1 * ((int)((pb >> 8) & 255u) - q0v);
+                    o4 |= ((uint32_t)((h0 << 8) + (int)yc1 * (h1 - h0) + 32768) >> 16) << (8 * i);
+                }
+            }
+            const uint32_t both = A8 & B8 & 0x3fu, any = (A8 | B8) & 0x3fu;
+            if (both == 0x3fu) nib = 0xfu >> max(x + 4 - D.w, 0);
+            else if (any) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (x + i < D.w) {
+                        const uint32_t tx = txs[i];
+                        const uint32_t sh = (tx >> 16) - (uint32_t)base, c1 = tx & 0xffffu;
+                        const uint32_t a2 = (A8 >> sh) & 3u, b2 = (B8 >> sh) & 3u;
+                        const uint32_t H0 = (a2 & 1u) * (256u - c1) + (a2 >> 1) * c1, H1 = (b2 & 1u) * (256u - c1) + (b2 >> 1) * c1;
+                        nib |= ((256u - yc1) * H0 + yc1 * H1 >= 65408u ? 1u : 0u) << i;
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<uint32_t*>(pyr + o) = o4;           // padding columns stay zero
+        const uint32_t wd = nib_gather8(nib, threadIdx.x);
+        if ((threadIdx.x & 7) == 7) mbits[(size_t)blockIdx.y * g.mstride + D.moff + (size_t)y * D.mpitch + (x >> 5)] = wd;
+        return;
+    }
     if (x >= D.w) {                                            // padding columns: keep them zero
         *reinterpret_cast<uint32_t*>(pyr + o) = 0;
         if (mpyr) *reinterpret_cast<uint32_t*>(mpyr + o) = 0;
@@ -295,9 +362,11 @@ __device__ __forceinline__ fs2 fpk(uint32_t hi_src, uint32_t lo_src, uint32_t se
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ mpyr,
                                               uint2* __restrict__ clist, int* __restrict__ ccnt, uint32_t* __restrict__ hist,
                                               uint8_t* __restrict__ blur, bh_gauss7 G,
-                                              bh_orb_geom g, const uint32_t* __restrict__ tile_tab, uint32_t* __restrict__ status)
+                                              bh_orb_geom g, const uint32_t* __restrict__ tile_tab, uint32_t* __restrict__ status,
+                                              const uint32_t* __restrict__ mbits)
 {
     __shared__ uint32_t s_px[FPX_H * FPW];
+    __shared__ uint32_t s_mask[TILE_H * (TILE_W / 32)];         // the tile of the bit-packed mask (no HBM round trip in phase 3)
     __shared__ uint32_t s_scw[FITEMS];
     __shared__ uint16_t s_list[4 * FITEMS];
     __shared__ uint32_t s_hist[256];
@@ -335,12 +404,18 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
         }
         pw[j] = v;
     }
+    uint32_t mw = 0;
+    if (mbits && tid < TILE_H * (TILE_W / 32)) {
+        const int my = y0 + tid / (TILE_W / 32), mwi = (x0 >> 5) + (tid & (TILE_W / 32 - 1));
+        if (my < L.h && mwi < (L.pitch >> 5)) mw = mbits[(size_t)frame * g.mstride + L.moff + (size_t)my * L.mpitch + mwi];
+    }
     const int thr = g.fast_thr, et = g.edge_thr;
     // Only pixels that can survive the border filter, or suppress a survivor in the 3x3 NMS, need a score:
     // [et-1, dim-et] intersected with the detector's own scan range [3, dim-4], and the tile's score columns x0-1 .. x0+128.
     const int xlo = max(max(3, et - 1), x0 - 1), xhi = min(min(L.w - 4, L.w - et), x0 + TILE_W);
     const int ylo = max(3, et - 1), yhi = min(L.h - 4, L.h - et);
     s_hist[tid] = 0;
+    if (tid < TILE_H * (TILE_W / 32)) s_mask[tid] = mw;
     if (tid == 0) { s_n = 0; s_k = 0; }
     if (tid < FPW) {                                             // per tile word: 0x80 in the bytes whose pixel is in [xlo, xhi]; pads 0
         const int xb = x0 - 8 + 4 * tid;
@@ -450,7 +525,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
         const bool keep = sc > q[-1] && sc > q[1] && sc > q[-FROW - 1] && sc > q[-FROW] && sc > q[-FROW + 1] &&
                           sc > q[FROW - 1] && sc > q[FROW] && sc > q[FROW + 1];
         if (!keep) continue;
-        if (mpyr && mpyr[fbase + (size_t)y * L.pitch + x] == 0) continue;
+        if (mbits) { if (!((s_mask[(sy - 1) * (TILE_W / 32) + ((xb - 8) >> 5)] >> ((xb - 8) & 31)) & 1u)) continue; }
+        else if (mpyr && mpyr[fbase + (size_t)y * L.pitch + x] == 0) continue;
         const int k = atomicAdd(&s_k, 1);
         s_out[k] = ((uint32_t)sc << 24) | (uint32_t)b;
         atomicAdd(&s_hist[sc], 1u);
@@ -939,7 +1015,8 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
     for (int p = 0; p < npipe; p++) {
         bh_orb_ws& Wk = ctx->ows[p];
         BH_TRY(bh_reserve(ctx, &Wk.pyr, ws + 256));             // +256: the 12-byte resize windows may read past the last row
-        if (has_mask) BH_TRY(bh_reserve(ctx, &Wk.mpyr, ws + 256));
+        if (mask) BH_TRY(bh_reserve(ctx, &Wk.mpyr, ws + 256));
+        else if (depth) BH_TRY(bh_reserve(ctx, &Wk.mpyr, sizeof(uint32_t) * (size_t)g.mstride * chunk));      // bit-packed: depth masks are binary
         BH_TRY(bh_reserve(ctx, &Wk.clist, sizeof(uint2) * (size_t)g.list_stride * chunk));
         BH_TRY(bh_reserve(ctx, &Wk.blur, ws));
         BH_TRY(bh_reserve(ctx, &Wk.hist, sizeof(uint32_t) * 257 * g.nlevels * chunk));      // histograms, then the corner counts
@@ -985,7 +1062,8 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
             if (mask) d_mask = mask + (size_t)f0 * fpx; else if (depth) d_depth = depth + (size_t)f0 * fpx;
             d_kps = kps + (size_t)f0 * max_kp; d_desc = desc + (size_t)f0 * max_kp * 32; d_nkp = n_kp + f0;
         }
-        uint8_t* pyr = (uint8_t*)Wk.pyr.p; uint8_t* mpyr = has_mask ? (uint8_t*)Wk.mpyr.p : nullptr;
+        uint8_t* pyr = (uint8_t*)Wk.pyr.p; uint8_t* mpyr = mask ? (uint8_t*)Wk.mpyr.p : nullptr;
+        uint32_t* mbits = (!mask && depth) ? (uint32_t*)Wk.mpyr.p : nullptr;
         uint2* clist = (uint2*)Wk.clist.p; uint8_t* blur = (uint8_t*)Wk.blur.p;
         uint32_t* hist = (uint32_t*)Wk.hist.p;
         int* ccnt = (int*)(hist + (size_t)256 * g.nlevels * chunk);
@@ -994,14 +1072,14 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         {
             const int n = (g.lv[0].pitch >> 2) * g.lv[0].h;
             BH_LAUNCH(ctx, BH_K_GRAY, k_gray_mask, dim3((n + 255) / 256, nb), dim3(256), st, d_img, channels, d_mask, d_depth,
-                               pyr, mpyr, W, H, g.lv[0].pitch, g.pyr_stride);
+                               pyr, mpyr, W, H, g.lv[0].pitch, g.pyr_stride, mbits, g.lv[0].mpitch, g.mstride);
         }
         for (int l = 1; l < g.nlevels; l++) {
             const int n = (g.lv[l].pitch >> 2) * g.lv[l].h;
-            BH_LAUNCH(ctx, BH_K_PYR, k_pyr_down, dim3((n + 255) / 256, nb), dim3(256), st, pyr, mpyr, g, l, (const uint32_t*)ctx->tab.p);
+            BH_LAUNCH(ctx, BH_K_PYR, k_pyr_down, dim3((n + 255) / 256, nb), dim3(256), st, pyr, mpyr, g, l, (const uint32_t*)ctx->tab.p, mbits);
         }
         BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, clist, ccnt, hist, blur, G, g,
-                  (const uint32_t*)ctx->tab.p + g.tab_len + 4, (uint32_t*)ctx->status.p);
+                  (const uint32_t*)ctx->tab.p + g.tab_len + 4, (uint32_t*)ctx->status.p, (const uint32_t*)mbits);
         BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, clist, ccnt, hist, g, sel_cap, (uint32_t*)Wk.sel_xy.p,
                   (float*)Wk.sel_resp.p, (int*)Wk.sel_cnt.p, (uint32_t*)ctx->status.p);
         BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3((max_kp + 3) / 4, nb), dim3(256), st, pyr, blur, g, (const uint32_t*)ctx->tab.p + g.tab_len + 4 + g.ntiles,
@@ -1014,7 +1092,7 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
             BH_HIP(ctx, hipMemcpyAsync(n_kp + f0, d_nkp, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
             BH_HIP(ctx, hipStreamSynchronize(st));
         }
-        ctx->last_B = nb; ctx->last_has_mask = has_mask; ctx->last_pipe = pipe;
+        ctx->last_B = nb; ctx->last_has_mask = has_mask; ctx->last_mask_bits = mbits != nullptr; ctx->last_pipe = pipe;
     }
     ctx->tstream = nullptr;
     for (int p = 1; p < npipe; p++) {                            // join: later work on the context's stream sees every chunk
@@ -1033,7 +1111,21 @@ extern "C" int bh_orb_debug_fetch(bh_ctx* ctx, int frame, uint8_t* pyr, uint8_t*
     const bh_orb_ws& Wk = ctx->ows[ctx->last_pipe];
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (pyr)  BH_HIP(ctx, hipMemcpy(pyr, (uint8_t*)Wk.pyr.p + o, n, hipMemcpyDeviceToHost));
-    if (mask_pyr && ctx->last_has_mask) BH_HIP(ctx, hipMemcpy(mask_pyr, (uint8_t*)Wk.mpyr.p + o, n, hipMemcpyDeviceToHost));
+    if (mask_pyr && ctx->last_has_mask && ctx->last_mask_bits) {      // bit-packed on the device: expanded to the byte layout of the image pyramid
+        const bh_orb_geom& g = ctx->geom;
+        uint32_t* bits = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)g.mstride);
+        hipError_t e = hipMemcpy(bits, (uint32_t*)Wk.mpyr.p + (size_t)frame * g.mstride, sizeof(uint32_t) * (size_t)g.mstride, hipMemcpyDeviceToHost);
+        memset(mask_pyr, 0, n);
+        if (e == hipSuccess)
+            for (int l = 0; l < g.nlevels; l++) {
+                const bh_level_geom& L = g.lv[l];
+                for (int y = 0; y < L.h; y++)
+                    for (int x = 0; x < L.w; x++)
+                        mask_pyr[L.off + (size_t)y * L.pitch + x] = ((bits[L.moff + (size_t)y * L.mpitch + (x >> 5)] >> (x & 31)) & 1u) ? 255 : 0;
+            }
+        free(bits);
+        if (e != hipSuccess) return bh_set_err(ctx, BH_ERR_HIP, "bh_orb_debug_fetch: %s", hipGetErrorString(e));
+    } else if (mask_pyr && ctx->last_has_mask) BH_HIP(ctx, hipMemcpy(mask_pyr, (uint8_t*)Wk.mpyr.p + o, n, hipMemcpyDeviceToHost));
     if (nms) {                                                   // the dense NMS score map no longer exists on the device: rebuild it from the corner lists
         const bh_orb_geom& g = ctx->geom;
         memset(nms, 0, n);

@@ -38,6 +38,39 @@ def test_odd_sizes_gray_and_bgr(ctx, H, W):
     _check(ctx, np.ascontiguousarray(crop[..., 1]), None, dict(nfeatures=200))
 
 
+@pytest.mark.parametrize("H,W", [(241, 322), (200, 203), (130, 161), (480, 636), (97, 129)])
+def test_depth_masks_take_the_bit_packed_pyramid(ctx, H, W):
+    """mask = (depth > 0) * 255 (camera.py:141) is binary, so the device keeps it one bit per pixel: salt-and-pepper holes (every
+    resize window mixed), rectangular holes (long uniform runs with edges), widths that are not multiples of 4 / 32 / 64."""
+    rng = np.random.default_rng(H * 7 + W)
+    bgr, _ = synth.render_batch(2)
+    oy, ox = min(7, 480 - H), min(11, 640 - W)
+    crop = np.ascontiguousarray(bgr[:, oy:oy + H, ox:ox + W])
+    depth = rng.integers(1, 5000, size=(2, H, W)).astype(np.uint16)
+    depth[0][rng.random((H, W)) < 0.15] = 0
+    for _ in range(12):
+        y, x, hh, ww = rng.integers(0, H - 8), rng.integers(0, W - 8), rng.integers(4, 60), rng.integers(4, 90)
+        depth[1, y:y + hh, x:x + ww] = 0
+    params_kw = dict(nfeatures=300)
+    params = frontend.make_params(**params_kw)
+    kps, desc, n = frontend.orb_detect_describe(ctx, crop, depth=depth, params=params)
+    mask = (depth > 0).astype(np.uint8) * 255
+    for f in range(2):
+        ok, od, rc, dbg = oracle.orb_detect_describe(crop[f], mask[f], oracle.orb_params(**params_kw), max_kp=4 * 300 + 256, debug=True)
+        dev = frontend.orb_debug_fetch(ctx, f, H, W, params)              # the mask pyramid itself, expanded from the bits
+        for l in range(params.nlevels):
+            w, h, p, o = int(dev["w"][l]), int(dev["h"][l]), int(dev["pitch"][l]), int(dev["off"][l])
+            got = dev["mask"][o:o + p * h].reshape(h, p)[:, :w]
+            ro = int(dbg["off"][l])
+            bad = np.argwhere(got != dbg["mask"][ro:ro + w * h].reshape(h, w))
+            assert len(bad) == 0, (f, l, len(bad), bad[:3])
+        assert rc == 0 and n[f] == len(ok), (f, n[f], len(ok))
+        assert np.array_equal(desc[f, :n[f]], od)
+        for fld in ("x", "y", "angle", "response", "size"):
+            assert np.array_equal(kps[f, :n[f]][fld].view(np.uint32), ok[fld].view(np.uint32)), fld
+    assert n.sum() > 0
+
+
 def test_single_level_and_three_levels(ctx):
     bgr, depth = synth.render_batch(2)
     mask = (depth > 0).astype(np.uint8) * 255
