@@ -73,6 +73,8 @@ def test_match_crosscheck_matches_oracle(ctx):
             t[b, (k * 7) % nt] = q[b, (k * 3) % nq] ^ np.uint8(1 << (k % 8))
         if nt > 3 and nq > 3:
             t[b, 1] = t[b, 0]; q[b, 2] = q[b, 1]
+        if nt > 40 and nq > 40:                                   # all-ones / all-zeros rows: |q| - 2 q.t goes down to -256 in the MFMA form
+            q[b, 30] = 255; t[b, 31] = 255; q[b, 33] = 0; t[b, 35] = 0; t[b, 36] = 255; q[b, 38] = 255
     nq = np.array([c[0] for c in cases], np.int32); nt = np.array([c[1] for c in cases], np.int32)
     qi, ti, d, nm = frontend.match_pairs(ctx, q, nq, t, nt)
     for b, (a, c) in enumerate(cases):
