@@ -699,7 +699,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 // One workgroup per (level, frame).  Input: the level's corner list written by k_fast (unordered) and its score histogram.
 // Output: the level's kept keypoints in raster order in a staging slot sel_xy/sel_resp[frame][level][sel_cap] + sel_cnt[frame][level];
 // k_describe turns slots into final keypoints.
-__global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ pyr, const uint2* __restrict__ clist,
+__global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_select(const uint8_t* __restrict__ pyr, const uint2* __restrict__ clist,
                                                   const int* __restrict__ ccnt, const uint32_t* __restrict__ hist, bh_orb_geom g,
                                                   int sel_cap, uint32_t* __restrict__ sel_xy, float* __restrict__ sel_resp,
                                                   int* __restrict__ sel_cnt, uint32_t* __restrict__ status)
@@ -743,24 +743,37 @@ __global__ __launch_bounds__(SEL_T) void k_select(const uint8_t* __restrict__ py
         const uint32_t xy = s_xy[i];
         const int cx = xy & 0xffffu, cy = xy >> 16;
         int a = 0, b = 0, c = 0;
-        int r0[9], r1[9], r2[9];
-        const uint8_t* p = img + (size_t)(cy - 4) * L.pitch + cx - 4;
-#pragma unroll
-        for (int k = 0; k < 9; k++) { r0[k] = p[k]; r1[k] = p[L.pitch + k]; }
+        // The 9 bytes of a window row are ONE aligned 12-byte load (rows are 64-B aligned, so the window's byte offset is cx - 4 mod 4)
+        // plus funnel shifts: 81 single-byte loads per corner, every lane on its own cache line, were the longest phase of this kernel.
+        // The Sobel products run on 16-bit pairs: with the column sums cs = r0 + 2 r1 + r2 and row differences rd = r2 - r0 as
+        // (even, odd) halves, Ix[k] = cs[k+1] - cs[k-1] is one v_pk_sub of neighbouring pairs, Iy[k] = rd[k-1] + 2 rd[k] + rd[k+1]
+        // two packed adds, and sum Ix^2, Iy^2, Ix Iy take two pixels per v_dot2_i32_i16 (|Ix|, |Iy| <= 1020; exact integers).
+        const uint8_t* p = img + (size_t)(cy - 4) * L.pitch + ((cx - 4) & ~3);
+        const uint32_t sh = ((uint32_t)(cx - 4) & 3u) << 3;
+        fs2 X0[5], X1[5], X2[5];
+#define SEL_ROW(X, row) { const uint32_t* q_ = reinterpret_cast<const uint32_t*>(p + (size_t)(row) * L.pitch); const uint32_t w0_ = q_[0], w1_ = q_[1], w2_ = q_[2]; \
+            const uint32_t lo_ = __builtin_amdgcn_alignbit(w1_, w0_, sh), hi_ = __builtin_amdgcn_alignbit(w2_, w1_, sh); \
+            X[0] = fpk(0, lo_, 0x0c010c00u); X[1] = fpk(0, lo_, 0x0c030c02u); X[2] = fpk(0, hi_, 0x0c010c00u); X[3] = fpk(0, hi_, 0x0c030c02u); \
+            X[4] = __builtin_bit_cast(fs2, (w2_ >> sh) & 255u); }
+        SEL_ROW(X0, 0); SEL_ROW(X1, 1);
 #pragma unroll
         for (int row = 2; row < 9; row++) {
-            const uint8_t* q = p + (size_t)row * L.pitch;
+            SEL_ROW(X2, row);
+            fs2 cs[5], rd[5];
 #pragma unroll
-            for (int k = 0; k < 9; k++) r2[k] = q[k];
+            for (int j = 0; j < 5; j++) { cs[j] = X0[j] + X2[j] + X1[j] + X1[j]; rd[j] = X2[j] - X0[j]; }
 #pragma unroll
-            for (int k = 1; k < 8; k++) {
-                const int Ix = (r1[k + 1] - r1[k - 1]) * 2 + (r0[k + 1] - r0[k - 1]) + (r2[k + 1] - r2[k - 1]);
-                const int Iy = (r2[k] - r0[k]) * 2 + (r2[k - 1] - r0[k - 1]) + (r2[k + 1] - r0[k + 1]);
-                a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+            for (int j = 0; j < 4; j++) {
+                fs2 ix = cs[j + 1] - cs[j];                          // (Ix[2j+1], Ix[2j+2])
+                const fs2 md = __builtin_bit_cast(fs2, __builtin_amdgcn_alignbit(__builtin_bit_cast(uint32_t, rd[j + 1]), __builtin_bit_cast(uint32_t, rd[j]), 16u));
+                fs2 iy = rd[j] + md + md + rd[j + 1];                // (Iy[2j+1], Iy[2j+2])
+                if (j == 3) { ix.y = 0; iy.y = 0; }                  // k = 8 is outside the 7x7 block
+                a = __builtin_amdgcn_sdot2(ix, ix, a, false); b = __builtin_amdgcn_sdot2(iy, iy, b, false); c = __builtin_amdgcn_sdot2(ix, iy, c, false);
             }
 #pragma unroll
-            for (int k = 0; k < 9; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
+            for (int j = 0; j < 5; j++) { X0[j] = X1[j]; X1[j] = X2[j]; }
         }
+#undef SEL_ROW
         const float scale = 1.f / ((1 << 2) * 7 * 255.f);
         const float scale_sq_sq = scale * scale * scale * scale;
         const float fa = (float)a, fbb = (float)b, fc = (float)c;
