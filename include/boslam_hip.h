@@ -161,7 +161,8 @@ int  bh_ba_get_log(bh_ba* ba, double* log, int max_rows);
 /* Test hook: one banded SPD solve S x = rhs with the reduced-camera-system kernels.  band f64[n][bw+1] holds the lower band,
  * element (r, c) at band[r*(bw+1) + c - r + bw]; mode 0 = panel kernel, 1 = on-chip sliding-window kernel (15 <= bw <= 256),
  * 3 = two workgroups eliminating from both ends (needs a band of exactly 16 tiles, 241 <= bw <= 256, and >= 40 block columns),
- * 4 = the whole factor on chip (n <= 288; the local-BA window and the separator system);
+ * 4 = the whole factor on chip (n <= 288; the local-BA window and the separator system),
+ * 5 = block cyclic reduction in 256 x 256 blocks over the whole chip (bw <= 256; the global-BA solver for n >= 2048);
  * clocks (may be NULL) receives i64[8] phase clocks of the window kernel (100 MHz ticks). */
 int  bh_ba_debug_band_solve(bh_ctx* ctx, const double* band, const double* rhs, int n, int bw, int mode, double* x,
                             long long* clocks);

@@ -8,7 +8,7 @@ import json, subprocess, sys, os
 root, fpl = sys.argv[1], int(sys.argv[2])
 here = os.path.dirname(os.path.abspath(__file__))
 d = json.loads(subprocess.run([sys.executable, os.path.join(here, "pmc_summary.py"), root], capture_output=True, text=True, check=True).stdout)
-WIDE = {"k_gray_mask": 2, "k_pyr_down": 2, "k_select": 2, "k_bow_scan": 2}      # >= 8 B per lane loads (12 B + 8 B, 12 B, 8 B records, 16 B)
+WIDE = {"k_gray_mask": 2, "k_pyr_down": 2, "k_pyr_down_bits": 2, "k_select": 2, "k_bow_scan": 2}      # >= 8 B per lane loads (12 B + 8 B, 12 B, 8 B records, 16 B)
 PER_LAUNCH = {"k_bow_scan", "k_bow_topk", "k_bow_topk_slices", "k_bow_pack"}                # reported per launch (= per query), not per frame
 out = {"_note": "HBM bytes per FRAME = (FETCH_SIZE x factor + WRITE_SIZE) KiB per launch / frames per launch; rocprofv3 --pmc, FETCH_SIZE and "
                 "WRITE_SIZE in separate passes, bench.py --frames 256 --pipelines 1 (launches of %d frames); k_pyr_down and k_blur are "
@@ -20,7 +20,7 @@ for k, v in d.items():
     if base.startswith("k_ba") or "FETCH_SIZE" not in v:
         continue
     per_launch = (v["FETCH_SIZE"] * WIDE.get(base, 1) + v.get("WRITE_SIZE", 0.0)) * 1024.0
-    launches_per_batch = 7 if base == "k_pyr_down" else 1
+    launches_per_batch = 7 if base in ("k_pyr_down", "k_pyr_down_bits") else 1
     agg[base] = agg.get(base, 0.0) + per_launch * launches_per_batch / (1 if base in PER_LAUNCH else fpl)
 for k, v in sorted(agg.items()):
     out[k] = int(round(v))
