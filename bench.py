@@ -288,9 +288,10 @@ def run_rank(args):
         fps_serial = B * args.steps / dt_serial
         # dominant kernel by summed hipEvent time; its own compulsory traffic per frame
         nf = args.nfeatures
-        per_frame_bytes = {"k_gray_mask": 921600 + 614400 + 2 * 307200, "k_pyr_down": 2 * (926546 + 643332),
+        per_frame_bytes = {"k_gray_mask": 921600 + 614400 + 307200 + 38400,     # BGR + depth in, gray + mask bits out
+                           "k_pyr_down": 926546 + 643332 + (926546 + 643332) // 8,   # levels 0-6 in, 1-7 out, bit-packed mask pyramid alongside
                            "k_fast": 2 * 950532 + 16 * nf,           # pyramid pixels in, blurred pyramid out, ~2 n corner records of 8 B
-                           "k_select": 16 * nf + 81 * 2 * nf + 8 * nf,   # corner records, the 9x9 Harris windows of ~2 n candidates, staging slots
+                           "k_select": 16 * nf + 108 * 2 * nf + 8 * nf,  # corner records, the Harris windows of ~2 n candidates (9 rows x 12 B), staging slots
                            "k_describe": 56 * nf + 2 * 950532, "k_match": 2 * 32 * nf + 12 * nf}
         dom = max(ktimes, key=lambda k: ktimes[k][0])
         dom_ms, dom_n = ktimes[dom]
