@@ -366,6 +366,7 @@ __device__ __forceinline__ int reflect101(int i, int n)
 #define FSC_H (TILE_H + 2)
 #define FROW  (4 * FPW)         // bytes per LDS row (144)
 #define FITEMS (FSC_H * FPW)    // 1224 (item, word) pairs of the score tile
+#define FLIST_CAP (2 * FITEMS)   // candidate list entries: half of the score tile's pixels
 #ifndef FBLUR_ROWS
 #define FBLUR_ROWS 4             // output rows per lane in the blur
 #endif
@@ -400,13 +401,17 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
                                               bh_orb_geom g, const uint32_t* __restrict__ tile_tab, uint32_t* __restrict__ status,
                                               const uint32_t* __restrict__ mbits)
 {
+    // 17.3 KB of LDS: eight workgroups per CU.  (26.2 KB allowed six, and the kernel is bound by the latency of its barrier-separated
+    // phases as much as by its instruction count: 2.18 -> 1.98 ms per 1000 frames.)  The candidate list holds HALF the score tile -
+    // a tile where more than half of the pixels pass the pretest (noise) takes the exact list-free path below - and the kept-corner
+    // staging array reuses the pixel tile, which is dead once phase 2 and the blur are through.
     __shared__ uint32_t s_px[FPX_H * FPW];
     __shared__ uint32_t s_mask[TILE_H * (TILE_W / 32)];         // the tile of the bit-packed mask (no HBM round trip in phase 3)
     __shared__ uint32_t s_scw[FITEMS];
-    __shared__ uint16_t s_list[4 * FITEMS];
+    __shared__ uint16_t s_list[FLIST_CAP];
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_vm[FPW];
-    __shared__ uint32_t s_out[TILE_W * TILE_H / 4];            // kept corners: strict 3x3 maxima, at most one per 2x2 block
+    uint32_t* const s_out = s_px;                               // kept corners (phase 3): strict 3x3 maxima, at most one per 2x2 block = 1024 <= FPX_H * FPW
     __shared__ int s_n, s_k, s_base;
 
     const int tid = threadIdx.x;
@@ -495,23 +500,33 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
 #ifdef FAST_APPEND_LOOP
                 do {                                                 // 1.1 survivors per non-empty word on average
                     const int k = (__ffs(P) - 1) >> 3;
-                    s_list[pos++] = (uint16_t)(4 * i + k);           // byte index into the score tile
+                    if (pos < FLIST_CAP) s_list[pos] = (uint16_t)(4 * i + k);           // byte index into the score tile
+                    pos++;
                     P &= P - 1;
                 } while (P);
 #else
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (P & (0x80u << (8 * k))) s_list[pos++] = (uint16_t)(4 * i + k);   // byte index into the score tile
+                for (int k = 0; k < 4; k++) if (P & (0x80u << (8 * k))) { if (pos < FLIST_CAP) s_list[pos] = (uint16_t)(4 * i + k); pos++; }   // byte index into the score tile
 #endif
             }
         }
     }
     __syncthreads();
     // ---- phase 2
-    const int n = s_n;
+    // More survivors than the list holds (more than half of the tile: noise): the list is dropped and EVERY pixel of the score tile
+    // takes the full ring test, filtered by the same validity mask as phase 1 - the pretest is only a necessary condition of that
+    // test, so the corners are the same.  Slow (19 rounds instead of 1) and exact.
+    const bool ovf = s_n > FLIST_CAP;
+    const int n = ovf ? 4 * FITEMS : s_n;
     for (int j0 = 0; j0 < n; j0 += 256) {
         const int j = j0 + tid;
         if (j >= n) continue;
-        const int b = s_list[j];
+        int b;
+        if (ovf) {
+            b = j;
+            const int sy = b / FROW, xb = b - sy * FROW, y = y0 - 1 + sy;
+            if (!(y >= ylo && y <= yhi && ((s_vm[xb >> 2] >> (8 * (xb & 3))) & 0x80u))) continue;
+        } else b = s_list[j];
         const uint8_t* c = px + b + 3 * FROW;
         const int v = c[0];
         int d[16];
@@ -545,44 +560,6 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
         s_sc[b] = (uint8_t)(-b0 - 1);
     }
     __syncthreads();
-    // ---- phase 3: kept corners are staged in LDS as (score << 24) | (score-tile byte index), then the tile reserves its
-    // range of the level's corner list with ONE global atomic (a returning atomic per wave was measured 35 % slower: every wave
-    // then waits out an L2 round trip on a counter all tiles of the level contend for)
-    for (int j = tid; j < n; j += 256) {
-        const int b = s_list[j];
-        const int sc = s_sc[b];
-        if (sc == 0) continue;
-        const int sy = b / FROW, xb = b - sy * FROW;
-        if (sy < 1 || sy > TILE_H || xb < 8 || xb >= 8 + TILE_W) continue;            // halo positions belong to the neighbour tiles
-        const int x = x0 - 8 + xb, y = y0 - 1 + sy;
-        if (!(x >= et && x < L.w - et && y >= et && y < L.h - et)) continue;
-        const uint8_t* q = s_sc + b;
-        const bool keep = sc > q[-1] && sc > q[1] && sc > q[-FROW - 1] && sc > q[-FROW] && sc > q[-FROW + 1] &&
-                          sc > q[FROW - 1] && sc > q[FROW] && sc > q[FROW + 1];
-        if (!keep) continue;
-        if (mbits) { if (!((s_mask[(sy - 1) * (TILE_W / 32) + ((xb - 8) >> 5)] >> ((xb - 8) & 31)) & 1u)) continue; }
-        else if (mpyr && mpyr[fbase + (size_t)y * L.pitch + x] == 0) continue;
-        const int k = atomicAdd(&s_k, 1);
-        s_out[k] = ((uint32_t)sc << 24) | (uint32_t)b;
-        atomicAdd(&s_hist[sc], 1u);
-    }
-    __syncthreads();
-    const int kk = s_k;
-    const size_t lv = (size_t)frame * g.nlevels + level;
-    if (tid == 0 && kk) s_base = atomicAdd(&ccnt[lv], kk);
-    if (s_hist[tid]) atomicAdd(&hist[lv * 256 + tid], s_hist[tid]);
-    __syncthreads();
-    if (kk) {
-        const int base = s_base;
-        uint2* dst = clist + (size_t)frame * g.list_stride + L.list_off;
-        for (int i = tid; i < kk; i += 256) {
-            const uint32_t e = s_out[i];
-            const int b = e & 0xffffffu, sy = b / FROW, xb = b - sy * FROW;
-            const uint32_t x = (uint32_t)(x0 - 8 + xb), y = (uint32_t)(y0 - 1 + sy);
-            if (base + i < L.list_cap) dst[base + i] = make_uint2((y << 16) | x, e >> 24);
-            else atomicOr(status, BH_ST_CAND_OVERFLOW);
-        }
-    }
     // ---- 7x7 sigma-2 Gaussian of the tile from the same LDS pixels (integer kernel, (sum + 32768) >> 16; the descriptor's input).
     // A lane owns a 4-pixel column strip and FBLUR_ROWS output rows (the row sums of FBLUR_ROWS + 6 input rows: taller strips recompute
     // fewer of them - 16 rows on one wave cost 2/3 of 4 rows on four waves): per input row three aligned LDS words, the 4 horizontal sums with
@@ -631,6 +608,45 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
 #pragma unroll
                 for (int i = 0; i < 4; i++) hprev[i] = h[i];
             }
+        }
+    }
+    __syncthreads();                                            // the pixel tile is dead from here on: s_out takes its place
+    // ---- phase 3: kept corners are staged in LDS as (score << 24) | (score-tile byte index), then the tile reserves its
+    // range of the level's corner list with ONE global atomic (a returning atomic per wave was measured 35 % slower: every wave
+    // then waits out an L2 round trip on a counter all tiles of the level contend for)
+    for (int j = tid; j < n; j += 256) {
+        const int b = ovf ? j : s_list[j];
+        const int sc = s_sc[b];
+        if (sc == 0) continue;
+        const int sy = b / FROW, xb = b - sy * FROW;
+        if (sy < 1 || sy > TILE_H || xb < 8 || xb >= 8 + TILE_W) continue;            // halo positions belong to the neighbour tiles
+        const int x = x0 - 8 + xb, y = y0 - 1 + sy;
+        if (!(x >= et && x < L.w - et && y >= et && y < L.h - et)) continue;
+        const uint8_t* q = s_sc + b;
+        const bool keep = sc > q[-1] && sc > q[1] && sc > q[-FROW - 1] && sc > q[-FROW] && sc > q[-FROW + 1] &&
+                          sc > q[FROW - 1] && sc > q[FROW] && sc > q[FROW + 1];
+        if (!keep) continue;
+        if (mbits) { if (!((s_mask[(sy - 1) * (TILE_W / 32) + ((xb - 8) >> 5)] >> ((xb - 8) & 31)) & 1u)) continue; }
+        else if (mpyr && mpyr[fbase + (size_t)y * L.pitch + x] == 0) continue;
+        const int k = atomicAdd(&s_k, 1);
+        s_out[k] = ((uint32_t)sc << 24) | (uint32_t)b;
+        atomicAdd(&s_hist[sc], 1u);
+    }
+    __syncthreads();
+    const int kk = s_k;
+    const size_t lv = (size_t)frame * g.nlevels + level;
+    if (tid == 0 && kk) s_base = atomicAdd(&ccnt[lv], kk);
+    if (s_hist[tid]) atomicAdd(&hist[lv * 256 + tid], s_hist[tid]);
+    __syncthreads();
+    if (kk) {
+        const int base = s_base;
+        uint2* dst = clist + (size_t)frame * g.list_stride + L.list_off;
+        for (int i = tid; i < kk; i += 256) {
+            const uint32_t e = s_out[i];
+            const int b = e & 0xffffffu, sy = b / FROW, xb = b - sy * FROW;
+            const uint32_t x = (uint32_t)(x0 - 8 + xb), y = (uint32_t)(y0 - 1 + sy);
+            if (base + i < L.list_cap) dst[base + i] = make_uint2((y << 16) | x, e >> 24);
+            else atomicOr(status, BH_ST_CAND_OVERFLOW);
         }
     }
 }

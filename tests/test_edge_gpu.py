@@ -71,6 +71,18 @@ def test_depth_masks_take_the_bit_packed_pyramid(ctx, H, W):
     assert n.sum() > 0
 
 
+def test_noise_tiles_take_the_list_free_path(ctx):
+    """White noise with a low FAST threshold: well over half of the pixels pass the detector's pretest, more than k_fast's candidate
+    list holds, so its tiles score every pixel with the full ring test instead - same keypoints and descriptors as the oracle.
+    Half of the second frame is flat, so both kinds of tile occur in one launch."""
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, size=(2, 200, 264), dtype=np.uint8)
+    img[1, :, 132:] = 90
+    for thr in (5, 20):
+        n = _check(ctx, img, None, dict(nfeatures=400, fastThreshold=thr))
+        assert n.min() > 100
+
+
 def test_single_level_and_three_levels(ctx):
     bgr, depth = synth.render_batch(2)
     mask = (depth > 0).astype(np.uint8) * 255
