@@ -878,14 +878,18 @@ __constant__ __attribute__((aligned(4))) signed char c_pattern[1024] = {
 #include "brief_pattern.h"
 };
 
-// One wave per (frame, level, slot).  The final keypoint index is the prefix of the per-level counts plus the slot
-// (canonical order: level-major, raster inside a level).  Intensity-centroid angle: lanes cover 2 rows x 32 columns of
-// the 31x31 patch per step, integer wave reduction, fastAtan2.  Steered BRIEF: lane l evaluates tests l, 64+l, 128+l,
-// 192+l; four ballots give the 32 descriptor bytes.
-// One wave per (frame, level, slot).  The final keypoint index is the prefix of the per-level counts plus the slot
-// (canonical order: level-major, raster inside a level).  Intensity-centroid angle: lanes cover 2 rows x 32 columns of
-// the 31x31 patch per step, integer wave reduction, fastAtan2.  Steered BRIEF: lane l evaluates tests l, 64+l, 128+l,
-// 192+l; four ballots give the 32 descriptor bytes.
+// One 256-lane workgroup per 64 final keypoints of a frame, 16 per wave (final index = prefix of the per-level counts + slot:
+// level-major, raster inside a level).  What a keypoint costs is split by who can share it:
+//   phase A  wave per keypoint: intensity-centroid sums over the 749-pixel disc (lanes cover 2 rows x 32 columns per step, integer DPP
+//            wave sums) -> m01, m10 into LDS;
+//   phase B  LANE per keypoint: fastAtan2, the f64 sin / cos of the angle, the scaled coordinates - the ~160 instructions that are
+//            the same in all 64 lanes when a wave owns one keypoint run once for 64 keypoints here; the keypoint record is stored
+//            (64 contiguous 24-B structs);
+//   phase C  wave per keypoint: steered BRIEF, lane l evaluates tests l, 64+l, 128+l, 192+l (its 16 pattern coordinates are
+//            converted to float once per wave and reused for all 16 keypoints); four ballots give the 32 descriptor bytes.
+#define DS_KPW 16
+#define DS_PR 39               // BRIEF window: |rotated pattern coordinate| <= 19
+#define DS_PW 12               // words per window row (39 bytes + up to 3 of alignment, 44 B, in 12 words)
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                   bh_orb_geom g, const uint32_t* __restrict__ ic_mask, float patch_size, int sel_cap, int max_kp,
                                                   const uint32_t* __restrict__ sel_xy, const float* __restrict__ sel_resp,
@@ -893,67 +897,145 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
                                                   uint8_t* __restrict__ desc, int* __restrict__ n_kp,
                                                   uint32_t* __restrict__ status)
 {
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);          // final keypoint index of this wave
+    __shared__ int s_m01[64], s_m10[64];
+    __shared__ uint32_t s_loc[64], s_bxy[64];                   // level << 28 | cy << 14 | cx (all ones: no keypoint);  by << 16 | bx
+    __shared__ float s_a[64], s_b[64], s_resp[64], s_scale[BH_MAX_LEVELS];
+    __shared__ uint32_t s_patch[4][2][DS_PR * DS_PW];            // per wave: the blurred 39 x 39 windows of two keypoints (rows of 12 words)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the level lookups stay scalar
     const size_t f = blockIdx.y;
     const int* cnt = sel_cnt + f * g.nlevels;
-    int level = -1, slot = 0, before = 0, tot = 0;
-    for (int l = 0; l < g.nlevels; l++) {
-        const int c = cnt[l];
-        if (level < 0 && k < tot + c) { level = l; slot = k - tot; before = tot; }
-        tot += c;
-    }
-    if (k == 0 && lane == 0) { n_kp[f] = min(tot, max_kp); if (tot > max_kp) atomicOr(status, BH_ST_KP_OVERFLOW); }
-    if (level < 0 || k >= max_kp) return;
-    (void)before;
-    const bh_level_geom L = g.lv[level];
-    const size_t si = (f * g.nlevels + level) * (size_t)sel_cap + slot;
-    const uint32_t xy = sel_xy[si];
-    const int cx = xy & 0xffffu, cy = xy >> 16;
-    const size_t lbase = f * g.pyr_stride + L.off;
-    // ---- intensity-centroid angle.  Lane = (row parity, column u): step `it` visits row v = 2 it + (lane >> 5) - 15.  Which steps fall
-    // inside the 749-pixel disc is a per-lane constant (ic_mask, built on the host from the reference's umax table), and with
-    // S = sum I, T = sum it*I over a lane's in-disc pixels: m10 = u S, m01 = 2 T + ((lane >> 5) - 15) S (integers, exact).
+    int tot = 0;
+    for (int l = 0; l < g.nlevels; l++) { tot += cnt[l]; if (tid == l) s_scale[l] = g.lv[l].scale; }
+    if (blockIdx.x == 0 && tid == 0) { n_kp[f] = min(tot, max_kp); if (tot > max_kp) atomicOr(status, BH_ST_KP_OVERFLOW); }
+    const int nk = min(tot, max_kp), kbase = blockIdx.x * 64 + wv * DS_KPW;
+    if (blockIdx.x * 64 >= nk) return;
+    // ---- phase A: intensity-centroid sums.  Lane = (row parity, column u): step `it` visits row v = 2 it + (lane >> 5) - 15.  Which steps
+    // fall inside the disc is a per-lane constant (ic_mask, built on the host from the reference's umax table), and with S = sum I,
+    // T = sum it*I over a lane's in-disc pixels: m10 = u S, m01 = 2 T + ((lane >> 5) - 15) S (integers, exact).
     const int u = (lane & 31) - 15, vb = (lane >> 5) - 15;
     const uint32_t msk = ic_mask[lane];
-    const uint8_t* c = pyr + lbase + (size_t)cy * L.pitch + cx;
-    const uint8_t* p = c + vb * L.pitch + u;
-    int S = 0, T = 0;
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-        int I = p[it * 2 * L.pitch];                           // unconditional (v <= 16, |u| <= 16: inside the level's 31-px border); 16 loads in flight
-        I = (msk >> it) & 1u ? I : 0;
-        S += I; T += it * I;
+    // lane i < 16 looks up keypoint i of this wave (level, position, response) - one round trip for all sixteen; the patch loads of FOUR
+    // keypoints are in flight together (a wave that walks its keypoints one dependent load chain at a time leaves the memory system
+    // idle: the kernel was 4 % slower than one wave per keypoint with 40 % fewer instructions)
+    uint32_t my_loc = 0xffffffffu; float my_resp = 0.f;
+    if (lane < DS_KPW && kbase + lane < nk) {
+        const int k = kbase + lane;
+        int level = 0, slot = 0, t2 = 0;
+        for (int l = 0; l < g.nlevels; l++) { const int c = cnt[l]; if (k >= t2 && k < t2 + c) { level = l; slot = k - t2; } t2 += c; }
+        const size_t si = (f * g.nlevels + level) * (size_t)sel_cap + slot;
+        const uint32_t xy = sel_xy[si];
+        my_loc = ((uint32_t)level << 28) | ((xy >> 16) << 14) | (xy & 0xffffu);
+        my_resp = sel_resp[si];
     }
-    const int m10 = wave_sum_dpp(u * S), m01 = wave_sum_dpp(2 * T + vb * S);
-    const float angle_deg = fast_atan2_deg((float)m01, (float)m10);
-    bh_kp kp;
-    kp.x = (float)cx * L.scale; kp.y = (float)cy * L.scale;
-    kp.size = patch_size * L.scale; kp.angle = angle_deg; kp.response = sel_resp[si]; kp.octave = level;
-    if (lane == 0) kps[f * max_kp + k] = kp;
-    // ---- steered BRIEF on the blurred level (centre recomputed from the scaled float coordinates, as the reference does)
-    const float inv = 1.f / L.scale;
-    const int bx = __float2int_rn(kp.x * inv), by = __float2int_rn(kp.y * inv);
-    float angle = angle_deg;
-    angle *= (float)(3.1415926535897932384626433832795 / 180.f);
-    double sd, cd;
-    sincos_small((double)angle, &sd, &cd);
-    const float a = (float)cd, b = (float)sd;
-    const uint8_t* center = blur + lbase + (size_t)by * L.pitch + bx;
-    unsigned long long bits[4];
+    if (lane < DS_KPW) { s_loc[wv * DS_KPW + lane] = my_loc; s_resp[wv * DS_KPW + lane] = my_resp; }
+#pragma unroll
+    for (int i0 = 0; i0 < DS_KPW; i0 += 4) {
+        int I[4][16];
+        uint32_t loc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            loc[q] = (uint32_t)__builtin_amdgcn_readlane((int)my_loc, i0 + q);
+            if (loc[q] == 0xffffffffu) continue;                 // wave-uniform
+            const bh_level_geom L = g.lv[loc[q] >> 28];
+            const uint8_t* p = pyr + f * g.pyr_stride + L.off + (size_t)((int)((loc[q] >> 14) & 0x3fffu) + vb) * L.pitch + (int)(loc[q] & 0x3fffu) + u;
+#pragma unroll
+            for (int it = 0; it < 16; it++) I[q][it] = p[it * 2 * L.pitch];      // unconditional (v <= 16, |u| <= 16: inside the level's 31-px border)
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (loc[q] == 0xffffffffu) continue;
+            int S = 0, T = 0;
+#pragma unroll
+            for (int it = 0; it < 16; it++) { const int v = (msk >> it) & 1u ? I[q][it] : 0; S += v; T += it * v; }
+            const int m10 = wave_sum_dpp(u * S), m01 = wave_sum_dpp(2 * T + vb * S);
+            if (lane == 0) { s_m10[wv * DS_KPW + i0 + q] = m10; s_m01[wv * DS_KPW + i0 + q] = m01; }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: one lane per keypoint
+    if (tid < 64 && s_loc[tid] != 0xffffffffu) {
+        const uint32_t loc = s_loc[tid];
+        const int level = loc >> 28, cx = loc & 0x3fffu, cy = (loc >> 14) & 0x3fffu;
+        const float scale = s_scale[level];
+        const float angle_deg = fast_atan2_deg((float)s_m01[tid], (float)s_m10[tid]);
+        bh_kp kp;
+        kp.x = (float)cx * scale; kp.y = (float)cy * scale;
+        kp.size = patch_size * scale; kp.angle = angle_deg; kp.response = s_resp[tid]; kp.octave = level;
+        kps[f * max_kp + blockIdx.x * 64 + tid] = kp;
+        // the BRIEF centre is recomputed from the scaled float coordinates, as the reference does
+        const float inv = 1.f / scale;
+        const int bx = __float2int_rn(kp.x * inv), by = __float2int_rn(kp.y * inv);
+        float angle = angle_deg;
+        angle *= (float)(3.1415926535897932384626433832795 / 180.f);
+        double sd, cd;
+        sincos_small((double)angle, &sd, &cd);
+        s_a[tid] = (float)cd; s_b[tid] = (float)sd; s_bxy[tid] = ((uint32_t)by << 16) | (uint32_t)bx;
+    }
+    __syncthreads();
+    // ---- phase C: steered BRIEF on the blurred level
+    float qx0[4], qy0[4], qx1[4], qy1[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int q4 = *reinterpret_cast<const int*>(c_pattern + (t * 64 + lane) * 4);       // the four signed bytes of test 64 t + lane
-        const float qx0 = (float)(signed char)q4, qy0 = (float)(signed char)(q4 >> 8), qx1 = (float)(signed char)(q4 >> 16), qy1 = (float)(q4 >> 24);
-        const float x0 = qx0 * a - qy0 * b, y0 = qx0 * b + qy0 * a;
-        const float x1 = qx1 * a - qy1 * b, y1 = qx1 * b + qy1 * a;
-        const int t0 = center[__float2int_rn(y0) * L.pitch + __float2int_rn(x0)];
-        const int t1 = center[__float2int_rn(y1) * L.pitch + __float2int_rn(x1)];
-        bits[t] = __ballot(t0 < t1);
+        qx0[t] = (float)(signed char)q4; qy0[t] = (float)(signed char)(q4 >> 8); qx1[t] = (float)(signed char)(q4 >> 16); qy1[t] = (float)(q4 >> 24);
     }
-    if (lane < 4) {
-        unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-        reinterpret_cast<unsigned long long*>(desc + (f * max_kp + k) * 32)[lane] = v;
+    // The 512 samples of a keypoint are 8 loads of 64 scattered bytes: one cache line per lane, which is what bounded this kernel
+    // (the address path, not the ALU: 40 % fewer instructions had changed nothing).  The 39 x 39 window they all fall into is staged
+    // in LDS with 7 coalesced word loads per wave instead, and the samples are ds_read_u8.
+#pragma unroll
+    for (int i0 = 0; i0 < DS_KPW; i0 += 2) {                     // two keypoints' windows in flight together
+        bool have[2];
+        float pa[2], pb[2];
+        int sh[2];
+        uint32_t wq[2][7];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int j = wv * DS_KPW + i0 + q;
+            have[q] = kbase + i0 + q < nk;
+            if (!have[q]) continue;
+            const uint32_t loc = s_loc[j], bxy = s_bxy[j];
+            const int level = __builtin_amdgcn_readfirstlane((int)(loc >> 28));
+            const bh_level_geom L = g.lv[level];
+            pa[q] = s_a[j]; pb[q] = s_b[j];
+            const int bx = (int)(bxy & 0xffffu) - 19, by = (int)(bxy >> 16) - 19;
+            sh[q] = bx & 3;
+            const uint8_t* org = blur + f * g.pyr_stride + L.off + (size_t)by * L.pitch + (bx & ~3);
+#pragma unroll
+            for (int m = 0; m < 7; m++) {
+                const int idx = min(lane + 64 * m, DS_PR * 11 - 1), row = idx / 11, dw = idx - row * 11;
+                wq[q][m] = *reinterpret_cast<const uint32_t*>(org + (size_t)row * L.pitch + 4 * dw);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (!have[q]) continue;
+#pragma unroll
+            for (int m = 0; m < 7; m++) {
+                const int idx = min(lane + 64 * m, DS_PR * 11 - 1), row = idx / 11, dw = idx - row * 11;
+                s_patch[wv][q][row * DS_PW + dw] = wq[q][m];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (!have[q]) continue;
+            const uint8_t* center = reinterpret_cast<const uint8_t*>(s_patch[wv][q]) + 19 * (4 * DS_PW) + 19 + sh[q];
+            const float a = pa[q], b = pb[q];
+            unsigned long long bits[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float x0 = qx0[t] * a - qy0[t] * b, y0 = qx0[t] * b + qy0[t] * a;
+                const float x1 = qx1[t] * a - qy1[t] * b, y1 = qx1[t] * b + qy1[t] * a;
+                const int t0 = center[__float2int_rn(y0) * (4 * DS_PW) + __float2int_rn(x0)];
+                const int t1 = center[__float2int_rn(y1) * (4 * DS_PW) + __float2int_rn(x1)];
+                bits[t] = __ballot(t0 < t1);
+            }
+            if (lane < 4) {
+                unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+                reinterpret_cast<unsigned long long*>(desc + (f * max_kp + kbase + i0 + q) * 32)[lane] = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -1161,7 +1243,7 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
                   (const uint32_t*)ctx->tab.p + g.tab_len + 4, (uint32_t*)ctx->status.p, (const uint32_t*)mbits);
         BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, clist, ccnt, hist, g, sel_cap, (uint32_t*)Wk.sel_xy.p,
                   (float*)Wk.sel_resp.p, (int*)Wk.sel_cnt.p, (uint32_t*)ctx->status.p);
-        BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3((max_kp + 3) / 4, nb), dim3(256), st, pyr, blur, g, (const uint32_t*)ctx->tab.p + g.tab_len + 4 + g.ntiles,
+        BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3((max_kp + 63) / 64, nb), dim3(256), st, pyr, blur, g, (const uint32_t*)ctx->tab.p + g.tab_len + 4 + g.ntiles,
                   (float)params->patchSize, sel_cap, max_kp, (const uint32_t*)Wk.sel_xy.p, (const float*)Wk.sel_resp.p,
                   (const int*)Wk.sel_cnt.p, d_kps, d_desc, d_nkp, (uint32_t*)ctx->status.p);
         BH_HIP(ctx, hipGetLastError());
