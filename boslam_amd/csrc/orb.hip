@@ -219,20 +219,29 @@ __global__ __launch_bounds__(256) void k_pyr_down_bits(uint8_t* __restrict__ pyr
         A8[k] = __builtin_amdgcn_alignbit(q0[1], q0[0], (uint32_t)base & 31u); B8[k] = __builtin_amdgcn_alignbit(q1[1], q1[0], (uint32_t)base & 31u);
     }
     uint32_t o4[PD_R], nb[PD_R];
+    // both source rows of a pixel ride in the two 16-bit halves of one register through the horizontal pass: (p0 << 8) + c1 (p1 - p0)
+    // stays below 2^16, so modular 16-bit arithmetic (v_pk_sub / v_pk_mad_u16) is exact; v_perm builds the (row 0, row 1) byte pairs
+    typedef unsigned short pd_us2 __attribute__((ext_vector_type(2)));
+    uint32_t shv[4]; pd_us2 C1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t tx = txs[i], c1 = tx & 0xffffu;
+        shv[i] = (((tx >> 16) - (uint32_t)base) & 7u) << 3;
+        C1[i] = pd_us2{ (unsigned short)c1, (unsigned short)c1 };
+    }
 #pragma unroll
     for (int k = 0; k < PD_R; k++) {
-        uint32_t v4 = 0, nib = 0;
+        uint32_t nib = 0, r[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t tx = txs[i];
-            const int sh = (int)(((tx >> 16) - (uint32_t)base) & 7u) << 3;
-            const uint32_t c1 = tx & 0xffffu;
-            const uint32_t pa = (uint32_t)(A[k] >> sh), pb = (uint32_t)(Bv[k] >> sh);
-            const int p0 = (int)(pa & 255u), p1 = (int)(pb & 255u);
-            const int h0 = (p0 << 8) + (int)c1 * ((int)((pa >> 8) & 255u) - p0);
-            const int h1 = (p1 << 8) + (int)c1 * ((int)((pb >> 8) & 255u) - p1);
-            v4 |= ((uint32_t)((h0 << 8) + (int)yc[k] * (h1 - h0) + 32768) >> 16) << (8 * i);
+            const uint32_t pa = (uint32_t)(A[k] >> shv[i]), pb = (uint32_t)(Bv[k] >> shv[i]);
+            const pd_us2 P0 = __builtin_bit_cast(pd_us2, __builtin_amdgcn_perm(pb, pa, 0x0c040c00u)), P1 = __builtin_bit_cast(pd_us2, __builtin_amdgcn_perm(pb, pa, 0x0c050c01u));
+            const pd_us2 P0s = __builtin_bit_cast(pd_us2, __builtin_amdgcn_perm(pb, pa, 0x040c000cu));
+            const uint32_t H = __builtin_bit_cast(uint32_t, (pd_us2)(C1[i] * (pd_us2)(P1 - P0) + P0s));
+            const int h0 = (int)(H & 0xffffu), h1 = (int)(H >> 16);
+            r[i] = (uint32_t)((h0 << 8) + 32768 + (int)yc[k] * (h1 - h0));       // result byte = bits 16..23
         }
+        const uint32_t v4 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(r[3], r[2], 0x0c0c0602u), __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0602u), 0x05040100u);
         const uint32_t both = A8[k] & B8[k] & 0x3fu, any = (A8[k] | B8[k]) & 0x3fu;
         if (both == 0x3fu) nib = 0xfu;
         else if (any) {
