@@ -358,7 +358,6 @@ __device__ __forceinline__ int tile_level(const bh_orb_geom& g, int tile)
 }
 
 // ------------------------------------------------------------------------------------------------ FAST-9/16 + NMS + 7x7 blur
-struct bh_gauss7 { int k[7]; };
 
 __device__ __forceinline__ int reflect101(int i, int n)
 {
@@ -376,9 +375,6 @@ __device__ __forceinline__ int reflect101(int i, int n)
 #define FROW  (4 * FPW)         // bytes per LDS row (144)
 #define FITEMS (FSC_H * FPW)    // 1224 (item, word) pairs of the score tile
 #define FLIST_CAP (2 * FITEMS)   // candidate list entries: half of the score tile's pixels
-#ifndef FBLUR_ROWS
-#define FBLUR_ROWS 4             // output rows per lane in the blur
-#endif
 
 typedef short fs2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ fs2 fswap(fs2 a) { return fs2{ a.y, a.x }; }
@@ -404,17 +400,17 @@ __device__ __forceinline__ fs2 fpk(uint32_t hi_src, uint32_t lo_src, uint32_t se
 //            doubling min/max tree over the 16 arcs; corners write their score into a sparse LDS score tile.
 //   phase 3  the same list again: strict 3x3 NMS against the score tile, border and mask filter; kept corners are appended to the
 //            level's corner list in HBM (one reservation per tile) and counted in the score histogram.  No dense score map exists.
-__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ mpyr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ mpyr,
                                               uint2* __restrict__ clist, int* __restrict__ ccnt, uint32_t* __restrict__ hist,
-                                              uint8_t* __restrict__ blur, bh_gauss7 G,
+                                              uint8_t* __restrict__ blur,
                                               bh_orb_geom g, const uint32_t* __restrict__ tile_tab, uint32_t* __restrict__ status,
-                                              const uint32_t* __restrict__ mbits)
+                                              const uint32_t* __restrict__ mbits, const uint32_t* __restrict__ gtab)
 {
     // 17.3 KB of LDS: eight workgroups per CU.  (26.2 KB allowed six, and the kernel is bound by the latency of its barrier-separated
     // phases as much as by its instruction count: 2.18 -> 1.98 ms per 1000 frames.)  The candidate list holds HALF the score tile -
     // a tile where more than half of the pixels pass the pretest (noise) takes the exact list-free path below - and the kept-corner
     // staging array reuses the pixel tile, which is dead once phase 2 and the blur are through.
-    __shared__ uint32_t s_px[FPX_H * FPW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_px[FPX_H * FPW + 8];      // +8: the last k-block of the blur reads 15 bytes past the last row (zero taps)
     __shared__ uint32_t s_mask[TILE_H * (TILE_W / 32)];         // the tile of the bit-packed mask (no HBM round trip in phase 3)
     __shared__ uint32_t s_scw[FITEMS];
     __shared__ uint16_t s_list[FLIST_CAP];
@@ -579,54 +575,73 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, c
         s_sc[b] = (uint8_t)(-b0 - 1);
     }
     __syncthreads();
-    // ---- 7x7 sigma-2 Gaussian of the tile from the same LDS pixels (integer kernel, (sum + 32768) >> 16; the descriptor's input).
-    // A lane owns a 4-pixel column strip and FBLUR_ROWS output rows (the row sums of FBLUR_ROWS + 6 input rows: taller strips recompute
-    // fewer of them - 16 rows on one wave cost 2/3 of 4 rows on four waves): per input row three aligned LDS words, the 4 horizontal sums with
-    // v_alignbyte + v_dot4_u32_u8 (taps {k0..k3} and {k4,k5,k6,0}); consecutive row sums are kept as 16-bit pairs P[q] = (h_q, h_q+1)
-    // and the column pass of output row y is dot2(P[y-3],(k0,k1)) + dot2(P[y-1],(k2,k3)) + dot2(P[y+1],(k4,k5)) + k6*h[y+3].
+    // ---- 7x7 sigma-2 Gaussian of the tile from the same LDS pixels (integer kernel, (sum + 32768) >> 16; the descriptor's input),
+    // ON THE MATRIX CORES.  A separable convolution is two products with banded Toeplitz matrices, and v_mfma_i32_32x32x32_i8 does a
+    // 32 x 32 x 32 block of one in 32 cycles - 95 % of the taps it multiplies are zeros and it still frees the vector ALU, which is
+    // what this kernel is bound by (the packed dot4 / dot2 version was 321 of its 1 080 vector instructions per wave).  Wave w owns the
+    // tile's 32-column block w:
+    //   pass 1 (rows)     T''[r][c] = sum_k (px[r][k] - 128) g[k - c - 5] + 128   for tile rows 0..31 and 32..63 (only 40 exist; the rest
+    //                     meets zero taps): A = 16 consecutive LDS bytes per lane (xor 0x80 makes them signed), B = taps from a table;
+    //                     two k-blocks of 32 bytes cover the 38 input columns.  T = sum g px = T'' + 32768 fits 16 bits (sum g = 257).
+    //   pass 2 (columns)  the accumulator tile IS the next product's A operand when that product sums over its ROW index
+    //                     (out' = T' G'): hi = T'' >> 8 (a signed byte as it stands), lo = (T'' & 255) - 128, packed with v_perm;
+    //                     out = 256 sum g hi + sum g lo + 257 (128 + 32768) + 32768, two accumulators, exact in int32.
+    //   The result tile has the output ROW on the lane and 4 consecutive columns in 4 registers: one dword each, transposed through
+    //   LDS (the pixel tile's own space, dead by then) so that the stores are whole 128-B row segments.
+    // The k order of an accumulator-turned-operand is permuted (element j of lane half h is row (j & 3) + 8 (j >> 2) + 4 h): the tap
+    // table of pass 2 is built in that order on the host.  Register budget: 64 per lane (eight waves per SIMD) - the passes are
+    // ordered so that at most two accumulator tiles, the packed operands and one pair of tap fragments are live at a time.
     {
-        const int strip = tid & (TILE_W / 4 - 1), grp = tid / (TILE_W / 4);
-        const int xs = x0 + 4 * strip;
-        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-        const uint32_t K03 = (uint32_t)G.k[0] | ((uint32_t)G.k[1] << 8) | ((uint32_t)G.k[2] << 16) | ((uint32_t)G.k[3] << 24);
-        const uint32_t K46 = (uint32_t)G.k[4] | ((uint32_t)G.k[5] << 8) | ((uint32_t)G.k[6] << 16);
-        const us2 K01 = { (unsigned short)G.k[0], (unsigned short)G.k[1] }, K23 = { (unsigned short)G.k[2], (unsigned short)G.k[3] },
-                  K45 = { (unsigned short)G.k[4], (unsigned short)G.k[5] };
-        constexpr int BR = FBLUR_ROWS;
-        for (int yb = grp * BR; yb < TILE_H; yb += BR * (256 / (TILE_W / 4))) {
-            if (xs >= L.w || y0 + yb >= L.h) continue;
-            const uint32_t* col = s_px + (yb + 1) * FPW + strip + 1;      // LDS row of y0 + yb - 3, word of pixels xs-4 .. xs-1
-            uint32_t pr[6][4];
-            uint32_t hprev[4] = { 0, 0, 0, 0 };
+        typedef int fv4 __attribute__((ext_vector_type(4)));
+        typedef int fv16 __attribute__((ext_vector_type(16)));
+        const int lane = tid & 63, wv = tid >> 6, n = lane & 31, h = lane >> 5;
+        const fv4* gt = reinterpret_cast<const fv4*>(gtab) + lane;
+        const uint8_t* pxb = reinterpret_cast<const uint8_t*>(s_px);
+        fv4 alo[2], ahi[2];
+        {
+            const fv4 P1B0 = gt[0], P1B1 = gt[64];
 #pragma unroll
-            for (int r = 0; r < BR + 6; r++) {
-                const uint32_t W0 = col[r * FPW], W1 = col[r * FPW + 1], W2 = col[r * FPW + 2];
-                uint32_t h[4];
-                h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 1), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 1), K46, 0u, false), false);
-                h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 2), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 2), K46, 0u, false), false);
-                h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 3), K03, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 3), K46, 0u, false), false);
-                h[3] = __builtin_amdgcn_udot4(W1, K03, __builtin_amdgcn_udot4(W2, K46, 0u, false), false);
-                if (r >= 1) {
+            for (int rb = 0; rb < 2; rb++) {
+                const uint8_t* rp = pxb + min(32 * rb + n, FPX_H - 1) * FROW + 32 * wv + 16 * h;
+                fv4 a0 = *reinterpret_cast<const fv4*>(rp), a1 = *reinterpret_cast<const fv4*>(rp + 32);
+                a0 ^= (int)0x80808080u; a1 ^= (int)0x80808080u;
+                fv16 acc = { 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128 };
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, P1B0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, P1B1, acc, 0, 0, 0);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) pr[(r - 1) % 6][i] = hprev[i] | (h[i] << 16);       // P[r-1] = (h_{r-1}, h_r)
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t q01 = __builtin_amdgcn_perm((uint32_t)acc[4 * d + 1], (uint32_t)acc[4 * d], 0x05010400u);      // (r0.b0, r1.b0, r0.b1, r1.b1)
+                    const uint32_t q23 = __builtin_amdgcn_perm((uint32_t)acc[4 * d + 3], (uint32_t)acc[4 * d + 2], 0x05010400u);
+                    alo[rb][d] = (int)(__builtin_amdgcn_perm(q23, q01, 0x05040100u) ^ 0x80808080u);
+                    ahi[rb][d] = (int)__builtin_amdgcn_perm(q23, q01, 0x07060302u);
                 }
-                if (r >= 6) {
-                    const int y = y0 + yb + r - 6;
-                    uint32_t out = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        uint32_t sm = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pr[(r - 6) % 6][i]), K01, 32768u, false);
-                        sm = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pr[(r - 4) % 6][i]), K23, sm, false);
-                        sm = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pr[(r - 2) % 6][i]), K45, sm, false);
-                        sm += __umul24(h[i], (uint32_t)G.k[6]);
-                        sm >>= 16;
-                        out |= min(sm, 255u) << (8 * i);
-                    }
-                    if (y < L.h) *reinterpret_cast<uint32_t*>(blur + fbase + (size_t)y * L.pitch + xs) = out;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++) hprev[i] = h[i];
             }
+        }
+        const fv4 P2B0 = gt[128], P2B1 = gt[192];
+        fv16 accH = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        accH = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi[0], P2B0, accH, 0, 0, 0);
+        accH = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi[1], P2B1, accH, 0, 0, 0);
+        const int CI = 257 * (128 + 32768) + 32768;
+        fv16 accL = { CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI };
+        accL = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo[0], P2B0, accL, 0, 0, 0);
+        accL = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo[1], P2B1, accL, 0, 0, 0);
+        // lane = output row n; registers 4 g .. 4 g + 3 = columns 32 w + 8 g + 4 h + (0..3): byte 2 of the clamped sums
+        uint32_t* s_o = s_px;                                      // 32 rows x 33 words
+        __syncthreads();                                           // every wave has read its pixels
+#pragma unroll
+        for (int g2 = 0; g2 < 4; g2++) {
+            uint32_t v[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) v[m] = min((uint32_t)((accH[4 * g2 + m] << 8) + accL[4 * g2 + m]), 0xffffffu);
+            const uint32_t p01 = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), p23 = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u);
+            s_o[n * 33 + 8 * wv + 2 * g2 + h] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int idx = tid + 256 * k, row = idx >> 5, wd = idx & 31;
+            const int xs = x0 + 4 * wd, y = y0 + row;
+            if (xs < L.w && y < L.h) *reinterpret_cast<uint32_t*>(blur + fbase + (size_t)y * L.pitch + xs) = s_o[row * 33 + wd];
         }
     }
     __syncthreads();                                            // the pixel tile is dead from here on: s_out takes its place
@@ -1096,7 +1111,8 @@ static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
         return BH_OK;
     bh_orb_geom g;
     if (build_geom(p, H, W, &g) != BH_OK) return bh_set_err(ctx, BH_ERR_INVALID, "unsupported ORB parameters / image size");
-    uint32_t* tab = (uint32_t*)calloc(g.tab_len + 4 + g.ntiles + 64, sizeof(uint32_t));
+    const int gt_off = align_up(g.tab_len + 4 + g.ntiles + 64, 4), tab_words = gt_off + 4 * 64 * 4;
+    uint32_t* tab = (uint32_t*)calloc(tab_words, sizeof(uint32_t));
     {   // k_describe's per-lane disc masks (after the tile table): bit `it` set iff pixel (u, v) = ((lane & 31) - 15, 2 it + (lane >> 5) - 15)
         // lies in the intensity-centroid disc of the reference (|v| <= 15, |u| <= umax[|v|])
         int um[17]; umax_table(um);
@@ -1110,6 +1126,19 @@ static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
             tab[g.tab_len + 4 + g.ntiles + lane] = m;
         }
     }
+    {   // k_fast's blur on the matrix cores: int8 tap fragments, [pass 1 k-block 0, 1][pass 2 k-block 0, 1][lane][16 bytes]
+        int gk[7]; gauss7_coeffs(gk);
+        int8_t* gt = reinterpret_cast<int8_t*>(tab + gt_off);
+        for (int kb = 0; kb < 2; kb++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 16; j++) {
+                    const int n = lane & 31, hh = lane >> 5;
+                    const int t1 = 32 * kb + 16 * hh + j - n - 5;                                    // pass 1: k = byte offset in the LDS row, n = output column
+                    const int t2 = 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh - n - 1;                // pass 2: k = tile row (accumulator order), n = output row
+                    gt[((0 + kb) * 64 + lane) * 16 + j] = (int8_t)((t1 >= 0 && t1 <= 6) ? gk[t1] : 0);
+                    gt[((2 + kb) * 64 + lane) * 16 + j] = (int8_t)((t2 >= 0 && t2 <= 6) ? gk[t2] : 0);
+                }
+    }
     for (int l = 0; l < g.nlevels; l++)                          // tile table, after the coefficient table (offset tab_len + 4)
         for (int t = 0; t < g.lv[l].tiles_x * g.lv[l].tiles_y; t++)
             tab[g.tab_len + 4 + g.lv[l].tile_base + t] = (uint32_t)l | ((uint32_t)(t % g.lv[l].tiles_x) << 4) | ((uint32_t)(t / g.lv[l].tiles_x) << 16);
@@ -1118,9 +1147,9 @@ static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
         for (int x = g.lv[l].w; x < align_up(g.lv[l].w, 4); x++) tab[g.lv[l].tabx_off + x] = tab[g.lv[l].tabx_off + g.lv[l].w - 1];
         lin_coeffs(g.lv[l - 1].h, g.lv[l].h, tab + g.lv[l].taby_off);
     }
-    int rc = bh_reserve(ctx, &ctx->tab, sizeof(uint32_t) * (g.tab_len + 4 + g.ntiles + 64));
+    int rc = bh_reserve(ctx, &ctx->tab, sizeof(uint32_t) * tab_words);
     if (rc == BH_OK) {
-        hipError_t e = hipMemcpyAsync(ctx->tab.p, tab, sizeof(uint32_t) * (g.tab_len + 4 + g.ntiles + 64), hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = hipMemcpyAsync(ctx->tab.p, tab, sizeof(uint32_t) * tab_words, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = bh_set_err(ctx, BH_ERR_HIP, "coefficient table upload failed: %s", hipGetErrorString(e));
     }
@@ -1206,7 +1235,6 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         for (int p = 1; p < npipe; p++) BH_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream[p - 1], ctx->ev_fork, 0));
     }
 
-    bh_gauss7 G; gauss7_coeffs(G.k);
 
     for (int f0 = 0, ci = 0; f0 < B; f0 += chunk, ci++) {
         const int nb = (B - f0) < chunk ? (B - f0) : chunk;
@@ -1248,8 +1276,9 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
                 BH_LAUNCH(ctx, BH_K_PYR, k_pyr_down, dim3((n + 255) / 256, nb), dim3(256), st, pyr, mpyr, g, l, (const uint32_t*)ctx->tab.p);
             }
         }
-        BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, clist, ccnt, hist, blur, G, g,
-                  (const uint32_t*)ctx->tab.p + g.tab_len + 4, (uint32_t*)ctx->status.p, (const uint32_t*)mbits);
+        BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, clist, ccnt, hist, blur, g,
+                  (const uint32_t*)ctx->tab.p + g.tab_len + 4, (uint32_t*)ctx->status.p, (const uint32_t*)mbits,
+                  (const uint32_t*)ctx->tab.p + align_up(g.tab_len + 4 + g.ntiles + 64, 4));
         BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, clist, ccnt, hist, g, sel_cap, (uint32_t*)Wk.sel_xy.p,
                   (float*)Wk.sel_resp.p, (int*)Wk.sel_cnt.p, (uint32_t*)ctx->status.p);
         BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3((max_kp + 63) / 64, nb), dim3(256), st, pyr, blur, g, (const uint32_t*)ctx->tab.p + g.tab_len + 4 + g.ntiles,
