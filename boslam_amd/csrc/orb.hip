@@ -3,14 +3,14 @@
 // Replaces cv2.ORB_create(**orb_params).detectAndCompute(frame, mask) — reference camera.py:49-62,141 — for a batch of
 // frames resident in HBM.  Stages (one kernel each, all frames and all pyramid levels per launch where the data
 // dependence allows):
-//   k_gray_mask   BGR -> gray (level 0) and depth/mask -> level-0 mask           streaming, 4 px / lane
-//   k_pyr_down    level l from level l-1 (bit-exact fixed-point bilinear), image and mask   (nlevels-1 launches)
-//   k_fast        FAST-9/16 corner test + score + 3x3 NMS + mask/border filter on 64x32 LDS tiles;
-//                 writes a dense u8 score map and a 256-bin score histogram per (frame, level)
-//   k_blur        7x7 sigma-2 fixed-point Gaussian: register-sliding 4-px column strips, v_dot4_u32_u8 row sums, no LDS
-//   k_select      one workgroup per (level, frame): retainBest(2 n_l) threshold from the histogram, raster compaction of
-//                 the score map, Harris response, retainBest(n_l) by rank counting in LDS -> per-level staging slots
-//   k_describe    one wave per keypoint: intensity-centroid angle, then 256 rotated pixel-pair tests, 4 ballots -> 32 B
+//   k_gray_mask   BGR -> gray (level 0) and depth -> level-0 mask BITS (mask bytes when the caller passes them)   streaming, 4 px / lane
+//   k_pyr_down_bits / k_pyr_down   level l from level l-1 (bit-exact fixed-point bilinear), image and mask   (nlevels-1 launches)
+//   k_fast        FAST-9/16 pretest + ring score + 3x3 NMS + mask/border filter on 128x32 LDS tiles -> per-level corner lists and
+//                 score histograms; the 7x7 sigma-2 Gaussian of the same tile as two int8 MFMA products (BRIEF's input)
+//   k_select      one workgroup per (level, frame): retainBest(2 n_l) threshold from the histogram, Harris response of the listed
+//                 corners, retainBest(n_l) by rank counting in LDS -> per-level staging slots in canonical (y, x) order
+//   k_describe    64 keypoints per workgroup: intensity-centroid sums (wave per keypoint), angle / sin / cos (lane per keypoint),
+//                 256 rotated pixel-pair tests from an LDS-staged window, 4 ballots -> 32 B
 // Every integer stage is exact; the float formulas (Harris response, fastAtan2, cos/sin of the angle) are written
 // one IEEE operation at a time and the file is compiled with -ffp-contract=off.
 #include "bh_internal.h"
