@@ -874,10 +874,10 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
     double* sx = sy + CD_MAXT * 16;                   // [NT*16] solution
     double* spart = sx + CD_MAXT * 16;                // [NT][16] partial L' x of the backward pass
     double* sz = spart + CD_MAXT * 16;                // [16]
-    __shared__ int s_fail;
+    __shared__ int s_fail, s_flag;                    // s_flag: the highest diagonal tile that has received its last update
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int NT = (n + 15) >> 4, T = NT * (NT - 1) / 2, LD = bw + 1;
-    if (tid == 0) s_fail = St->chol_ok ? 0 : 1;
+    if (tid == 0) { s_fail = St->chol_ok ? 0 : 1; s_flag = 0; }
     for (int i = tid; i < NT * 16; i += 1024) sy[i] = i < n ? bs[i] : 0.0;
     for (int e = tid; e < NT * 256; e += 1024) {      // diagonal tiles: lower part, identity padding
         const int j = e >> 8, rr = (e >> 4) & 15, cc = e & 15, r = 16 * j + rr, c = 16 * j + cc;
@@ -891,7 +891,9 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
         // ================================================================ panel wave
         const int rl = lane & 15;                     // lanes 16..63 mirror lanes 0..15 (duplicates keep every v_readlane source defined)
         for (int J = 0; J < NT; J++) {
-            __syncthreads();                          // B1: diagonal tile J has received its last update
+            // look-ahead: diagonal tile J received its last update from the wave that owns it at the START of that wave's step [4] of
+            // column J - 1; the panel wave factors it while the tile waves are still updating their tiles of the trailing matrix
+            if (J > 0) while (__atomic_load_n(&s_flag, __ATOMIC_ACQUIRE) < J) __builtin_amdgcn_s_sleep(1);
             double row[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) row[k] = Dg[J * CD_TILE + rl * CD_P + k];
@@ -939,20 +941,6 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
             __syncthreads();                          // B2: Linv_J and y_J are ready
             if (s_fail) break;
             __syncthreads();                          // B3: column J published, y updated
-            // [4] (panel wave's share): the diagonal tiles j > J, in LDS: D_j -= L(j,J) L(j,J)'
-            {
-                const int col = lane & 15, r0 = lane >> 4;
-                for (int j = J + 1; j < NT; j++) {
-                    ba_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-                    for (int ks = 0; ks < 4; ks++) {
-                        const double o = Lc[j * CD_TILE + col * CD_P + 4 * ks + r0];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o, o, acc, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int rg = 0; rg < 4; rg++) Dg[j * CD_TILE + (r0 + 4 * rg) * CD_P + col] -= acc[rg];
-                }
-            }
         }
         if (!BCR && !s_fail)
             for (int J = NT - 1; J >= 0; J--) {
@@ -1000,7 +988,6 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
             // the J loop and the tiles spill (same cure as in k_ba_chol_sw)
             int col = colq, r0 = r0q;
             asm volatile("" : "+v"(col), "+v"(r0), "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]));
-            __syncthreads();                          // B1
             __syncthreads();                          // B2
             if (s_fail) { failed = true; break; }
             // [3] column J: L(i,J) = T(i,J) Linv'.  The raw tile goes to its Lc slot, is read back as the A operand, and the slot is
@@ -1035,7 +1022,27 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
                 }
             }
             __syncthreads();                          // B3
-            // [4] trailing update T(i,j) -= L(i,J) L(j,J)' of my register tiles
+            // [4] first the diagonal tiles this wave owns (tile wv, and tile wv + 15 when n > 256), in LDS: D_j -= L(j,J) L(j,J)' - the
+            // next one to be factored before anything else, so that the panel wave can start on it
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int jd = wv + 15 * q;                   // (left transparent: made opaque, or scalar, the tiles spill)
+                if (jd > J && jd < NT) {
+                    ba_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) {
+                        const double o = Lc[jd * CD_TILE + col * CD_P + 4 * ks + r0];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o, o, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) Dg[jd * CD_TILE + (r0 + 4 * rg) * CD_P + col] -= acc[rg];
+                    if (jd == J + 1) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __atomic_store_n(&s_flag, J + 1, __ATOMIC_RELEASE);
+                    }
+                }
+            }
+            // then the trailing update T(i,j) -= L(i,J) L(j,J)' of my register tiles
 #pragma unroll
             for (int k = 0; k < CD_NTW; k++) {
                 const int id = CD_TIJ(k);
