@@ -1,0 +1,9 @@
+import sys, os; sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import numpy as np
+from boslam_amd import Context
+from test_band_solve_gpu import band_system, gpu_solve
+ctx = Context(0)
+for n in (256, 288):
+    low, rhs = band_system(n, n - 1, 1)
+    for _ in range(3): x, clk = gpu_solve(ctx, low, rhs, n - 1, 4)
+    print(n, "prologue %.1f us, columns %.1f us (wait %.1f, factor %.1f), backward+out %.1f us" % tuple(c / 100.0 for c in (clk[0], clk[1], clk[3], clk[4], clk[2])))
