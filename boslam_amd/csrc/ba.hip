@@ -877,6 +877,10 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
     __shared__ int s_fail, s_flag;                    // s_flag: the highest diagonal tile that has received its last update
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int NT = (n + 15) >> 4, T = NT * (NT - 1) / 2, LD = bw + 1;
+#ifdef CD_CLOCKS                                     // phase clocks of the panel wave (tools/chol_clocks.py; build ba.hip with -DCD_CLOCKS)
+    const long long tk0 = wall_clock64();
+    long long tkA = 0, tkB = 0, tkW = 0, tkF = 0;
+#endif
     if (tid == 0) { s_fail = St->chol_ok ? 0 : 1; s_flag = 0; }
     for (int i = tid; i < NT * 16; i += 1024) sy[i] = i < n ? bs[i] : 0.0;
     for (int e = tid; e < NT * 256; e += 1024) {      // diagonal tiles: lower part, identity padding
@@ -888,12 +892,21 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
     }
     __syncthreads();
     if (wv == 0) {
+#ifdef CD_CLOCKS
+        tkA = wall_clock64();
+#endif
         // ================================================================ panel wave
         const int rl = lane & 15;                     // lanes 16..63 mirror lanes 0..15 (duplicates keep every v_readlane source defined)
         for (int J = 0; J < NT; J++) {
             // look-ahead: diagonal tile J received its last update from the wave that owns it at the START of that wave's step [4] of
             // column J - 1; the panel wave factors it while the tile waves are still updating their tiles of the trailing matrix
+#ifdef CD_CLOCKS
+            const long long w0 = wall_clock64();
+#endif
             if (J > 0) while (__atomic_load_n(&s_flag, __ATOMIC_ACQUIRE) < J) __builtin_amdgcn_s_sleep(1);
+#ifdef CD_CLOCKS
+            const long long f0 = wall_clock64(); tkW += f0 - w0;
+#endif
             double row[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) row[k] = Dg[J * CD_TILE + rl * CD_P + k];
@@ -938,10 +951,16 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
             for (int c = 0; c < 16; c++) acc = __builtin_fma(Li[J * CD_TILE + rl * CD_P + c], sy[16 * J + c], acc);
             CD_WAVE_SYNC();                           // every lane has read all 16 old values
             if (lane < 16) sy[16 * J + rl] = acc;
+#ifdef CD_CLOCKS
+            tkF += wall_clock64() - f0;
+#endif
             __syncthreads();                          // B2: Linv_J and y_J are ready
             if (s_fail) break;
             __syncthreads();                          // B3: column J published, y updated
         }
+#ifdef CD_CLOCKS
+        tkB = wall_clock64();
+#endif
         if (!BCR && !s_fail)
             for (int J = NT - 1; J >= 0; J--) {
                 __syncthreads();                      // the partials of column J are in spart
@@ -1088,6 +1107,9 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
     }
     if (s_fail) { if (tid == 0) St->chol_ok = 0; for (int i = tid; i < n; i += 1024) x[i] = 0; return; }
     for (int i = tid; i < n; i += 1024) x[i] = sx[i];
+#ifdef CD_CLOCKS
+    if (tid == 0) { St->dbg[0] = tkA - tk0; St->dbg[1] = tkB - tkA; St->dbg[2] = wall_clock64() - tkB; St->dbg[3] = tkW; St->dbg[4] = tkF; }
+#endif
 #undef CD_A
 }
 

@@ -1,3 +1,6 @@
+"""Phase clocks of k_ba_chol_dense (the panel wave): build boslam_amd/csrc/ba.hip with -DCD_CLOCKS into a side library and point
+BH_LIB_PATH at it.  r02: n = 256: prologue 4.6 us, columns 105.8 us (factor + inverse of the diagonal tiles 69.0, waiting for their
+last update 9.0), backward substitution + output 16.8 us - the panel wave's readlane-driven 16 x 16 factorisation is the chain."""
 import sys, os; sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np
 from boslam_amd import Context
