@@ -71,6 +71,17 @@ def test_depth_masks_take_the_bit_packed_pyramid(ctx, H, W):
     assert n.sum() > 0
 
 
+def test_non_binary_mask_bytes_keep_the_byte_pyramid(ctx):
+    """A caller-supplied mask may hold any byte: level 0 filters on != 0, the levels above are resize + threshold(254) of the bytes
+    (a 254 next to 255s can still round to 255).  That path keeps the byte mask pyramid; only depth-derived masks are bit-packed."""
+    rng = np.random.default_rng(123)
+    bgr, _ = synth.render_batch(2)
+    mask = rng.choice(np.array([0, 1, 128, 254, 255], np.uint8), size=(2, 480, 640), p=[0.1, 0.05, 0.05, 0.2, 0.6])
+    mask[1, 100:300, 200:500] = 255
+    n = _check(ctx, bgr, mask, dict(nfeatures=500))
+    assert n.sum() > 0
+
+
 def test_noise_tiles_take_the_list_free_path(ctx):
     """White noise with a low FAST threshold: well over half of the pixels pass the detector's pretest, more than k_fast's candidate
     list holds, so its tiles score every pixel with the full ring test instead - same keypoints and descriptors as the oracle.
