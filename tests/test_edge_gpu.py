@@ -71,6 +71,26 @@ def test_depth_masks_take_the_bit_packed_pyramid(ctx, H, W):
     assert n.sum() > 0
 
 
+@pytest.mark.parametrize("nlevels", [1, 3, 12])
+def test_depth_masks_at_other_pyramid_depths(ctx, nlevels):
+    """The bit-packed mask path with no resize at all (one level), a short pyramid, and levels smaller than the border."""
+    rng = np.random.default_rng(nlevels)
+    bgr, depth = synth.render_batch(2)
+    depth = depth.copy()
+    depth[0][rng.random(depth[0].shape) < 0.2] = 0
+    depth[1, 200:300, 100:400] = 0
+    kw = dict(nfeatures=400, nlevels=nlevels)
+    params = frontend.make_params(**kw)
+    kps, desc, n = frontend.orb_detect_describe(ctx, bgr, depth=depth, params=params)
+    mask = (depth > 0).astype(np.uint8) * 255
+    for f in range(2):
+        ok, od, rc = oracle.orb_detect_describe(bgr[f], mask[f], oracle.orb_params(**kw), max_kp=4 * 400 + 256)
+        assert rc == 0 and n[f] == len(ok), (f, n[f], len(ok))
+        assert np.array_equal(desc[f, :n[f]], od)
+        for fld in ("x", "y", "angle", "response", "size"):
+            assert np.array_equal(kps[f, :n[f]][fld].view(np.uint32), ok[fld].view(np.uint32)), fld
+
+
 def test_non_binary_mask_bytes_keep_the_byte_pyramid(ctx):
     """A caller-supplied mask may hold any byte: level 0 filters on != 0, the levels above are resize + threshold(254) of the bytes
     (a 254 next to 255s can still round to 255).  That path keeps the byte mask pyramid; only depth-derived masks are bit-packed."""
