@@ -449,15 +449,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int r = i / FRW, c = i - r * FRW;
         const int y = y0 - 4 + r, x = x0 - 4 + c * 4;
         uint32_t v = 0;
-        if (i < FPX_H * FRW && y < L.h + 8 && x < L.w + 8) {
-            const uint8_t* row = img + (size_t)reflect101(y, L.h) * L.pitch;
-            if (x >= 0 && x + 3 < L.w) v = *reinterpret_cast<const uint32_t*>(row + x);
-            else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) v |= (uint32_t)row[reflect101(x + k, L.w)] << (8 * k);
-            }
-        }
+        if (i < FPX_H * FRW && y < L.h + 8 && x >= 0 && x + 3 < L.w) v = *reinterpret_cast<const uint32_t*>(img + (size_t)reflect101(y, L.h) * L.pitch + x);
         pw[j] = v;
+    }
+    // The words that straddle or lie just beyond the left / right border (one on the left, at most three on the right, per row) are
+    // gathered byte by byte with reflection - by 160 dedicated lanes, once: as a branch of the loop above, every wave of a border tile
+    // ran the 4-byte gather for each of its six loads because some lane always needed it (~300 of the tile's ~1 000 instructions per wave).
+    const bool xedge = !interior && (x0 == 0 || x0 + TILE_W + 4 > L.w);
+    uint32_t fixv = 0; int fixi = -1;
+    if (xedge && tid < 4 * FPX_H) {
+        const int r = tid >> 2, q = tid & 3, y = y0 - 4 + r;
+        const int c = q == 0 ? 0 : ((L.w - x0 + 4) >> 2) + q - 1, x = x0 - 4 + 4 * c;
+        if (c < FRW && y < L.h + 8 && x < L.w + 8 && (x < 0 || x + 3 >= L.w)) {
+            const uint8_t* row = img + (size_t)reflect101(y, L.h) * L.pitch;
+#pragma unroll
+            for (int k = 0; k < 4; k++) fixv |= (uint32_t)row[reflect101(x + k, L.w)] << (8 * k);
+            fixi = r * FPW + 1 + c;
+        }
     }
     uint32_t mw = 0;
     if (mbits && tid < TILE_H * (TILE_W / 32)) {
@@ -485,6 +493,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (i < FPX_H * FRW) s_px[r * FPW + 1 + c] = pw[j];
     }
     __syncthreads();
+    if (xedge) { if (fixi >= 0) s_px[fixi] = fixv; __syncthreads(); }
 
     const uint8_t* px = reinterpret_cast<const uint8_t*>(s_px);
     uint8_t* s_sc = reinterpret_cast<uint8_t*>(s_scw);
