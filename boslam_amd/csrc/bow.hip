@@ -167,10 +167,18 @@ __global__ __launch_bounds__(BOW_T) void k_bow_scan(const long long* __restrict_
     for (long long e = (long long)blockIdx.x * (BOW_T / 64) + wv; e < n_entries; e += wstride) {
         const long long a = pstart[e], b = pstart[e + 1];
         double acc = 0.0; bool any = false;
-        for (long long c0 = a; c0 < b; c0 += 256) {
-            const long long i = c0 + 4 * lane;
-            uint4 w4 = make_uint4(BOW_PAD_WORD, BOW_PAD_WORD, BOW_PAD_WORD, BOW_PAD_WORD);
-            if (i < b) w4 = *reinterpret_cast<const uint4*>(pw + i);
+        for (long long c1 = a; c1 < b; c1 += 1024) {              // four 256-word chunks' loads in flight (an entry of configs[3] is exactly one round)
+            uint4 wq[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const long long i = c1 + 256 * u + 4 * lane;
+                wq[u] = make_uint4(BOW_PAD_WORD, BOW_PAD_WORD, BOW_PAD_WORD, BOW_PAD_WORD);
+                if (i < b) wq[u] = *reinterpret_cast<const uint4*>(pw + i);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+            const long long i = c1 + 256 * u + 4 * lane;
+            const uint4 w4 = wq[u];
             const uint32_t ws[4] = { w4.x, w4.y, w4.z, w4.w };
             double val[4] = { 0, 0, 0, 0 };
             int hitm = 0;
@@ -196,6 +204,7 @@ __global__ __launch_bounds__(BOW_T) void k_bow_scan(const long long* __restrict_
                 for (int k = 0; k < 4; k++) { const double v = bow_shfl(val[k], src); if (hm & (1 << k)) acc += v; }
                 any = true;
             }
+        }
         }
         if (lane == 0) acc_out[e] = any ? acc : INFINITY;        // +inf: no common word, entry absent from the results
     }
