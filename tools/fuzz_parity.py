@@ -1,0 +1,70 @@
+"""Randomised parity sweep (GPU box): front end, matcher and the cyclic-reduction solver against the CPU checker on random shapes and
+parameters.  Not part of the test suite (minutes, not seconds): python tools/fuzz_parity.py [seconds]"""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np
+import oracle
+from boslam_amd import Context, frontend, synth, _lib
+from test_band_solve_gpu import band_system, scipy_solve, gpu_solve
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+ctx = Context(0)
+rng = np.random.default_rng(int(time.time()) & 0xffff)
+bgr_all, depth_all = synth.render_batch(4)
+t_end = time.time() + budget
+n_fe = n_m = n_b = 0
+while time.time() < t_end:
+    # ---- front end
+    H, W = int(rng.integers(70, 481)), int(rng.integers(70, 641))
+    oy, ox = int(rng.integers(0, 481 - H)), int(rng.integers(0, 641 - W))
+    kw = dict(nfeatures=int(rng.integers(1, 1500)), nlevels=int(rng.integers(1, 11)), scaleFactor=float(rng.choice([1.1, 1.2, 1.25, 1.3])),
+              fastThreshold=int(rng.choice([5, 10, 20, 40])))
+    kind = int(rng.integers(0, 4))
+    img = np.ascontiguousarray(bgr_all[:2, oy:oy + H, ox:ox + W])
+    if kind == 3:
+        img = rng.integers(0, 256, size=(2, H, W, 3), dtype=np.uint8)                      # noise: list-free path of k_fast
+    depth = rng.integers(1, 4000, size=(2, H, W)).astype(np.uint16)
+    depth[0][rng.random((H, W)) < rng.random() * 0.5] = 0
+    for _ in range(int(rng.integers(0, 8))):
+        y, x = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 4))
+        depth[1, y:y + int(rng.integers(2, 80)), x:x + int(rng.integers(2, 120))] = 0
+    params = frontend.make_params(**kw)
+    use_depth = kind != 1
+    mask = (depth > 0).astype(np.uint8) * 255
+    try:
+        if use_depth:
+            kps, desc, n = frontend.orb_detect_describe(ctx, img, depth=depth, params=params, max_kp=4 * kw["nfeatures"] + 512)
+        else:
+            mask = rng.choice(np.array([0, 7, 254, 255], np.uint8), size=(2, H, W), p=[0.2, 0.05, 0.05, 0.7])
+            kps, desc, n = frontend.orb_detect_describe(ctx, img, mask=mask, params=params, max_kp=4 * kw["nfeatures"] + 512)
+    except Exception as e:                                                                  # noqa: BLE001
+        print("front end raised", H, W, kw, kind, e); raise
+    for f in range(2):
+        ok, od, rc = oracle.orb_detect_describe(img[f], mask[f], oracle.orb_params(**kw), max_kp=4 * kw["nfeatures"] + 512)
+        good = rc == 0 and n[f] == len(ok) and np.array_equal(desc[f, :n[f]], od) and all(
+            np.array_equal(kps[f, :n[f]][fld].view(np.uint32), ok[fld].view(np.uint32)) for fld in ("x", "y", "angle", "response", "size"))
+        if not good:
+            print("FRONT-END MISMATCH", H, W, oy, ox, kw, "kind", kind, "frame", f, n[f], len(ok)); sys.exit(1)
+    n_fe += 1
+    # ---- matcher
+    nq, nt = int(rng.integers(1, 2600)), int(rng.integers(1, 2600))
+    q = rng.integers(0, 256, size=(1, nq, 32), dtype=np.uint8); t = rng.integers(0, 256, size=(1, nt, 32), dtype=np.uint8)
+    for k in range(min(nq, nt) // 3):
+        t[0, rng.integers(0, nt)] = q[0, rng.integers(0, nq)] ^ np.uint8(1 << int(rng.integers(0, 8)))
+    if rng.random() < 0.3:
+        q[0, : nq // 2] = q[0, 0]                                                           # many exact ties
+    qi, ti, d, nm = frontend.match_pairs(ctx, q, np.array([nq], np.int32), t, np.array([nt], np.int32))
+    oq, ot, od = oracle.match_crosscheck(q[0], t[0])
+    if not (nm[0] == len(oq) and np.array_equal(qi[0, :nm[0]], oq) and np.array_equal(ti[0, :nm[0]], ot) and np.array_equal(d[0, :nm[0]], od)):
+        print("MATCH MISMATCH", nq, nt); sys.exit(1)
+    n_m += 1
+    # ---- cyclic-reduction solver
+    n_ = int(rng.integers(10, 6000)); bw = int(rng.integers(1, min(n_ - 1, 256) + 1))
+    low, rhs = band_system(n_, bw, seed=int(rng.integers(0, 1 << 30)))
+    ref = scipy_solve(low, rhs, bw)
+    x, _ = gpu_solve(ctx, low, rhs, bw, 5)
+    if not np.abs(x - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()):
+        print("BCR MISMATCH", n_, bw, np.abs(x - ref).max()); sys.exit(1)
+    n_b += 1
+print(f"fuzz ok: {n_fe} front-end cases, {n_m} matcher cases, {n_b} solver cases")
