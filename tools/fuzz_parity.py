@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
 import oracle
-from boslam_amd import Context, frontend, synth, _lib
+from boslam_amd import Context, frontend, synth, _lib, pnp, ba
 from test_band_solve_gpu import band_system, scipy_solve, gpu_solve
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -13,7 +13,25 @@ ctx = Context(0)
 rng = np.random.default_rng(int(time.time()) & 0xffff)
 bgr_all, depth_all = synth.render_batch(4)
 t_end = time.time() + budget
-n_fe = n_m = n_b = 0
+n_fe = n_m = n_b = n_p = n_po = n_lb = 0
+K4 = np.array([synth.FX, synth.FY, synth.CX, synth.CY])
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-12, np.abs(np.asarray(b)).max())
+
+
+def pnp_problem(n):
+    R = synth._rodrigues(rng.normal(0, 0.3, 3)); t = rng.normal(0, 0.3, 3) + [0, 0, 0.5]
+    X = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1, 1, n), rng.uniform(1.5, 5, n)], 1)
+    pc = X @ R.T + t
+    uv = np.stack([synth.FX * pc[:, 0] / pc[:, 2] + synth.CX, synth.FY * pc[:, 1] / pc[:, 2] + synth.CY], 1) + rng.normal(0, rng.random() * 1.5, (n, 2))
+    bad = rng.random(n) < rng.random() * 0.5
+    uv[bad] += rng.normal(0, 50, (int(bad.sum()), 2))
+    return X, uv
+
+
+it = 0
 while time.time() < t_end:
     # ---- front end
     H, W = int(rng.integers(70, 481)), int(rng.integers(70, 641))
@@ -67,4 +85,39 @@ while time.time() < t_end:
     if not np.abs(x - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()):
         print("BCR MISMATCH", n_, bw, np.abs(x - ref).max()); sys.exit(1)
     n_b += 1
-print(f"fuzz ok: {n_fe} front-end cases, {n_m} matcher cases, {n_b} solver cases")
+    it += 1
+    if it % 4 == 0:
+        # ---- PnP-RANSAC: bit-identical poses and inlier sets
+        sizes = [int(rng.integers(5, 700)) for _ in range(6)]
+        probs = [pnp_problem(n) for n in sizes]
+        S = max(sizes)
+        obj = np.zeros((6, S, 3)); im2 = np.zeros((6, S, 2))
+        for b_, (X, uv) in enumerate(probs):
+            obj[b_, :len(X)] = X; im2[b_, :len(X)] = uv
+        rv, tv, inl, ni, ok = pnp.solve_pnp_ransac_batch(ctx, obj, im2, sizes, K4)
+        for b_, (X, uv) in enumerate(probs):
+            o_ok, orv, otv, oinl = oracle.solve_pnp_ransac(X, uv, K4)
+            if ok[b_] != o_ok or (o_ok and not (np.array_equal(inl[b_, :ni[b_]], oinl) and np.array_equal(rv[b_], orv) and np.array_equal(tv[b_], otv))):
+                print("PNP MISMATCH", sizes[b_]); sys.exit(1)
+        n_p += 6
+        # ---- pose-only BA
+        p = synth.pose_problem(n=int(rng.integers(12, 900)), seed=int(rng.integers(0, 1 << 30)), outlier_frac=float(rng.random() * 0.4))
+        R, t, chi2, inlp, st = ba.pose_only_ba_batch(ctx, p["pix"][None], p["pts"][None], [len(p["pix"])], p["K"])
+        o = oracle.pose_only_ba(p["pix"], p["pts"], p["K"])
+        if st[0] == 0 and o["rc"] == 0:
+            if not (rel(R[0], o["R"]) < 1e-4 and rel(t[0], o["t"]) < 1e-4 and np.array_equal(inlp[0, :len(p["pix"])], o["inlier"])):
+                print("POSE BA MISMATCH", len(p["pix"])); sys.exit(1)
+        elif (st[0] == 0) != (o["rc"] == 0):
+            print("POSE BA STATUS MISMATCH", st[0], o["rc"]); sys.exit(1)
+        n_po += 1
+    if it % 16 == 0:
+        # ---- local BA (dense window), 5 LM iterations
+        pr = synth.ba_problem(n_kf=int(rng.integers(3, 20)), n_pts=int(rng.integers(60, 1500)), seed=int(rng.integers(0, 1 << 30)))
+        o = oracle.ba_optimize(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"], pr["K"], 5, ba.HUBER_DELTA, verbose_errors=True)
+        sb = ba.LocalBA(ctx, pr["K"]); sb.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+        done = sb.optimize(5, ba.HUBER_DELTA, verbose_errors=True)
+        Rb, tb = sb.poses(); pb = sb.points(); lg = sb.log()[:done]; sb.close()
+        if not (done == o["iters_done"] and np.array_equal(lg[:, 2:], o["log"][:, 2:]) and rel(Rb, o["R"]) < 1e-4 and rel(tb, o["t"]) < 1e-4 and rel(pb, o["pts"]) < 1e-4):
+            print("LOCAL BA MISMATCH", len(pr["fixed"]), len(pr["pts"])); sys.exit(1)
+        n_lb += 1
+print(f"fuzz ok: {n_fe} front-end cases, {n_m} matcher cases, {n_b} solver cases, {n_p} PnP problems, {n_po} pose-only BA problems, {n_lb} local BA problems")
