@@ -555,20 +555,10 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
     int* out_idx = inliers + b * (size_t)stride;
     if (n < 5) { if (tid == 0) { ok_out[b] = 0; n_inliers[b] = 0; } return; }
     const int niter0 = n == 5 ? 1 : max(1, min(iterations, PNP_MAX_HYP));
-    // phase 0: the sample stream of cv::RNG((uint64)-1)
-    if (tid == 0) {
-        unsigned long long st = ~0ull;
-        for (int it = 0; it < niter0; it++) {
-            int* idx = s_idx + 5 * it;
-            if (n == 5) { for (int i = 0; i < 5; i++) idx[i] = i; continue; }
-            for (int i = 0; i < 5;) {
-                int j;
-                for (;;) { idx[i] = (int)(p_rng_next(&st) % (unsigned)n); for (j = 0; j < i; j++) if (idx[i] == idx[j]) break; if (j == i) break; }
-                i++;
-            }
-        }
-    }
-    __syncthreads();
+    // phase 0: the sample stream of cv::RNG((uint64)-1) is drawn LAZILY, five indices at the start of each iteration, by lane 0 (an
+    // accepted model shrinks the iteration budget to one or two on a tracking problem; drawing all `iterations` samples up front was
+    // 28 us of a single lane's 64-bit modulo arithmetic per problem)
+    unsigned long long rng_st = ~0ull;
     // phases 1-3: the RANSAC iterations in sequence, exactly as the reference runs them (an accepted model shrinks niters, so a
     // typical tracking problem needs a handful of hypotheses, not all `iterations`); inside an iteration the wave cooperates:
     // EPnP's 12x12 eigen-decomposition in LDS, the reprojection test one point per lane
@@ -577,6 +567,17 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
         int best = -1, max_good = 0, niters = niter0;
         double bR[9], bt[3];
         for (int it = 0; it < niters; it++) {
+            if (tid == 0) {
+                int* idx = s_idx + 5 * it;
+                if (n == 5) { for (int i = 0; i < 5; i++) idx[i] = i; }
+                else
+                    for (int i = 0; i < 5;) {
+                        int j;
+                        for (;;) { idx[i] = (int)(p_rng_next(&rng_st) % (unsigned)n); for (j = 0; j < i; j++) if (idx[i] == idx[j]) break; if (j == i) break; }
+                        i++;
+                    }
+            }
+            __syncthreads();
             double* so = s_samp; double* si = s_samp + 15;      // the sample, in LDS (every lane writes and reads the same values)
             double R[9], t[3];
             for (int i = 0; i < 5; i++) {
