@@ -479,7 +479,13 @@ __device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rb
     rho[3] = p_dist2(cws[1], cws[2]); rho[4] = p_dist2(cws[1], cws[3]); rho[5] = p_dist2(cws[2], cws[3]);
     for (int i = 0; i < 60; i++) PTR(340 + i, L[i]);
     for (int i = 0; i < 6; i++) PTR(400 + i, rho[i]);
-    double best = DBL_MAX;
+    // The three beta approximations are three small least-squares problems solved one after the other by the whole wave; what follows
+    // each of them - five Gauss-Newton steps and the (R, t) estimate with its 3 x 3 Jacobi SVD, ~50 us of wave-uniform f64 arithmetic
+    // per variant - is the same code on different numbers, so lanes 0, 1, 2 run the three variants at once (every lane executes the
+    // same instruction stream anyway) and the winner is picked by the reference's sequential rule afterwards.  Bit for bit the
+    // same values as running them in turn.
+    double b3[3][4];
+#pragma unroll
     for (int N = 1; N <= 3; N++) {
         double betas[4] = {0, 0, 0, 0}, A[30], x[5];
         if (N == 1) {
@@ -501,15 +507,36 @@ __device__ void p_epnp5(const double* pws, const double* us, pnp_K K, double* Rb
             if (x[1] < 0) betas[0] = -betas[0];
             betas[2] = x[3] / betas[0];
         }
-        for (int i = 0; i < 4; i++) PTR(406 + 21 * (N - 1) + i, betas[i]);
+        for (int i = 0; i < 4; i++) { PTR(406 + 21 * (N - 1) + i, betas[i]); b3[N - 1][i] = betas[i]; }
+    }
+    {
+        const int ln = (int)(threadIdx.x & 63), var = ln < 2 ? ln : 2;      // lanes 3.. repeat the third variant
+        double betas[4];
+        for (int i = 0; i < 4; i++) betas[i] = var == 0 ? b3[0][i] : (var == 1 ? b3[1][i] : b3[2][i]);
         p_gauss_newton(L, rho, betas, ws2);
         double R[9], t[3];
         const double err = p_epnp_R_t(pws, us, alphas, K, ut, betas, R, t);
-        for (int i = 0; i < 4; i++) PTR(406 + 21 * (N - 1) + 4 + i, betas[i]);
-        for (int i = 0; i < 9; i++) PTR(406 + 21 * (N - 1) + 8 + i, R[i]);
-        for (int i = 0; i < 3; i++) PTR(406 + 21 * (N - 1) + 17 + i, t[i]);
-        PTR(406 + 21 * (N - 1) + 20, err);
-        if (err < best || N == 1) { best = err; for (int i = 0; i < 9; i++) Rbest[i] = R[i]; for (int i = 0; i < 3; i++) tbest[i] = t[i]; }
+        double* sv = ws;                                                     // [3][17]: R, t, err, betas of the variants (the eigen-solver's A is dead)
+        __syncthreads();
+        if (ln < 3) {
+            for (int i = 0; i < 9; i++) sv[17 * ln + i] = R[i];
+            for (int i = 0; i < 3; i++) sv[17 * ln + 9 + i] = t[i];
+            sv[17 * ln + 12] = err;
+            for (int i = 0; i < 4; i++) sv[17 * ln + 13 + i] = betas[i];
+        }
+        __syncthreads();
+        int pick = 0;
+        double best = sv[12];
+        for (int N = 2; N <= 3; N++) { const double e = sv[17 * (N - 1) + 12]; if (e < best) { best = e; pick = N - 1; } }
+        for (int i = 0; i < 9; i++) Rbest[i] = sv[17 * pick + i];
+        for (int i = 0; i < 3; i++) tbest[i] = sv[17 * pick + 9 + i];
+        for (int N = 1; N <= 3; N++) {
+            for (int i = 0; i < 4; i++) PTR(406 + 21 * (N - 1) + 4 + i, sv[17 * (N - 1) + 13 + i]);
+            for (int i = 0; i < 9; i++) PTR(406 + 21 * (N - 1) + 8 + i, sv[17 * (N - 1) + i]);
+            for (int i = 0; i < 3; i++) PTR(406 + 21 * (N - 1) + 17 + i, sv[17 * (N - 1) + 9 + i]);
+            PTR(406 + 21 * (N - 1) + 20, sv[17 * (N - 1) + 12]);
+        }
+        __syncthreads();                                                     // sv is read before the next hypothesis reuses ws
     }
 }
 
