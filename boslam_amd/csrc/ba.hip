@@ -279,7 +279,8 @@ __global__ __launch_bounds__(PB_T) void k_pose_ba(const double* __restrict__ pix
             rho /= scale;
             __syncthreads();
             if (rho > 0 && isfinite(tempChi)) {
-                double alpha = 1. - pow((2 * rho - 1), 3);
+                const double q1_ = 2 * rho - 1;                  // (2 rho - 1)^3 by two multiplications (a generic f64 pow is ~200 instructions; the checker does the same)
+                double alpha = 1. - __dmul_rn(__dmul_rn(q1_, q1_), q1_);
                 alpha = fmin(alpha, 2. / 3.);
                 lambda *= fmax(1. / 3., alpha); ni = 2; chi = tempChi;
             } else {
@@ -1992,7 +1993,8 @@ __global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ c
         rho /= scale;
         S->chi_trial = tempChi; S->scale = scale; S->rho = rho;
         if (rho > 0 && isfinite(tempChi)) {
-            double alpha = 1. - pow((2 * rho - 1), 3);
+            const double q1_ = 2 * rho - 1;
+            double alpha = 1. - __dmul_rn(__dmul_rn(q1_, q1_), q1_);
             alpha = fmin(alpha, 2. / 3.);
             S->lambda = lambda * fmax(1. / 3., alpha); S->ni = 2; S->chi_cur = tempChi; S->accepted = 1;
         } else {

@@ -340,7 +340,10 @@ int orc_ba_optimize(int C, double* R, double* t, const uint8_t* cam_fixed, int P
             scale += 1e-3;
             rho /= scale;
             if (rho > 0 && isfinite(tempChi)) {
-                double alpha = 1. - pow((2*rho - 1), 3);
+                const double q1_ = 2*rho - 1;
+                volatile double q2_ = q1_ * q1_;               /* (2 rho - 1)^3 by two rounded multiplications, as the device does */
+                volatile double q3_ = q2_ * q1_;
+                double alpha = 1. - q3_;
                 alpha = fmin(alpha, 2./3.);
                 double sf = fmax(1./3., alpha);
                 lambda *= sf; ni = 2; chi = tempChi; accepted = 1;
