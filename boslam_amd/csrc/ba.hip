@@ -2141,19 +2141,29 @@ __global__ void k_bld_slot(const int* __restrict__ flag, const int* __restrict__
     if (i < n) slot[i] = flag[i] ? scan[i] : -1;
     if (i == n - 1) *total = scan[i] + flag[i];
 }
+#define BLD_CC 1024
 __global__ void k_bld_edges(const int* __restrict__ ep, const int* __restrict__ pp, int E, const int* __restrict__ pt_slot,
                             const int* __restrict__ cam_slot, int* __restrict__ e_pt, unsigned long long* __restrict__ key, int* __restrict__ idx,
-                            int* __restrict__ p_cnt, int* __restrict__ c_cnt)
+                            int* __restrict__ p_cnt, int* __restrict__ c_cnt, int Cf)
 {
+    // per-camera counts through a workgroup-private LDS histogram when the free cameras fit (a local window: 48 counters would take
+    // all 80 k global atomics), straight to global otherwise
+    __shared__ int s_cc[BLD_CC];
+    const bool priv = Cf <= BLD_CC;
+    if (priv) for (int i = threadIdx.x; i < Cf; i += 256) s_cc[i] = 0;
+    __syncthreads();
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= E) return;
-    const int c = ep[e], j = pt_slot[pp[e]];
-    e_pt[e] = j;
-    key[e] = ((unsigned long long)(unsigned)j << 32) | (unsigned)c;
-    idx[e] = e;
-    atomicAdd(&p_cnt[j], 1);
-    const int sl = cam_slot[c];
-    if (sl >= 0) atomicAdd(&c_cnt[sl], 1);
+    if (e < E) {
+        const int c = ep[e], j = pt_slot[pp[e]];
+        e_pt[e] = j;
+        key[e] = ((unsigned long long)(unsigned)j << 32) | (unsigned)c;
+        idx[e] = e;
+        atomicAdd(&p_cnt[j], 1);
+        const int sl = cam_slot[c];
+        if (sl >= 0) { if (priv) atomicAdd(&s_cc[sl], 1); else atomicAdd(&c_cnt[sl], 1); }
+    }
+    __syncthreads();
+    if (priv) for (int i = threadIdx.x; i < Cf; i += 256) { const int v = s_cc[i]; if (v) atomicAdd(&c_cnt[i], v); }
 }
 __global__ void k_bld_camkey(const int* __restrict__ order, const int* __restrict__ ep, const int* __restrict__ cam_slot, int E, int Cf,
                              unsigned* __restrict__ key2)
@@ -2176,7 +2186,10 @@ __global__ void k_bld_pairs_mark(const int* __restrict__ p_start, const int* __r
                 const int s2 = cam_slot[ep[p_edges[v]]]; if (s2 < 0) continue;
                 const int lo = s1 < s2 ? s1 : s2, hi = s1 < s2 ? s2 : s1;
                 const unsigned long long bit = (unsigned long long)lo * Cf + hi;
-                atomicOr(&bits[bit >> 5], 1u << (bit & 31));
+                // test before set: in a dense window every point marks the same few words (48 x 48 bits: 280 k atomics on 72 words
+                // took 0.65 ms of a 1.7 ms set-up); a stale read only costs one redundant atomic
+                const unsigned m = 1u << (bit & 31);
+                if (!(__atomic_load_n(&bits[bit >> 5], __ATOMIC_RELAXED) & m)) atomicOr(&bits[bit >> 5], m);
                 bw = max(bw, hi - lo);
             }
         }
@@ -2184,7 +2197,8 @@ __global__ void k_bld_pairs_mark(const int* __restrict__ p_start, const int* __r
         const unsigned long long bit = (unsigned long long)(j - Pa) * Cf + (j - Pa);
         atomicOr(&bits[bit >> 5], 1u << (bit & 31));
     }
-    if (bw) atomicMax(&info[1], bw);                                              // info[1]: max |s1 - s2| over the pairs
+    for (int mm = 32; mm > 0; mm >>= 1) bw = max(bw, __shfl_xor(bw, mm, 64));      // one atomic per wave
+    if (bw && (threadIdx.x & 63) == 0) atomicMax(&info[1], bw);                   // info[1]: max |s1 - s2| over the pairs
 }
 __global__ void k_bld_popc(const unsigned* __restrict__ bits, long long nw, int* __restrict__ cnt)
 {
@@ -2319,7 +2333,7 @@ static int ba_build_device(bh_ba* ba, int C, const uint8_t* fixed, int P, const 
     int* e_pt = (int*)ba->e_pt.p;
     if (E) {
         BH_HIP(ctx, hipMemcpyAsync(ba->e_cam.p, ep, sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_bld_edges, G(E), T, 0, st, (const int*)ep, (const int*)pp, E, (const int*)pt_slot, (const int*)cam_slot, e_pt, key, idx, p_cnt, c_cnt);
+        hipLaunchKernelGGL(k_bld_edges, G(E), T, 0, st, (const int*)ep, (const int*)pp, E, (const int*)pt_slot, (const int*)cam_slot, e_pt, key, idx, p_cnt, c_cnt, Cf);
         // p_edges: stable sort by (point slot, camera); ties keep the input position
         int bits_c = 1; while ((1ll << bits_c) < C) bits_c++;
         int bits_p = 1; while ((1ll << bits_p) < std::max(Pa, 1)) bits_p++;
@@ -2355,12 +2369,12 @@ static int ba_build_device(bh_ba* ba, int C, const uint8_t* fixed, int P, const 
         size_t need2 = 0; BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, need2, wcnt, woff, (int)(nw + 1), st));
         BH_TRY(bh_reserve(ctx, &ctx->st_g, need2 + 256));
         BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->st_g.p, need2, wcnt, woff, (int)(nw + 1), st));
-        int hv[3];
-        BH_HIP(ctx, hipMemcpyAsync(&hv[0], woff + nw, sizeof(int), hipMemcpyDeviceToHost, st));
-        BH_HIP(ctx, hipMemcpyAsync(&hv[1], info + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-        BH_HIP(ctx, hipMemcpyAsync(&hv[2], (int*)ba->c_start.p + Cf, sizeof(int), hipMemcpyDeviceToHost, st));
+        int hv[8];                                             // the three counts come back in ONE host read (each pageable read is a ~20 us stall)
+        BH_HIP(ctx, hipMemcpyAsync(info + 4, woff + nw, sizeof(int), hipMemcpyDeviceToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(info + 5, (int*)ba->c_start.p + Cf, sizeof(int), hipMemcpyDeviceToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(hv, info, sizeof(hv), hipMemcpyDeviceToHost, st));
         BH_HIP(ctx, hipStreamSynchronize(st));
-        npairs = hv[0]; bwb = hv[1]; c_total = hv[2];
+        npairs = hv[4]; bwb = hv[1]; c_total = hv[5];
         BH_TRY(bh_reserve(ctx, &ba->pairs, sizeof(int2) * ((size_t)npairs + 1)));
         hipLaunchKernelGGL(k_bld_pairs_emit, G(nw), T, 0, st, (const unsigned*)bits, (const int*)woff, nw, Cf, (int2*)ba->pairs.p);
     }
