@@ -394,14 +394,14 @@ struct bh_ba {
 
 // ---- k_ba_point: 8 lanes per active point; residual + Huber + Jacobians; Hll, bl, per-edge Hpl, per-edge error/chi
 #define BP_G 8
-__global__ __launch_bounds__(256) void k_ba_point(const ba_cam* __restrict__ cams, const double* __restrict__ pts,
+__device__ __forceinline__ void ba_point_body(int bid, const ba_cam* __restrict__ cams, const double* __restrict__ pts,
                                                   const int* __restrict__ e_cam, const double* __restrict__ e_meas,
                                                   const int* __restrict__ cslot, const int* __restrict__ p_start,
                                                   const int* __restrict__ p_edges, int Pa, ba_K K, double delta,
                                                   double* __restrict__ Hpl, double* __restrict__ Hll, double* __restrict__ bl,
                                                   double* __restrict__ err, double* __restrict__ chi_e, double* __restrict__ pdiag)
 {
-    const int gid = (blockIdx.x * 256 + threadIdx.x) / BP_G, sub = threadIdx.x & (BP_G - 1);
+    const int gid = (bid * 256 + threadIdx.x) / BP_G, sub = threadIdx.x & (BP_G - 1);
     const bool live = gid < Pa;
     const int j = live ? gid : 0;
     const double X[3] = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
@@ -440,14 +440,14 @@ __global__ __launch_bounds__(256) void k_ba_point(const ba_cam* __restrict__ cam
 }
 
 // ---- k_ba_cam: workgroup per free camera: Hpp (6x6) and bp (6) over the camera's edges
-__global__ __launch_bounds__(256) void k_ba_cam(const ba_cam* __restrict__ cams, const double* __restrict__ pts,
+__device__ __forceinline__ void ba_cam_body(int s, const ba_cam* __restrict__ cams, const double* __restrict__ pts,
                                                 const int* __restrict__ e_cam, const int* __restrict__ e_pt,
                                                 const double* __restrict__ e_meas, const int* __restrict__ c_start,
                                                 const int* __restrict__ c_edges, ba_K K, double delta,
                                                 double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ cdiag)
 {
     __shared__ double s_red[27 * 4];
-    const int s = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0;
@@ -480,6 +480,21 @@ __global__ __launch_bounds__(256) void k_ba_cam(const ba_cam* __restrict__ cams,
 
 // ---- k_ba_partial: first stage of the big sums (global-BA sizes): block b sums its contiguous slice of the edges / points
 // in a fixed order into part[b] = {sum chi, sum dx (lambda dx + b)}; k_ba_prep / k_ba_decide add the BA_NPART partials.
+// ---- k_ba_linearize: the per-landmark and the per-camera halves of buildSystem in ONE launch (workgroups [0, nbp) take landmarks,
+// the rest one free camera each): they are independent, and as two launches of 18 us each the second - 48 workgroups on a local
+// window - left most of the chip idle.
+__global__ __launch_bounds__(256) void k_ba_linearize(int nbp, const ba_cam* __restrict__ cams, const double* __restrict__ pts,
+                                                      const int* __restrict__ e_cam, const int* __restrict__ e_pt, const double* __restrict__ e_meas,
+                                                      const int* __restrict__ cslot, const int* __restrict__ p_start, const int* __restrict__ p_edges,
+                                                      const int* __restrict__ c_start, const int* __restrict__ c_edges, int Pa, ba_K K, double delta,
+                                                      double* __restrict__ Hpl, double* __restrict__ Hll, double* __restrict__ bl,
+                                                      double* __restrict__ err, double* __restrict__ chi_e, double* __restrict__ pdiag,
+                                                      double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ cdiag)
+{
+    if ((int)blockIdx.x < nbp) ba_point_body(blockIdx.x, cams, pts, e_cam, e_meas, cslot, p_start, p_edges, Pa, K, delta, Hpl, Hll, bl, err, chi_e, pdiag);
+    else ba_cam_body(blockIdx.x - nbp, cams, pts, e_cam, e_pt, e_meas, c_start, c_edges, K, delta, Hpp, bp, cdiag);
+}
+
 #define BA_NPART 256
 __global__ __launch_bounds__(1024) void k_ba_partial(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxl,
                                                      const double* __restrict__ bl, int n3, const ba_state* __restrict__ S,
@@ -2640,10 +2655,11 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
     int rc = BH_OK;
     for (int it = 0; it < iters; it++) {
         const ba_cam* cams = (const ba_cam*)ba->cams[ba->cur].p; const double* pts = (const double*)ba->pts[ba->cur].p;
-        BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_ba_point, dim3((Pa * BP_G + 255) / 256), dim3(256), st, cams, pts, e_cam, e_meas, cslot, p_start,
-                  p_edges, Pa, ba->K, huber_delta, Hpl, Hll, bl, (double*)ba->err[0].p, (double*)ba->chi_e[0].p, pdiag);
-        if (Cf) BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_ba_cam, dim3(Cf), dim3(256), st, cams, pts, e_cam, e_pt, e_meas, c_start, c_edges, ba->K,
-                          huber_delta, Hpp, bp, cdiag);
+        {
+            const int nbp = (Pa * BP_G + 255) / 256;
+            BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_ba_linearize, dim3(nbp + Cf), dim3(256), st, nbp, cams, pts, e_cam, e_pt, e_meas, cslot, p_start, p_edges,
+                      c_start, c_edges, Pa, ba->K, huber_delta, Hpl, Hll, bl, (double*)ba->err[0].p, (double*)ba->chi_e[0].p, pdiag, Hpp, bp, cdiag);
+        }
         if (dist && Cf) {                                  // Hpp, bp: partial over this rank's edges -> full on every rank
             BH_TRY(ba_allreduce(ba, Hpp, 36LL * Cf, 0)); BH_TRY(ba_allreduce(ba, bp, n6, 0));
             hipLaunchKernelGGL(k_ba_cdiag, dim3((Cf + 63) / 64), dim3(64), 0, st, (const double*)Hpp, Cf, cdiag);
