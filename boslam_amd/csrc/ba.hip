@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void k_ba_dinv(const double* __restrict__ Hll,
 
 // ---- k_ba_schur_S: workgroup per camera pair (s1 <= s2): S[s1][s2] = [s1==s2](Hpp + lambda I) - sum_j Hpl_1j Dinv_j Hpl_2j'
 template <int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_ba_schur_S(const int2* __restrict__ pairs, const int* __restrict__ j_start,
+__device__ __forceinline__ void ba_schur_S_body(const int bid, const int ngrid, const int2* __restrict__ pairs, const int* __restrict__ j_start,
                                                     const int2* __restrict__ join, const int* __restrict__ e_pt,
                                                     const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                                                     const double* __restrict__ Hpp, const ba_state* __restrict__ St,
@@ -592,8 +592,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     // workgroups are dealt to the 8 XCDs round-robin; each XCD takes one contiguous eighth of the (s1, s2)-sorted pair list, so that
     // the blocks of camera s1 (shared by its ~2 x band pairs in a row) and of s2 (met again at (s1 + 1, s2), one band later) are still
     // in that XCD's own L2 - dealt pair by pair, every reuse was a miss in seven other L2s
-    const int chunk = (gridDim.x + 7) >> 3;
-    const int pid = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int chunk = (ngrid + 7) >> 3;
+    const int pid = (bid & 7) * chunk + (bid >> 3);
     if (pid >= npairs) return;
     const int s1 = pairs[pid].x, s2 = pairs[pid].y;
     const int t0 = j_start[pid], t1 = j_start[pid + 1];
@@ -661,13 +661,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 }
 
 // ---- k_ba_schur_b: per free camera  b~ = bp - sum_e Hpl_e (Dinv bl)_pt(e)
-__global__ __launch_bounds__(256) void k_ba_schur_b(const int* __restrict__ c_start, const int* __restrict__ c_edges,
+__device__ __forceinline__ void ba_schur_b_body(const int s, const int* __restrict__ c_start, const int* __restrict__ c_edges,
                                                     const int* __restrict__ e_pt, const double* __restrict__ Hpl,
                                                     const double* __restrict__ db, const double* __restrict__ bp,
                                                     int use_bp, double* __restrict__ bs)
 {
     __shared__ double s_red[6 * 4];
-    const int s = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
     for (int u = c_start[s] + tid; u < c_start[s + 1]; u += 256) {
         const int e = c_edges[u];
@@ -677,6 +677,36 @@ __global__ __launch_bounds__(256) void k_ba_schur_b(const int* __restrict__ c_st
     }
     d_block_sum<6, 256>(acc, s_red);
     if (tid < 6) bs[6 * s + tid] = (use_bp ? bp[6 * s + tid] : 0.0) - acc[tid];
+}
+
+// The kernels: S alone (one wave per pair: the global-BA form), b~ alone, and both in one launch for the 256-thread form (a local
+// window: 48 workgroups of b~ next to 1 176 of S instead of after them).
+template <int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_ba_schur_S(const int2* __restrict__ pairs, const int* __restrict__ j_start,
+                                                    const int2* __restrict__ join, const int* __restrict__ e_pt,
+                                                    const double* __restrict__ Hpl, const double* __restrict__ Dinv,
+                                                    const double* __restrict__ Hpp, const ba_state* __restrict__ St,
+                                                    int bw, int add_diag, double* __restrict__ Sm, int npairs)
+{
+    ba_schur_S_body<NT>(blockIdx.x, gridDim.x, pairs, j_start, join, e_pt, Hpl, Dinv, Hpp, St, bw, add_diag, Sm, npairs);
+}
+__global__ __launch_bounds__(256) void k_ba_schur_b(const int* __restrict__ c_start, const int* __restrict__ c_edges,
+                                                    const int* __restrict__ e_pt, const double* __restrict__ Hpl,
+                                                    const double* __restrict__ db, const double* __restrict__ bp,
+                                                    int use_bp, double* __restrict__ bs)
+{
+    ba_schur_b_body(blockIdx.x, c_start, c_edges, e_pt, Hpl, db, bp, use_bp, bs);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_ba_schur_Sb(int ngS, const int2* __restrict__ pairs, const int* __restrict__ j_start,
+                                                    const int2* __restrict__ join, const int* __restrict__ e_pt,
+                                                    const double* __restrict__ Hpl, const double* __restrict__ Dinv,
+                                                    const double* __restrict__ Hpp, const ba_state* __restrict__ St,
+                                                    int bw, int add_diag, double* __restrict__ Sm, int npairs,
+                                                    const int* __restrict__ c_start, const int* __restrict__ c_edges, const double* __restrict__ db,
+                                                    const double* __restrict__ bp, int use_bp, double* __restrict__ bs)
+{
+    if ((int)blockIdx.x < ngS) ba_schur_S_body<256>(blockIdx.x, ngS, pairs, j_start, join, e_pt, Hpl, Dinv, Hpp, St, bw, add_diag, Sm, npairs);
+    else ba_schur_b_body(blockIdx.x - ngS, c_start, c_edges, e_pt, Hpl, db, bp, use_bp, bs);
 }
 
 // ---- k_ba_chol: one workgroup, blocked right-looking Cholesky of the BANDED reduced camera system + both substitutions.
@@ -2689,11 +2719,15 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                 if (ba->schur_wave)
                     BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<64>), dim3((ba->npairs + 7) / 8 * 8), dim3(64), st, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
                               (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S, ba->npairs);
-                else
-                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<256>), dim3((ba->npairs + 7) / 8 * 8), dim3(256), st, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
-                              (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S, ba->npairs);
-                BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_b, dim3(Cf), dim3(256), st, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)db,
-                          (const double*)bp, dist ? lead : 1, bs);
+                else {
+                    const int ngS = (ba->npairs + 7) / 8 * 8;
+                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_Sb, dim3(ngS + Cf), dim3(256), st, ngS, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
+                              (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S, ba->npairs,
+                              c_start, c_edges, (const double*)db, (const double*)bp, dist ? lead : 1, bs);
+                }
+                if (ba->schur_wave)
+                    BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_b, dim3(Cf), dim3(256), st, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)db,
+                              (const double*)bp, dist ? lead : 1, bs);
                 if (dist) { BH_TRY(ba_allreduce(ba, S, (long long)n6 * (ba->bw + 1), 0)); BH_TRY(ba_allreduce(ba, bs, n6, 0)); }
                 {
                     const int nbsel = ba->chol_nb, bw = ba->bw;
