@@ -382,6 +382,8 @@ struct bh_ba {
     int chol_window = 0;               // on-chip sliding-window banded Cholesky (k_ba_chol_sw) instead of the panel kernel
     int chol_dense = 0;                // whole factor on chip (k_ba_chol_dense): 6 Cf <= 288, the local-BA window
     int chol_bcr = 0;                  // block cyclic reduction over the whole chip (long narrow systems: global BA)
+    ba_state* h_state = nullptr;       // pinned, device-writable: k_ba_decide's verdict (polled by bh_ba_optimize)
+    int seq = 0;
     struct bcr_dev* bcr = nullptr;
     int schur_wave = 0;                // one wave per camera pair (many short edge lists) instead of a 256-thread workgroup
     int last_err_sel = 0;              // which err buffer holds "the last computeActiveErrors"
@@ -2012,7 +2014,7 @@ __global__ __launch_bounds__(256) void k_ba_err(const ba_cam* __restrict__ cams,
 __global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxp,
                                                     const double* __restrict__ bp, int n6, const double* __restrict__ dxl,
                                                     const double* __restrict__ bl, int n3, int phase, int cam_part,
-                                                    const double* __restrict__ part, ba_state* __restrict__ S)
+                                                    const double* __restrict__ part, ba_state* __restrict__ S, ba_state* host_out, int seq)
 {
     // phases as in k_ba_prep; cam_part: this rank contributes the (replicated) camera part of the gain-ratio denominator
     __shared__ double s_red[2 * 16];
@@ -2049,6 +2051,12 @@ __global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ c
         S->again = (rho < 0 && S->qmax < 10) ? 1 : 0;
         S->terminate = (!S->again && (S->qmax == 10 || rho == 0)) ? 1 : 0;
         S->chol_ok = 1;                                  // re-arm for the next trial
+        if (host_out) {                                  // the host polls pinned memory for the verdict instead of waiting on a copy + stream sync
+            ba_state t = *S; t.pad = 0;
+            *host_out = t;
+            __threadfence_system();
+            __atomic_store_n(&host_out->pad, seq, __ATOMIC_RELEASE);
+        }
     }
 }
 
@@ -2107,6 +2115,9 @@ extern "C" int bh_ba_create(bh_ctx* ctx, const double K[5], bh_ba** out)
     (void)hipFuncSetAttribute((const void*)k_ba_chol_sw, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     bh_ba* ba = new bh_ba();
     ba->ctx = ctx; ba->K = { K[0], K[1], K[2], K[3] };
+    (void)hipSetDevice(ctx->device);
+    if (hipHostMalloc((void**)&ba->h_state, sizeof(ba_state), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { ba->h_state = nullptr; (void)hipGetLastError(); }
+    else memset(ba->h_state, 0, sizeof(ba_state));
     *out = ba;
     return BH_OK;
 }
@@ -2121,6 +2132,7 @@ extern "C" void bh_ba_destroy(bh_ba* ba)
                       &ba->chi_e[1], &ba->Hpl, &ba->Hll, &ba->bl, &ba->Hpp, &ba->bp, &ba->pdiag, &ba->cdiag, &ba->Dinv,
                       &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch, &ba->join, &ba->j_start };
     for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    if (ba->h_state) (void)hipHostFree(ba->h_state);
     delete ba->bcr;
     delete ba;
 }
@@ -2749,16 +2761,26 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                       e_meas, Ea, huber_delta, (double*)ba->err[1].p, (double*)ba->chi_e[1].p);
             if (part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_partial, dim3(BA_NPART), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxl,
                                 (const double*)bl, 3 * Pa, (const ba_state*)state, part);
+            const int seq = ++ba->seq;
+            ba_state* hpin = ba->h_state;                // may be null (allocation failed): then the copy + sync path below
             BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_decide, dim3(1), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxp, (const double*)bp,
-                      n6, (const double*)dxl, (const double*)bl, 3 * Pa, dist ? 1 : 0, dist ? lead : 1, (const double*)part, state);
+                      n6, (const double*)dxl, (const double*)bl, 3 * Pa, dist ? 1 : 0, dist ? lead : 1, (const double*)part, state, dist ? (ba_state*)nullptr : hpin, seq);
             if (dist) {
                 BH_TRY(ba_allreduce(ba, red, 3, 0));
                 BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_decide, dim3(1), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxp, (const double*)bp,
-                          n6, (const double*)dxl, (const double*)bl, 3 * Pa, 2, lead, (const double*)part, state);
+                          n6, (const double*)dxl, (const double*)bl, 3 * Pa, 2, lead, (const double*)part, state, hpin, seq);
             }
             BH_HIP(ctx, hipGetLastError());
-            BH_HIP(ctx, hipMemcpyAsync(&hs, state, sizeof(hs), hipMemcpyDeviceToHost, st));
-            BH_HIP(ctx, hipStreamSynchronize(st));
+            bool polled = false;
+            if (hpin) {                                  // poll the pinned verdict: a copy + stream sync costs ~40 us of wake-up per trial
+                for (long spin = 0; spin < 200000000L; spin++)
+                    if (__atomic_load_n(&hpin->pad, __ATOMIC_ACQUIRE) == seq) { polled = true; break; }
+                if (polled) memcpy(&hs, hpin, sizeof(hs));
+            }
+            if (!polled) {                               // a kernel fault never delivers the verdict: the stream reports it here
+                BH_HIP(ctx, hipMemcpyAsync(&hs, state, sizeof(hs), hipMemcpyDeviceToHost, st));
+                BH_HIP(ctx, hipStreamSynchronize(st));
+            }
             ba->last_err_sel = 1;                       // the trial's errors are the last computeActiveErrors
             if (hs.accepted) { ba->cur ^= 1; cams = (const ba_cam*)ba->cams[ba->cur].p; pts = (const double*)ba->pts[ba->cur].p; }
         } while (hs.again);
