@@ -199,13 +199,18 @@ __global__ __launch_bounds__(256) void k_pyr_down_bits(uint8_t* __restrict__ pyr
     }
     const int x = (idx - yb * groups) << 2, y0 = yb * PD_R;
     if (y0 >= D.h) return;                                     // whole rows (pitch / 4 is a multiple of 16 lanes)
-    const size_t fb = (size_t)blockIdx.y * g.pyr_stride;
+    // wave-uniform 64-bit bases, 32-bit lane offsets: the loads and stores take the scalar-base + vector-offset form instead of a 64-bit
+    // multiply-add per address on the vector ALU
+    const uint8_t* __restrict__ src = pyr + (size_t)blockIdx.y * g.pyr_stride + S.off;
+    uint8_t* __restrict__ dst = pyr + (size_t)blockIdx.y * g.pyr_stride + D.off;
     const int over = min(max(x + 4 - D.w, 0), 4);              // outputs of this lane beyond the row
     const int xc = over == 4 ? 0 : x;
     const uint4 tx4 = *reinterpret_cast<const uint4*>(tab + D.tabx_off + xc);
     const uint32_t txs[4] = { tx4.x, tx4.y, tx4.z, tx4.w };
     const int base = (int)(tx4.x >> 16);
-    const uint32_t* ms = mbits + (size_t)blockIdx.y * g.mstride + S.moff + (base >> 5);
+    const uint32_t* __restrict__ ms = mbits + (size_t)blockIdx.y * g.mstride + S.moff;
+    uint32_t* __restrict__ md = mbits + (size_t)blockIdx.y * g.mstride + D.moff;
+    const uint32_t mcol = (uint32_t)base >> 5;
     unsigned long long A[PD_R], Bv[PD_R];
     uint32_t A8[PD_R], B8[PD_R], yc[PD_R];
 #pragma unroll
@@ -214,9 +219,9 @@ __global__ __launch_bounds__(256) void k_pyr_down_bits(uint8_t* __restrict__ pyr
         const uint32_t ty = tab[D.taby_off + y];
         const int r0 = ty >> 16, r1 = min(r0 + 1, S.h - 1);
         yc[k] = ty & 0xffffu;
-        A[k] = pyr_load8(pyr, fb + S.off + (size_t)r0 * S.pitch + base); Bv[k] = pyr_load8(pyr, fb + S.off + (size_t)r1 * S.pitch + base);
-        const uint32_t* q0 = ms + (size_t)r0 * S.mpitch; const uint32_t* q1 = ms + (size_t)r1 * S.mpitch;
-        A8[k] = __builtin_amdgcn_alignbit(q0[1], q0[0], (uint32_t)base & 31u); B8[k] = __builtin_amdgcn_alignbit(q1[1], q1[0], (uint32_t)base & 31u);
+        A[k] = pyr_load8(src, (uint32_t)(r0 * S.pitch + base)); Bv[k] = pyr_load8(src, (uint32_t)(r1 * S.pitch + base));
+        const uint32_t o0 = (uint32_t)(r0 * S.mpitch) + mcol, o1 = (uint32_t)(r1 * S.mpitch) + mcol;
+        A8[k] = __builtin_amdgcn_alignbit(ms[o0 + 1], ms[o0], (uint32_t)base & 31u); B8[k] = __builtin_amdgcn_alignbit(ms[o1 + 1], ms[o1], (uint32_t)base & 31u);
     }
     uint32_t o4[PD_R], nb[PD_R];
     // both source rows of a pixel ride in the two 16-bit halves of one register through the horizontal pass: (p0 << 8) + c1 (p1 - p0)
@@ -261,8 +266,8 @@ __global__ __launch_bounds__(256) void k_pyr_down_bits(uint8_t* __restrict__ pyr
     for (int k = 0; k < PD_R; k++) {
         const int y = y0 + k;
         if (y < D.h) {
-            *reinterpret_cast<uint32_t*>(pyr + fb + D.off + (size_t)y * D.pitch + x) = o4[k];
-            if ((threadIdx.x & 7) == 7) mbits[(size_t)blockIdx.y * g.mstride + D.moff + (size_t)y * D.mpitch + (x >> 5)] = nb[k];
+            *reinterpret_cast<uint32_t*>(dst + (uint32_t)(y * D.pitch + x)) = o4[k];
+            if ((threadIdx.x & 7) == 7) md[(uint32_t)(y * D.mpitch + (x >> 5))] = nb[k];
         }
     }
 }
