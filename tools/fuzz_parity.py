@@ -13,7 +13,7 @@ ctx = Context(0)
 rng = np.random.default_rng(int(time.time()) & 0xffff)
 bgr_all, depth_all = synth.render_batch(4)
 t_end = time.time() + budget
-n_fe = n_m = n_b = n_p = n_po = n_lb = 0
+n_fe = n_m = n_b = n_p = n_po = n_lb = n_cap = 0
 K4 = np.array([synth.FX, synth.FY, synth.CX, synth.CY])
 
 
@@ -56,7 +56,11 @@ while time.time() < t_end:
         else:
             mask = rng.choice(np.array([0, 7, 254, 255], np.uint8), size=(2, H, W), p=[0.2, 0.05, 0.05, 0.7])
             kps, desc, n = frontend.orb_detect_describe(ctx, img, mask=mask, params=params, max_kp=4 * kw["nfeatures"] + 512)
-    except Exception as e:                                                                  # noqa: BLE001
+    except _lib.BhError as e:
+        # white noise at a low threshold can tie thousands of corners at retainBest's cut: more than k_select stages (CAND_CAP = 4096
+        # per level) - reported as BH_ERR_CAPACITY, never truncated silently.  Anything else is a failure.
+        if e.code == -3 and kind == 3:
+            n_cap += 1; continue
         print("front end raised", H, W, kw, kind, e); raise
     for f in range(2):
         ok, od, rc = oracle.orb_detect_describe(img[f], mask[f], oracle.orb_params(**kw), max_kp=4 * kw["nfeatures"] + 512)
@@ -120,4 +124,4 @@ while time.time() < t_end:
         if not (done == o["iters_done"] and np.array_equal(lg[:, 2:], o["log"][:, 2:]) and rel(Rb, o["R"]) < 1e-4 and rel(tb, o["t"]) < 1e-4 and rel(pb, o["pts"]) < 1e-4):
             print("LOCAL BA MISMATCH", len(pr["fixed"]), len(pr["pts"])); sys.exit(1)
         n_lb += 1
-print(f"fuzz ok: {n_fe} front-end cases, {n_m} matcher cases, {n_b} solver cases, {n_p} PnP problems, {n_po} pose-only BA problems, {n_lb} local BA problems")
+print(f"fuzz ok: {n_fe} front-end cases, {n_m} matcher cases, {n_b} solver cases, {n_p} PnP problems, {n_po} pose-only BA problems, {n_lb} local BA problems; {n_cap} noise cases stopped by the documented candidate capacity")
