@@ -1017,6 +1017,13 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         const int q4 = *reinterpret_cast<const int*>(c_pattern + (t * 64 + lane) * 4);       // the four signed bytes of test 64 t + lane
         qx0[t] = (float)(signed char)q4; qy0[t] = (float)(signed char)(q4 >> 8); qx1[t] = (float)(signed char)(q4 >> 16); qy1[t] = (float)(q4 >> 24);
     }
+    // which (row, word) of the window a lane stages in load m does not depend on the keypoint: row | byte offset << 6 | LDS word << 12
+    uint32_t stg[7];
+#pragma unroll
+    for (int m = 0; m < 7; m++) {
+        const int idx = min(lane + 64 * m, DS_PR * 11 - 1), row = idx / 11, dw = idx - row * 11;
+        stg[m] = (uint32_t)row | ((uint32_t)(4 * dw) << 6) | ((uint32_t)(row * DS_PW + dw) << 12);
+    }
     // The 512 samples of a keypoint are 8 loads of 64 scattered bytes: one cache line per lane, which is what bounded this kernel
     // (the address path, not the ALU: 40 % fewer instructions had changed nothing).  The 39 x 39 window they all fall into is staged
     // in LDS with 7 coalesced word loads per wave instead, and the samples are ds_read_u8.
@@ -1039,19 +1046,13 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             sh[q] = bx & 3;
             const uint8_t* org = blur + f * g.pyr_stride + L.off + (size_t)by * L.pitch + (bx & ~3);
 #pragma unroll
-            for (int m = 0; m < 7; m++) {
-                const int idx = min(lane + 64 * m, DS_PR * 11 - 1), row = idx / 11, dw = idx - row * 11;
-                wq[q][m] = *reinterpret_cast<const uint32_t*>(org + (size_t)row * L.pitch + 4 * dw);
-            }
+            for (int m = 0; m < 7; m++) wq[q][m] = *reinterpret_cast<const uint32_t*>(org + (uint32_t)((int)(stg[m] & 63u) * L.pitch + (int)((stg[m] >> 6) & 63u)));
         }
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             if (!have[q]) continue;
 #pragma unroll
-            for (int m = 0; m < 7; m++) {
-                const int idx = min(lane + 64 * m, DS_PR * 11 - 1), row = idx / 11, dw = idx - row * 11;
-                s_patch[wv][q][row * DS_PW + dw] = wq[q][m];
-            }
+            for (int m = 0; m < 7; m++) s_patch[wv][q][stg[m] >> 12] = wq[q][m];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
