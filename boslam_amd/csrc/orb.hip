@@ -926,8 +926,10 @@ __constant__ __attribute__((aligned(4))) signed char c_pattern[1024] = {
 //   phase C  wave per keypoint: steered BRIEF, lane l evaluates tests l, 64+l, 128+l, 192+l (its 16 pattern coordinates are
 //            converted to float once per wave and reused for all 16 keypoints); four ballots give the 32 descriptor bytes.
 #define DS_KPW 16
-#define DS_PR 39               // BRIEF window: |rotated pattern coordinate| <= 19
-#define DS_PW 12               // words per window row (39 bytes + up to 3 of alignment, 44 B, in 12 words)
+#define DS_PR 37               // BRIEF window: the pattern's largest radius is 18.385, so a rotated, rounded coordinate is within +-18
+#define DS_PH 18
+#define DS_NL ((DS_PR * 10 + 63) / 64)   // staging loads per lane (6)
+#define DS_PW 10               // words per window row (37 bytes + up to 3 of alignment = 40 B)
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                   bh_orb_geom g, const uint32_t* __restrict__ ic_mask, float patch_size, int sel_cap, int max_kp,
                                                   const uint32_t* __restrict__ sel_xy, const float* __restrict__ sel_resp,
@@ -938,7 +940,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     __shared__ int s_m01[64], s_m10[64];
     __shared__ uint32_t s_loc[64], s_bxy[64];                   // level << 28 | cy << 14 | cx (all ones: no keypoint);  by << 16 | bx
     __shared__ float s_a[64], s_b[64], s_resp[64], s_scale[BH_MAX_LEVELS];
-    __shared__ uint32_t s_patch[4][2][DS_PR * DS_PW];            // per wave: the blurred 39 x 39 windows of two keypoints (rows of 12 words)
+    __shared__ uint32_t s_patch[4][2][DS_PR * DS_PW];            // per wave: the blurred 37 x 37 windows of two keypoints (rows of 10 words)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the level lookups stay scalar
     const size_t f = blockIdx.y;
     const int* cnt = sel_cnt + f * g.nlevels;
@@ -1018,21 +1020,21 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         qx0[t] = (float)(signed char)q4; qy0[t] = (float)(signed char)(q4 >> 8); qx1[t] = (float)(signed char)(q4 >> 16); qy1[t] = (float)(q4 >> 24);
     }
     // which (row, word) of the window a lane stages in load m does not depend on the keypoint: row | byte offset << 6 | LDS word << 12
-    uint32_t stg[7];
+    uint32_t stg[DS_NL];
 #pragma unroll
-    for (int m = 0; m < 7; m++) {
-        const int idx = min(lane + 64 * m, DS_PR * 11 - 1), row = idx / 11, dw = idx - row * 11;
+    for (int m = 0; m < DS_NL; m++) {
+        const int idx = min(lane + 64 * m, DS_PR * DS_PW - 1), row = idx / DS_PW, dw = idx - row * DS_PW;
         stg[m] = (uint32_t)row | ((uint32_t)(4 * dw) << 6) | ((uint32_t)(row * DS_PW + dw) << 12);
     }
     // The 512 samples of a keypoint are 8 loads of 64 scattered bytes: one cache line per lane, which is what bounded this kernel
-    // (the address path, not the ALU: 40 % fewer instructions had changed nothing).  The 39 x 39 window they all fall into is staged
-    // in LDS with 7 coalesced word loads per wave instead, and the samples are ds_read_u8.
+    // (the address path, not the ALU: 40 % fewer instructions had changed nothing).  The 37 x 37 window they all fall into is staged
+    // in LDS with 6 coalesced word loads per wave instead, and the samples are ds_read_u8.
 #pragma unroll
     for (int i0 = 0; i0 < DS_KPW; i0 += 2) {                     // two keypoints' windows in flight together
         bool have[2];
         float pa[2], pb[2];
         int sh[2];
-        uint32_t wq[2][7];
+        uint32_t wq[2][DS_NL];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int j = wv * DS_KPW + i0 + q;
@@ -1042,23 +1044,23 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             const int level = __builtin_amdgcn_readfirstlane((int)(loc >> 28));
             const bh_level_geom L = g.lv[level];
             pa[q] = s_a[j]; pb[q] = s_b[j];
-            const int bx = (int)(bxy & 0xffffu) - 19, by = (int)(bxy >> 16) - 19;
+            const int bx = (int)(bxy & 0xffffu) - DS_PH, by = (int)(bxy >> 16) - DS_PH;
             sh[q] = bx & 3;
             const uint8_t* org = blur + f * g.pyr_stride + L.off + (size_t)by * L.pitch + (bx & ~3);
 #pragma unroll
-            for (int m = 0; m < 7; m++) wq[q][m] = *reinterpret_cast<const uint32_t*>(org + (uint32_t)((int)(stg[m] & 63u) * L.pitch + (int)((stg[m] >> 6) & 63u)));
+            for (int m = 0; m < DS_NL; m++) wq[q][m] = *reinterpret_cast<const uint32_t*>(org + (uint32_t)((int)(stg[m] & 63u) * L.pitch + (int)((stg[m] >> 6) & 63u)));
         }
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             if (!have[q]) continue;
 #pragma unroll
-            for (int m = 0; m < 7; m++) s_patch[wv][q][stg[m] >> 12] = wq[q][m];
+            for (int m = 0; m < DS_NL; m++) s_patch[wv][q][stg[m] >> 12] = wq[q][m];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             if (!have[q]) continue;
-            const uint8_t* center = reinterpret_cast<const uint8_t*>(s_patch[wv][q]) + 19 * (4 * DS_PW) + 19 + sh[q];
+            const uint8_t* center = reinterpret_cast<const uint8_t*>(s_patch[wv][q]) + DS_PH * (4 * DS_PW) + DS_PH + sh[q];
             const float a = pa[q], b = pb[q];
             unsigned long long bits[4];
 #pragma unroll
