@@ -977,9 +977,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             loc[q] = (uint32_t)__builtin_amdgcn_readlane((int)my_loc, i0 + q);
             if (loc[q] == 0xffffffffu) continue;                 // wave-uniform
             const bh_level_geom L = g.lv[loc[q] >> 28];
-            const uint8_t* p = pyr + f * g.pyr_stride + L.off + (size_t)((int)((loc[q] >> 14) & 0x3fffu) + vb) * L.pitch + (int)(loc[q] & 0x3fffu) + u;
+            const uint8_t* __restrict__ lvl = pyr + f * g.pyr_stride + L.off;           // wave-uniform base, 32-bit lane offsets
+            const uint32_t o = (uint32_t)(((int)((loc[q] >> 14) & 0x3fffu) + vb) * L.pitch + (int)(loc[q] & 0x3fffu) + u);
 #pragma unroll
-            for (int it = 0; it < 16; it++) I[q][it] = p[it * 2 * L.pitch];      // unconditional (v <= 16, |u| <= 16: inside the level's 31-px border)
+            for (int it = 0; it < 16; it++) I[q][it] = lvl[o + (uint32_t)(it * 2 * L.pitch)];      // unconditional (v <= 16, |u| <= 16: inside the level's 31-px border)
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
