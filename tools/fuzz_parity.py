@@ -32,7 +32,10 @@ def pnp_problem(n):
 
 
 it = 0
+t_say = time.time() + 30
 while time.time() < t_end:
+    if time.time() > t_say:
+        print(f"... {n_fe} front-end, {n_m} matcher, {n_b} solver, {n_p} PnP, {n_po} pose BA, {n_lb} local BA cases so far", flush=True); t_say = time.time() + 30
     # ---- front end
     H, W = int(rng.integers(70, 481)), int(rng.integers(70, 641))
     oy, ox = int(rng.integers(0, 481 - H)), int(rng.integers(0, 641 - W))
