@@ -179,7 +179,8 @@ def run_rank(args):
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    from boslam_amd import dist as shard
+    rank, world, _ = shard.env_rank_world()
     out = {"metric": "rgbd_frames_per_sec_orb_match_640x480", "value": None, "unit": "frames/s", "n_gpus": world}
     failed = []
 
@@ -224,7 +225,9 @@ def run_rank(args):
     ctx = Context(local)
     params = frontend.make_params(nfeatures=args.nfeatures)
     B = args.frames
-    bgr, depth = gen_frames_device(torch, B, dev, start=rank * B)
+    f_start, f_stop, _halo = shard.frame_shard(world * B, rank, world)   # rank g: frames [gB, (g+1)B) of ONE sequence; the halo row travels in DeviceFrontEnd
+    assert f_stop - f_start == B
+    bgr, depth = gen_frames_device(torch, B, dev, start=f_start)
     fe = frontend.DeviceFrontEnd(ctx, B, 480, 640, params, torch_device=dev, dist=dist, backend=backend)
     torch.cuda.synchronize()
 
@@ -275,13 +278,11 @@ def run_rank(args):
         os.environ["BH_ORB_PIPELINES"] = str(args.pipelines)
     else:
         os.environ.pop("BH_ORB_PIPELINES", None)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.reduce_max(dt, dist, dev if backend == "nccl" else "cpu")           # MAX over ranks
 
     n_kp = fe.n_kp.cpu().numpy(); n_match = fe.n_match.cpu().numpy()
-    pairs_local = B - 1 + (1 if rank > 0 else 0)
+    p_start, p_stop = shard.pair_shard(world * B, rank, world)
+    pairs_local = p_stop - p_start
     pairs_total = int(sum_over_ranks(pairs_local if B > 1 or rank > 0 else 0))
     if rank == 0:
         fps = world * B * args.steps / dt

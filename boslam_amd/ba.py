@@ -83,6 +83,10 @@ class LocalBA:
         self.ctx.check(_lib.lib().bh_ba_get_log(self.h, _lib.ptr(lg), max_rows))
         return lg
 
+    def solver(self):
+        """Name of the reduced-camera-system solver set_problem selected (bh_ba_solver)."""
+        return {0: "panel", 1: "dense", 2: "window", 3: "twoway", 4: "bcr"}.get(_lib.lib().bh_ba_solver(self.h), "none")
+
     def close(self):
         if getattr(self, "h", None):
             _lib.lib().bh_ba_destroy(self.h)

@@ -36,19 +36,36 @@ def run(ctx, dev=None, repeats=5):
            "final_robust_chi2": float(lg[-1, 0]), "trials": int(lg[:, 2].sum()),
            "kernel_ms_per_iter": {k: round(v[0] / iters, 4) for k, v in sorted(kt.items()) if k.startswith("k_ba")},
            "pose_err_before_m": float(np.abs(pr["t"] - pr["tgt"]).max()), "pose_err_after_m": float(np.abs(t - pr["tgt"]).max())}
-    # matrix-core roofline of the dense reduced-camera solve (panel kernel, NB = 32): per panel the trailing update issues
-    # nt(nt+1)/2 tiles x 8 v_mfma_f64_16x16x4 (nt = rows below the panel / 16); one workgroup = one CU by design
+    # matrix-core roofline of the reduced-camera solve, for the solver bh_ba_set_problem actually selected (bh_ba_solver):
+    # v_mfma_f64_16x16x4_f64 = 2 048 flop.  "dense" (k_ba_chol_dense<false>, n <= 288, the whole factor on one CU): per block
+    # column J of NT = ceil(n/16): the NT-1-J tiles below the diagonal take 4 MFMAs each for L(i,J) = T(i,J) Linv_J', and the
+    # (NT-1-J)(NT-J)/2 lower tiles of the trailing matrix (diagonal ones included) 4 MFMAs each.  "panel" (k_ba_chol<NB>): per
+    # NB-column panel nt(nt+1)/2 trailing tiles x NB/4 MFMAs.
     n6 = 6 * int((1 - pr["fixed"]).sum())
+    solver = s.solver()
     flops = 0
-    for j0 in range(0, n6, 32):
-        nt = (max(n6 - j0 - 32, 0) + 15) // 16
-        flops += nt * (nt + 1) // 2 * 8 * 2048
+    if solver == "dense":
+        NT = (n6 + 15) // 16
+        for J in range(NT):
+            below = NT - 1 - J
+            flops += (below * 4 + below * (below + 1) // 2 * 4) * 2048
+        kname = "k_ba_chol_dense<false>"
+        note = ("a %d x %d dense system factored on ONE CU (1024-thread workgroup, 16 x 16 f64 tiles in MFMA accumulator layout): %d dependent block "
+                "columns, latency-bound; the iteration as a whole is launch/latency-bound (2.4 MB of algorithmic traffic)" % (n6, n6, NT))
+    else:
+        NB = 16
+        for j0 in range(0, n6, NB):
+            nt = (max(n6 - j0 - NB, 0) + 15) // 16
+            flops += nt * (nt + 1) // 2 * (NB // 4) * 2048
+        kname = "k_ba_chol<16>" if solver == "panel" else solver
+        note = "a %d x %d system, solver '%s': dependent panels on one CU, latency-bound" % (n6, n6, solver)
     ms = out["kernel_ms_per_iter"].get("k_ba_solve", 0.0)
+    out["solver"] = solver
     if ms > 0:
-        out["solve_roofline"] = {"bound": "mfma", "kernel": "k_ba_chol<32>", "achieved": round(flops / (ms * 1e-3) / 1e12, 6), "unit": "TFLOP/s",
+        out["solve_roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(flops / (ms * 1e-3) / 1e12, 6), "unit": "TFLOP/s",
                                  "peak": 78.6, "frac": round(flops / (ms * 1e-3) / 78.6e12, 7), "cus_used": 1,
                                  "frac_of_cus_used": round(flops / (ms * 1e-3) / (78.6e12 / 256), 4), "mfma_flops_per_solve": int(flops),
-                                 "note": "a %d x %d dense system: 9 dependent panels on one CU, latency-bound; the iteration as a whole is launch/latency-bound (2.4 MB of algorithmic traffic)" % (n6, n6)}
+                                 "note": note}
     s.close()
     return out
 

@@ -119,6 +119,16 @@ __device__ __forceinline__ void d_edge_jac(const double* n, const double* dR, co
     }
 }
 
+// x^3 as the reference's pow(x, 3) returns it (g2o OptimizationAlgorithmLevenberg: alpha = 1. - pow((2*rho-1), 3)): the cube is carried
+// as an unevaluated sum of two doubles (error-free products by fma) and rounded once, i.e. correctly rounded except in
+// ~2^-50 of the arguments - where libm's pow (< 1 ulp) may round either way itself.  Two plain multiplications are 1 ulp off in ~25 %.
+__device__ __forceinline__ double d_cube(double x)
+{
+    const double h = __dmul_rn(x, x), l = __fma_rn(x, x, -h);      // x^2 = h + l
+    const double p = __dmul_rn(h, x), e = __fma_rn(h, x, -p);      // h x = p + e
+    return __dadd_rn(p, __fma_rn(l, x, e));
+}
+
 __device__ __forceinline__ void d_huber(double e2, double delta, double* rho0, double* rho1)
 {
     if (delta <= 0) { *rho0 = e2; *rho1 = 1.0; return; }
@@ -279,8 +289,7 @@ __global__ __launch_bounds__(PB_T) void k_pose_ba(const double* __restrict__ pix
             rho /= scale;
             __syncthreads();
             if (rho > 0 && isfinite(tempChi)) {
-                const double q1_ = 2 * rho - 1;                  // (2 rho - 1)^3 by two multiplications (a generic f64 pow is ~200 instructions; the checker does the same)
-                double alpha = 1. - __dmul_rn(__dmul_rn(q1_, q1_), q1_);
+                double alpha = 1. - d_cube(2 * rho - 1);         // g2o: 1. - pow((2*rho-1), 3)
                 alpha = fmin(alpha, 2. / 3.);
                 lambda *= fmax(1. / 3., alpha); ni = 2; chi = tempChi;
             } else {
@@ -1627,6 +1636,7 @@ static int sw_solve(bh_ctx* ctx, hipStream_t st, double* S, const double* bs, in
     if (!split) {
         hipLaunchKernelGGL(k_ba_chol_sw, dim3(1), dim3(SW_NT), lds, st, S, bs, n, bw, x, state, 0, 0, (double*)nullptr, (const double*)nullptr, 0,
                            (double*)nullptr, 0, xch);
+        BH_HIP(ctx, hipGetLastError());
         return BH_OK;
     }
     const int nblk = (n + 15) / 16, npad = 16 * nblk, nb2 = nblk - split - 16, n1 = 16 * (nb2 + 16);
@@ -1640,6 +1650,7 @@ static int sw_solve(bh_ctx* ctx, hipStream_t st, double* S, const double* bs, in
     hipLaunchKernelGGL(k_sw_rev_vec, dim3(1), dim3(256), 0, st, x, x1, n, npad, n1, 0);
     hipLaunchKernelGGL(k_ba_chol_sw, dim3(2), dim3(SW_NT), lds, st, S, bs, n, bw, x, state, 2, split, S1, (const double*)bs1, n1, x1, nb2, xch);
     hipLaunchKernelGGL(k_sw_rev_vec, dim3((n1 + 255) / 256), dim3(256), 0, st, x, x1, n, npad, n1, 1);
+    BH_HIP(ctx, hipGetLastError());
     return BH_OK;
 }
 
@@ -2040,8 +2051,7 @@ __global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ c
         rho /= scale;
         S->chi_trial = tempChi; S->scale = scale; S->rho = rho;
         if (rho > 0 && isfinite(tempChi)) {
-            const double q1_ = 2 * rho - 1;
-            double alpha = 1. - __dmul_rn(__dmul_rn(q1_, q1_), q1_);
+            double alpha = 1. - d_cube(2 * rho - 1);             // g2o: 1. - pow((2*rho-1), 3)
             alpha = fmin(alpha, 2. / 3.);
             S->lambda = lambda * fmax(1. / 3., alpha); S->ni = 2; S->chi_cur = tempChi; S->accepted = 1;
         } else {
@@ -2744,15 +2754,17 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                 {
                     const int nbsel = ba->chol_nb, bw = ba->bw;
                     const size_t lds = sizeof(double) * ((size_t)std::min(n6, nbsel + bw) * (nbsel + 1) + 1100);
+                    int solve_rc = BH_OK;
                     bh_time_begin(ctx, BH_K_BA_SOLVE);
-                    if (ba->chol_bcr) (void)bcr_solve(ctx, st, ba->bcr, (const double*)S, (const double*)bs, n6, bw, dxp, state);
-                    else if (ba->chol_window) (void)sw_solve(ctx, st, S, (const double*)bs, n6, bw, dxp, state, ba->chol_split, (double*)ba->xch.p);
+                    if (ba->chol_bcr) solve_rc = bcr_solve(ctx, st, ba->bcr, (const double*)S, (const double*)bs, n6, bw, dxp, state);
+                    else if (ba->chol_window) solve_rc = sw_solve(ctx, st, S, (const double*)bs, n6, bw, dxp, state, ba->chol_split, (double*)ba->xch.p);
                     else if (ba->chol_dense) hipLaunchKernelGGL(k_ba_chol_dense<false>, dim3(1), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)S, (const double*)bs, n6, bw, dxp, state,
                                                                  (const bcr_elim*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
                     else if (nbsel == 32) hipLaunchKernelGGL(k_ba_chol<32>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     else if (nbsel == 16) hipLaunchKernelGGL(k_ba_chol<16>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     else hipLaunchKernelGGL(k_ba_chol<8>, dim3(1), dim3(1024), lds, st, S, (const double*)bs, n6, bw, dxp, state);
                     bh_time_end(ctx);
+                    BH_TRY(solve_rc);                       // a failed launch inside the multi-kernel solvers (the error text is set there)
                 }
             }
             BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_update, dim3(pblocks + cblocks), dim3(256), st, cams, cams_t, pts, pts_t, cslot, C, Pa, pblocks,
@@ -2893,6 +2905,14 @@ extern "C" int bh_ba_get_chi2(bh_ba* ba, double* chi2, int mem)
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int e = 0; e < ba->E; e++) chi2[e] = err[2 * (size_t)e] * err[2 * (size_t)e] + err[2 * (size_t)e + 1] * err[2 * (size_t)e + 1];
     return BH_OK;
+}
+
+extern "C" int bh_ba_solver(bh_ba* ba)
+{
+    if (!ba || ba->C <= 0) return BH_ERR_INVALID;
+    if (ba->chol_bcr) return 4;
+    if (ba->chol_window) return ba->chol_split ? 3 : 2;
+    return ba->chol_dense ? 1 : 0;
 }
 
 extern "C" int bh_ba_get_log(bh_ba* ba, double* log, int max_rows)

@@ -4,11 +4,16 @@ The reference loads its vocabulary with `self.voc.load("/DBow3/orbvoc.dbow3")` (
 DBoW3 sources are in the reference repository, so the two on-disk formats are restated from DBoW3's published
 Vocabulary::load / toStream / save [upstream, from memory - unpinned; the reference's fork is BOpermanis/DBow3 HEAD]:
 
-  binary (what `.dbow3` files are):  u64 signature 88877711233 | u8 compressed | u32 nnodes |
+  binary (what `.dbow3` files are; Vocabulary::toStream / fromStream):
+        u64 signature 88877711233 | u8 compressed | u32 nnodes (root included) |
         i32 k | i32 L | i32 scoring | i32 weighting |
-        for node 1 .. nnodes-1:  u32 parent | descriptor (i32 cv type, i32 cols, i32 rows, cols*rows bytes) | f64 weight | u8 isLeaf
-        Leaves get word ids in file order.  The QuickLZ-compressed variant (compressed = 1) is not supported: re-save the
-        vocabulary uncompressed (DBoW3's Vocabulary::save(path, binary_compressed=False)) or as YAML.
+        nnodes-1 node records, written by a depth-first walk with an explicit stack (so NOT in id order; the children of one
+        parent are consecutive and in their stored order):
+            u32 nodeId | u32 parentId | f64 weight | descriptor (DescManip::toStream: i32 cols, i32 rows, i32 cv type, bytes)
+        u32 nwords | nwords x (u32 nodeId, u32 wordId)
+        A node's children are its records in file order (fromStream push_backs them as it reads); leaves are the nodes named in
+        the word table.  The QuickLZ-compressed variant (compressed = 1) is not supported: re-save the vocabulary uncompressed
+        (Vocabulary::save(path, binary_compressed=False)) or as YAML.
   YAML (OpenCV FileStorage, optionally gzip):  vocabulary: { k, L, scoringType, weightingType,
         nodes: [ { nodeId, parentId, weight, descriptor:"dbw3 <type> <cols> b0 b1 ..." | "b0 b1 ... b31" } ],
         words: [ { wordId, nodeId } ] }
@@ -24,11 +29,15 @@ SIGNATURE = 88877711233
 TF_IDF, L1_NORM = 0, 0
 
 
-def _flat(parent, desc, weight, is_leaf, word_of_node=None, k=None, L=None, scoring=L1_NORM, weighting=TF_IDF):
-    """parent[i] (node 0 = root, parent[0] ignored), desc u8[n][32], weight f64[n], is_leaf bool[n] -> bh_voc_create arrays."""
+def _flat(parent, desc, weight, is_leaf, word_of_node=None, k=None, L=None, scoring=L1_NORM, weighting=TF_IDF, child_rank=None):
+    """parent[i] (node 0 = root, parent[0] ignored), desc u8[n][32], weight f64[n], is_leaf bool[n] -> bh_voc_create arrays.
+    child_rank[i] (optional): position of node i's record in the file; siblings keep that order (default: id order)."""
     n = len(parent)
     parent = np.asarray(parent, np.int64)
-    order = np.argsort(parent[1:], kind="stable") + 1                      # children grouped by parent, file order kept
+    if child_rank is None:
+        order = np.argsort(parent[1:], kind="stable") + 1                  # children grouped by parent, id (= file) order kept
+    else:
+        order = np.lexsort((np.asarray(child_rank)[1:], parent[1:])) + 1   # grouped by parent, siblings by file position
     counts = np.bincount(parent[1:], minlength=n)
     child_start = np.zeros(n + 1, np.int32); child_start[1:] = np.cumsum(counts)
     child_idx = order.astype(np.int32)
@@ -50,39 +59,63 @@ def _check(voc, path):
     return voc
 
 
+def _desc_header(h, path, what):
+    """DescManip::toStream writes (cols, rows, type); a 1 x 32 CV_8U ORB descriptor is (32, 1, 0).  (type, cols, rows) = (0, 32, 1),
+    the order an older DBoW3 revision used, is accepted too - for ORB the two cannot be confused."""
+    h = tuple(int(v) for v in h)
+    if h in ((32, 1, 0), (0, 32, 1)):
+        return 32
+    raise ValueError(f"{path}: {what}: descriptor header {h}; only 1 x 32 CV_8U (ORB) descriptors are supported")
+
+
 def load_binary(path):
     with open(path, "rb") as f:
         raw = f.read()
+    if len(raw) < 13:
+        raise ValueError(f"{path}: truncated DBoW3 header")
     sig, compressed, nnodes = struct.unpack_from("<QBI", raw, 0)
     if sig != SIGNATURE:
         raise ValueError(f"{path}: not a DBoW3 binary vocabulary (signature {sig})")
     if compressed:
         raise ValueError(f"{path}: QuickLZ-compressed DBoW3 stream; re-save uncompressed or as YAML")
+    if nnodes == 0:
+        raise ValueError(f"{path}: empty vocabulary")
     off = 13
     k, L, scoring, weighting = struct.unpack_from("<iiii", raw, off); off += 16
-    parent = np.zeros(nnodes, np.int64); weight = np.zeros(nnodes); leaf = np.zeros(nnodes, bool)
-    desc = np.zeros((nnodes, 32), np.uint8)
-    # fixed-size records when every descriptor is 1 x 32 CV_8U (ORB): parse them in one shot
-    rec = 4 + 12 + 32 + 8 + 1
-    if len(raw) - off == rec * (nnodes - 1):
-        a = np.frombuffer(raw, dtype=np.uint8, count=rec * (nnodes - 1), offset=off).reshape(nnodes - 1, rec)
-        hdr = a[:, 4:16].copy().view("<i4")
-        if np.all(hdr[:, 1] * hdr[:, 2] == 32):
-            parent[1:] = a[:, 0:4].copy().view("<u4")[:, 0]
-            desc[1:] = a[:, 16:48]
-            weight[1:] = a[:, 48:56].copy().view("<f8")[:, 0]
-            leaf[1:] = a[:, 56] != 0
-            return _check(_flat(parent, desc, weight, leaf, k=k, L=L, scoring=scoring, weighting=weighting), path)
-    for i in range(1, nnodes):
-        parent[i], = struct.unpack_from("<I", raw, off); off += 4
-        _type, cols, rows = struct.unpack_from("<iii", raw, off); off += 12
-        nb = cols * rows
-        if nb != 32:
-            raise ValueError(f"{path}: node {i} has a {rows}x{cols} descriptor; ORB descriptors are 32 bytes")
-        desc[i] = np.frombuffer(raw, np.uint8, 32, off); off += 32
-        weight[i], = struct.unpack_from("<d", raw, off); off += 8
-        leaf[i] = raw[off] != 0; off += 1
-    return _check(_flat(parent, desc, weight, leaf, k=k, L=L, scoring=scoring, weighting=weighting), path)
+    rec = 4 + 4 + 8 + 12 + 32                                     # nodeId, parentId, weight, (cols, rows, type), 32 bytes
+    need = off + rec * (nnodes - 1) + 4
+    if len(raw) < need:
+        raise ValueError(f"{path}: truncated: {nnodes} nodes need {need} bytes, the file has {len(raw)}")
+    a = np.frombuffer(raw, dtype=np.uint8, count=rec * (nnodes - 1), offset=off).reshape(nnodes - 1, rec)
+    off += rec * (nnodes - 1)
+    nid = a[:, 0:4].copy().view("<u4")[:, 0].astype(np.int64)
+    pid = a[:, 4:8].copy().view("<u4")[:, 0].astype(np.int64)
+    hdr = a[:, 16:28].copy().view("<i4")
+    if nnodes > 1:
+        _desc_header(hdr[0], path, f"node {int(nid[0])}")
+        if not np.all(hdr == hdr[0]):
+            bad = int(np.flatnonzero(np.any(hdr != hdr[0], axis=1))[0])
+            _desc_header(hdr[bad], path, f"node {int(nid[bad])}")
+    if np.any(nid <= 0) or np.any(nid >= nnodes) or np.any(pid >= nnodes) or len(np.unique(nid)) != nnodes - 1:
+        raise ValueError(f"{path}: node ids are not a permutation of 1..{nnodes - 1}")
+    parent = np.zeros(nnodes, np.int64); weight = np.zeros(nnodes); desc = np.zeros((nnodes, 32), np.uint8)
+    parent[nid] = pid
+    weight[nid] = a[:, 8:16].copy().view("<f8")[:, 0]
+    desc[nid] = a[:, 28:60]
+    nwords, = struct.unpack_from("<I", raw, off); off += 4
+    if len(raw) < off + 8 * nwords:
+        raise ValueError(f"{path}: truncated word table ({nwords} words)")
+    wt = np.frombuffer(raw, dtype="<u4", count=2 * nwords, offset=off).reshape(nwords, 2).astype(np.int64)
+    if np.any(wt[:, 0] >= nnodes) or np.any(wt[:, 1] >= nwords) or len(np.unique(wt[:, 1])) != nwords:
+        raise ValueError(f"{path}: word table does not map {nwords} word ids onto nodes")
+    word_of_node = np.full(nnodes, -1, np.int32)
+    word_of_node[wt[:, 0]] = wt[:, 1]
+    if np.any(word_of_node[pid] >= 0):
+        raise ValueError(f"{path}: a word node has children")
+    # children in FILE order (fromStream: m_nodes[parent].children.push_back as records arrive): rank nodes by file position
+    file_pos = np.zeros(nnodes, np.int64); file_pos[nid] = np.arange(1, nnodes)
+    return _check(_flat(parent, desc, weight, word_of_node >= 0, word_of_node=word_of_node, k=k, L=L, scoring=scoring, weighting=weighting,
+                        child_rank=file_pos), path)
 
 
 _NODE = re.compile(r"nodeId:\s*(\d+)\s*,\s*parentId:\s*(\d+)\s*,\s*weight:\s*([-+.eE\d]+)\s*,\s*descriptor:\s*\"([^\"]*)\"", re.S)
@@ -138,13 +171,25 @@ def _parents(voc):
     return parent
 
 
+def _stack_order(voc):
+    """The order Vocabulary::toStream writes node records in: parents = [root]; pop the LAST one, write its children in stored order,
+    push those that have children.  Returns the node ids (of `voc`) in that order, root excluded."""
+    cs, ci = np.asarray(voc["child_start"], np.int64), np.asarray(voc["child_idx"], np.int64)
+    out = []
+    stack = [0]
+    while stack:
+        pid = stack.pop()
+        kids = ci[cs[pid]:cs[pid + 1]]
+        out.append(kids)
+        stack.extend(int(c) for c in kids if cs[c + 1] > cs[c])
+    return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+
 def _file_order(voc):
-    """Node numbering a DBoW3 file needs: ids 1..N in an order in which every parent's children appear in their stored order and
-    leaves are numbered by word id (the binary format derives word ids from leaf order).  Returns new_id[old_id]."""
+    """A node numbering 1..N in which every parent's children are consecutive and in their stored order (breadth first); what the
+    YAML writer uses (its reader wants ids in file order).  Returns new_id[old_id]."""
     n = len(voc["node_word"])
-    cs, ci = voc["child_start"], voc["child_idx"]
-    # BFS, level by level: keeps each parent's children contiguous and in their stored order
-    cs, ci = np.asarray(cs, np.int64), np.asarray(ci, np.int64)
+    cs, ci = np.asarray(voc["child_start"], np.int64), np.asarray(voc["child_idx"], np.int64)
     level = np.array([0], np.int64); order = [level]
     while len(level):
         cnt = cs[level + 1] - cs[level]
@@ -158,7 +203,7 @@ def _file_order(voc):
 
 
 def renumber_words_in_file_order(voc):
-    """Copy of the tree whose word ids follow the leaves' file order (what the binary format implies)."""
+    """Copy of the tree whose word ids follow the leaves' breadth-first order (kept for tools; no file format needs it)."""
     new_id = _file_order(voc)
     old = np.argsort(new_id)
     out = dict(voc)
@@ -170,26 +215,31 @@ def renumber_words_in_file_order(voc):
 
 
 def save_binary(path, voc):
-    """Uncompressed DBoW3 binary stream.  Word ids are implied by leaf order in the file, so the tree must number its leaves in
-    that order (true for trees this module loaded; renumber_words_in_file_order makes any tree so)."""
-    new_id = _file_order(voc)
-    n = len(new_id)
-    old = np.argsort(new_id)
+    """Uncompressed DBoW3 binary stream as Vocabulary::toStream lays it out (module docstring): records in stack order with explicit
+    node and parent ids, then the (nodeId, wordId) table in word-id order."""
+    n = len(voc["node_word"])
+    o = _stack_order(voc)
+    if len(o) != n - 1:
+        raise ValueError("save_binary: the tree does not reach every node from the root")
     parent = _parents(voc)
-    leaf_words = voc["node_word"][old][voc["node_word"][old] >= 0]
-    if not np.array_equal(leaf_words, np.arange(len(leaf_words))):
-        raise ValueError("save_binary: word ids must follow the leaves' file order")
-    o = old[1:]
-    rec = np.zeros((n - 1, 57), np.uint8)
-    rec[:, 0:4] = new_id[parent[o]].astype("<u4").view(np.uint8).reshape(-1, 4)
-    rec[:, 4:16] = np.tile(np.array([0, 32, 1], "<i4").view(np.uint8), (n - 1, 1))          # CV_8U, cols 32, rows 1
-    rec[:, 16:48] = voc["node_desc"][o]
-    rec[:, 48:56] = np.asarray(voc["node_weight"], np.float64)[o].astype("<f8").view(np.uint8).reshape(-1, 8)
-    rec[:, 56] = voc["node_word"][o] >= 0
+    rec = np.zeros((n - 1, 60), np.uint8)
+    rec[:, 0:4] = o.astype("<u4").view(np.uint8).reshape(-1, 4)
+    rec[:, 4:8] = parent[o].astype("<u4").view(np.uint8).reshape(-1, 4)
+    rec[:, 8:16] = np.asarray(voc["node_weight"], np.float64)[o].astype("<f8").view(np.uint8).reshape(-1, 8)
+    rec[:, 16:28] = np.tile(np.array([32, 1, 0], "<i4").view(np.uint8), (n - 1, 1))          # cols 32, rows 1, CV_8U
+    rec[:, 28:60] = voc["node_desc"][o]
+    nw = np.asarray(voc["node_word"], np.int64)
+    nodes_of_words = np.flatnonzero(nw >= 0)
+    nodes_of_words = nodes_of_words[np.argsort(nw[nodes_of_words], kind="stable")]
+    if not np.array_equal(nw[nodes_of_words], np.arange(len(nodes_of_words))):
+        raise ValueError("save_binary: word ids must be 0..nwords-1")
+    tab = np.stack([nodes_of_words, nw[nodes_of_words]], axis=1).astype("<u4")
     with open(path, "wb") as f:
         f.write(struct.pack("<QBI", SIGNATURE, 0, n))
         f.write(struct.pack("<iiii", int(voc.get("k") or 10), int(voc.get("L") or 0), L1_NORM, TF_IDF))
         f.write(rec.tobytes())
+        f.write(struct.pack("<I", len(tab)))
+        f.write(tab.tobytes())
 
 
 def save_yaml(path, voc):

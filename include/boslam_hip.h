@@ -157,6 +157,10 @@ int  bh_ba_get_points(bh_ba* ba, double* points, int mem);
 int  bh_ba_get_chi2(bh_ba* ba, double* chi2, int mem);
 /* per-iteration log of the last optimize: f64[iters_done][4] = {robust chi2 after, lambda, trials, accepted} */
 int  bh_ba_get_log(bh_ba* ba, double* log, int max_rows);
+/* which reduced-camera-system solver bh_ba_set_problem selected for the current problem (so that a test which claims to
+ * compare two of them can assert it): 0 = panel kernel, 1 = whole factor on chip (n <= 288), 2 = on-chip sliding window,
+ * 3 = two-way window elimination, 4 = block cyclic reduction over the whole chip; < 0 = no problem set. */
+int  bh_ba_solver(bh_ba* ba);
 
 /* Test hook: one banded SPD solve S x = rhs with the reduced-camera-system kernels.  band f64[n][bw+1] holds the lower band,
  * element (r, c) at band[r*(bw+1) + c - r + bw]; mode 0 = panel kernel, 1 = on-chip sliding-window kernel (15 <= bw <= 256),

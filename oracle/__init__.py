@@ -288,6 +288,23 @@ def rodrigues(v):
     r = np.zeros(3); lib().orc_rodrigues_mat2vec(_p(v.reshape(9)), _p(r)); return r
 
 
+def ps_qr_solve_6x4(A, b):
+    """pnp_small.h: least-squares solution of a 6 x 4 system by Householder QR (EPnP's Gauss-Newton step)."""
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(6, 4); b = np.ascontiguousarray(b, dtype=np.float64).reshape(6)
+    x = np.zeros(4); lib().orc_ps_qr_solve_6x4(_p(A), _p(b), _p(x)); return x
+
+
+def ps_chol6_solve(A, b):
+    """pnp_small.h: 6 x 6 SPD solve by Cholesky (lower triangle read).  Returns (ok, x); x = 0 when a pivot fails."""
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(6, 6); b = np.ascontiguousarray(b, dtype=np.float64).reshape(6)
+    x = np.zeros(6); ok = lib().orc_ps_chol6_solve(_p(A), _p(b), _p(x)); return bool(ok), x
+
+
+def ba_cube_mode(two_mul=None):
+    """(2 rho - 1)^3 of the Levenberg lambda update: 0 = pow() as g2o (default), 1 = two rounded multiplications.  Returns the old mode."""
+    return int(lib().orc_ba_cube_mode(-1 if two_mul is None else int(bool(two_mul))))
+
+
 def solve_pnp_ransac(obj, img, K4, iterations=100, reproj_error=8.0, confidence=0.99):
     obj = np.ascontiguousarray(obj, dtype=np.float64).reshape(-1, 3); img = np.ascontiguousarray(img, dtype=np.float64).reshape(-1, 2)
     n = len(obj)

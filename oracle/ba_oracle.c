@@ -199,6 +199,10 @@ static int inv3(const double* m, double* o)
  * chi2_out f64[E]; log f64[iters][4] = {robust chi2 after the iteration, lambda, trials, accepted}; may be NULL.
  * returns 0 ok, -1 bad input, -5 if the first linearisation is not finite.
  */
+/* 0 (default): (2 rho - 1)^3 by pow() as g2o's OptimizationAlgorithmLevenberg does; 1: by two rounded multiplications. */
+static int orc_cube_two_mul = 0;
+int orc_ba_cube_mode(int two_mul) { const int old = orc_cube_two_mul; if (two_mul >= 0) orc_cube_two_mul = two_mul ? 1 : 0; return old; }
+
 int orc_ba_optimize(int C, double* R, double* t, const uint8_t* cam_fixed, int P, double* pts, const uint8_t* pt_fixed,
                     int E, const int* ecam, const int* ept, const double* meas, const double* K,
                     int iters, double huber_delta, int verbose_errors, double* chi2_out, double* log, int* iters_done)
@@ -340,9 +344,12 @@ int orc_ba_optimize(int C, double* R, double* t, const uint8_t* cam_fixed, int P
             scale += 1e-3;
             rho /= scale;
             if (rho > 0 && isfinite(tempChi)) {
+                /* g2o: alpha = 1. - pow((2*rho-1), 3) - libm's pow, the default.  orc_ba_cube_mode(1) selects two rounded
+                   multiplications instead (<= 1 ulp away): tests/test_oracle_cpu.py checks that the LM decisions do not depend on it. */
                 const double q1_ = 2*rho - 1;
-                volatile double q2_ = q1_ * q1_;               /* (2 rho - 1)^3 by two rounded multiplications, as the device does */
-                volatile double q3_ = q2_ * q1_;
+                double q3_;
+                if (orc_cube_two_mul) { volatile double q2_ = q1_ * q1_; volatile double q3v_ = q2_ * q1_; q3_ = q3v_; }
+                else q3_ = pow(q1_, 3);
                 double alpha = 1. - q3_;
                 alpha = fmin(alpha, 2./3.);
                 double sf = fmax(1./3., alpha);

@@ -587,3 +587,13 @@ void orc_detmath_eval(const double* x, int n, double* out)
         out[4 * n + i] = dm_pow5(x[i]);
     }
 }
+
+/* Test hooks: the two small dense solves of pnp_small.h, callable on their own so that tests/test_oracle_cpu.py can check them
+   against numpy.linalg (the header's text is shared with the kernel, so "HIP == oracle" says nothing about its correctness). */
+void orc_ps_qr_solve_6x4(const double* A, const double* b, double* x)
+{
+    double Ac[24], bc[6];
+    memcpy(Ac, A, sizeof(Ac)); memcpy(bc, b, sizeof(bc));
+    ps_qr_solve_6x4(Ac, bc, x);
+}
+int orc_ps_chol6_solve(const double* A, const double* b, double* x) { return ps_chol6_solve(A, b, x); }

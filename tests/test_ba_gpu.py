@@ -189,23 +189,47 @@ def test_global_ba_scale_properties(ctx):
     assert np.abs(pts - pr["Xgt"]).mean() < np.abs(pr["pts"] - pr["Xgt"]).mean()
 
 
-def test_global_ba_config5_full_size(ctx):
+def test_bcr_inside_lm_matches_dense_oracle(ctx, monkeypatch):
+    """The production solver of long banded systems - block cyclic reduction, selected for >= 2 048 unknowns - inside the
+    Levenberg loop against the DENSE CPU oracle: 400 keyframes (398 free, n = 2 388), once with a narrow band (window 6) and once
+    with the widest one BCR takes (window 20: bw = 245).  LM log equal, states within 1e-4; and the same problem through the
+    two-way window kernels (BH_BA_CHOL_BCR=0) takes the same decisions."""
+    for window, seed in ((6, 3), (20, 21)):
+        pr = synth.ba_problem_sequence(n_kf=400, n_pts=12000, window=window, seed=seed)
+        o = oracle.ba_optimize(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"], pr["K"], 5, ba.HUBER_DELTA)
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("BH_BA_CHOL_BCR", mode)
+            s = ba.LocalBA(ctx, pr["K"])
+            s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+            assert s.solver() in (("bcr",) if mode == "1" else ("window", "twoway")), s.solver()
+            done = s.optimize(5)
+            res[mode] = (s.poses(), s.points().copy(), s.log()[:done].copy(), done)
+            s.close()
+        monkeypatch.delenv("BH_BA_CHOL_BCR")
+        for mode in ("1", "0"):
+            (R, t), pts, lg, done = res[mode]
+            assert done == o["iters_done"] and np.array_equal(lg[:, 2:], o["log"][:, 2:])
+            assert np.allclose(lg[:, 0], o["log"][:, 0], rtol=1e-8)
+            assert _rel(R, o["R"]) < RTOL and _rel(t, o["t"]) < RTOL and _rel(pts, o["pts"]) < RTOL
+
+
+def test_global_ba_config5_full_size(ctx, monkeypatch):
     """BASELINE configs[4] at its full size (5 000 keyframes, 500 k landmarks, 3.9 M observations): too big for the dense oracle;
-    the two solve schedules (one workgroup / two-way elimination from both ends) must agree, chi2 must fall monotonically with
-    every step accepted, and the estimate must move towards the ground truth."""
-    import os
+    the two solvers of the reduced camera system (block cyclic reduction over the whole chip = the default; two-way window
+    elimination = BH_BA_CHOL_BCR=0) must agree, chi2 must fall monotonically with every step accepted, and the estimate must
+    move towards the ground truth."""
     pr = synth.ba_problem_sequence()
     res = {}
     for mode in ("1", "0"):
-        os.environ["BH_BA_CHOL_TWOWAY"] = mode
-        try:
-            s = ba.LocalBA(ctx, pr["K"])
-            s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
-            done = s.optimize(4)
-            res[mode] = (s.poses()[1].copy(), s.points().copy(), s.log()[:done].copy())
-            s.close()
-        finally:
-            os.environ.pop("BH_BA_CHOL_TWOWAY", None)
+        monkeypatch.setenv("BH_BA_CHOL_BCR", mode)
+        s = ba.LocalBA(ctx, pr["K"])
+        s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+        assert s.solver() in (("bcr",) if mode == "1" else ("window", "twoway")), s.solver()
+        done = s.optimize(4)
+        res[mode] = (s.poses()[1].copy(), s.points().copy(), s.log()[:done].copy())
+        s.close()
+    monkeypatch.delenv("BH_BA_CHOL_BCR")
     t, pts, lg = res["1"]
     assert len(lg) == 4 and (lg[:, 3] == 1).all() and np.all(np.diff(lg[:, 0]) < 0)
     assert np.array_equal(lg[:, 2:], res["0"][2][:, 2:]) and np.allclose(lg[:, 0], res["0"][2][:, 0], rtol=1e-10)

@@ -127,7 +127,7 @@ def test_real_shape_vocabulary_k10_L6_from_a_dbow3_file(ctx, tmp_path):
     """The shape of the reference's /DBow3/orbvoc.dbow3 (slam/bow_db.py:17-18): k = 10, L = 6, 10^6 words, read back from a DBoW3
     binary file; quantisation on the GPU is bit-identical to the oracle's walk of the same tree."""
     from boslam_amd import dbow3_io
-    voc = dbow3_io.renumber_words_in_file_order(synth.vocabulary(k=10, L=6, seed=3))
+    voc = synth.vocabulary(k=10, L=6, seed=3)
     p = tmp_path / "orbvoc.dbow3"
     dbow3_io.save_binary(p, voc)
     loaded = dbow3_io.load_vocabulary(p)
@@ -146,7 +146,7 @@ def test_dbow_from_file_subset_query_and_compare_frames(ctx, tmp_path):
     """slam/bow_db.py end to end from a vocabulary FILE: Dbow(path), query(frame, subset_inds) (the fork's target_inds), compareFrames
     (the fork's compareBowsL1), and the live call of slam/loop_closing.py:15 with the local window excluded."""
     from boslam_amd import dbow3_io, loop_closing
-    voc = dbow3_io.renumber_words_in_file_order(synth.vocabulary(k=10, L=3, seed=8))
+    voc = synth.vocabulary(k=10, L=3, seed=8)
     p = tmp_path / "voc.yml.gz"
     dbow3_io.save_yaml(p, voc)
 

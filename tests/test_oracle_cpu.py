@@ -346,3 +346,71 @@ def test_detmath_tracks_libm():
         d = np.abs(got[big].view(np.int64) - want[big].view(np.int64))
         assert d.max() <= (3 if name == "pow5" else 2), (name, int(d.max()))
         assert np.allclose(got, want, rtol=1e-15, atol=1e-16), name
+
+
+# ------------------------------------------------------------------------------------------------ pnp_small.h, independently
+def test_pnp_small_qr_matches_numpy_lstsq():
+    """ps_qr_solve_6x4 (oracle/pnp_small.h, the same text the HIP kernel compiles) against numpy.linalg.lstsq: random systems,
+    badly scaled columns, a negative leading entry (the sign branch of the reflector), and the zero-column exit."""
+    rng = np.random.default_rng(17)
+    for k in range(300):
+        A = rng.normal(size=(6, 4)); b = rng.normal(size=6)
+        if k % 3 == 1:
+            A *= 10.0 ** rng.integers(-6, 7, size=(1, 4))
+        if k % 3 == 2:
+            A[0, 0] = -abs(A[0, 0]) - 1.0
+        x = oracle.ps_qr_solve_6x4(A, b)
+        ref = np.linalg.lstsq(A, b, rcond=None)[0]
+        assert np.allclose(x, ref, rtol=1e-9 * np.linalg.cond(A), atol=1e-12 * np.abs(ref).max()), k
+        assert np.abs(A.T @ (A @ x - b)).max() <= 1e-9 * np.abs(A).max() * (np.abs(b).max() + np.abs(A @ x).max())      # normal equations
+    A = rng.normal(size=(6, 4)); A[:, 2] = 0.0                                # rank-deficient: a zero pivot column -> x = 0 (documented exit)
+    assert np.array_equal(oracle.ps_qr_solve_6x4(A, rng.normal(size=6)), np.zeros(4))
+    assert np.array_equal(oracle.ps_qr_solve_6x4(np.zeros((6, 4)), np.ones(6)), np.zeros(4))
+
+
+def test_pnp_small_chol6_matches_numpy_and_rejects_bad_pivots():
+    """ps_chol6_solve against numpy.linalg.solve / cholesky: SPD systems over 12 orders of magnitude in condition, only the lower
+    triangle is read, and a non-positive, NaN or overflowing pivot returns (0, x = 0)."""
+    rng = np.random.default_rng(18)
+    for k in range(300):
+        M = rng.normal(size=(6, 6)); A = M @ M.T + 10.0 ** rng.uniform(-8, 2) * np.eye(6); b = rng.normal(size=6)
+        ok, x = oracle.ps_chol6_solve(A, b)
+        assert ok
+        assert np.allclose(x, np.linalg.solve(A, b), rtol=1e-10 * np.linalg.cond(A), atol=0), k
+        L = np.linalg.cholesky(A)
+        assert np.allclose(L @ (L.T @ x), b, rtol=0, atol=1e-9 * np.abs(b).max() * max(1.0, np.linalg.cond(A) * 1e-7))
+        U = A.copy(); U[np.triu_indices(6, 1)] = 1e30                          # garbage above the diagonal must not matter
+        ok2, x2 = oracle.ps_chol6_solve(U, b)
+        assert ok2 and np.array_equal(x, x2)
+    v = rng.normal(size=(6, 1))
+    for A in (v @ v.T,                                                         # singular (rank 1): a zero / negative pivot
+              -np.eye(6), np.diag([1, 1, -1e-30, 1, 1, 1.0]), np.diag([1, np.nan, 1, 1, 1, 1.0]), np.diag([1, 1, 1, 1e301, 1, 1.0])):
+        ok, x = oracle.ps_chol6_solve(A, np.ones(6))
+        assert not ok and np.array_equal(x, np.zeros(6))
+
+
+def test_lm_decisions_do_not_depend_on_how_the_cube_is_rounded():
+    """g2o's lambda update is 1 - pow(2 rho - 1, 3).  The oracle calls pow (default); the HIP kernels round the exact cube once
+    (d_cube, ba.hip); a cube by two rounded multiplications is <= 1 ulp away.  On the golden problems the Levenberg decisions
+    (trial counts, accept flags) are identical either way and the states agree far inside the 1e-4 contract."""
+    probs = [synth.ba_problem(n_kf=6, n_pts=150, seed=1), synth.ba_problem(n_kf=12, n_pts=500, seed=4),
+             synth.ba_problem_sequence(n_kf=40, n_pts=1200, window=6, seed=3)]
+    assert oracle.ba_cube_mode() == 0
+    for pr in probs:
+        res = []
+        for mode in (0, 1):
+            oracle.ba_cube_mode(mode)
+            try:
+                res.append(oracle.ba_optimize(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"], pr["K"], 7, np.sqrt(7.815)))
+            finally:
+                oracle.ba_cube_mode(0)
+        a, b = res
+        assert a["iters_done"] == b["iters_done"] and np.array_equal(a["log"][:, 2:], b["log"][:, 2:])
+        assert np.allclose(a["log"][:, :2], b["log"][:, :2], rtol=1e-12)
+        assert np.allclose(a["t"], b["t"], rtol=0, atol=1e-10) and np.allclose(a["pts"], b["pts"], rtol=0, atol=1e-10)
+    x = np.random.default_rng(5).uniform(-1, 1, 20000)                        # pow(x, 3) of libm is the correctly rounded cube (exact rational check)
+    from fractions import Fraction
+    for v in x[:2000]:
+        exact = Fraction(v) ** 3
+        got = float(np.float64(v) ** 3)                                        # numpy -> libm pow
+        assert abs(Fraction(got) - exact) <= abs(Fraction(np.nextafter(got, np.inf)) - Fraction(got)) * Fraction(51, 100)
