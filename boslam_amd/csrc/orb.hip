@@ -16,6 +16,8 @@
 #include "bh_internal.h"
 #include <math.h>
 #include <float.h>
+#include <vector>
+#include <algorithm>
 
 #ifndef TILE_W
 #define TILE_W 128
@@ -183,91 +185,152 @@ __device__ __forceinline__ unsigned long long pyr_load8(const uint8_t* __restric
 #ifndef PD_R
 #define PD_R 2
 #endif
+typedef unsigned short pd_us2 __attribute__((ext_vector_type(2)));
+
+// ---- level l from level l-1, depth-mask form, round 3.  One lane = 4 output pixels x PD_R rows, lanes flattened over (row block,
+// column group) so that every lane of every wave holds real work.  The kernel is bound by its vector instructions (measured in three
+// forms this round: fewer vector-memory instructions through an LDS copy of the source rows, fewer dependent loads through a row loop
+// per lane, and fused small levels all ran at the same ~36 lane-instructions per output pixel), so what is spent per pixel is what counts:
+//   * everything that depends on x only - tap offsets, packed coefficients, v_perm selectors - is set up once per lane (pyr_xsetup);
+//   * horizontal pass: per pixel ONE v_perm per tap builds (row a, row b) as two 16-bit halves from the rows' 4-byte windows, then
+//     H = (256 - c1) P0 + c1 P1 is a packed multiply + multiply-add (<= 65 280: exact in 16 bits) for both rows at once;
+//   * vertical pass: v = ((256 - yc) Ha + yc Hb + 32768) >> 16 is one v_dot2_u32_u16 of (Ha, Hb) with (256 - yc, yc);
+//   * mask: with 0 / 255 inputs the reference's resize + threshold(254) is "the taps that are clear weigh <= 128 of 65 536"
+//     (T >= 65 408, verified exhaustively in round 2).  When the smallest weight product min(c1, 256 - c1) min(yc, 256 - yc) exceeds 128
+//     that is the AND of the four taps (one shift-and chain per lane).  A wave in which some lane has a possibly ignorable tap AND a
+//     window with some but not all bits set evaluates T for its mixed lanes instead (bit-field extracts feeding 24-bit multiply-adds).
+struct pyr_xs {
+    uint32_t selP0[4];          // v_perm selector of tap 0 of pixel i: (row a byte s, 0, row b byte s, 0); tap 1 = + 0x00010001
+    pd_us2 C0[4], C1[4];        // (256 - c1, 256 - c1), (c1, c1)
+    uint32_t sv[4];             // tap-0 column of pixel i relative to the window's first column (0 .. 4)
+    uint32_t mmin;              // min over the pixels of min(c1, 256 - c1)
+    uint32_t boff, shb, shm;    // byte offset of the aligned 12-byte window inside a source row; funnel shifts (bits) to the window / its second word
+    uint32_t mcol, mbit;        // mask: first word of the row, bit inside it
+    int over, x;
+};
+struct pyr_ld { uint32_t a0, a1, a2, b0, b1, b2, ma0, ma1, mb0, mb1; };
+
+__device__ __forceinline__ void pyr_xsetup(pyr_xs& X, const bh_level_geom& D, const uint32_t* __restrict__ tab, int x)
+{
+    X.x = x;
+    X.over = min(max(x + 4 - D.w, 0), 4);                      // outputs of this lane beyond the row
+    const uint4 tx4 = *reinterpret_cast<const uint4*>(tab + D.tabx_off + (X.over == 4 ? 0 : x));
+    const uint32_t txs[4] = { tx4.x, tx4.y, tx4.z, tx4.w };
+    const uint32_t base = tx4.x >> 16;
+    X.mmin = 256u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t c1 = txs[i] & 0xffffu;
+        X.sv[i] = (txs[i] >> 16) - base;
+        X.C1[i] = pd_us2{ (unsigned short)c1, (unsigned short)c1 };
+        X.C0[i] = pd_us2{ (unsigned short)(256u - c1), (unsigned short)(256u - c1) };
+        X.mmin = min(X.mmin, min(c1, 256u - c1));
+    }
+    // pixels 0, 1 read the window word at byte 0 (their tap 0 is at byte <= 2), pixels 2, 3 the word at byte m = min(s_2, 2)
+    // (s - m <= 2), so a tap pair (s, s + 1) never leaves its word
+    const uint32_t m2 = min(X.sv[2], 2u);
+#pragma unroll
+    for (int i = 0; i < 4; i++) X.selP0[i] = 0x0c040c00u + (i < 2 ? X.sv[i] : X.sv[i] - m2) * 0x00010001u;
+    X.boff = base & ~3u; X.shb = (base & 3u) << 3; X.shm = m2 << 3;
+    X.mcol = base >> 5; X.mbit = base & 31u;
+}
+
+__device__ __forceinline__ void pyr_load(pyr_ld& L, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ms, const bh_level_geom& S,
+                                         const pyr_xs& X, int r0, int r1)
+{
+    const uint32_t* qa = reinterpret_cast<const uint32_t*>(src + (uint32_t)(r0 * S.pitch) + X.boff);
+    const uint32_t* qb = reinterpret_cast<const uint32_t*>(src + (uint32_t)(r1 * S.pitch) + X.boff);
+    L.a0 = qa[0]; L.a1 = qa[1]; L.a2 = qa[2]; L.b0 = qb[0]; L.b1 = qb[1]; L.b2 = qb[2];
+    const uint32_t* pa = ms + (uint32_t)(r0 * S.mpitch) + X.mcol; const uint32_t* pb = ms + (uint32_t)(r1 * S.mpitch) + X.mcol;
+    L.ma0 = pa[0]; L.ma1 = pa[1]; L.mb0 = pb[0]; L.mb1 = pb[1];
+}
+
+__device__ __forceinline__ void pyr_row(const pyr_ld& L, const pyr_xs& X, uint32_t yc, int lane, uint32_t* o4, uint32_t* nbw)
+{
+    const pd_us2 Wy = pd_us2{ (unsigned short)(256u - yc), (unsigned short)yc };
+    const uint32_t alo = __builtin_amdgcn_alignbit(L.a1, L.a0, X.shb), ahi = __builtin_amdgcn_alignbit(L.a2, L.a1, X.shb);
+    const uint32_t blo = __builtin_amdgcn_alignbit(L.b1, L.b0, X.shb), bhi = __builtin_amdgcn_alignbit(L.b2, L.b1, X.shb);
+    const uint32_t wa[2] = { alo, __builtin_amdgcn_alignbit(ahi, alo, X.shm) }, wb[2] = { blo, __builtin_amdgcn_alignbit(bhi, blo, X.shm) };
+    uint32_t r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const pd_us2 P0 = __builtin_bit_cast(pd_us2, __builtin_amdgcn_perm(wb[i >> 1], wa[i >> 1], X.selP0[i]));
+        const pd_us2 P1 = __builtin_bit_cast(pd_us2, __builtin_amdgcn_perm(wb[i >> 1], wa[i >> 1], X.selP0[i] + 0x00010001u));
+        const pd_us2 Hh = (pd_us2)(X.C1[i] * P1 + (pd_us2)(X.C0[i] * P0));          // (Ha, Hb)
+        r[i] = __builtin_amdgcn_udot2(Hh, Wy, 32768u, false);                       // result byte = bits 16 .. 23
+    }
+    const uint32_t v4 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(r[3], r[2], 0x0c0c0602u), __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0602u), 0x05040100u);
+    const uint32_t A8 = __builtin_amdgcn_alignbit(L.ma1, L.ma0, X.mbit), B8 = __builtin_amdgcn_alignbit(L.mb1, L.mb0, X.mbit);
+    const uint32_t both = A8 & B8 & 0x3fu, any = (A8 | B8) & 0x3fu;
+    const bool mixed = both != 0x3fu && any != 0u;
+    uint32_t nib = both == 0x3fu ? 0xfu : 0u;
+    if (__builtin_amdgcn_ballot_w64(mixed && X.mmin * min(yc, 256u - yc) <= 128u) == 0ull) {      // wave-uniform: no tap of any mixed lane can be ignored
+        if (mixed) {                                             // every tap weighs more than 128: set <=> all four taps set
+            const uint32_t a4 = A8 & (A8 >> 1) & B8 & (B8 >> 1);
+#pragma unroll
+            for (int i = 0; i < 4; i++) nib |= __builtin_amdgcn_ubfe(a4, X.sv[i], 1u) << i;
+        }
+    } else if (mixed) {
+        const uint32_t wy0 = 256u - yc;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t w1 = X.C1[i].x, w0 = X.C0[i].x;
+            const uint32_t H0 = __builtin_amdgcn_ubfe(A8, X.sv[i], 1u) * w0 + __builtin_amdgcn_ubfe(A8, X.sv[i] + 1u, 1u) * w1;
+            const uint32_t H1 = __builtin_amdgcn_ubfe(B8, X.sv[i], 1u) * w0 + __builtin_amdgcn_ubfe(B8, X.sv[i] + 1u, 1u) * w1;
+            nib |= (wy0 * H0 + yc * H1 >= 65408u ? 1u : 0u) << i;
+        }
+    }
+    *o4 = X.over == 4 ? 0u : (v4 & (0xffffffffu >> (8 * X.over)));      // padding columns stay zero
+    *nbw = nib_gather8(nib & (0xfu >> X.over), lane);
+}
+
+// item index -> (row block, column group) without the generic 32-bit division: both are multiples of 16 apart from idx's low bits, the
+// divisor is at most 256, and a float quotient off by one is put right by the remainder
+__device__ __forceinline__ int pyr_div_groups(int idx, int groups)
+{
+    const int q = idx >> 4, d = groups >> 4;
+    int yb = (int)((float)q * __builtin_amdgcn_rcpf((float)d));
+    const int r = q - yb * d;
+    yb += r >= d ? 1 : (r < 0 ? -1 : 0);
+    return yb;
+}
+
+#ifndef PD_R
+#define PD_R 2
+#endif
 __global__ __launch_bounds__(256) void k_pyr_down_bits(uint8_t* __restrict__ pyr, bh_orb_geom g, int level, const uint32_t* __restrict__ tab,
                                                        uint32_t* __restrict__ mbits)
 {
     const bh_level_geom S = g.lv[level - 1], D = g.lv[level];
     const int groups = D.pitch >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    int yb;
-    {   // idx / groups without the generic 32-bit division sequence: both are multiples of 16 apart from idx's low bits, the divisor is
-        // at most 256, and a float quotient off by one is put right by the remainder
-        const int q = idx >> 4, d = groups >> 4;
-        yb = (int)((float)q * __builtin_amdgcn_rcpf((float)d));
-        const int r = q - yb * d;
-        yb += r >= d ? 1 : (r < 0 ? -1 : 0);
-    }
+    const int yb = pyr_div_groups(idx, groups);
     const int x = (idx - yb * groups) << 2, y0 = yb * PD_R;
-    if (y0 >= D.h) return;                                     // whole rows (pitch / 4 is a multiple of 16 lanes)
-    // wave-uniform 64-bit bases, 32-bit lane offsets: the loads and stores take the scalar-base + vector-offset form instead of a 64-bit
-    // multiply-add per address on the vector ALU
+    if (y0 >= D.h) return;                                     // whole rows (pitch / 4 is a multiple of 16 lanes: DPP rows leave together)
+    // wave-uniform 64-bit bases, 32-bit lane offsets: the loads and stores take the scalar-base + vector-offset form
     const uint8_t* __restrict__ src = pyr + (size_t)blockIdx.y * g.pyr_stride + S.off;
     uint8_t* __restrict__ dst = pyr + (size_t)blockIdx.y * g.pyr_stride + D.off;
-    const int over = min(max(x + 4 - D.w, 0), 4);              // outputs of this lane beyond the row
-    const int xc = over == 4 ? 0 : x;
-    const uint4 tx4 = *reinterpret_cast<const uint4*>(tab + D.tabx_off + xc);
-    const uint32_t txs[4] = { tx4.x, tx4.y, tx4.z, tx4.w };
-    const int base = (int)(tx4.x >> 16);
     const uint32_t* __restrict__ ms = mbits + (size_t)blockIdx.y * g.mstride + S.moff;
     uint32_t* __restrict__ md = mbits + (size_t)blockIdx.y * g.mstride + D.moff;
-    const uint32_t mcol = (uint32_t)base >> 5;
-    unsigned long long A[PD_R], Bv[PD_R];
-    uint32_t A8[PD_R], B8[PD_R], yc[PD_R];
+    pyr_xs X;
+    pyr_xsetup(X, D, tab, x);
+    pyr_ld L[PD_R]; uint32_t yc[PD_R];
 #pragma unroll
-    for (int k = 0; k < PD_R; k++) {
-        const int y = min(y0 + k, D.h - 1);                    // rows beyond the level repeat the last one and are not stored
-        const uint32_t ty = tab[D.taby_off + y];
-        const int r0 = ty >> 16, r1 = min(r0 + 1, S.h - 1);
+    for (int k = 0; k < PD_R; k++) {                            // all loads of the PD_R rows before the first store (same pointer: they would serialise)
+        const uint32_t ty = tab[D.taby_off + min(y0 + k, D.h - 1)];      // rows beyond the level repeat the last one and are not stored
+        const int r0 = (int)(ty >> 16), r1 = min(r0 + 1, S.h - 1);
         yc[k] = ty & 0xffffu;
-        A[k] = pyr_load8(src, (uint32_t)(r0 * S.pitch + base)); Bv[k] = pyr_load8(src, (uint32_t)(r1 * S.pitch + base));
-        const uint32_t o0 = (uint32_t)(r0 * S.mpitch) + mcol, o1 = (uint32_t)(r1 * S.mpitch) + mcol;
-        A8[k] = __builtin_amdgcn_alignbit(ms[o0 + 1], ms[o0], (uint32_t)base & 31u); B8[k] = __builtin_amdgcn_alignbit(ms[o1 + 1], ms[o1], (uint32_t)base & 31u);
+        pyr_load(L[k], src, ms, S, X, r0, r1);
     }
-    uint32_t o4[PD_R], nb[PD_R];
-    // both source rows of a pixel ride in the two 16-bit halves of one register through the horizontal pass: (p0 << 8) + c1 (p1 - p0)
-    // stays below 2^16, so modular 16-bit arithmetic (v_pk_sub / v_pk_mad_u16) is exact; v_perm builds the (row 0, row 1) byte pairs
-    typedef unsigned short pd_us2 __attribute__((ext_vector_type(2)));
-    uint32_t shv[4]; pd_us2 C1[4];
+    uint32_t o4[PD_R], nbw[PD_R];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t tx = txs[i], c1 = tx & 0xffffu;
-        shv[i] = (((tx >> 16) - (uint32_t)base) & 7u) << 3;
-        C1[i] = pd_us2{ (unsigned short)c1, (unsigned short)c1 };
-    }
-#pragma unroll
-    for (int k = 0; k < PD_R; k++) {
-        uint32_t nib = 0, r[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t pa = (uint32_t)(A[k] >> shv[i]), pb = (uint32_t)(Bv[k] >> shv[i]);
-            const pd_us2 P0 = __builtin_bit_cast(pd_us2, __builtin_amdgcn_perm(pb, pa, 0x0c040c00u)), P1 = __builtin_bit_cast(pd_us2, __builtin_amdgcn_perm(pb, pa, 0x0c050c01u));
-            const pd_us2 P0s = __builtin_bit_cast(pd_us2, __builtin_amdgcn_perm(pb, pa, 0x040c000cu));
-            const uint32_t H = __builtin_bit_cast(uint32_t, (pd_us2)(C1[i] * (pd_us2)(P1 - P0) + P0s));
-            const int h0 = (int)(H & 0xffffu), h1 = (int)(H >> 16);
-            r[i] = (uint32_t)((h0 << 8) + 32768 + (int)yc[k] * (h1 - h0));       // result byte = bits 16..23
-        }
-        const uint32_t v4 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(r[3], r[2], 0x0c0c0602u), __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0602u), 0x05040100u);
-        const uint32_t both = A8[k] & B8[k] & 0x3fu, any = (A8[k] | B8[k]) & 0x3fu;
-        if (both == 0x3fu) nib = 0xfu;
-        else if (any) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t tx = txs[i];
-                const uint32_t sh = ((tx >> 16) - (uint32_t)base) & 7u, c1 = tx & 0xffffu;
-                const uint32_t a2 = (A8[k] >> sh) & 3u, b2 = (B8[k] >> sh) & 3u;
-                const uint32_t H0 = (a2 & 1u) * (256u - c1) + (a2 >> 1) * c1, H1 = (b2 & 1u) * (256u - c1) + (b2 >> 1) * c1;
-                nib |= ((256u - yc[k]) * H0 + yc[k] * H1 >= 65408u ? 1u : 0u) << i;
-            }
-        }
-        o4[k] = over == 4 ? 0u : (v4 & (0xffffffffu >> (8 * over)));      // padding columns stay zero
-        nb[k] = nib_gather8(nib & (0xfu >> over), threadIdx.x);
-    }
+    for (int k = 0; k < PD_R; k++) pyr_row(L[k], X, yc[k], threadIdx.x, &o4[k], &nbw[k]);
 #pragma unroll
     for (int k = 0; k < PD_R; k++) {
         const int y = y0 + k;
         if (y < D.h) {
             *reinterpret_cast<uint32_t*>(dst + (uint32_t)(y * D.pitch + x)) = o4[k];
-            if ((threadIdx.x & 7) == 7) md[(uint32_t)(y * D.mpitch + (x >> 5))] = nb[k];
+            if ((threadIdx.x & 7) == 7) md[(uint32_t)(y * D.mpitch + (x >> 5))] = nbw[k];
         }
     }
 }
@@ -436,25 +499,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // The tile's halo outside the level image is filled by reflection (BORDER_REFLECT_101, what the 7x7 blur below needs; FAST never
     // scores a pixel whose ring leaves the image).  Words inside the image are one aligned load; the few that straddle or lie
     // just beyond the left / right border gather their 4 bytes; anything further than 8 px beyond the border is never read.
-    constexpr int NLD = (FPX_H * FRW + 255) / 256;
+    // Lane -> (row r0 + 7 j, word c) with r0 = tid / 34, c = tid % 34: one division per lane instead of one per load (238 of the 256
+    // lanes load; six rounds cover the 40 rows).
+    constexpr int NLD = (FPX_H + 6) / 7;
     uint32_t pw[NLD];
+    const int lr0 = tid / FRW, lc = tid - lr0 * FRW;
+    const bool ldl = tid < 7 * FRW;
     const bool interior = x0 >= 4 && x0 + TILE_W + 4 <= L.w && y0 >= 4 && y0 + TILE_H + 4 <= L.h;      // 37 % of the tiles at 640 x 480
     if (interior) {                                              // halo and all inside the level: plain aligned word loads
-        const uint8_t* org = img + (size_t)(y0 - 4) * L.pitch + (x0 - 4);
+        const uint8_t* org = img + (size_t)(y0 - 4) * L.pitch + (x0 - 4) + 4 * lc;
 #pragma unroll
         for (int j = 0; j < NLD; j++) {
-            const int i = min(tid + 256 * j, FPX_H * FRW - 1);
-            const int r = i / FRW, c = i - r * FRW;
-            pw[j] = *reinterpret_cast<const uint32_t*>(org + r * L.pitch + 4 * c);
+            const int r = min(lr0 + 7 * j, FPX_H - 1);
+            pw[j] = *reinterpret_cast<const uint32_t*>(org + r * L.pitch);
         }
     } else
 #pragma unroll
     for (int j = 0; j < NLD; j++) {
-        const int i = tid + 256 * j;
-        const int r = i / FRW, c = i - r * FRW;
-        const int y = y0 - 4 + r, x = x0 - 4 + c * 4;
+        const int r = lr0 + 7 * j;
+        const int y = y0 - 4 + r, x = x0 - 4 + lc * 4;
         uint32_t v = 0;
-        if (i < FPX_H * FRW && y < L.h + 8 && x >= 0 && x + 3 < L.w) v = *reinterpret_cast<const uint32_t*>(img + (size_t)reflect101(y, L.h) * L.pitch + x);
+        if (ldl && r < FPX_H && y < L.h + 8 && x >= 0 && x + 3 < L.w) v = *reinterpret_cast<const uint32_t*>(img + (size_t)reflect101(y, L.h) * L.pitch + x);
         pw[j] = v;
     }
     // The words that straddle or lie just beyond the left / right border (one on the left, at most three on the right, per row) are
@@ -493,25 +558,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (int i = tid; i < FITEMS; i += 256) s_scw[i] = 0;
 #pragma unroll
     for (int j = 0; j < NLD; j++) {
-        const int i = tid + 256 * j;
-        const int r = i / FRW, c = i - r * FRW;
-        if (i < FPX_H * FRW) s_px[r * FPW + 1 + c] = pw[j];
+        const int r = lr0 + 7 * j;
+        if (ldl && r < FPX_H) s_px[r * FPW + 1 + lc] = pw[j];
     }
     __syncthreads();
     if (xedge) { if (fixi >= 0) s_px[fixi] = fixv; __syncthreads(); }
 
     const uint8_t* px = reinterpret_cast<const uint8_t*>(s_px);
     uint8_t* s_sc = reinterpret_cast<uint8_t*>(s_scw);
+#if defined(FAST_STOP) && FAST_STOP == 1      // diagnostic builds (tools/fast_phases.sh): where does the kernel's time go
+    if (s_px[tid] == 0x12345678u) status[1] = 1;
+    return;
+#endif
     // ---- phase 1
+    // Lane -> (score row sy0 + 7 it, word w) with sy0 = tid / 36, w = tid % 36 (252 lanes, five rounds): the word's column mask is
+    // loaded once, no division per item.  A lane collects the verdicts of its <= 20 pixels in one register (bit 8 k + it = pixel k of
+    // round it) and reserves its list entries with ONE LDS atomic; the entries are written by a loop over the set bits (about one per
+    // lane: ~5 % of the pixels pass) instead of four predicated blocks per item.
     {
         const fs2 T = fs2{ (short)thr, (short)thr };
+        const int sy0 = tid / FPW, w = tid - sy0 * FPW;
+        const uint32_t vmw = tid < 7 * FPW ? s_vm[w] : 0u;
+        uint32_t M = 0;
 #pragma unroll
-        for (int it = 0; it < (FITEMS + 255) / 256; it++) {
-            const int i = tid + 256 * it;
-            const int sy = i / FPW, w = i - sy * FPW;
+        for (int it = 0; it < (FSC_H + 6) / 7; it++) {
+            const int sy = sy0 + 7 * it;
             const int y = y0 - 1 + sy;
-            const uint32_t vm = (sy < FSC_H && y >= ylo && y <= yhi) ? s_vm[w] : 0u;
-            const uint32_t* cw = s_px + min(i, FITEMS - 1) + 3 * FPW;
+            const uint32_t vm = (sy < FSC_H && y >= ylo && y <= yhi) ? vmw : 0u;
+            const uint32_t* cw = s_px + min(sy, FSC_H - 1) * FPW + w + 3 * FPW;
             const uint32_t W0 = cw[0], Wm = cw[-1], Wp = cw[1], U = cw[-3 * FPW], D = cw[3 * FPW];
             // packed 16-bit operand pairs: pixels (0,1) and (2,3) of the word; left = pixel - 3, right = pixel + 3
             const fs2 C0 = fpk(0, W0, 0x0c010c00u), C1 = fpk(0, W0, 0x0c030c02u);
@@ -523,24 +597,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const fs2 dk1 = fmx(fmn(D1, U1), fmn(R1, L1)), br1 = fmn(fmx(D1, U1), fmx(R1, L1));
             const fs2 m0 = ((dk0 + T) - C0) | ((C0 + T) - br0);    // negative <=> darker pair below v - thr, or brighter pair above v + thr
             const fs2 m1 = ((dk1 + T) - C1) | ((C1 + T) - br1);
-            uint32_t P = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, m1), __builtin_bit_cast(uint32_t, m0), 0x07050301u) & vm;
-            if (P) {
-                int pos = lds_add_rtn(&s_n, __popc(P));              // same-address LDS atomic from the few lanes that have survivors
-#ifdef FAST_APPEND_LOOP
-                do {                                                 // 1.1 survivors per non-empty word on average
-                    const int k = (__ffs(P) - 1) >> 3;
-                    if (pos < FLIST_CAP) s_list[pos] = (uint16_t)(4 * i + k);           // byte index into the score tile
-                    pos++;
-                    P &= P - 1;
-                } while (P);
-#else
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (P & (0x80u << (8 * k))) { if (pos < FLIST_CAP) s_list[pos] = (uint16_t)(4 * i + k); pos++; }   // byte index into the score tile
-#endif
-            }
+            const uint32_t P = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, m1), __builtin_bit_cast(uint32_t, m0), 0x07050301u) & vm;
+            M |= P >> (7 - it);                                      // vm leaves only the sign bits 7, 15, 23, 31
+        }
+        if (M) {
+            int pos = lds_add_rtn(&s_n, __popc(M));
+            const int b0 = 4 * (sy0 * FPW + w);
+            do {
+                const int q = __ffs(M) - 1;
+                M &= M - 1;
+                if (pos < FLIST_CAP) s_list[pos] = (uint16_t)(b0 + (q & 7) * (4 * 7 * FPW) + (q >> 3));      // byte index into the score tile
+                pos++;
+            } while (M);
         }
     }
     __syncthreads();
+#if defined(FAST_STOP) && FAST_STOP == 2
+    if (s_n == 0x12345678) status[1] = 1;
+    return;
+#endif
     // ---- phase 2
     // More survivors than the list holds (more than half of the tile: noise): the list is dropped and EVERY pixel of the score tile
     // takes the full ring test, filtered by the same validity mask as phase 1 - the pretest is only a necessary condition of that
@@ -556,19 +631,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const int sy = b / FROW, xb = b - sy * FROW, y = y0 - 1 + sy;
             if (!(y >= ylo && y <= yhi && ((s_vm[xb >> 2] >> (8 * (xb & 3))) & 0x80u))) continue;
         } else b = s_list[j];
+        // The ring as 8 registers (ring[k] | ring[k + 8] << 16): one v_lshl_or per pair, then the 16 differences are 8 packed subtractions.
+        // (ds_read_u8_d16 / _d16_hi would fill the halves for free, but with SRAM ECC on - gfx950 - a d16 load clears the other half.)
         const uint8_t* c = px + b + 3 * FROW;
-        const int v = c[0];
-        int d[16];
-        d[0] = v - c[3 * FROW];       d[1] = v - c[3 * FROW + 1];   d[2] = v - c[2 * FROW + 2];   d[3] = v - c[FROW + 3];
-        d[4] = v - c[3];              d[5] = v - c[-FROW + 3];      d[6] = v - c[-2 * FROW + 2];  d[7] = v - c[-3 * FROW + 1];
-        d[8] = v - c[-3 * FROW];      d[9] = v - c[-3 * FROW - 1];  d[10] = v - c[-2 * FROW - 2]; d[11] = v - c[-FROW - 3];
-        d[12] = v - c[-3];            d[13] = v - c[FROW - 3];      d[14] = v - c[2 * FROW - 2];  d[15] = v - c[3 * FROW - 1];
+        const uint32_t vc = c[0];
+        const fs2 VV = __builtin_bit_cast(fs2, vc | (vc << 16));
+        fs2 R8[8];
+        R8[0] = __builtin_bit_cast(fs2, (uint32_t)c[3 * FROW]      | ((uint32_t)c[-3 * FROW] << 16));
+        R8[1] = __builtin_bit_cast(fs2, (uint32_t)c[3 * FROW + 1]  | ((uint32_t)c[-3 * FROW - 1] << 16));
+        R8[2] = __builtin_bit_cast(fs2, (uint32_t)c[2 * FROW + 2]  | ((uint32_t)c[-2 * FROW - 2] << 16));
+        R8[3] = __builtin_bit_cast(fs2, (uint32_t)c[FROW + 3]      | ((uint32_t)c[-FROW - 3] << 16));
+        R8[4] = __builtin_bit_cast(fs2, (uint32_t)c[3]             | ((uint32_t)c[-3] << 16));
+        R8[5] = __builtin_bit_cast(fs2, (uint32_t)c[-FROW + 3]     | ((uint32_t)c[FROW - 3] << 16));
+        R8[6] = __builtin_bit_cast(fs2, (uint32_t)c[-2 * FROW + 2] | ((uint32_t)c[2 * FROW - 2] << 16));
+        R8[7] = __builtin_bit_cast(fs2, (uint32_t)c[-3 * FROW + 1] | ((uint32_t)c[3 * FROW - 1] << 16));
         // Packed 16-bit lanes: P[k] = (d[k], d[k+8]); the ring rotated by j is P[k+j], with P[8+i] = swap(P[i]).
         // A = max over the 16 arcs of min(d over 9 ring pixels), Bn = min over arcs of max(d): the pixel is a corner iff
         // A > thr or -Bn > thr, and its score (cornerScore<16>) is max(thr, A, -Bn) - 1.
         fs2 P[8], mn[8], mx[8], t0[8], t1[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) P[k] = fs2{ (short)d[k], (short)d[k + 8] };
+        for (int k = 0; k < 8; k++) P[k] = VV - R8[k];
 #pragma unroll
         for (int k = 0; k < 8; k++) { const fs2 nx = k < 7 ? P[k + 1] : fswap(P[0]); mn[k] = fmn(P[k], nx); mx[k] = fmx(P[k], nx); }
 #pragma unroll
@@ -589,6 +671,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         s_sc[b] = (uint8_t)(-b0 - 1);
     }
     __syncthreads();
+#if defined(FAST_STOP) && FAST_STOP == 3
+    if (s_scw[tid] == 0x12345678u) status[1] = 1;
+    return;
+#endif
     // ---- 7x7 sigma-2 Gaussian of the tile from the same LDS pixels (integer kernel, (sum + 32768) >> 16; the descriptor's input),
     // ON THE MATRIX CORES.  A separable convolution is two products with banded Toeplitz matrices, and v_mfma_i32_32x32x32_i8 does a
     // 32 x 32 x 32 block of one in 32 cycles - 95 % of the taps it multiplies are zeros and it still frees the vector ALU, which is
@@ -631,6 +717,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
             }
         }
+        asm volatile("" ::: "memory");                             // keep the pass-2 tap loads below pass 1 (hoisted, they cost a spilled register quad)
         const fv4 P2B0 = gt[128], P2B1 = gt[192];
         fv16 accH = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
         accH = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi[0], P2B0, accH, 0, 0, 0);
@@ -659,6 +746,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
     }
     __syncthreads();                                            // the pixel tile is dead from here on: s_out takes its place
+#if defined(FAST_STOP) && FAST_STOP == 4
+    return;
+#endif
     // ---- phase 3: kept corners are staged in LDS as (score << 24) | (score-tile byte index), then the tile reserves its
     // range of the level's corner list with ONE global atomic (a returning atomic per wave was measured 35 % slower: every wave
     // then waits out an L2 round trip on a counter all tiles of the level contend for)
