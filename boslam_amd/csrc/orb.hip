@@ -443,6 +443,7 @@ __device__ __forceinline__ int reflect101(int i, int n)
 #define FROW  (4 * FPW)         // bytes per LDS row (144)
 #define FITEMS (FSC_H * FPW)    // 1224 (item, word) pairs of the score tile
 #define FLIST_CAP (2 * FITEMS)   // candidate list entries: half of the score tile's pixels
+#define FCL_CAP 1536             // corner list entries (more: phase 3 walks the candidate list instead)
 
 typedef short fs2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ fs2 fswap(fs2 a) { return fs2{ a.y, a.x }; }
@@ -467,9 +468,10 @@ __device__ __forceinline__ fs2 fpk(uint32_t hi_src, uint32_t lo_src, uint32_t se
 //   phase 2  full 16-pixel ring on the survivors: score = largest threshold at which the pixel is still a corner, by a packed
 //            doubling min/max tree over the 16 arcs; corners write their score into a sparse LDS score tile.
 //   phase 3  the same list again: strict 3x3 NMS against the score tile, border and mask filter; kept corners are appended to the
-//            level's corner list in HBM (one reservation per tile) and counted in the score histogram.  No dense score map exists.
+//            level's corner list in HBM (one reservation per tile).  No dense score map exists; the score histogram retainBest needs is
+//            built by k_select from the list (round 2 added ~60 global atomics per tile for it here).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ mpyr,
-                                              uint2* __restrict__ clist, int* __restrict__ ccnt, uint32_t* __restrict__ hist,
+                                              uint2* __restrict__ clist, int* __restrict__ ccnt,
                                               uint8_t* __restrict__ blur,
                                               bh_orb_geom g, const uint32_t* __restrict__ tile_tab, uint32_t* __restrict__ status,
                                               const uint32_t* __restrict__ mbits, const uint32_t* __restrict__ gtab)
@@ -482,10 +484,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ uint32_t s_mask[TILE_H * (TILE_W / 32)];         // the tile of the bit-packed mask (no HBM round trip in phase 3)
     __shared__ uint32_t s_scw[FITEMS];
     __shared__ uint16_t s_list[FLIST_CAP];
-    __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_vm[FPW];
+    __shared__ uint16_t s_cl[FCL_CAP];                          // the candidates phase 2 found to be corners: phase 3 walks these, not the whole candidate list
     uint32_t* const s_out = s_px;                               // kept corners (phase 3): strict 3x3 maxima, at most one per 2x2 block = 1024 <= FPX_H * FPW
-    __shared__ int s_n, s_k, s_base;
+    __shared__ int s_n, s_k, s_base, s_c;
 
     const int tid = threadIdx.x;
     const uint32_t tt = tile_tab[blockIdx.x];                   // level | tile column << 4 | tile row << 16 (host-built: no per-wave level search / division)
@@ -547,9 +549,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // [et-1, dim-et] intersected with the detector's own scan range [3, dim-4], and the tile's score columns x0-1 .. x0+128.
     const int xlo = max(max(3, et - 1), x0 - 1), xhi = min(min(L.w - 4, L.w - et), x0 + TILE_W);
     const int ylo = max(3, et - 1), yhi = min(L.h - 4, L.h - et);
-    s_hist[tid] = 0;
     if (tid < TILE_H * (TILE_W / 32)) s_mask[tid] = mw;
-    if (tid == 0) { s_n = 0; s_k = 0; }
+    if (tid == 0) { s_n = 0; s_k = 0; s_c = 0; }
     if (tid < FPW) {                                             // per tile word: 0x80 in the bytes whose pixel is in [xlo, xhi]; pads 0
         const int xb = x0 - 8 + 4 * tid;
         const int lo = min(max(xlo - xb, 0), 4), hi = min(max(xhi - xb + 1, 0), 4);
@@ -669,6 +670,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int a0 = max(thr, A);
         const int b0 = min(Bn, -a0);
         s_sc[b] = (uint8_t)(-b0 - 1);
+        const int cp = atomicAdd(&s_c, 1);                        // (one LDS atomic per wave: the compiler aggregates a uniform increment)
+        if (cp < FCL_CAP) s_cl[cp] = (uint16_t)b;
     }
     __syncthreads();
 #if defined(FAST_STOP) && FAST_STOP == 3
@@ -752,8 +755,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // ---- phase 3: kept corners are staged in LDS as (score << 24) | (score-tile byte index), then the tile reserves its
     // range of the level's corner list with ONE global atomic (a returning atomic per wave was measured 35 % slower: every wave
     // then waits out an L2 round trip on a counter all tiles of the level contend for)
-    for (int j = tid; j < n; j += 256) {
-        const int b = ovf ? j : s_list[j];
+    const int nc = s_c;
+    const bool cl = nc <= FCL_CAP;                              // corners listed: ~60 % of the candidates; otherwise walk the candidates as before
+    const int n3 = cl ? nc : n;
+    for (int j = tid; j < n3; j += 256) {
+        const int b = cl ? s_cl[j] : (ovf ? j : s_list[j]);
         const int sc = s_sc[b];
         if (sc == 0) continue;
         const int sy = b / FROW, xb = b - sy * FROW;
@@ -768,13 +774,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         else if (mpyr && mpyr[fbase + (size_t)y * L.pitch + x] == 0) continue;
         const int k = atomicAdd(&s_k, 1);
         s_out[k] = ((uint32_t)sc << 24) | (uint32_t)b;
-        atomicAdd(&s_hist[sc], 1u);
     }
     __syncthreads();
     const int kk = s_k;
     const size_t lv = (size_t)frame * g.nlevels + level;
     if (tid == 0 && kk) s_base = atomicAdd(&ccnt[lv], kk);
-    if (s_hist[tid]) atomicAdd(&hist[lv * 256 + tid], s_hist[tid]);
     __syncthreads();
     if (kk) {
         const int base = s_base;
@@ -854,7 +858,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 // Output: the level's kept keypoints in raster order in a staging slot sel_xy/sel_resp[frame][level][sel_cap] + sel_cnt[frame][level];
 // k_describe turns slots into final keypoints.
 __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_select(const uint8_t* __restrict__ pyr, const uint2* __restrict__ clist,
-                                                  const int* __restrict__ ccnt, const uint32_t* __restrict__ hist, bh_orb_geom g,
+                                                  const int* __restrict__ ccnt, bh_orb_geom g,
                                                   int sel_cap, uint32_t* __restrict__ sel_xy, float* __restrict__ sel_resp,
                                                   int* __restrict__ sel_cnt, uint32_t* __restrict__ status)
 {
@@ -870,8 +874,12 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const bh_level_geom L = g.lv[level];
     const int n2 = 2 * L.nfeat;
     // (a) retainBest(2 n_l) threshold on the u8 FAST score: largest s with #(score >= s) >= 2 n_l
-    if (tid < 256) s_hs[tid] = hist[(f * g.nlevels + level) * 256 + tid];
+    const uint2* lst = clist + f * (size_t)g.list_stride + L.list_off;
+    const int nc = min(ccnt[f * g.nlevels + level], L.list_cap);
+    if (tid < 256) s_hs[tid] = 0;
     if (tid == 0) { s_thr = 1; s_m = 0; s_kept = 0; }
+    __syncthreads();
+    for (int i = tid; i < nc; i += SEL_T) atomicAdd(&s_hs[lst[i].y & 255u], 1u);      // score histogram of the level's corners
     __syncthreads();
     if (tid >= 1 && tid < 256) {
         uint32_t suf = 0;
@@ -882,8 +890,6 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     __syncthreads();
     const uint32_t thr = n2 > 0 ? (uint32_t)s_thr : 256u;
     // (b) the corners at or above the threshold (ties at the cut all kept), in whatever order the list has them
-    const uint2* lst = clist + f * (size_t)g.list_stride + L.list_off;
-    const int nc = min(ccnt[f * g.nlevels + level], L.list_cap);
     for (int i = tid; i < nc; i += SEL_T) {
         const uint2 r = lst[i];
         if (r.y >= thr) { const int pos = atomicAdd(&s_m, 1); if (pos < CAND_CAP) s_xy[pos] = r.x; }
@@ -1369,7 +1375,7 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         uint32_t* hist = (uint32_t*)Wk.hist.p;
         int* ccnt = (int*)(hist + (size_t)256 * g.nlevels * chunk);
 
-        BH_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(uint32_t) * 257 * g.nlevels * chunk, st));
+        BH_HIP(ctx, hipMemsetAsync(ccnt, 0, sizeof(int) * g.nlevels * chunk, st));
         {
             const int n = (g.lv[0].pitch >> 2) * g.lv[0].h;
             BH_LAUNCH(ctx, BH_K_GRAY, k_gray_mask, dim3((n + 255) / 256, nb), dim3(256), st, d_img, channels, d_mask, d_depth,
@@ -1384,10 +1390,10 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
                 BH_LAUNCH(ctx, BH_K_PYR, k_pyr_down, dim3((n + 255) / 256, nb), dim3(256), st, pyr, mpyr, g, l, (const uint32_t*)ctx->tab.p);
             }
         }
-        BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, clist, ccnt, hist, blur, g,
+        BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, clist, ccnt, blur, g,
                   (const uint32_t*)ctx->tab.p + g.tab_len + 4, (uint32_t*)ctx->status.p, (const uint32_t*)mbits,
                   (const uint32_t*)ctx->tab.p + align_up(g.tab_len + 4 + g.ntiles + 64, 4));
-        BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, clist, ccnt, hist, g, sel_cap, (uint32_t*)Wk.sel_xy.p,
+        BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, clist, ccnt, g, sel_cap, (uint32_t*)Wk.sel_xy.p,
                   (float*)Wk.sel_resp.p, (int*)Wk.sel_cnt.p, (uint32_t*)ctx->status.p);
         BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3((max_kp + 63) / 64, nb), dim3(256), st, pyr, blur, g, (const uint32_t*)ctx->tab.p + g.tab_len + 4 + g.ntiles,
                   (float)params->patchSize, sel_cap, max_kp, (const uint32_t*)Wk.sel_xy.p, (const float*)Wk.sel_resp.p,
