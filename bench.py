@@ -362,7 +362,14 @@ def run_rank(args):
 
     if not args.no_ba:                                        # local BA / tracking do not shard: one replica per rank, values summed
         from boslam_amd import ba_bench, track_bench
-        for name, fn in (("local_ba", lambda: ba_bench.run(ctx, dev)), ("tracking", lambda: track_bench.run(ctx))):
+        def local_ba():
+            r = ba_bench.run(ctx, dev)
+            if rank == 0:                                       # W windows in one batch (bh_ba_batch_optimize): the replicas of SURVEY 8(e) inside one GPU
+                r["batched"] = {"configs2_windows": ba_bench.run_batch(ctx, W=64, repeats=2),
+                                "live_windows": ba_bench.run_batch(ctx, W=64, n_kf=10, n_pts=600, iters=7, repeats=2,
+                                                                   label="live size (slam/covisibility_graph.py:220: 7 iterations, ~10 keyframes x 600 map points)")}
+            return r
+        for name, fn in (("local_ba", local_ba), ("tracking", lambda: track_bench.run(ctx))):
             stage["name"] = name
             try:
                 res = fn()

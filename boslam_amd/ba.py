@@ -99,6 +99,35 @@ class LocalBA:
             pass
 
 
+class LocalBABatch:
+    """bh_ba_batch: W LocalBA windows (each with a problem set) optimised together, every kernel of a Levenberg trial launched once
+    for all windows (slam/local_mapping.py:46-47 runs one window at a time).  Results are read from the windows as usual."""
+
+    def __init__(self, ctx, windows):
+        self.ctx = ctx
+        self.windows = list(windows)
+        arr = (C.c_void_p * len(self.windows))(*[w.h for w in self.windows])
+        h = C.c_void_p()
+        ctx.check(_lib.lib().bh_ba_batch_create(ctx.h, len(self.windows), arr, C.byref(h)))
+        self.h = h
+
+    def optimize(self, iters=20, huber_delta=HUBER_DELTA, verbose_errors=True):
+        done = np.zeros(len(self.windows), np.int32)
+        self.ctx.check(_lib.lib().bh_ba_batch_optimize(self.h, int(iters), float(huber_delta), 1 if verbose_errors else 0, _lib.ptr(done)))
+        return done
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().bh_ba_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------------------------------------- multi-GPU global BA
 _AR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int)
 

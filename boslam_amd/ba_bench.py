@@ -70,6 +70,51 @@ def run(ctx, dev=None, repeats=5):
     return out
 
 
+def run_batch(ctx, W=64, n_kf=50, n_pts=10000, iters=10, repeats=3, n_distinct=8, label="configs[2]"):
+    """W local windows optimised together (bh_ba_batch_optimize): aggregate LM iterations/s, and the same windows one after the other
+    through bh_ba_optimize for the ratio.  The windows cycle through `n_distinct` different problems of the given size."""
+    probs = [synth.ba_problem(n_kf=n_kf, n_pts=n_pts, seed=7 + k) for k in range(n_distinct)]
+    wins = [ba.LocalBA(ctx, probs[w % n_distinct]["K"]) for w in range(W)]
+
+    def set_all():
+        for w, s in enumerate(wins):
+            pr = probs[w % n_distinct]
+            s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+    batch = ba.LocalBABatch(ctx, wins)
+    t_set, t_opt, done = [], [], None
+    for r in range(repeats + 1):
+        ctx.synchronize(); t0 = time.perf_counter()
+        set_all()
+        ctx.synchronize(); t1 = time.perf_counter()
+        done = batch.optimize(iters)
+        ctx.synchronize(); t2 = time.perf_counter()
+        if r:
+            t_set.append(t1 - t0); t_opt.append(t2 - t1)
+    # one window at a time, same problems
+    t_one = []
+    for r in range(2):
+        set_all()
+        ctx.synchronize(); t0 = time.perf_counter()
+        for s in wins[:8]:
+            s.optimize(iters)
+        ctx.synchronize()
+        if r:
+            t_one.append((time.perf_counter() - t0) / 8)
+    tot = int(done.sum())
+    opt = float(np.median(t_opt)); st = float(np.median(t_set)); one = float(np.median(t_one))
+    chi = [float(s.log()[:int(done[w])][-1, 0]) for w, s in enumerate(wins[:n_distinct])]
+    out = {"metric": "local_ba_lm_iters_per_sec_batched", "windows": W, "workload": f"{label}: {W} windows of {n_kf} keyframes x {n_pts} landmarks x "
+           f"{len(probs[0]['ecam'])} observations, {iters} LM iterations each ({n_distinct} distinct problems)",
+           "value": round(tot / opt, 1), "unit": "iters/s", "ms_per_round": round(opt / max(int(done.max()), 1) * 1e3, 3),
+           "value_incl_set_problem": round(tot / (opt + st), 1), "set_problem_ms_per_window": round(st / W * 1e3, 3),
+           "single_window_iters_per_s": round(iters / one, 1), "speedup_vs_one_at_a_time": round((tot / opt) / (iters / one), 1),
+           "iters_done_min_max": [int(done.min()), int(done.max())], "final_robust_chi2_first_windows": chi}
+    batch.close()
+    for s in wins:
+        s.close()
+    return out
+
+
 def run_global(ctx, n_kf=5000, n_pts=500000, iters=5, window=20, dist=None, device=None):
     """BASELINE configs[4]: 5 000 keyframes x 500 k landmarks (~3.9 M observations, band +-2*window keyframes); with `dist`
     the landmarks are sharded over the ranks (strong scaling: the problem is fixed) and S / b~ are all-reduced over RCCL.

@@ -361,6 +361,8 @@ struct ba_state {                 // device-resident LM control block
     int qmax, accepted, again, terminate, chol_ok, pad;
     double red[4];                // partial sums handed to the all-reduce hook (multi-GPU global BA)
     long long dbg[8];             // k_ba_chol_sw phase clocks (bh_ba_debug_band_solve)
+    // batched local BA (bh_ba_batch_optimize): the Levenberg control flow of a window, kept on the device
+    int b_it, b_iters, b_need_lin, b_done, b_cur, b_last_err, b_verbose, b_fail;
 };
 
 struct bh_ba {
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(int nbp, const ba_cam* __r
 }
 
 #define BA_NPART 256
-__global__ __launch_bounds__(1024) void k_ba_partial(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxl,
+__device__ __forceinline__ void ba_partial_body(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxl,
                                                      const double* __restrict__ bl, int n3, const ba_state* __restrict__ S,
                                                      double* __restrict__ part)
 {
@@ -524,9 +526,15 @@ __global__ __launch_bounds__(1024) void k_ba_partial(const double* __restrict__ 
     d_block_sum<2, 1024>(v, s_red);
     if (tid == 0) { part[2 * b] = v[0]; part[2 * b + 1] = v[1]; }
 }
+__global__ __launch_bounds__(1024) void k_ba_partial(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxl,
+                                                     const double* __restrict__ bl, int n3, const ba_state* __restrict__ S,
+                                                     double* __restrict__ part)
+{
+    ba_partial_body(chi_e, Ea, dxl, bl, n3, S, part);
+}
 
 // ---- k_ba_prep: chi at the current state; lambda init on the first iteration
-__global__ __launch_bounds__(1024) void k_ba_prep(const double* __restrict__ chi_e, int Ea, const double* __restrict__ pdiag, int Pa,
+__device__ __forceinline__ void ba_prep_body(const double* __restrict__ chi_e, int Ea, const double* __restrict__ pdiag, int Pa,
                                                   const double* __restrict__ cdiag, int Cf, int first, int phase,
                                                   const double* __restrict__ part, ba_state* __restrict__ S)
 {
@@ -557,6 +565,12 @@ __global__ __launch_bounds__(1024) void k_ba_prep(const double* __restrict__ chi
         S->qmax = 0; S->accepted = 0; S->again = 0; S->terminate = 0; S->rho = 0; S->chol_ok = 1;
     }
 }
+__global__ __launch_bounds__(1024) void k_ba_prep(const double* __restrict__ chi_e, int Ea, const double* __restrict__ pdiag, int Pa,
+                                                  const double* __restrict__ cdiag, int Cf, int first, int phase,
+                                                  const double* __restrict__ part, ba_state* __restrict__ S)
+{
+    ba_prep_body(chi_e, Ea, pdiag, Pa, cdiag, Cf, first, phase, part, S);
+}
 
 __device__ __forceinline__ bool d_inv3(const double* m, double* o)
 {
@@ -570,7 +584,7 @@ __device__ __forceinline__ bool d_inv3(const double* m, double* o)
 }
 
 // ---- k_ba_dinv: per point (Hll + lambda I)^-1 and Dinv * bl
-__global__ __launch_bounds__(256) void k_ba_dinv(const double* __restrict__ Hll, const double* __restrict__ bl, int Pa,
+__device__ __forceinline__ void ba_dinv_body(const double* __restrict__ Hll, const double* __restrict__ bl, int Pa,
                                                  ba_state* __restrict__ S, double* __restrict__ Dinv, double* __restrict__ db)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -585,6 +599,11 @@ __global__ __launch_bounds__(256) void k_ba_dinv(const double* __restrict__ Hll,
     for (int i = 0; i < 9; i++) Dinv[9 * (size_t)j + i] = Di[i];
 #pragma unroll
     for (int a = 0; a < 3; a++) db[3 * j + a] = Di[3 * a] * bl[3 * j] + Di[3 * a + 1] * bl[3 * j + 1] + Di[3 * a + 2] * bl[3 * j + 2];
+}
+__global__ __launch_bounds__(256) void k_ba_dinv(const double* __restrict__ Hll, const double* __restrict__ bl, int Pa,
+                                                 ba_state* __restrict__ S, double* __restrict__ Dinv, double* __restrict__ db)
+{
+    ba_dinv_body(Hll, bl, Pa, S, Dinv, db);
 }
 
 // ---- k_ba_schur_S: workgroup per camera pair (s1 <= s2): S[s1][s2] = [s1==s2](Hpp + lambda I) - sum_j Hpl_1j Dinv_j Hpl_2j'
@@ -912,7 +931,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
 // leaves y = L^-1 g in yv; no backward pass.
 struct bcr_elim { int e, l, r, sl, sr; };            // block to eliminate, its chain neighbours (-1: none), the coupling slots (e x l), (e x r)
 template <bool BCR>
-__global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict__ A_, const double* __restrict__ bs_, int n, int bw,
+__device__ __forceinline__ void ba_chol_dense_body(const double* __restrict__ A_, const double* __restrict__ bs_, int n, int bw,
                                                         double* __restrict__ x, ba_state* __restrict__ St, const bcr_elim* __restrict__ el,
                                                         double* Dblk, const double* gv, double* yv)
 {
@@ -1168,6 +1187,13 @@ __global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict
     if (tid == 0) { St->dbg[0] = tkA - tk0; St->dbg[1] = tkB - tkA; St->dbg[2] = wall_clock64() - tkB; St->dbg[3] = tkW; St->dbg[4] = tkF; }
 #endif
 #undef CD_A
+}
+template <bool BCR>
+__global__ __launch_bounds__(1024) void k_ba_chol_dense(const double* __restrict__ A_, const double* __restrict__ bs_, int n, int bw,
+                                                        double* __restrict__ x, ba_state* __restrict__ St, const bcr_elim* __restrict__ el,
+                                                        double* Dblk, const double* gv, double* yv)
+{
+    ba_chol_dense_body<BCR>(A_, bs_, n, bw, x, St, el, Dblk, gv, yv);
 }
 
 // ---- k_ba_chol_sw: banded Cholesky with the whole trailing window ON CHIP (global-BA sizes: n >> bw, bw <= 256).
@@ -1968,7 +1994,7 @@ static int bcr_solve(bh_ctx* ctx, hipStream_t st, const bcr_dev* dv, const doubl
 }
 
 // ---- k_ba_update: trial state = current state (+) step.  blocks [0, pblocks): points (back-substitution); rest: cameras
-__global__ __launch_bounds__(256) void k_ba_update(const ba_cam* __restrict__ cams, ba_cam* __restrict__ cams_t,
+__device__ __forceinline__ void ba_update_body(const ba_cam* __restrict__ cams, ba_cam* __restrict__ cams_t,
                                                    const double* __restrict__ pts, double* __restrict__ pts_t,
                                                    const int* __restrict__ cslot, int C, int Pa, int pblocks,
                                                    const int* __restrict__ p_start, const int* __restrict__ p_edges,
@@ -2006,9 +2032,19 @@ __global__ __launch_bounds__(256) void k_ba_update(const ba_cam* __restrict__ ca
         cams_t[i] = c;
     }
 }
+__global__ __launch_bounds__(256) void k_ba_update(const ba_cam* __restrict__ cams, ba_cam* __restrict__ cams_t,
+                                                   const double* __restrict__ pts, double* __restrict__ pts_t,
+                                                   const int* __restrict__ cslot, int C, int Pa, int pblocks,
+                                                   const int* __restrict__ p_start, const int* __restrict__ p_edges,
+                                                   const int* __restrict__ e_cam, const double* __restrict__ Hpl,
+                                                   const double* __restrict__ Dinv, const double* __restrict__ bl,
+                                                   const double* __restrict__ dxp, double* __restrict__ dxl, ba_K K)
+{
+    ba_update_body(cams, cams_t, pts, pts_t, cslot, C, Pa, pblocks, p_start, p_edges, e_cam, Hpl, Dinv, bl, dxp, dxl, K);
+}
 
 // ---- k_ba_err: per-edge error and robust chi at the trial state
-__global__ __launch_bounds__(256) void k_ba_err(const ba_cam* __restrict__ cams, const double* __restrict__ pts,
+__device__ __forceinline__ void ba_err_body(const ba_cam* __restrict__ cams, const double* __restrict__ pts,
                                                 const int* __restrict__ e_cam, const int* __restrict__ e_pt,
                                                 const double* __restrict__ e_meas, int Ea, double delta,
                                                 double* __restrict__ err, double* __restrict__ chi_e)
@@ -2020,9 +2056,16 @@ __global__ __launch_bounds__(256) void k_ba_err(const ba_cam* __restrict__ cams,
     d_huber(er[0] * er[0] + er[1] * er[1], delta, &r0, &r1);
     err[2 * e] = er[0]; err[2 * e + 1] = er[1]; chi_e[e] = r0;
 }
+__global__ __launch_bounds__(256) void k_ba_err(const ba_cam* __restrict__ cams, const double* __restrict__ pts,
+                                                const int* __restrict__ e_cam, const int* __restrict__ e_pt,
+                                                const double* __restrict__ e_meas, int Ea, double delta,
+                                                double* __restrict__ err, double* __restrict__ chi_e)
+{
+    ba_err_body(cams, pts, e_cam, e_pt, e_meas, Ea, delta, err, chi_e);
+}
 
 // ---- k_ba_decide: Levenberg gain ratio and lambda schedule (OptimizationAlgorithmLevenberg::solve)
-__global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxp,
+__device__ __forceinline__ void ba_decide_body(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxp,
                                                     const double* __restrict__ bp, int n6, const double* __restrict__ dxl,
                                                     const double* __restrict__ bl, int n3, int phase, int cam_part,
                                                     const double* __restrict__ part, ba_state* __restrict__ S, ba_state* host_out, int seq)
@@ -2067,6 +2110,147 @@ __global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ c
             __threadfence_system();
             __atomic_store_n(&host_out->pad, seq, __ATOMIC_RELEASE);
         }
+    }
+}
+__global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxp,
+                                                    const double* __restrict__ bp, int n6, const double* __restrict__ dxl,
+                                                    const double* __restrict__ bl, int n3, int phase, int cam_part,
+                                                    const double* __restrict__ part, ba_state* __restrict__ S, ba_state* host_out, int seq)
+{
+    ba_decide_body(chi_e, Ea, dxp, bp, n6, dxl, bl, n3, phase, cam_part, part, S, host_out, seq);
+}
+
+// ================================================================================================ batched local BA
+// W independent windows (different sizes) advance in lockstep: one launch of every kernel per Levenberg trial covers all of them,
+// gridded over (item, window); the window's arrays come from a descriptor (ba_view), its control flow - which state buffer is current,
+// whether the next round starts a new iteration (linearisation) or retries with a larger lambda, when it is finished - lives in its
+// ba_state on the device.  The kernels are the bodies of the single-window kernels, so a window's result is bitwise the one
+// bh_ba_optimize gives.  slam/local_mapping.py:46-47 optimises one window at a time; SURVEY 8(e) "replicas only".
+struct ba_view {
+    ba_cam* cams[2]; double* pts[2];
+    const int *e_cam, *e_pt; const double* e_meas; const int* cslot;
+    const int *p_start, *p_edges, *c_start, *c_edges;
+    double *err[2], *chi_e[2];
+    double *Hpl, *Hll, *bl, *Hpp, *bp, *pdiag, *cdiag, *Dinv, *db, *S, *bs, *dxp, *dxl, *part;
+    const int2* pairs; const int* j_start; const int2* join;
+    ba_state* state; ba_state* hstate;
+    int C, Cf, Pa, Ea, npairs, bw, n6, pad;
+    ba_K K;
+};
+
+__global__ void k_bb_init(const ba_view* __restrict__ views, int W, int iters, int verbose)
+{
+    const int w = blockIdx.x * 64 + threadIdx.x;
+    if (w >= W) return;
+    ba_state* S = views[w].state;
+    S->b_it = 0; S->b_iters = iters; S->b_need_lin = 1; S->b_done = (views[w].Ea == 0 || iters <= 0) ? 1 : 0; S->b_last_err = 0; S->b_verbose = verbose; S->b_fail = 0;
+}
+__global__ void k_bb_setcur(const ba_view* __restrict__ views, const int* __restrict__ cur, int W)
+{
+    const int w = blockIdx.x * 64 + threadIdx.x;
+    if (w < W) views[w].state->b_cur = cur[w];
+}
+
+__global__ __launch_bounds__(256) void k_bb_linearize(const ba_view* __restrict__ views, double delta)
+{
+    const ba_view& V = views[blockIdx.y];
+    const ba_state* S = V.state;
+    if (S->b_done || !S->b_need_lin) return;
+    const int nbp = (V.Pa * BP_G + 255) / 256, cur = S->b_cur;
+    if ((int)blockIdx.x < nbp) ba_point_body(blockIdx.x, V.cams[cur], V.pts[cur], V.e_cam, V.e_meas, V.cslot, V.p_start, V.p_edges, V.Pa, V.K, delta, V.Hpl, V.Hll, V.bl,
+                                             V.err[0], V.chi_e[0], V.pdiag);
+    else if ((int)blockIdx.x < nbp + V.Cf) ba_cam_body(blockIdx.x - nbp, V.cams[cur], V.pts[cur], V.e_cam, V.e_pt, V.e_meas, V.c_start, V.c_edges, V.K, delta, V.Hpp, V.bp, V.cdiag);
+}
+__global__ __launch_bounds__(1024) void k_bb_partial(const ba_view* __restrict__ views, int trial)
+{
+    const ba_view& V = views[blockIdx.y];
+    const ba_state* S = V.state;
+    if (S->b_done || !V.part || (!trial && !S->b_need_lin)) return;
+    ba_partial_body(V.chi_e[trial], V.Ea, trial ? V.dxl : nullptr, V.bl, 3 * V.Pa, S, V.part);
+}
+__global__ __launch_bounds__(1024) void k_bb_prep(const ba_view* __restrict__ views)
+{
+    const ba_view& V = views[blockIdx.y];
+    ba_state* S = V.state;
+    if (S->b_done || !S->b_need_lin) return;
+    const int first = S->b_it == 0 ? 1 : 0;
+    ba_prep_body(V.chi_e[0], V.Ea, V.pdiag, V.Pa, V.cdiag, V.Cf, first, 0, V.part, S);
+    if (threadIdx.x == 0) {
+        S->b_last_err = 0;
+        if (first && !isfinite(S->max_diag)) { S->b_done = 1; S->b_fail = 1; }          // non-finite Hessian at the initial estimate
+    }
+}
+__global__ __launch_bounds__(256) void k_bb_dinv(const ba_view* __restrict__ views)
+{
+    const ba_view& V = views[blockIdx.y];
+    if (V.state->b_done || (int)blockIdx.x * 256 >= V.Pa) return;
+    ba_dinv_body(V.Hll, V.bl, V.Pa, V.state, V.Dinv, V.db);
+}
+__global__ __launch_bounds__(256) void k_bb_zeroS(const ba_view* __restrict__ views)
+{
+    const ba_view& V = views[blockIdx.y];
+    if (V.state->b_done) return;
+    const size_t n = (size_t)V.n6 * (V.bw + 1);
+    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) V.S[i] = 0.0;
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_bb_schur(const ba_view* __restrict__ views)
+{
+    const ba_view& V = views[blockIdx.y];
+    if (V.state->b_done) return;
+    const int ngS = (V.npairs + 7) / 8 * 8;
+    if ((int)blockIdx.x < ngS) ba_schur_S_body<256>(blockIdx.x, ngS, V.pairs, V.j_start, V.join, V.e_pt, V.Hpl, V.Dinv, V.Hpp, V.state, V.bw, 1, V.S, V.npairs);
+    else if ((int)blockIdx.x < ngS + V.Cf) ba_schur_b_body(blockIdx.x - ngS, V.c_start, V.c_edges, V.e_pt, V.Hpl, V.db, V.bp, 1, V.bs);
+}
+__global__ __launch_bounds__(1024) void k_bb_chol(const ba_view* __restrict__ views)
+{
+    const ba_view& V = views[blockIdx.x];
+    if (V.state->b_done || V.Cf == 0) return;
+    ba_chol_dense_body<false>(V.S, V.bs, V.n6, V.bw, V.dxp, V.state, nullptr, nullptr, nullptr, nullptr);
+}
+__global__ __launch_bounds__(256) void k_bb_update(const ba_view* __restrict__ views)
+{
+    const ba_view& V = views[blockIdx.y];
+    const ba_state* S = V.state;
+    const int pblocks = (V.Pa + 255) / 256, cblocks = (V.C + 255) / 256;
+    if (S->b_done || (int)blockIdx.x >= pblocks + cblocks) return;
+    const int cur = S->b_cur;
+    ba_update_body(V.cams[cur], V.cams[cur ^ 1], V.pts[cur], V.pts[cur ^ 1], V.cslot, V.C, V.Pa, pblocks, V.p_start, V.p_edges, V.e_cam, V.Hpl, V.Dinv, V.bl, V.dxp, V.dxl, V.K);
+}
+__global__ __launch_bounds__(256) void k_bb_err(const ba_view* __restrict__ views, double delta)
+{
+    const ba_view& V = views[blockIdx.y];
+    const ba_state* S = V.state;
+    if (S->b_done || (int)blockIdx.x * 256 >= V.Ea) return;
+    const int cur = S->b_cur;
+    ba_err_body(V.cams[cur ^ 1], V.pts[cur ^ 1], V.e_cam, V.e_pt, V.e_meas, V.Ea, delta, V.err[1], V.chi_e[1]);
+}
+__global__ __launch_bounds__(1024) void k_bb_decide(const ba_view* __restrict__ views, int seq)
+{
+    const ba_view& V = views[blockIdx.y];
+    ba_state* S = V.state;
+    if (S->b_done) {
+        if (threadIdx.x == 0 && S->b_fail == 1) {                // a window that failed in k_bb_prep: tell the host once
+            S->b_fail = 2;
+            ba_state t = *S; t.pad = 0;
+            *V.hstate = t;
+            __threadfence_system();
+            __atomic_store_n(&V.hstate->pad, seq, __ATOMIC_RELEASE);
+        }
+        return;
+    }
+    ba_decide_body(V.chi_e[1], V.Ea, V.dxp, V.bp, V.n6, V.dxl, V.bl, 3 * V.Pa, 0, 1, V.part, S, nullptr, 0);
+    if (threadIdx.x == 0) {                                      // the control flow of bh_ba_optimize's host loop
+        if (S->accepted) S->b_cur ^= 1;
+        S->b_last_err = 1;                                       // the trial's errors are the last computeActiveErrors
+        if (!S->again) {                                         // the iteration is over
+            if (S->b_verbose && !S->accepted) S->b_last_err = 0; // verbose branch of SparseOptimizer::optimize: errors at the restored estimate
+            S->b_it += 1; S->b_need_lin = 1;
+            if (S->terminate || S->b_it >= S->b_iters) S->b_done = 1;
+        } else S->b_need_lin = 0;
+        ba_state t = *S; t.pad = 0;
+        *V.hstate = t;
+        __threadfence_system();
+        __atomic_store_n(&V.hstate->pad, seq, __ATOMIC_RELEASE);
     }
 }
 
@@ -2805,6 +2989,140 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
     }
     if (iters_done) *iters_done = ba->iters_done;
     ba->verbose_last = verbose_errors;
+    return rc;
+}
+
+// ---- batched local BA: W windows that each hold a problem (bh_ba_set_problem) advance together, one launch per kernel and trial
+struct bh_ba_batch {
+    bh_ctx* ctx = nullptr;
+    std::vector<bh_ba*> win;
+    bh_buf views, curs;
+    ba_state* hstates = nullptr;      // pinned, one per window: k_bb_decide's verdicts
+    int seq = 0;
+};
+
+extern "C" int bh_ba_batch_create(bh_ctx* ctx, int W, bh_ba* const* windows, bh_ba_batch** out)
+{
+    if (!ctx || !windows || !out || W < 1) return ctx ? bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_create: bad argument") : BH_ERR_INVALID;
+    for (int w = 0; w < W; w++)
+        if (!windows[w] || windows[w]->ctx != ctx) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_create: window %d belongs to another context", w);
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    (void)hipFuncSetAttribute((const void*)k_bb_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
+    bh_ba_batch* b = new bh_ba_batch();
+    b->ctx = ctx; b->win.assign(windows, windows + W);
+    if (hipHostMalloc((void**)&b->hstates, sizeof(ba_state) * W, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError(); delete b;
+        return bh_set_err(ctx, BH_ERR_HIP, "bh_ba_batch_create: pinned allocation failed");
+    }
+    memset(b->hstates, 0, sizeof(ba_state) * W);
+    *out = b;
+    return BH_OK;
+}
+
+extern "C" void bh_ba_batch_destroy(bh_ba_batch* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->hstates) (void)hipHostFree(b->hstates);
+    for (bh_buf* q : { &b->views, &b->curs }) { if (q->p) (void)hipFree(q->p); q->p = nullptr; q->cap = 0; }
+    delete b;
+}
+
+extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delta, int verbose_errors, int* iters_done)
+{
+    if (!b) return BH_ERR_INVALID;
+    bh_ctx* ctx = b->ctx;
+    const int W = (int)b->win.size();
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<ba_view> hv(W);
+    std::vector<int> hcur(W);
+    int g_lin = 1, g_pb = 1, g_schur = 1, g_upd = 1, g_eb = 1, any_part = 0;
+    for (int w = 0; w < W; w++) {
+        bh_ba* ba = b->win[w];
+        if (!ba->have_problem) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_optimize: window %d has no problem set", w);
+        if (ba->ar) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_optimize: window %d is a sharded (multi-GPU) problem", w);
+        if (ba->Cf > 0 && (!ba->chol_dense || ba->schur_wave))
+            return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_optimize: window %d has %d free keyframes; the batch takes local windows (<= %d unknowns): use bh_ba_optimize", w, ba->Cf, 16 * CD_MAXT);
+        ba_view& V = hv[w];
+        memset(&V, 0, sizeof(V));
+        for (int k = 0; k < 2; k++) { V.cams[k] = (ba_cam*)ba->cams[k].p; V.pts[k] = (double*)ba->pts[k].p; V.err[k] = (double*)ba->err[k].p; V.chi_e[k] = (double*)ba->chi_e[k].p; }
+        V.e_cam = (const int*)ba->e_cam.p; V.e_pt = (const int*)ba->e_pt.p; V.e_meas = (const double*)ba->e_meas.p; V.cslot = (const int*)ba->cslot.p;
+        V.p_start = (const int*)ba->p_start.p; V.p_edges = (const int*)ba->p_edges.p; V.c_start = (const int*)ba->c_start.p; V.c_edges = (const int*)ba->c_edges.p;
+        V.Hpl = (double*)ba->Hpl.p; V.Hll = (double*)ba->Hll.p; V.bl = (double*)ba->bl.p; V.Hpp = (double*)ba->Hpp.p; V.bp = (double*)ba->bp.p;
+        V.pdiag = (double*)ba->pdiag.p; V.cdiag = (double*)ba->cdiag.p; V.Dinv = (double*)ba->Dinv.p; V.db = (double*)ba->db.p;
+        V.S = (double*)ba->S.p; V.bs = (double*)ba->bs.p; V.dxp = (double*)ba->dxp.p; V.dxl = (double*)ba->dxl.p;
+        V.part = ba->Ea > 16384 ? (double*)ba->part.p : nullptr;              // the same two-stage sums as bh_ba_optimize
+        V.pairs = (const int2*)ba->pairs.p; V.j_start = (const int*)ba->j_start.p; V.join = (const int2*)ba->join.p;
+        V.state = (ba_state*)ba->state.p; V.hstate = b->hstates + w;
+        V.C = ba->C; V.Cf = ba->Cf; V.Pa = ba->Pa; V.Ea = ba->Ea; V.npairs = ba->npairs; V.bw = ba->bw; V.n6 = 6 * ba->Cf; V.K = ba->K;
+        hcur[w] = ba->cur;
+        ba->log.clear(); ba->iters_done = 0;
+        g_lin = std::max(g_lin, (ba->Pa * BP_G + 255) / 256 + ba->Cf);
+        g_pb = std::max(g_pb, (ba->Pa + 255) / 256);
+        g_schur = std::max(g_schur, (ba->npairs + 7) / 8 * 8 + ba->Cf);
+        g_upd = std::max(g_upd, (ba->Pa + 255) / 256 + (ba->C + 255) / 256);
+        g_eb = std::max(g_eb, (ba->Ea + 255) / 256);
+        any_part |= V.part != nullptr;
+        if (iters_done) iters_done[w] = 0;
+    }
+    BH_TRY(bh_reserve(ctx, &b->views, sizeof(ba_view) * W)); BH_TRY(bh_reserve(ctx, &b->curs, sizeof(int) * W));
+    BH_HIP(ctx, hipMemcpyAsync(b->views.p, hv.data(), sizeof(ba_view) * W, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipMemcpyAsync(b->curs.p, hcur.data(), sizeof(int) * W, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipStreamSynchronize(st));                     // hv / hcur go out of scope below
+    const ba_view* views = (const ba_view*)b->views.p;
+    hipLaunchKernelGGL(k_bb_init, dim3((W + 63) / 64), dim3(64), 0, st, views, W, iters, verbose_errors ? 1 : 0);
+    hipLaunchKernelGGL(k_bb_setcur, dim3((W + 63) / 64), dim3(64), 0, st, views, (const int*)b->curs.p, W);
+    std::vector<char> done(W, 0);
+    int active = 0;
+    for (int w = 0; w < W; w++) { done[w] = (b->win[w]->Ea == 0 || iters <= 0) ? 1 : 0; active += !done[w]; b->win[w]->last_err_sel = 0; }
+    bool need_lin = true;
+    int rc = BH_OK;
+    for (int round = 0; active > 0 && round < iters * 10 + 2; round++) {
+        if (need_lin) {
+            BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_bb_linearize, dim3(g_lin, W), dim3(256), st, views, huber_delta);
+            if (any_part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_partial, dim3(BA_NPART, W), dim3(1024), st, views, 0);
+            BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_prep, dim3(1, W), dim3(1024), st, views);
+        }
+        BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_dinv, dim3(g_pb, W), dim3(256), st, views);
+        BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_zeroS, dim3(8, W), dim3(256), st, views);
+        BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_schur, dim3(g_schur, W), dim3(256), st, views);
+        bh_time_begin(ctx, BH_K_BA_SOLVE);
+        hipLaunchKernelGGL(k_bb_chol, dim3(W), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, views);
+        bh_time_end(ctx);
+        BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_bb_update, dim3(g_upd, W), dim3(256), st, views);
+        BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_bb_err, dim3(g_eb, W), dim3(256), st, views, huber_delta);
+        if (any_part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_partial, dim3(BA_NPART, W), dim3(1024), st, views, 1);
+        const int seq = ++b->seq;
+        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_decide, dim3(1, W), dim3(1024), st, views, seq);
+        BH_HIP(ctx, hipGetLastError());
+        need_lin = false;
+        for (int w = 0; w < W; w++) {
+            if (done[w]) continue;
+            ba_state* hp = b->hstates + w;
+            bool got = false;
+            for (long spin = 0; spin < 400000000L; spin++)
+                if (__atomic_load_n(&hp->pad, __ATOMIC_ACQUIRE) == seq) { got = true; break; }
+            if (!got) {                                          // a kernel fault never delivers the verdict: the stream reports it
+                BH_HIP(ctx, hipStreamSynchronize(st));
+                return bh_set_err(ctx, BH_ERR_HIP, "bh_ba_batch_optimize: no verdict from window %d", w);
+            }
+            ba_state hs; memcpy(&hs, hp, sizeof(hs));
+            bh_ba* ba = b->win[w];
+            if (hs.b_fail) { done[w] = 1; active--; rc = bh_set_err(ctx, BH_ERR_NUMERIC, "bh_ba_batch_optimize: non-finite Hessian at the initial estimate of window %d", w); continue; }
+            ba->cur = hs.b_cur; ba->last_err_sel = hs.b_last_err;
+            if (!hs.again) {
+                ba->log.push_back(hs.accepted ? hs.chi_cur : hs.chi_trial); ba->log.push_back(hs.lambda);
+                ba->log.push_back((double)hs.qmax); ba->log.push_back((double)hs.accepted);
+                ba->iters_done = hs.b_it;
+                if (iters_done) iters_done[w] = hs.b_it;
+                need_lin = true;
+            }
+            if (hs.b_done) { done[w] = 1; active--; }
+        }
+    }
+    for (int w = 0; w < W; w++) b->win[w]->verbose_last = verbose_errors;
     return rc;
 }
 

@@ -162,6 +162,18 @@ int  bh_ba_get_log(bh_ba* ba, double* log, int max_rows);
  * 3 = two-way window elimination, 4 = block cyclic reduction over the whole chip; < 0 = no problem set. */
 int  bh_ba_solver(bh_ba* ba);
 
+/* Batched local BA: W windows, each a bh_ba handle of `ctx` that holds a problem (bh_ba_set_problem; windows may differ in size),
+ * advance together - every kernel of a Levenberg trial is launched once for all of them, gridded over (item, window), and each
+ * window's dense reduced-camera factorisation takes its own workgroup, so W windows keep W CUs busy where bh_ba_optimize keeps one.
+ * The reference optimises one window at a time on the mapping thread (slam/local_mapping.py:46-47 -> slam/covisibility_graph.py:186-235);
+ * SURVEY 8(e) "local BA: replicas only (different windows)".  A window's result is bitwise the one bh_ba_optimize gives; afterwards
+ * the usual getters (bh_ba_get_poses / _points / _chi2 / _log) read each window.  Windows must be local ones (<= 48 free keyframes,
+ * not sharded); iters_done (may be NULL) receives int[W]. */
+typedef struct bh_ba_batch bh_ba_batch;
+int  bh_ba_batch_create(bh_ctx* ctx, int W, bh_ba* const* windows, bh_ba_batch** out);
+void bh_ba_batch_destroy(bh_ba_batch* batch);
+int  bh_ba_batch_optimize(bh_ba_batch* batch, int iters, double huber_delta, int verbose_errors, int* iters_done);
+
 /* Test hook: one banded SPD solve S x = rhs with the reduced-camera-system kernels.  band f64[n][bw+1] holds the lower band,
  * element (r, c) at band[r*(bw+1) + c - r + bw]; mode 0 = panel kernel, 1 = on-chip sliding-window kernel (15 <= bw <= 256),
  * 3 = two workgroups eliminating from both ends (needs a band of exactly 16 tiles, 241 <= bw <= 256, and >= 40 block columns),

@@ -261,3 +261,52 @@ def test_device_built_problem_equals_host_built(ctx, monkeypatch):
         (Rd, td), pd, cd, ld = res[0]; (Rh, th), ph, ch, lh = res[1]
         assert np.array_equal(ld, lh) and np.array_equal(Rd, Rh) and np.array_equal(td, th)
         assert np.array_equal(pd, ph, equal_nan=True) and np.array_equal(cd, ch)
+
+
+def test_batched_windows_equal_single_window_runs_bitwise(ctx):
+    """bh_ba_batch_optimize: W windows of different sizes advance in lockstep (one launch per kernel and trial for all of them).  Every
+    window must come out bit for bit as bh_ba_optimize leaves it: poses, landmarks, per-edge chi2, the Levenberg log - including a
+    window that needs retries (a gross outlier start), one with no free landmark edges removed, and non-verbose error semantics."""
+    probs = [synth.ba_problem(n_kf=6, n_pts=150, seed=1), synth.ba_problem(n_kf=12, n_pts=500, seed=4), synth.ba_problem(n_kf=50, n_pts=10000, seed=7),
+             synth.ba_problem(n_kf=20, n_pts=1500, seed=9), synth.ba_problem(n_kf=9, n_pts=200, seed=2), synth.ba_problem(n_kf=30, n_pts=4000, seed=12)]
+    for seed in (9, 14):                                                    # small windows that reach the numerical floor: rejected trials, lambda grows
+        bad = synth.ba_problem(n_kf=5, n_pts=60, seed=seed)
+        rng = np.random.default_rng(seed)
+        probs.append(dict(bad, t=bad["t"] + rng.normal(0, 0.1, bad["t"].shape) * (1 - bad["fixed"])[:, None], pts=bad["pts"] + rng.normal(0, 0.3, bad["pts"].shape)))
+    NIT = 10
+    for verbose in (True, False):
+        single = []
+        for pr in probs:
+            s = ba.LocalBA(ctx, pr["K"])
+            s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+            done = s.optimize(NIT, verbose_errors=verbose)
+            single.append((done, s.poses(), s.points().copy(), s.chi2().copy(), s.log()[:done].copy()))
+            s.close()
+        wins = []
+        for pr in probs:
+            s = ba.LocalBA(ctx, pr["K"])
+            s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+            wins.append(s)
+        batch = ba.LocalBABatch(ctx, wins)
+        done = batch.optimize(NIT, verbose_errors=verbose)
+        assert any(sg[4][:, 2].max() > 1 for sg in single), "no window exercised the retry path"
+        for w, s in enumerate(wins):
+            d0, (R0, t0), p0, c0, l0 = single[w]
+            assert done[w] == d0
+            R, t = s.poses()
+            assert np.array_equal(R, R0) and np.array_equal(t, t0) and np.array_equal(s.points(), p0, equal_nan=True)
+            assert np.array_equal(s.chi2(), c0) and np.array_equal(s.log()[:d0], l0)
+        # a second run on the same handles continues from the optimised state exactly like the single-window path does
+        done2 = batch.optimize(2, verbose_errors=verbose)
+        assert (done2 >= 1).all()
+        batch.close()
+        for s in wins:
+            s.close()
+    # a window the batch does not take (a long banded problem) is refused with a message, not run
+    pr = synth.ba_problem_sequence(n_kf=150, n_pts=4000, window=6, seed=3)
+    s = ba.LocalBA(ctx, pr["K"])
+    s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+    batch = ba.LocalBABatch(ctx, [s])
+    with pytest.raises(Exception, match="local windows"):
+        batch.optimize(2)
+    batch.close(); s.close()
