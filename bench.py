@@ -369,7 +369,22 @@ def run_rank(args):
                                 "live_windows": ba_bench.run_batch(ctx, W=64, n_kf=10, n_pts=600, iters=7, repeats=2,
                                                                    label="live size (slam/covisibility_graph.py:220: 7 iterations, ~10 keyframes x 600 map points)")}
             return r
-        for name, fn in (("local_ba", local_ba), ("tracking", lambda: track_bench.run(ctx))):
+        def tracking_stage():
+            r = track_bench.run(ctx)
+            # ORB + back-projection + the whole _track_wrt_refkf chain (match, filter, gathers, CamOnlyBA, inlier count) for frame i against
+            # frame i-1 on the benchmark's own HBM-resident frames: bh_track_refkf, no host hop
+            K5 = np.array([384.239013671875, 384.239013671875, 322.432373046875, 239.6533203125, 0.06])      # config.py:36-41
+            trk = frontend.DeviceTracker(ctx, B, 480, 640, params, K5, torch_device=dev)
+            el = timed(trk, bgr, depth, 5, 2)
+            st = trk.status[1:].cpu().numpy()
+            r["frames_per_s"] = round(B * 5 / el, 1)
+            r["device_resident_chain"] = {"frames_per_s": round(B * 5 / el, 1), "ms_per_step": round(el / 5 * 1e3, 3), "frames": B,
+                                          "stages": "ORB detect+describe -> kp_arr + cloud_kp -> match(i, i-1) -> distance < 30 -> CamOnlyBA -> >= 15 inliers",
+                                          "tracked_pairs": int((st == 0).sum()), "pairs": int(len(st)),
+                                          "mean_matches": float(trk.n_match[1:].float().mean().item()), "mean_inliers": float(trk.n_inlier[1:].float().mean().item())}
+            del trk
+            return r
+        for name, fn in (("local_ba", local_ba), ("tracking", tracking_stage)):
             stage["name"] = name
             try:
                 res = fn()

@@ -1,0 +1,146 @@
+// track.hip — one tracking step of slam/tracking.py on the device, batched over (frame, reference) pairs.
+//
+// Tracker._track_wrt_refkf (slam/tracking.py:54-89) and the second half of Tracker._track_local_map (:121-136) are the same chain:
+//     matches = matcher.match(frame.des, ref_des)                      cross-check Hamming matcher
+//     matches = [m for m in matches if m.distance < d_hamming_max]     (<= in the local-map leg, :121)
+//     need >= min_matches (min_matches_cg = 15, :62 / 15, :123)
+//     CamOnlyBA(frame.kp_arr[inds_f], ref_points[inds_ref], cam)       pose-only BA, identity start
+//     need >= 15 inliers (:83, :136)
+// Round 2 ran the two kernels with the filter / index extraction / gathers as host Python between them.  Here the
+// whole chain is enqueued on the context's stream: k_match -> k_track_gather (distance filter with ordered compaction, gather of the
+// int64 pixels and f64 points into the pose-BA layout) -> k_pose_ba -> k_track_finish (inlier count, verdict).  No host hop.
+#include "bh_internal.h"
+
+// One workgroup per pair: ordered compaction of the raw match list by the distance test, gather of the BA inputs.
+__global__ __launch_bounds__(256) void k_track_gather(const int* __restrict__ rq, const int* __restrict__ rt, const int* __restrict__ rd,
+                                                      const int* __restrict__ rn, int raw_stride, int d_max, int inclusive, int min_matches,
+                                                      const long long* __restrict__ q_xy, int q_stride, const double* __restrict__ t_pts, int t_stride,
+                                                      int* __restrict__ qidx, int* __restrict__ tidx, int* __restrict__ dist, int* __restrict__ n_match,
+                                                      int out_stride, double* __restrict__ pix, double* __restrict__ pts, int* __restrict__ n_ba)
+{
+    __shared__ int s_wsum[4], s_base;
+    const size_t b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = min(rn[b], raw_stride);
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        int q = 0, t = 0, d = 0;
+        bool keep = false;
+        if (i < n) {
+            q = rq[b * raw_stride + i]; t = rt[b * raw_stride + i]; d = rd[b * raw_stride + i];
+            keep = inclusive ? d <= d_max : d < d_max;
+        }
+        const unsigned long long bm = __ballot(keep);
+        const int before = __popcll(bm & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wsum[wv] = __popcll(bm);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wv; w++) off += s_wsum[w];
+        const int pos = off + before;
+        if (keep && pos < out_stride) {
+            const size_t o = b * out_stride + pos;
+            qidx[o] = q; tidx[o] = t; dist[o] = d;
+            const long long* xy = q_xy + ((size_t)b * q_stride + q) * 2;
+            pix[2 * o] = (double)xy[0]; pix[2 * o + 1] = (double)xy[1];
+            const double* p = t_pts + ((size_t)b * t_stride + t) * 3;
+            pts[3 * o] = p[0]; pts[3 * o + 1] = p[1]; pts[3 * o + 2] = p[2];
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int m = min(s_base, out_stride);
+        n_match[b] = m;
+        n_ba[b] = m >= min_matches && m > 0 ? m : 0;             // too few matches: CamOnlyBA is not called (tracking.py:58-65, :123)
+    }
+}
+
+__global__ __launch_bounds__(256) void k_track_finish(const int* __restrict__ n_match, const int* __restrict__ n_ba, const uint8_t* __restrict__ inlier,
+                                                      const int* __restrict__ ba_status, int out_stride, int min_inliers,
+                                                      int* __restrict__ n_inlier, int* __restrict__ status)
+{
+    __shared__ int s_cnt;
+    const size_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    const int n = n_ba[b];
+    int c = 0;
+    for (int i = tid; i < n; i += 256) c += inlier[b * out_stride + i] ? 1 : 0;
+    for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((tid & 63) == 0 && c) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (tid == 0) {
+        n_inlier[b] = s_cnt;
+        status[b] = n == 0 ? BH_TRACK_FEW_MATCHES : (ba_status[b] != BH_OK ? BH_TRACK_BA_FAILED : (s_cnt < min_inliers ? BH_TRACK_FEW_INLIERS : BH_TRACK_OK));
+    }
+}
+
+extern "C" int bh_track_refkf(bh_ctx* ctx, const uint8_t* q_desc, const int* nq, const int64_t* q_xy, int q_stride,
+                              const uint8_t* t_desc, const int* nt, const double* t_pts, int t_stride, int B,
+                              int d_max, int inclusive, int min_matches, int min_inliers,
+                              const double K[5], int iters, double huber_delta, double chi2_thr,
+                              int* qidx, int* tidx, int* dist, int* n_match, double* R, double* t, uint8_t* inlier, int* n_inlier,
+                              int* status, int out_stride, int mem)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (!q_desc || !nq || !q_xy || !t_desc || !nt || !t_pts || !K || !qidx || !tidx || !dist || !n_match || !R || !t || !inlier || !n_inlier || !status ||
+        B < 0 || q_stride < 1 || t_stride < 1 || out_stride < 1 || (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_track_refkf: bad argument");
+    if (B == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t no = (size_t)B * out_stride;
+    // intermediates: raw matches (3 ints per slot + counts), gathered pixels / points, per-edge chi2, BA status / sizes
+    const size_t w_raw = sizeof(int) * (3 * no + B), w_pix = sizeof(double) * 2 * no, w_pts = sizeof(double) * 3 * no, w_chi = sizeof(double) * no;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    BH_TRY(bh_reserve(ctx, &ctx->tr_w, al(w_raw) + al(w_pix) + al(w_pts) + al(w_chi) + al(sizeof(int) * 2 * B)));
+    char* wp = (char*)ctx->tr_w.p;
+    int* rq = (int*)wp; int* rt = rq + no; int* rd = rt + no; int* rn = rd + no; wp += al(w_raw);
+    double* pix = (double*)wp; wp += al(w_pix);
+    double* pts = (double*)wp; wp += al(w_pts);
+    double* chi = (double*)wp; wp += al(w_chi);
+    int* n_ba = (int*)wp; int* ba_st = n_ba + B;
+    const uint8_t* d_q = q_desc; const uint8_t* d_t = t_desc; const int* d_nq = nq; const int* d_nt = nt; const long long* d_xy = (const long long*)q_xy; const double* d_tp = t_pts;
+    int *d_qi = qidx, *d_ti = tidx, *d_di = dist, *d_nm = n_match, *d_ni = n_inlier, *d_st = status;
+    double *d_R = R, *d_tt = t; uint8_t* d_in = inlier;
+    if (mem == BH_MEM_HOST) {
+        for (int b = 0; b < B; b++) if (nq[b] < 0 || nt[b] < 0 || nq[b] > q_stride || nt[b] > t_stride) return bh_set_err(ctx, BH_ERR_INVALID, "bh_track_refkf: row count outside [0, stride]");
+        const size_t qb = (size_t)B * q_stride * 32, tb = (size_t)B * t_stride * 32, xb = sizeof(long long) * 2 * (size_t)B * q_stride, pb = sizeof(double) * 3 * (size_t)B * t_stride;
+        const size_t ob = al(sizeof(int) * no) * 3 + al(sizeof(int) * B) * 3 + al(sizeof(double) * 12 * B) + al(no);
+        BH_TRY(bh_reserve(ctx, &ctx->tr_in, al(qb) + al(tb) + al(xb) + al(pb) + al(sizeof(int) * 2 * B) + ob));
+        char* ip = (char*)ctx->tr_in.p;
+        BH_HIP(ctx, hipMemcpyAsync(ip, q_desc, qb, hipMemcpyHostToDevice, st)); d_q = (const uint8_t*)ip; ip += al(qb);
+        BH_HIP(ctx, hipMemcpyAsync(ip, t_desc, tb, hipMemcpyHostToDevice, st)); d_t = (const uint8_t*)ip; ip += al(tb);
+        BH_HIP(ctx, hipMemcpyAsync(ip, q_xy, xb, hipMemcpyHostToDevice, st)); d_xy = (const long long*)ip; ip += al(xb);
+        BH_HIP(ctx, hipMemcpyAsync(ip, t_pts, pb, hipMemcpyHostToDevice, st)); d_tp = (const double*)ip; ip += al(pb);
+        BH_HIP(ctx, hipMemcpyAsync(ip, nq, sizeof(int) * B, hipMemcpyHostToDevice, st)); d_nq = (const int*)ip;
+        BH_HIP(ctx, hipMemcpyAsync(ip + sizeof(int) * B, nt, sizeof(int) * B, hipMemcpyHostToDevice, st)); d_nt = d_nq + B; ip += al(sizeof(int) * 2 * B);
+        d_qi = (int*)ip; ip += al(sizeof(int) * no); d_ti = (int*)ip; ip += al(sizeof(int) * no); d_di = (int*)ip; ip += al(sizeof(int) * no);
+        d_nm = (int*)ip; ip += al(sizeof(int) * B); d_ni = (int*)ip; ip += al(sizeof(int) * B); d_st = (int*)ip; ip += al(sizeof(int) * B);
+        d_R = (double*)ip; d_tt = d_R + 9 * (size_t)B; ip += al(sizeof(double) * 12 * B);
+        d_in = (uint8_t*)ip;
+    }
+    BH_TRY(bh_match_hamming_crosscheck(ctx, d_q, d_nq, q_stride, d_t, d_nt, t_stride, B, rq, rt, rd, rn, out_stride, BH_MEM_DEVICE));
+    BH_LAUNCH(ctx, BH_K_MATCH, k_track_gather, dim3(B), dim3(256), st, (const int*)rq, (const int*)rt, (const int*)rd, (const int*)rn, out_stride, d_max, inclusive ? 1 : 0,
+              min_matches, d_xy, q_stride, d_tp, t_stride, d_qi, d_ti, d_di, d_nm, out_stride, pix, pts, n_ba);
+    BH_TRY(bh_pose_only_ba(ctx, pix, pts, n_ba, B, out_stride, K, iters, huber_delta, chi2_thr, d_R, d_tt, chi, d_in, ba_st, BH_MEM_DEVICE));
+    BH_LAUNCH(ctx, BH_K_POSE_BA, k_track_finish, dim3(B), dim3(256), st, (const int*)d_nm, (const int*)n_ba, (const uint8_t*)d_in, (const int*)ba_st, out_stride, min_inliers, d_ni, d_st);
+    BH_HIP(ctx, hipGetLastError());
+    if (mem == BH_MEM_HOST) {
+        BH_HIP(ctx, hipMemcpyAsync(qidx, d_qi, sizeof(int) * no, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(tidx, d_ti, sizeof(int) * no, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(dist, d_di, sizeof(int) * no, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(n_match, d_nm, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(n_inlier, d_ni, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(status, d_st, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(R, d_R, sizeof(double) * 9 * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(t, d_tt, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(inlier, d_in, no, hipMemcpyDeviceToHost, st));
+        return bh_ctx_status(ctx);                               // synchronises; the matcher's capacity flags
+    }
+    return BH_OK;
+}

@@ -182,6 +182,45 @@ class DeviceFrontEnd:
                     self.max_kp, BH_MEM_DEVICE))
 
 
+class DeviceTracker:
+    """RsCamera.get + Tracker._track_wrt_refkf for a batch of HBM-resident frames with no host hop (camera.py:131-168, slam/tracking.py:54-89):
+    ORB on B frames -> int keypoints + depth back-projection (kp_arr, cloud_kp) -> for every frame i >= 1 against frame i-1 as the
+    reference keyframe: cross-check match, `distance < d_hamming_max`, >= min_matches, CamOnlyBA, >= 15 inliers (bh_track_refkf)."""
+
+    def __init__(self, ctx, B, H, W, params, K, max_kp=None, torch_device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.ctx, self.B, self.H, self.W, self.params = ctx, B, H, W, params
+        self.K = np.ascontiguousarray(K, dtype=np.float64)
+        self.max_kp = max_kp or default_max_kp(params)
+        dev, m = torch_device, self.max_kp
+        self.kps = torch.zeros((B, m, 6), dtype=torch.float32, device=dev)
+        self.desc = torch.zeros((B, m, 32), dtype=torch.uint8, device=dev)
+        self.n_kp = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.kp_xy = torch.zeros((B, m, 2), dtype=torch.int64, device=dev)
+        self.cloud = torch.zeros((B, m, 3), dtype=torch.float64, device=dev)
+        self.qidx = torch.zeros((B, m), dtype=torch.int32, device=dev); self.tidx = torch.zeros_like(self.qidx); self.dist = torch.zeros_like(self.qidx)
+        self.n_match = torch.zeros((B,), dtype=torch.int32, device=dev); self.n_inlier = torch.zeros_like(self.n_match); self.status = torch.zeros_like(self.n_match)
+        self.R = torch.zeros((B, 9), dtype=torch.float64, device=dev); self.t = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+        self.inlier = torch.zeros((B, m), dtype=torch.uint8, device=dev)
+
+    def run(self, bgr, depth):
+        """Enqueues ORB, the back-projection and the B - 1 tracking problems; does not synchronise.  Pair i (frame i vs i-1) at row i."""
+        from . import tracking
+        L, c, m = _lib.lib(), self.ctx, self.max_kp
+        ch = 1 if bgr.dim() == 3 else bgr.shape[3]
+        c.check(L.bh_orb_detect_describe(c.h, _lib.ptr(bgr), ch, None, _lib.ptr(depth), self.B, self.H, self.W, C.byref(self.params), m,
+                                         _lib.ptr(self.kps), _lib.ptr(self.desc), _lib.ptr(self.n_kp), BH_MEM_DEVICE))
+        c.check(L.bh_kp_backproject(c.h, _lib.ptr(self.kps), _lib.ptr(self.n_kp), _lib.ptr(depth), self.B, self.H, self.W, m,
+                                    float(self.K[0]), float(self.K[1]), float(self.K[2]), float(self.K[3]), _lib.ptr(self.kp_xy), _lib.ptr(self.cloud), BH_MEM_DEVICE))
+        if self.B > 1:
+            out = dict(qidx=self.qidx.data_ptr() + 4 * m, tidx=self.tidx.data_ptr() + 4 * m, dist=self.dist.data_ptr() + 4 * m, n_match=self.n_match.data_ptr() + 4,
+                       R=self.R.data_ptr() + 72, t=self.t.data_ptr() + 24, inlier=self.inlier.data_ptr() + m, n_inlier=self.n_inlier.data_ptr() + 4,
+                       status=self.status.data_ptr() + 4)
+            tracking.track_refkf_device(c, self.desc.data_ptr() + 32 * m, self.n_kp.data_ptr() + 4, self.kp_xy.data_ptr() + 16 * m, m,
+                                        self.desc.data_ptr(), self.n_kp.data_ptr(), self.cloud.data_ptr(), m, self.B - 1, self.K, out, m)
+
+
 def medoid_descriptors(ctx, desc, k):
     """MapPoint.add_observation's medoid choice (slam/nodes.py:142-154) for a batch: desc u8[M][10][32], k int[M] -> idx int[M]."""
     desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 10, 32)

@@ -160,6 +160,39 @@ def pose_problem(n=200, seed=3, outlier_frac=0.2, int_pixels=True):
     return dict(pix=uv.astype(np.float64), pts=X, R=R, t=t, outlier=bad, K=np.array([FX, FY, CX, CY, BASELINE]))
 
 
+def tracking_pairs(B=8, n_ref=600, n_frame=600, seed=5, frac_seen=0.7, flip_bits=6, outlier_frac=0.1):
+    """B (frame, reference keyframe) pairs shaped like Tracker._track_wrt_refkf's inputs (slam/tracking.py:54-73): the reference holds
+    n_ref descriptors with 3-D points (kf_ref.cloud_kp), the frame re-observes a fraction of them from a pose a few cm away - descriptors
+    with a few flipped bits, integer pixels (camera.py:142) - plus unrelated features; some re-observations carry a wrong pixel.
+    Returns q_desc u8[B][n_frame][32], nq, q_xy i64[B][n_frame][2], t_desc u8[B][n_ref][32], nt, t_pts f64[B][n_ref][3], K, poses."""
+    rng = np.random.default_rng(seed)
+    q_desc = rng.integers(0, 256, (B, n_frame, 32), dtype=np.uint8); t_desc = rng.integers(0, 256, (B, n_ref, 32), dtype=np.uint8)
+    q_xy = np.zeros((B, n_frame, 2), np.int64); t_pts = np.zeros((B, n_ref, 3))
+    nq = np.zeros(B, np.int32); nt = np.zeros(B, np.int32)
+    Rs, ts = [], []
+    for b in range(B):
+        nt[b] = n_ref - (b % 3) * 7; nq[b] = n_frame - (b % 4) * 5
+        R = _rodrigues(rng.normal(0, 0.03, 3)); t = rng.normal(0, 0.05, 3)
+        X = np.stack([rng.uniform(-1.5, 1.5, n_ref), rng.uniform(-1.0, 1.0, n_ref), rng.uniform(1.0, 4.0, n_ref)], axis=1)
+        t_pts[b] = X
+        uv, _ = project(R, t, X)
+        uv = uv + rng.normal(0, 0.7, uv.shape)
+        q_xy[b] = rng.integers(0, 480, (n_frame, 2))
+        seen = rng.permutation(int(nt[b]))[:int(frac_seen * min(nq[b], nt[b]))]
+        slots = rng.permutation(int(nq[b]))[:len(seen)]
+        d = t_desc[b, seen].copy()
+        for k in range(len(seen)):
+            for bit in rng.integers(0, 256, rng.integers(0, flip_bits + 1)):
+                d[k, bit >> 3] ^= np.uint8(1 << (bit & 7))
+        q_desc[b, slots] = d
+        px = uv[seen].copy()
+        bad = rng.random(len(seen)) < outlier_frac
+        px[bad] += rng.normal(0, 60.0, (int(bad.sum()), 2))
+        q_xy[b, slots] = np.trunc(px).astype(np.int64)
+        Rs.append(R); ts.append(t)
+    return dict(q_desc=q_desc, nq=nq, q_xy=q_xy, t_desc=t_desc, nt=nt, t_pts=t_pts, K=np.array([FX, FY, CX, CY, BASELINE]), R=np.stack(Rs), t=np.stack(ts))
+
+
 def ba_problem_frontal(n_kf=6, n_pts=120, seed=21, pix_noise=0.7):
     """Local-window flavour of the live system: keyframes a few cm / degrees from identity looking down +z at points
     2..5 m away (so the reference's 640x480 admission gate, optimizer.py:52-54, admits most edges); int pixels."""

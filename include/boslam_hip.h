@@ -134,6 +134,27 @@ int bh_pose_only_ba(bh_ctx* ctx, const double* pix, const double* pts, const int
                     const double K[5], int iters, double huber_delta, double chi2_thr,
                     double* R, double* t, double* chi2, uint8_t* inlier, int* status, int mem);
 
+/* ---- one tracking step on the device ------------------------------------------------------------------------------
+ * Tracker._track_wrt_refkf (slam/tracking.py:54-89) and the matching half of Tracker._track_local_map (slam/tracking.py:121-136),
+ * batched over B (frame, reference) pairs with no host hop between the stages:
+ *   matcher.match(frame.des, ref_des) -> keep distance < d_max (`inclusive` != 0: <= d_max, tracking.py:121) -> need >= min_matches
+ *   -> CamOnlyBA(frame.kp_arr[inds_f], ref_points[inds_ref], cam) (identity start, optimizer.py:82-142) -> need >= min_inliers.
+ * Inputs: q_desc u8[B][q_stride][32], nq[B], q_xy i64[B][q_stride][2] (frame.kp_arr); t_desc u8[B][t_stride][32], nt[B],
+ *   t_pts f64[B][t_stride][3] (kf_ref.cloud_kp, or the map points that passed bh_visibility_gate); K = {fx, fy, cx, cy, baseline}.
+ * Outputs, pair b at out_stride*b: qidx / tidx / dist of the matches that pass the distance test (ascending queryIdx), n_match[b];
+ *   R f64[B][9], t f64[B][3] (camera-in-world as CamOnlyBA returns them), inlier u8 per kept match, n_inlier[B];
+ *   status[b] = BH_TRACK_OK | BH_TRACK_FEW_MATCHES (CamOnlyBA not run, R / t untouched) | BH_TRACK_BA_FAILED | BH_TRACK_FEW_INLIERS. */
+#define BH_TRACK_OK           0
+#define BH_TRACK_FEW_MATCHES  1
+#define BH_TRACK_BA_FAILED    2
+#define BH_TRACK_FEW_INLIERS  3
+int bh_track_refkf(bh_ctx* ctx, const uint8_t* q_desc, const int* nq, const int64_t* q_xy, int q_stride,
+                   const uint8_t* t_desc, const int* nt, const double* t_pts, int t_stride, int B,
+                   int d_max, int inclusive, int min_matches, int min_inliers,
+                   const double K[5], int iters, double huber_delta, double chi2_thr,
+                   int* qidx, int* tidx, int* dist, int* n_match, double* R, double* t, uint8_t* inlier, int* n_inlier,
+                   int* status, int out_stride, int mem);
+
 /* ---- local bundle adjustment --------------------------------------------------------------------------------------
  * Replaces the g2o graph of BundleAdjustment — slam/optimizer.py:8-79 — as driven by
  * CovisibilityGraph.optimize_local — slam/covisibility_graph.py:186-235.
