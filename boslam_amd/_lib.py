@@ -70,6 +70,7 @@ _SIGS = {
     "bh_bow_create": (_i, [_vp, C.POINTER(_vp)]),
     "bh_bow_destroy": (None, [_vp]),
     "bh_bow_set_db": (_i, [_vp, C.c_longlong, _vp, _vp, _vp, _i]),
+    "bh_bow_set_mode": (_i, [_vp, _i]),
     "bh_bow_add_entry": (_i, [_vp, _vp, _vp, _i, C.POINTER(_i)]),
     "bh_bow_erase_entry": (_i, [_vp, _i]),
     "bh_voc_create": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),

@@ -74,6 +74,10 @@ class BowDatabase:
                                                       _lib.ptr(ids), _lib.ptr(sc), C.byref(n), BH_MEM_HOST))
         return ids[:n.value].copy(), sc[:n.value].copy()
 
+    def set_mode(self, mode):
+        """'inverted' (default: inverted-file query, scan as the fallback) or 'scan' (always stream the database)."""
+        self.ctx.check(_lib.lib().bh_bow_set_mode(self.h, {"inverted": 0, "scan": 1}[mode]))
+
     def compare(self, i, j):
         """compareBowsL1 of two stored entries -> (number of common words, L1 score)."""
         cnt = C.c_int(0); score = C.c_double(0.0)

@@ -14,6 +14,7 @@
 #include "bh_internal.h"
 #include <math.h>
 #include <vector>
+#include <hipcub/hipcub.hpp>
 
 // ================================================================================================ visibility gate
 __global__ __launch_bounds__(1024) void k_gate(const double* __restrict__ pts, const double* __restrict__ nrm,
@@ -106,6 +107,15 @@ struct bh_bow {
     long long n_entries = 0, n_elems = 0;          // padded element count
     std::vector<long long> h_pstart;               // host mirror of the padded row offsets (for appends)
     bh_buf pstart, words, vals, acc, qw, qv, res;
+    // inverted file (DBoW3's own structure: word -> (entry, weight) rows), rebuilt lazily after the database changed
+    bh_buf inv_start, inv_entry, inv_val, inv_tmp, bcnt, bkey, bval, cand_v, cand_i;
+    int inv_ready = 0;             // rows are current
+    int inv_usable = 1;            // every word id < 2^20 (else only the scan can answer)
+    int mode = 0;                  // 0 = inverted file where possible, 1 = always scan (bh_bow_set_mode)
+    long long inv_nb = 0;          // buckets of 64 entries
+    int bcap = 0;                  // hit records a bucket can hold
+    char* hq = nullptr;            // pinned, device-visible: the query going in, the results coming out
+    size_t hq_cap = 0;
 };
 
 // grow a device buffer keeping its first `keep` bytes
@@ -293,8 +303,10 @@ extern "C" void bh_bow_destroy(bh_bow* bow)
     if (!bow) return;
     (void)hipSetDevice(bow->ctx->device);
     (void)hipStreamSynchronize(bow->ctx->stream);
-    bh_buf* all[] = { &bow->pstart, &bow->words, &bow->vals, &bow->acc, &bow->qw, &bow->qv, &bow->res };
+    bh_buf* all[] = { &bow->pstart, &bow->words, &bow->vals, &bow->acc, &bow->qw, &bow->qv, &bow->res,
+                      &bow->inv_start, &bow->inv_entry, &bow->inv_val, &bow->inv_tmp, &bow->bcnt, &bow->bkey, &bow->bval, &bow->cand_v, &bow->cand_i };
     for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    if (bow->hq) (void)hipHostFree(bow->hq);
     delete bow;
 }
 
@@ -320,6 +332,7 @@ extern "C" int bh_bow_set_db(bh_bow* bow, long long n_entries, const int64_t* st
     }
     const long long nel = hstart[n_entries] - hstart[0], npad = pst[n_entries];
     bow->n_entries = n_entries; bow->n_elems = npad; bow->h_pstart = pst;
+    bow->inv_ready = 0;
     BH_TRY(bh_reserve(ctx, &bow->pstart, sizeof(long long) * (n_entries + 1)));
     BH_TRY(bh_reserve(ctx, &bow->words, sizeof(uint32_t) * (npad + 4))); BH_TRY(bh_reserve(ctx, &bow->vals, sizeof(double) * (npad + 4)));
     BH_TRY(bh_reserve(ctx, &bow->acc, sizeof(double) * (n_entries + 1)));
@@ -366,6 +379,411 @@ extern "C" int bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const doubl
     return bow_query_impl(bow, q_words, q_vals, nq, nullptr, 0, max_results, ids, scores, n_results, mem);
 }
 
+// ================================================================================================ inverted-file query
+// DBoW3 answers a query through its inverted file: for every word of the query it walks that word's row of (entry, weight) items
+// (Database::queryL1, behind slam/bow_db.py:37-42 -> docker/pydbow3/src/dbow3.cpp:147-152).  A query of ~1000 words against configs[3]
+// touches ~100 items per word, 1.2 MB, where the scan above streams the word ids of the whole database (400 MB).
+//   build (lazy, after the database changed)  word histogram -> exclusive scan -> scatter of (entry, weight) into the rows (order
+//          inside a row is arbitrary);
+//   k_inv_gather   one wave per query word: every item of the row becomes a hit record (entry & 63 << 11 | rank of the word in the
+//          query, term |q - d| - |q| - |d|) appended to one of the four lists of its bucket of 64 entries (four, picked by the rank's
+//          low bits: a relocalisation query hits its near-duplicate entry ~1000 times, and returning atomics on ONE counter serialise);
+//          what a list cannot hold goes to a global overflow list with the full entry id;
+//   k_inv_reduce   one wave per bucket: ranks the bucket's records by (entry, word rank) and adds them IN THAT ORDER - per entry the
+//          ascending word order of DBoW3's accumulation, so scores are bit-identical to the scan and to the oracle; buckets that
+//          overflowed are only noted;
+//   k_inv_heavy    one 1024-lane workgroup per noted bucket: its lists + its share of the overflow list, the same ranking and ordered sums;
+//   k_inv_select   one workgroup: a threshold from the 16 wave minima (k <= 16 of them are k actual values, so at least k accumulators
+//          lie at or below it), the few accumulators at or below it collected and ordered by (value, id), results to pinned host memory.
+// Anything that does not fit (overflow list, heavy-bucket table, a heavy bucket beyond 4096 records) raises a flag: the scan answers.
+#define INV_WORDS BOW_BITS
+#define INV_KMAX 16                                           // results the select kernel can deliver (k <= 16 wave minima)
+#define INV_NSUB 4                                            // lists per bucket
+#define INV_RANK_BITS 11                                      // query ranks < 2048 (BOW_QMAX = 1536)
+#define INV_OVF_CAP 65536                                     // records of the global overflow list
+#define INV_HEAVY_MAX 32                                      // buckets that may overflow in one query
+#define INV_HCAP 4096                                         // records a heavy bucket's workgroup can rank
+#define INV_SELCAP 1024                                       // accumulators at or below the threshold
+
+struct inv_ctl { int ovf_cnt, heavy_cnt, flags, pad; int heavy_bk[INV_HEAVY_MAX]; int heavy_n[INV_HEAVY_MAX][INV_NSUB]; };
+
+__global__ __launch_bounds__(256) void k_inv_count(const uint32_t* __restrict__ pw, long long n, uint32_t* __restrict__ cnt, int* __restrict__ bad)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const uint32_t w = pw[i];
+        if (w == BOW_PAD_WORD) continue;
+        if (w >= INV_WORDS) { *bad = 1; continue; }
+        atomicAdd(&cnt[w], 1u);
+    }
+}
+__global__ __launch_bounds__(256) void k_inv_fill(const long long* __restrict__ pstart, const uint32_t* __restrict__ pw, const double* __restrict__ pv,
+                                                  long long n_entries, const long long* __restrict__ inv_start, uint32_t* __restrict__ cursor,
+                                                  uint32_t* __restrict__ inv_entry, double* __restrict__ inv_val)
+{
+    const long long e = blockIdx.x;
+    if (e >= n_entries) return;
+    const long long a = pstart[e], b = pstart[e + 1];
+    for (long long i = a + threadIdx.x; i < b; i += 256) {
+        const uint32_t w = pw[i];
+        if (w >= INV_WORDS) continue;                          // padding (and out-of-range ids: inv_usable is off then)
+        const long long pos = inv_start[w] + atomicAdd(&cursor[w], 1u);
+        inv_entry[pos] = (uint32_t)e; inv_val[pos] = pv[i];
+    }
+}
+__global__ void k_inv_widen(const uint32_t* __restrict__ cnt, long long* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = cnt[i];
+}
+
+__global__ __launch_bounds__(256) void k_inv_gather(const uint32_t* __restrict__ qw, const double* __restrict__ qv, int nq,
+                                                    const long long* __restrict__ inv_start, const uint32_t* __restrict__ inv_entry,
+                                                    const double* __restrict__ inv_val, int* __restrict__ bcnt, uint32_t* __restrict__ bkey,
+                                                    double* __restrict__ bval, int scap, inv_ctl* __restrict__ ctl, uint32_t* __restrict__ okey,
+                                                    double* __restrict__ oval)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= nq) return;
+    const uint32_t w = qw[r];
+    if (w >= INV_WORDS) return;                                // no row: no database entry holds such a word
+    const double q = qv[r];
+    const long long a = inv_start[w], b = inv_start[w + 1];
+    for (long long i = a + lane; i < b; i += 64) {
+        const uint32_t e = inv_entry[i];
+        const double d = inv_val[i];
+        const double term = fabs(q - d) - fabs(q) - fabs(d);
+        const size_t li = (size_t)(e >> 6) * INV_NSUB + (r & (INV_NSUB - 1));
+        const int pos = atomicAdd(&bcnt[li], 1);
+        if (pos < scap) { bkey[li * scap + pos] = ((e & 63u) << INV_RANK_BITS) | (uint32_t)r; bval[li * scap + pos] = term; }
+        else {
+            const int p2 = atomicAdd(&ctl->ovf_cnt, 1);
+            if (p2 < INV_OVF_CAP) { okey[p2] = (e << INV_RANK_BITS) | (uint32_t)r; oval[p2] = term; }
+            else ctl->flags = 1;
+        }
+    }
+}
+
+// rank sort of n records (keys unique) held in s_key / s_val by `nthr` cooperating lanes -> s_okey / s_oval; caller synchronises around it
+__device__ __forceinline__ void inv_rank_sort(const uint32_t* s_key, const double* s_val, uint32_t* s_okey, double* s_oval, int n, int t, int nthr)
+{
+    for (int i = t; i < n; i += nthr) {
+        const uint32_t key = s_key[i];
+        int pos = 0;
+        for (int j = 0; j < n; j++) pos += s_key[j] < key ? 1 : 0;
+        s_okey[pos] = key; s_oval[pos] = s_val[i];
+    }
+}
+// the ordered sum of entry-slot l's records in a list sorted by (slot << INV_RANK_BITS | rank).  Both ends of the slot's segment are
+// found by binary search first: a loop that tests every loaded key before it adds serialises on the LDS latency (57 us for the 800
+// hits of a relocalisation query's near-duplicate entry).
+__device__ __forceinline__ int inv_lower_bound(const uint32_t* s_okey, int n, uint32_t k0)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_okey[mid] < k0) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ double inv_ordered_sum(const uint32_t* s_okey, const double* s_oval, int n, int l, bool* any)
+{
+    const int a = inv_lower_bound(s_okey, n, (uint32_t)l << INV_RANK_BITS), b = inv_lower_bound(s_okey, n, (uint32_t)(l + 1) << INV_RANK_BITS);
+    double acc = 0.0;
+    for (int i = a; i < b; i++) acc += s_oval[i];
+    *any = b > a;
+    return acc;
+}
+// minimum of the wave's 64 values -> lane 0
+__device__ __forceinline__ double inv_wave_min(double v, int lane)
+{
+    for (int m = 32; m > 0; m >>= 1) v = fmin(v, bow_shfl(v, lane ^ m));
+    return v;
+}
+
+#define INV_LCAP 256                                           // records a light bucket's wave ranks (4 lists x 64)
+__global__ __launch_bounds__(256) void k_inv_reduce(int* __restrict__ bcnt, const uint32_t* __restrict__ bkey, const double* __restrict__ bval, int scap,
+                                                    long long n_entries, const uint8_t* __restrict__ keep, double* __restrict__ acc_out, long long nb,
+                                                    inv_ctl* __restrict__ ctl, double* __restrict__ bmin)
+{
+    __shared__ uint32_t s_key[4][INV_LCAP], s_okey[4][INV_LCAP];
+    __shared__ double s_val[4][INV_LCAP], s_oval[4][INV_LCAP];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long bk = (long long)blockIdx.x * 4 + wv;
+    if (bk >= nb) return;
+    int c[INV_NSUB], n = 0; bool heavy = false;
+#pragma unroll
+    for (int u = 0; u < INV_NSUB; u++) { c[u] = bcnt[bk * INV_NSUB + u]; heavy = heavy || c[u] > scap; }
+    if (lane < INV_NSUB) bcnt[bk * INV_NSUB + lane] = 0;       // ready for the next query
+    if (heavy) {                                               // some of its records sit in the overflow list: k_inv_heavy takes the bucket
+        if (lane == 0) {
+            const int hp = atomicAdd(&ctl->heavy_cnt, 1);
+            if (hp < INV_HEAVY_MAX) { ctl->heavy_bk[hp] = (int)bk; for (int u = 0; u < INV_NSUB; u++) ctl->heavy_n[hp][u] = min(c[u], scap); }
+            else ctl->flags = 1;
+        }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < INV_NSUB; u++) {
+        for (int i = lane; i < c[u]; i += 64) { s_key[wv][n + i] = bkey[((size_t)bk * INV_NSUB + u) * scap + i]; s_val[wv][n + i] = bval[((size_t)bk * INV_NSUB + u) * scap + i]; }
+        n += c[u];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    inv_rank_sort(s_key[wv], s_val[wv], s_okey[wv], s_oval[wv], n, lane, 64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bool any;
+    const double acc = inv_ordered_sum(s_okey[wv], s_oval[wv], n, lane, &any);   // lane l owns entry 64 bk + l: its hits in ascending word order
+    const long long e = bk * 64 + lane;
+    const double v = (any && e < n_entries && (!keep || keep[e])) ? acc : INFINITY;
+    if (e < n_entries) acc_out[e] = v;
+    const double bm = inv_wave_min(v, lane);
+    if (lane == 0) bmin[bk] = bm;
+}
+
+__global__ __launch_bounds__(1024) void k_inv_heavy(const uint32_t* __restrict__ bkey, const double* __restrict__ bval, int scap, long long n_entries,
+                                                    const uint8_t* __restrict__ keep, double* __restrict__ acc_out, inv_ctl* __restrict__ ctl,
+                                                    const uint32_t* __restrict__ okey, const double* __restrict__ oval, double* __restrict__ bmin)
+{
+    extern __shared__ uint32_t hsm[];
+    uint32_t* s_key = hsm; uint32_t* s_okey = hsm + INV_HCAP;
+    double* s_val = reinterpret_cast<double*>(hsm + 2 * INV_HCAP); double* s_oval = s_val + INV_HCAP;
+    __shared__ int s_n;
+    const int hb = blockIdx.x, tid = threadIdx.x;
+    if (hb >= min(ctl->heavy_cnt, INV_HEAVY_MAX)) return;
+    const long long bk = ctl->heavy_bk[hb];
+    int n0 = 0;
+    for (int u = 0; u < INV_NSUB; u++) {
+        const int cu = ctl->heavy_n[hb][u];
+        for (int i = tid; i < cu; i += 1024) { s_key[n0 + i] = bkey[((size_t)bk * INV_NSUB + u) * scap + i]; s_val[n0 + i] = bval[((size_t)bk * INV_NSUB + u) * scap + i]; }
+        n0 += cu;
+    }
+    if (tid == 0) s_n = n0;
+    __syncthreads();
+    const int novf = min(ctl->ovf_cnt, INV_OVF_CAP);
+    for (int i0 = 0; i0 < novf; i0 += 1024) {                  // (whole waves iterate: the append below is aggregated per wave - 800 returning
+        const int i = i0 + tid;                                //  LDS atomics on one counter serialise: 38 us)
+        const uint32_t k = i < novf ? okey[i] : 0xffffffffu;
+        const bool mine = i < novf && (long long)(k >> (INV_RANK_BITS + 6)) == bk;
+        const unsigned long long bm = __ballot(mine);
+        if (bm) {
+            const int lane = tid & 63, leader = __ffsll((long long)bm) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_n, __popcll(bm));
+            base = __shfl(base, leader, 64);
+            const int pos = base + __popcll(bm & ((1ull << lane) - 1ull));
+            if (mine && pos < INV_HCAP) { s_key[pos] = k & ((64u << INV_RANK_BITS) - 1u); s_val[pos] = oval[i]; }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n > INV_HCAP) { if (tid == 0) ctl->flags = 1; return; }
+    // Sort by (slot, rank) in O(n): the (slot, rank) pairs are distinct, so a bitmap of 64 slots x 2048 ranks says where every record
+    // goes: position = records of earlier slots + set bits of the slot below the rank.  (Ranking every record against every other,
+    // as the light buckets do, is 740 k comparisons on one CU for a relocalisation query's near-duplicate entry: 28 us.)
+    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_oval + INV_HCAP);       // [64][64] words
+    int* s_wp = reinterpret_cast<int*>(s_bm + 4096);                        // [64][64] set bits of the slot before word w
+    int* s_so = s_wp + 4096;                                                // [64] records of earlier slots
+    for (int i = tid; i < 4096; i += 1024) s_bm[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) { const uint32_t key = s_key[i]; atomicOr(&s_bm[key >> 5], 1u << (key & 31)); }      // key = slot << 11 | rank: word = key >> 5
+    __syncthreads();
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int sl = wv; sl < 64; sl += 16) {                 // a wave per slot: exclusive prefix of its 64 words' popcounts
+            const int c = __popc(s_bm[sl * 64 + lane]);
+            int incl = c;
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+            s_wp[sl * 64 + lane] = incl - c;
+            if (lane == 63) s_so[sl] = incl;                   // the slot's total for now
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {                                            // exclusive prefix over the slots
+        const int c = s_so[tid];
+        int incl = c;
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (tid >= d) incl += o; }
+        s_so[tid] = incl - c;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const uint32_t key = s_key[i];
+        const int pos = s_so[key >> INV_RANK_BITS] + s_wp[key >> 5] + __popc(s_bm[key >> 5] & ((1u << (key & 31)) - 1u));
+        s_okey[pos] = key; s_oval[pos] = s_val[i];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        bool any;
+        const double acc = inv_ordered_sum(s_okey, s_oval, n, tid, &any);
+        const long long e = bk * 64 + tid;
+        const double v = (any && e < n_entries && (!keep || keep[e])) ? acc : INFINITY;
+        if (e < n_entries) acc_out[e] = v;
+        const double bm = inv_wave_min(v, tid);
+        if (tid == 0) bmin[bk] = bm;
+    }
+}
+
+// results -> pinned host memory: [int n][int fallback][double scores[k]][int ids[k]].  Works from the buckets' minima: the k-th
+// smallest of the 16 wave minima T is an upper bound of the k-th best accumulator (k <= 16 distinct buckets hold a value <= T); only
+// buckets whose minimum is <= T can hold a result, and there are few of them.
+__global__ __launch_bounds__(1024) void k_inv_select(const double* __restrict__ acc, const double* __restrict__ bmin, long long nb, long long n_entries, int k,
+                                                     inv_ctl* __restrict__ ctl, char* __restrict__ hout)
+{
+    __shared__ double s_wmin[16];
+    __shared__ double s_cv[INV_SELCAP];
+    __shared__ int s_ci[INV_SELCAP];
+    __shared__ int s_bl[INV_SELCAP / 16];
+    __shared__ int s_m, s_nb;
+    __shared__ double s_T;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double mn = INFINITY, mine[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const long long b = tid + 1024 * u; mine[u] = b < nb ? bmin[b] : INFINITY; mn = fmin(mn, mine[u]); }
+    for (long long b = tid + 4096; b < nb; b += 1024) mn = fmin(mn, bmin[b]);
+    mn = inv_wave_min(mn, lane);
+    if (lane == 0) s_wmin[wv] = mn;
+    if (tid == 0) { s_m = 0; s_nb = 0; }
+    __syncthreads();
+    if (tid == 0) {
+        double v[16];
+        for (int i = 0; i < 16; i++) v[i] = s_wmin[i];
+        for (int i = 0; i < 16; i++) for (int j = i + 1; j < 16; j++) if (v[j] < v[i]) { const double t = v[i]; v[i] = v[j]; v[j] = t; }
+        s_T = v[k - 1];
+    }
+    __syncthreads();
+    const double T = s_T;                                      // +inf when fewer than k waves saw a hit: then every bucket with a hit is listed
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long long b = tid + 1024 * u;
+        if (mine[u] <= T && mine[u] < INFINITY) { const int p = atomicAdd(&s_nb, 1); if (p < INV_SELCAP / 16) s_bl[p] = (int)b; }
+    }
+    for (long long b = tid + 4096; b < nb; b += 1024) {
+        const double v = bmin[b];
+        if (v <= T && v < INFINITY) { const int p = atomicAdd(&s_nb, 1); if (p < INV_SELCAP / 16) s_bl[p] = (int)b; }
+    }
+    __syncthreads();
+    const int nbl = s_nb;
+    int* hi = reinterpret_cast<int*>(hout);
+    bool bad = nbl > INV_SELCAP / 16;
+    if (!bad) {
+        for (int i = wv; i < nbl; i += 16) {                   // a wave per listed bucket: one accumulator per lane
+            const long long e = (long long)s_bl[i] * 64 + lane;
+            const double v = e < n_entries ? acc[e] : INFINITY;
+            if (v <= T && v < INFINITY) { const int p = atomicAdd(&s_m, 1); if (p < INV_SELCAP) { s_cv[p] = v; s_ci[p] = (int)e; } }
+        }
+    }
+    __syncthreads();
+    const int m = s_m;
+    bad = bad || m > INV_SELCAP;
+    if (bad) { if (tid == 0) { hi[0] = 0; hi[1] = 1; ctl->ovf_cnt = 0; ctl->heavy_cnt = 0; ctl->flags = 0; } return; }
+    if (tid < m) {                                             // order by (value, id): position = number of candidates that come first
+        const double v = s_cv[tid]; const int id = s_ci[tid];
+        int pos = 0;
+        for (int j = 0; j < m; j++) { const double ov = s_cv[j]; pos += (ov < v || (ov == v && s_ci[j] < id)) ? 1 : 0; }
+        if (pos < k) { reinterpret_cast<double*>(hout + 8)[pos] = -v / 2.0; reinterpret_cast<int*>(hout + 8 + 8 * k)[pos] = id; }
+    }
+    if (tid == 0) { hi[0] = min(m, k); hi[1] = ctl->flags; ctl->ovf_cnt = 0; ctl->heavy_cnt = 0; ctl->flags = 0; }      // counters ready for the next query
+}
+
+static int inv_build(bh_bow* bow)
+{
+    bh_ctx* ctx = bow->ctx;
+    hipStream_t st = ctx->stream;
+    const long long nel = bow->n_elems, ne = bow->n_entries;
+    BH_TRY(bh_reserve(ctx, &bow->inv_start, sizeof(long long) * (INV_WORDS + 2)));
+    BH_TRY(bh_reserve(ctx, &bow->inv_entry, sizeof(uint32_t) * (size_t)(nel + 4))); BH_TRY(bh_reserve(ctx, &bow->inv_val, sizeof(double) * (size_t)(nel + 4)));
+    size_t scan_bytes = 0;
+    BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const long long*)nullptr, (long long*)nullptr, INV_WORDS + 1, st));
+    const size_t off_cnt = 0, off_wide = off_cnt + sizeof(uint32_t) * (INV_WORDS + 64), off_scan = off_wide + sizeof(long long) * (INV_WORDS + 2);
+    BH_TRY(bh_reserve(ctx, &bow->inv_tmp, off_scan + scan_bytes + 256));
+    uint32_t* cnt = (uint32_t*)((char*)bow->inv_tmp.p + off_cnt); long long* wide = (long long*)((char*)bow->inv_tmp.p + off_wide);
+    int* bad = (int*)(cnt + INV_WORDS + 8);
+    BH_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (INV_WORDS + 64), st));
+    const int g = (int)std::min<long long>(4096, (nel + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_inv_count, dim3(g), dim3(256), 0, st, (const uint32_t*)bow->words.p, nel, cnt, bad);
+    hipLaunchKernelGGL(k_inv_widen, dim3((INV_WORDS + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)cnt, wide, INV_WORDS + 1);
+    BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum((char*)bow->inv_tmp.p + off_scan, scan_bytes, (const long long*)wide, (long long*)bow->inv_start.p, INV_WORDS + 1, st));
+    int hbad = 0;
+    BH_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    BH_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * INV_WORDS, st));                      // now the per-row fill cursors
+    hipLaunchKernelGGL(k_inv_fill, dim3((unsigned)ne), dim3(256), 0, st, (const long long*)bow->pstart.p, (const uint32_t*)bow->words.p, (const double*)bow->vals.p,
+                       ne, (const long long*)bow->inv_start.p, cnt, (uint32_t*)bow->inv_entry.p, (double*)bow->inv_val.p);
+    BH_HIP(ctx, hipGetLastError());
+    BH_HIP(ctx, hipStreamSynchronize(st));
+    bow->inv_usable = hbad ? 0 : 1;
+    // buckets of 64 entries, INV_NSUB lists each: a list holds 3 x the hits a full 1536-word query expects of it, 16 .. 64
+    bow->inv_nb = (ne + 63) / 64;
+    const double per_entry = ne ? (double)nel / (double)ne : 0.0;                               // words per entry (padded)
+    const long long cap = (long long)(3.0 * 64.0 * per_entry * (double)BOW_QMAX / (double)INV_WORDS / INV_NSUB) + 16;
+    bow->bcap = (int)std::min<long long>(INV_LCAP / INV_NSUB, (cap + 15) / 16 * 16);          // per list
+    const size_t nl = (size_t)bow->inv_nb * INV_NSUB;
+    BH_TRY(bh_reserve(ctx, &bow->bcnt, sizeof(int) * (nl + 64) + sizeof(inv_ctl)));
+    BH_TRY(bh_reserve(ctx, &bow->bkey, sizeof(uint32_t) * nl * bow->bcap + 64)); BH_TRY(bh_reserve(ctx, &bow->bval, sizeof(double) * nl * bow->bcap + 64));
+    BH_TRY(bh_reserve(ctx, &bow->cand_v, sizeof(double) * (INV_OVF_CAP + (size_t)bow->inv_nb + 8))); BH_TRY(bh_reserve(ctx, &bow->cand_i, sizeof(uint32_t) * INV_OVF_CAP));      // the overflow list; bucket minima behind its values
+    BH_HIP(ctx, hipMemsetAsync(bow->bcnt.p, 0, sizeof(int) * (nl + 64) + sizeof(inv_ctl), st));
+    BH_HIP(ctx, hipStreamSynchronize(st));
+    bow->inv_ready = 1;
+    return BH_OK;
+}
+
+// The inverted-file query, host arrays in and out.  Returns BH_OK with *used = 1 when it answered, *used = 0 when the scan must.
+static int inv_query(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, const int* subset, int n_subset, int max_results,
+                     int* ids, double* scores, int* n_results, int* used)
+{
+    bh_ctx* ctx = bow->ctx;
+    hipStream_t st = ctx->stream;
+    *used = 0;
+    if (max_results > INV_KMAX) return BH_OK;
+    if (!bow->inv_ready) BH_TRY(inv_build(bow));
+    if (!bow->inv_usable) return BH_OK;
+    // pinned, device-visible block: the query in, the results out - no staging copies, one synchronisation
+    const size_t qoff_v = ((sizeof(uint32_t) * (size_t)nq + 15) & ~(size_t)15), roff = qoff_v + sizeof(double) * (size_t)nq, need = roff + 8 + 12 * (size_t)max_results + 64;
+    if (need > bow->hq_cap) {
+        if (bow->hq) (void)hipHostFree(bow->hq);
+        bow->hq = nullptr; bow->hq_cap = 0;
+        const size_t want = std::max<size_t>(need, 64 * 1024);
+        if (hipHostMalloc((void**)&bow->hq, want, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); bow->hq = nullptr; return BH_OK; }
+        bow->hq_cap = want;
+    }
+    memcpy(bow->hq, q_words, sizeof(uint32_t) * (size_t)nq); memcpy(bow->hq + qoff_v, q_vals, sizeof(double) * (size_t)nq);
+    const uint8_t* keep = nullptr;
+    if (n_subset > 0) {
+        BH_TRY(bh_reserve(ctx, &ctx->st_g, (size_t)bow->n_entries + sizeof(int) * (size_t)n_subset + 16));
+        uint8_t* flag = (uint8_t*)ctx->st_g.p; int* d_sub = (int*)(flag + (((size_t)bow->n_entries + 15) & ~(size_t)15));
+        BH_HIP(ctx, hipMemsetAsync(flag, 0, (size_t)bow->n_entries, st));
+        BH_HIP(ctx, hipMemcpyAsync(d_sub, subset, sizeof(int) * (size_t)n_subset, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_bow_flag_set, dim3((n_subset + 255) / 256), dim3(256), 0, st, (const int*)d_sub, n_subset, bow->n_entries, flag);
+        keep = flag;
+    }
+    const int k = max_results;
+    static bool heavy_attr = false;
+    const size_t hlds = (sizeof(uint32_t) + sizeof(double)) * 2 * INV_HCAP + sizeof(uint32_t) * (4096 + 4096 + 64);
+    if (!heavy_attr) { BH_HIP(ctx, hipFuncSetAttribute((const void*)k_inv_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds)); heavy_attr = true; }
+    const size_t nl = (size_t)bow->inv_nb * INV_NSUB;
+    inv_ctl* ctl = (inv_ctl*)((int*)bow->bcnt.p + nl + 64);
+    uint32_t* okey = (uint32_t*)bow->cand_i.p; double* oval = (double*)bow->cand_v.p; double* bmin = oval + INV_OVF_CAP;
+    bh_time_begin(ctx, BH_K_BOW_INV);
+    hipLaunchKernelGGL(k_inv_gather, dim3((nq + 3) / 4), dim3(256), 0, st, (const uint32_t*)bow->hq, (const double*)(bow->hq + qoff_v), nq, (const long long*)bow->inv_start.p,
+                       (const uint32_t*)bow->inv_entry.p, (const double*)bow->inv_val.p, (int*)bow->bcnt.p, (uint32_t*)bow->bkey.p, (double*)bow->bval.p, bow->bcap, ctl, okey, oval);
+    hipLaunchKernelGGL(k_inv_reduce, dim3((unsigned)((bow->inv_nb + 3) / 4)), dim3(256), 0, st, (int*)bow->bcnt.p, (const uint32_t*)bow->bkey.p, (const double*)bow->bval.p, bow->bcap,
+                       bow->n_entries, keep, (double*)bow->acc.p, bow->inv_nb, ctl, bmin);
+    hipLaunchKernelGGL(k_inv_heavy, dim3(INV_HEAVY_MAX), dim3(1024), hlds, st, (const uint32_t*)bow->bkey.p, (const double*)bow->bval.p, bow->bcap, bow->n_entries, keep,
+                       (double*)bow->acc.p, ctl, (const uint32_t*)okey, (const double*)oval, bmin);
+    hipLaunchKernelGGL(k_inv_select, dim3(1), dim3(1024), 0, st, (const double*)bow->acc.p, (const double*)bmin, bow->inv_nb, bow->n_entries, k, ctl, bow->hq + roff);
+    bh_time_end(ctx);
+    BH_HIP(ctx, hipGetLastError());
+    BH_HIP(ctx, hipStreamSynchronize(st));
+    const int nres = reinterpret_cast<const int*>(bow->hq + roff)[0], fallback = reinterpret_cast<const int*>(bow->hq + roff)[1];
+    if (fallback) return BH_OK;                                // something did not fit this query: the scan answers
+    *n_results = nres;
+    memcpy(scores, bow->hq + roff + 8, sizeof(double) * (size_t)nres);
+    memcpy(ids, bow->hq + roff + 8 + 8 * (size_t)max_results, sizeof(int) * (size_t)nres);
+    *used = 1;
+    return BH_OK;
+}
+
+extern "C" int bh_bow_set_mode(bh_bow* bow, int mode)
+{
+    if (!bow || (mode != 0 && mode != 1)) return BH_ERR_INVALID;
+    bow->mode = mode;
+    return BH_OK;
+}
+
 static int bow_query_impl(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, const int* subset, int n_subset,
                           int max_results, int* ids, double* scores, int* n_results, int mem)
 {
@@ -379,6 +797,12 @@ static int bow_query_impl(bh_bow* bow, const uint32_t* q_words, const double* q_
     if (bow->n_entries == 0 || nq == 0) {
         if (mem == BH_MEM_HOST) *n_results = 0; else BH_HIP(ctx, hipMemsetAsync(n_results, 0, sizeof(int), st));
         return BH_OK;
+    }
+    if (mem == BH_MEM_HOST && bow->mode == 0) {                 // DBoW3's own structure first; the scan when it cannot answer
+        for (int i = 1; i < nq; i++) if (q_words[i] <= q_words[i - 1]) return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_query_l1: query words must be strictly ascending");
+        int used = 0;
+        BH_TRY(inv_query(bow, q_words, q_vals, nq, subset, n_subset, max_results, ids, scores, n_results, &used));
+        if (used) return BH_OK;
     }
     const uint32_t* d_qw = q_words; const double* d_qv = q_vals; int* d_ids = ids; double* d_sc = scores; int* d_n = n_results;
     if (mem == BH_MEM_HOST) {
@@ -501,6 +925,7 @@ extern "C" int bh_bow_add_entry(bh_bow* bow, const uint32_t* words, const double
     bow->h_pstart.push_back(a + npad);
     if (entry_id) *entry_id = (int)bow->n_entries;
     bow->n_entries += 1; bow->n_elems = a + npad;
+    bow->inv_ready = 0;
     return BH_OK;
 }
 
@@ -516,5 +941,6 @@ extern "C" int bh_bow_erase_entry(bh_bow* bow, int entry_id)
     const long long a = bow->h_pstart[entry_id], e = bow->h_pstart[entry_id + 1];
     if (e > a) BH_HIP(ctx, hipMemsetAsync((uint32_t*)bow->words.p + a, 0xff, sizeof(uint32_t) * (size_t)(e - a), ctx->stream));
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    bow->inv_ready = 0;
     return BH_OK;
 }

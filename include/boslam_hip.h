@@ -294,6 +294,11 @@ int  bh_bow_query_l1_subset(bh_bow* bow, const uint32_t* q_words, const double* 
 /* The fork's Database::compareBowsL1(i, j, cnt, score) behind Dbow.compareFrames — slam/bow_db.py:47-57 -> dbow3.cpp:154-162:
  * number of words the two stored entries share and their L1 score -sum(|a - b| - |a| - |b|) / 2 over those words. */
 int  bh_bow_compare_l1(bh_bow* bow, int entry_i, int entry_j, int* n_common, double* score);
+/* How host-side queries are answered: 0 (default) = through the inverted file (word -> (entry, weight) rows, DBoW3's own structure,
+ * built on the device after the database changed; ~1 MB touched per query of configs[3]) with the streaming scan as the fallback
+ * (word ids >= 2^20, max_results > 16, a query that overflows a bucket's hit list); 1 = always the scan (400 MB streamed per query).
+ * Both give bit-identical ids and scores.  BH_MEM_DEVICE queries always scan. */
+int  bh_bow_set_mode(bh_bow* bow, int mode);
 
 /* Database::add at the BoW-vector level — slam/bow_db.py:26 -> dbow3.cpp:138-140: appends one entry (host arrays, words
  * strictly ascending), returns its entry id. */

@@ -28,10 +28,12 @@ def test_bow_query_matches_oracle(ctx, n_entries, wpe, k):
     db = synth.bow_database(n_entries=n_entries, words_per_entry=wpe, query_entry=n_entries // 3, seed=n_entries)
     d = bow.BowDatabase(ctx)
     d.set_db(db["start"], db["words"], db["vals"])
-    ids, sc = d.query(db["q_words"], db["q_vals"], k)
     oi, os_ = oracle.bow_query_l1(db["q_words"], db["q_vals"], db["start"], db["words"], db["vals"], k)
-    assert np.array_equal(ids, oi)
-    assert np.array_equal(sc.view(np.uint64), os_.view(np.uint64)), "scores must be bit-identical (same summation order)"
+    for mode in ("scan", "inverted"):                                         # the streaming scan and the inverted-file walk (DBoW3's own structure)
+        d.set_mode(mode)
+        ids, sc = d.query(db["q_words"], db["q_vals"], k)
+        assert np.array_equal(ids, oi), mode
+        assert np.array_equal(sc.view(np.uint64), os_.view(np.uint64)), "scores must be bit-identical (same summation order)"
     assert ids[0] == db["query_entry"] and sc[0] > 0.5                        # relocalisation finds the perturbed entry
     i1, s1 = d.query(db["q_words"], db["q_vals"], 1)                          # the reference asks for top-1 (bow_db.py:39)
     assert i1[0] == oi[0] and s1[0] == os_[0]
@@ -47,10 +49,12 @@ def test_bow_ragged_and_empty_entries(ctx):
     qw = np.sort(rng.choice(5000, size=600, replace=False)).astype(np.uint32); qv = rng.random(600)
     d = bow.BowDatabase(ctx)
     d.set_db(start, words, vals)
-    ids, sc = d.query(qw, qv, 8)
     oi, os_ = oracle.bow_query_l1(qw, qv, start, words, vals, 8)
-    assert np.array_equal(ids, oi) and np.array_equal(sc, os_)
-    assert 0 not in ids and 3 not in ids                                       # empty entries never appear
+    for mode in ("scan", "inverted"):
+        d.set_mode(mode)
+        ids, sc = d.query(qw, qv, 8)
+        assert np.array_equal(ids, oi) and np.array_equal(sc, os_), mode
+        assert 0 not in ids and 3 not in ids                                   # empty entries never appear
     # a query sharing no word with anything returns nothing
     ids, sc = d.query(np.array([6000, 6001], np.uint32), np.array([0.5, 0.5]), 3)
     assert len(ids) == 0
@@ -62,10 +66,55 @@ def test_bow_config4_full_size_and_roofline(ctx):
     db = synth.bow_database()
     d = bow.BowDatabase(ctx)
     d.set_db(db["start"], db["words"], db["vals"])
-    ids, sc = d.query(db["q_words"], db["q_vals"], 10)
     oi, os_ = oracle.bow_query_l1(db["q_words"], db["q_vals"], db["start"], db["words"], db["vals"], 10)
-    assert np.array_equal(ids, oi) and np.array_equal(sc, os_)
-    assert ids[0] == 12345
+    for mode in ("scan", "inverted"):
+        d.set_mode(mode)
+        ids, sc = d.query(db["q_words"], db["q_vals"], 10)
+        assert np.array_equal(ids, oi) and np.array_equal(sc, os_), mode
+        assert ids[0] == 12345
+    d.close()
+
+
+def test_bow_inverted_file_follows_the_database_and_falls_back(ctx):
+    """The inverted file is rebuilt after add / erase; a query that hits one bucket of 64 entries more often than its hit list holds
+    (64 near-copies of the query side by side) is answered by the scan instead - same ids, same bits; subsets and top-k > 16 too."""
+    rng = np.random.default_rng(8)
+    qw = np.sort(rng.choice(200000, size=900, replace=False)).astype(np.uint32); qv = rng.random(900); qv /= qv.sum()
+    rows = []
+    for e in range(400):
+        if 128 <= e < 192:                                                     # one whole bucket of near-duplicates of the query: 64 x ~850 hits
+            w = np.sort(rng.choice(qw, size=850, replace=False)).astype(np.uint32)
+        else:
+            w = np.sort(np.concatenate([rng.choice(qw, size=rng.integers(0, 30), replace=False), rng.choice(np.arange(200000, 400000), size=200, replace=False)])).astype(np.uint32)
+        v = rng.random(len(w)); rows.append((w, v / v.sum()))
+    start = np.concatenate([[0], np.cumsum([len(r[0]) for r in rows])]).astype(np.int64)
+    words = np.concatenate([r[0] for r in rows]); vals = np.concatenate([r[1] for r in rows])
+    d = bow.BowDatabase(ctx)
+    d.set_db(start, words, vals)
+    oi, os_ = oracle.bow_query_l1(qw, qv, start, words, vals, 10)
+    ids, sc = d.query(qw, qv, 10)                                              # inverted by default -> overflow -> scan
+    assert np.array_equal(ids, oi) and np.array_equal(sc, os_) and 128 <= ids[0] < 192
+    sub = [3, 7, 150, 151, 399]
+    oi2, os2 = oracle.bow_query_l1_subset(qw, qv, start, words, vals, sub, 3)
+    ids, sc = d.query(qw, qv, 3, subset=sub)
+    assert np.array_equal(ids, oi2) and np.array_equal(sc, os2)
+    ids, sc = d.query(qw, qv, 40)                                              # more results than a bucket reports candidates for
+    oi3, os3 = oracle.bow_query_l1(qw, qv, start, words, vals, 40)
+    assert np.array_equal(ids, oi3) and np.array_equal(sc, os3)
+    # a sparse query stays on the inverted file; then the database changes under it
+    q2 = qw[::9].copy(); v2 = np.full(len(q2), 1.0 / len(q2))
+    oi4, os4 = oracle.bow_query_l1(q2, v2, start, words, vals, 5)
+    ids, sc = d.query(q2, v2, 5)
+    assert np.array_equal(ids, oi4) and np.array_equal(sc, os4)
+    ids, sc = d.query(q2, v2, 4, subset=[1, 2, 130, 140, 300])
+    oi5, os5 = oracle.bow_query_l1_subset(q2, v2, start, words, vals, [1, 2, 130, 140, 300], 4)
+    assert np.array_equal(ids, oi5) and np.array_equal(sc, os5)
+    new = d.add(q2, v2)                                                        # an exact copy of the query: must win after the rebuild
+    ids, sc = d.query(q2, v2, 2)
+    assert ids[0] == new and abs(sc[0] - 1.0) < 1e-12
+    d.erase(new)
+    ids, sc = d.query(q2, v2, 5)
+    assert np.array_equal(ids, oi4) and np.array_equal(sc, os4)
     d.close()
 
 

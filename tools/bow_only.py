@@ -1,4 +1,6 @@
-import sys, os, json; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+"""configs[3] BoW query on one GPU (both paths): python tools/bow_only.py"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from boslam_amd import Context, bow_bench
 ctx = Context(0)
-print(json.dumps(bow_bench.run_sharded(ctx, repeats=10)))
+print(json.dumps(bow_bench.run_sharded(ctx, None, "cuda:0")))
