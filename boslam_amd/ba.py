@@ -85,7 +85,7 @@ class LocalBA:
 
     def solver(self):
         """Name of the reduced-camera-system solver set_problem selected (bh_ba_solver)."""
-        return {0: "panel", 1: "dense", 2: "window", 3: "twoway", 4: "bcr"}.get(_lib.lib().bh_ba_solver(self.h), "none")
+        return {0: "panel", 1: "dense", 2: "window", 3: "twoway", 4: "bcr", 5: "bcr-segments"}.get(_lib.lib().bh_ba_solver(self.h), "none")
 
     def close(self):
         if getattr(self, "h", None):
@@ -147,19 +147,41 @@ def make_allreduce_hook(ctx, dist, device=None):
     L = _lib.lib()
 
     def hook(user, dev, count, op):
+        # op 0 / 1: all-reduce sum / max; op 2: reduce-scatter sum (world equal chunks, chunk `rank` receives the sum); op 3: all-gather
+        # (chunk `rank` is this rank's contribution) - all in place on the library's device buffer
         try:
-            rop = dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM
+            count = int(count)
+            world, rank = dist.get_world_size(), dist.get_rank()
             if on_device:
                 t = torch.as_tensor(_DeviceF64(dev, count), device=device or "cuda")
-                dist.all_reduce(t, op=rop)
+                if op < 2:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+                else:
+                    ch = count // world
+                    mine = t[rank * ch:(rank + 1) * ch]
+                    if op == 2:
+                        dist.reduce_scatter_tensor(mine, t)                 # RCCL: in place (output = the rank's chunk of the input)
+                    else:
+                        dist.all_gather_into_tensor(t, mine)                # RCCL: in place
                 torch.cuda.current_stream(t.device).synchronize()
-            else:
-                h = np.empty(int(count), np.float64)
-                if L.bh_ctx_copy(ctx.h, _lib.ptr(h), C.c_void_p(dev), 8 * int(count), 0) != 0:
+            else:                                                            # gloo rehearsal: staged through host memory
+                h = np.empty(count, np.float64)
+                if L.bh_ctx_copy(ctx.h, _lib.ptr(h), C.c_void_p(dev), 8 * count, 0) != 0:
                     return 2
                 t = torch.from_numpy(h)
-                dist.all_reduce(t, op=rop)
-                if L.bh_ctx_copy(ctx.h, C.c_void_p(dev), _lib.ptr(h), 8 * int(count), 1) != 0:
+                if op < 2:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+                else:
+                    ch = count // world
+                    if op == 2:                                              # gloo has no reduce-scatter: one reduce per owner
+                        for dst in range(world):
+                            dist.reduce(t[dst * ch:(dst + 1) * ch], dst=dst, op=dist.ReduceOp.SUM)
+                    else:
+                        parts = [torch.empty(ch, dtype=torch.float64) for _ in range(world)]
+                        dist.all_gather(parts, t[rank * ch:(rank + 1) * ch].clone())
+                        for r_, p_ in enumerate(parts):
+                            t[r_ * ch:(r_ + 1) * ch] = p_
+                if L.bh_ctx_copy(ctx.h, C.c_void_p(dev), _lib.ptr(h), 8 * count, 1) != 0:
                     return 2
             return 0
         except Exception:                       # never let an exception cross the C boundary
@@ -171,9 +193,11 @@ def make_allreduce_hook(ctx, dist, device=None):
 
 
 class GlobalBA(LocalBA):
-    """Landmark-sharded global BA (BASELINE configs[4]): every rank holds all keyframes and the landmarks
-    j with j % world == rank (plus their observations); S, b~, Hpp, bp and the LM scalars are all-reduced once per
-    Levenberg trial through the hook; the banded Cholesky and the keyframe update are replicated."""
+    """Sharded global BA (BASELINE configs[4]): every rank holds all keyframes and the landmarks j with
+    j % world == rank (plus their observations).  Per Levenberg trial: Hpp / bp / b~ and three scalars are all-reduced; the reduced
+    camera system is cut by keyframe into one segment per rank - reduce-scatter of S, local elimination of the segment's interior,
+    all-gather of the segments' end blocks, a small replicated chain, local back-substitution, all-gather of the step (see
+    include/boslam_hip.h, bh_ba_set_allreduce).  Short or dense systems keep the round-2 scheme (S all-reduced, solve replicated)."""
 
     def __init__(self, ctx, K, dist, device=None):
         super().__init__(ctx, K)
@@ -204,6 +228,13 @@ class GlobalBA(LocalBA):
         else:
             self.dist.all_reduce(t)
         return out
+
+    def comm_detail(self):
+        """Bytes received by kind of exchange, the replicated part of the solves (ms, count), whether the segment-wise solve is on."""
+        o = np.zeros(8)
+        self.ctx.check(_lib.lib().bh_ba_get_comm_detail(self.h, _lib.ptr(o)))
+        return dict(allreduce_bytes=int(o[0]), reduce_scatter_bytes=int(o[1]), all_gather_bytes=int(o[2]), replicated_ms=float(o[3]),
+                    solves=int(o[4]), segment_solve=bool(o[5]), blocks_this_rank=int(o[6]), blocks_per_rank=int(o[7]))
 
     def comm(self):
         ms = C.c_double(0); nb = C.c_longlong(0)

@@ -396,6 +396,8 @@ struct bh_ba {
     ba_state* h_state = nullptr;       // pinned, device-writable: k_ba_decide's verdict (polled by bh_ba_optimize)
     int seq = 0;
     struct bcr_dev* bcr = nullptr;
+    struct dbcr_dev* dsol = nullptr;   // distributed reduced-camera solve (sharded mode, long banded systems)
+    long long ar_bytes = 0;            // of comm_bytes: plain all-reduces
     int schur_wave = 0;                // one wave per camera pair (many short edge lists) instead of a 256-thread workgroup
     int last_err_sel = 0;              // which err buffer holds "the last computeActiveErrors"
     // landmark-sharded multi-GPU mode (bh_ba_set_allreduce)
@@ -1973,10 +1975,9 @@ static int bcr_prepare(bh_ctx* ctx, hipStream_t st, bcr_dev* dv, int n, void* sc
         BH_HIP(ctx, hipMemcpyAsync(dv->work, dv->plan.work.data(), sizeof(bcr_work) * dv->plan.work.size(), hipMemcpyHostToDevice, st));
     return BH_OK;
 }
-static int bcr_solve(bh_ctx* ctx, hipStream_t st, const bcr_dev* dv, const double* S, const double* bs, int n, int bw, double* x, ba_state* state)
+static void bcr_forward(hipStream_t st, const bcr_dev* dv, ba_state* state)
 {
     const bcr_plan& P = dv->plan;
-    hipLaunchKernelGGL(k_bcr_extract, dim3(2 * P.N - 1, 256), dim3(256), 0, st, S, bs, n, bw, P.N, dv->D, dv->C, dv->g);
     for (int lv = 0; lv < P.nlev; lv++) {
         const int ne = P.e_off[lv + 1] - P.e_off[lv], nw = P.w_off[lv + 1] - P.w_off[lv];
         hipLaunchKernelGGL(k_ba_chol_dense<true>, dim3(ne), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)nullptr, (const double*)nullptr, 256, 255,
@@ -1986,10 +1987,182 @@ static int bcr_solve(bh_ctx* ctx, hipStream_t st, const bcr_dev* dv, const doubl
             hipLaunchKernelGGL(k_bcr_update, dim3(64, nw), dim3(256), 0, st, (const bcr_work*)(dv->work + P.w_off[lv]), dv->D, dv->C, dv->g, (const double*)dv->y);
         }
     }
+}
+static void bcr_backward(hipStream_t st, const bcr_dev* dv, double* x, int n, ba_state* state)
+{
+    const bcr_plan& P = dv->plan;
     for (int lv = P.nlev - 1; lv >= 0; lv--)
-        hipLaunchKernelGGL(k_bcr_back, dim3(P.e_off[lv + 1] - P.e_off[lv]), dim3(1024), 0, st, (const bcr_elim*)(dv->elim + P.e_off[lv]), (const double*)dv->D,
-                           (const double*)dv->C, (const double*)dv->y, dv->xp, x, n, (const ba_state*)state);
+        if (P.e_off[lv + 1] > P.e_off[lv])
+            hipLaunchKernelGGL(k_bcr_back, dim3(P.e_off[lv + 1] - P.e_off[lv]), dim3(1024), 0, st, (const bcr_elim*)(dv->elim + P.e_off[lv]), (const double*)dv->D,
+                               (const double*)dv->C, (const double*)dv->y, dv->xp, x, n, (const ba_state*)state);
+}
+static int bcr_solve(bh_ctx* ctx, hipStream_t st, const bcr_dev* dv, const double* S, const double* bs, int n, int bw, double* x, ba_state* state)
+{
+    const bcr_plan& P = dv->plan;
+    hipLaunchKernelGGL(k_bcr_extract, dim3(2 * P.N - 1, 256), dim3(256), 0, st, S, bs, n, bw, P.N, dv->D, dv->C, dv->g);
+    bcr_forward(st, dv, state);
+    bcr_backward(st, dv, x, n, state);
     BH_HIP(ctx, hipGetLastError());
+    return BH_OK;
+}
+
+// ================================================================================================ distributed reduced-camera solve
+// Global BA over R GPUs (BASELINE configs[4]).  Round 2 all-reduced the whole band of S (59 MB at configs[4]) to every rank once per
+// Levenberg trial and every rank then ran the same 1.6 ms block cyclic reduction: at most 1.8x on 8 GPUs before any communication
+// (VERDICT r02).  Now the chain of 256-row blocks is cut into R contiguous segments, one per rank:
+//   1. the partial S of every rank is REDUCE-SCATTERED: rank r receives the summed band rows of its own segment only (59 MB / R);
+//   2. rank r eliminates the interior blocks of its segment with the cyclic-reduction kernels (same kernels, a plan in which the
+//      segment's first and last block are never eliminated) - no communication; what is left is the Schur complement of its
+//      interior on its two end blocks: D_first, D_last, the fill between them, their right-hand sides;
+//   3. those, with the original coupling to the previous segment's last block, are ALL-GATHERED (4 blocks = 2 MB per rank) and form a
+//      chain of 2R blocks, which every rank reduces and solves - the only replicated arithmetic left (4 levels at R = 8);
+//   4. the end blocks' solution in hand, rank r back-substitutes through its interior, and the step of the keyframes is all-gathered
+//      (240 KB at configs[4]).
+// This is the nested-dissection factorisation of the single-GPU solver with the separators chosen at the rank boundaries: the same
+// solution up to rounding (the tests ask 1e-9 and the same Levenberg decisions).
+struct dbcr_dev {
+    int active = 0;
+    int seg = 0, B0 = 0, nb = 0;       // blocks per rank (equal chunks; the last rank's may reach past N), first block, blocks this rank holds (>= 2)
+    bcr_dev loc, glob;                  // loc: the segment (local block ids 0 .. nb-1, ends pinned); glob: the chain of 2R end blocks
+    std::vector<uint8_t> orient;        // level-0 coupling p of the segment (local blocks p, p+1): 1 = rows on block p, 0 = rows on block p+1
+    int fslot = 0;                      // slot of the coupling between the two end blocks once the interior is gone
+    bh_buf buf_loc, buf_glob, gather, orient_d;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double ms_replicated = 0; int n_replicated = 0;
+    long long bytes_rs = 0, bytes_ag = 0;
+};
+static void dbcr_release(dbcr_dev* d);
+#define DBCR_CH (4 * BCR_BLK + 512)     // one rank's share of the gathered end blocks: D_first | D_last | F | C_prev | g_first | g_last (doubles)
+
+// Plan for a chain 0 .. nb-1 whose two ends are pinned: per level every other block of what is left of the interior.  T[b] = level at
+// which block b goes (pinned: never); every coupling is stored with its rows on the end that goes first.
+static void dbcr_make_plan(int nb, bcr_plan* P, std::vector<uint8_t>* orient0, int* fslot)
+{
+    const int NEVER = 1 << 30;
+    std::vector<int> T(nb, NEVER);
+    {   // pass 1: elimination levels
+        std::vector<int> chain(nb); for (int i = 0; i < nb; i++) chain[i] = i;
+        for (int lv = 0;; lv++) {
+            std::vector<int> next; bool any = false, prev = false;
+            for (int i = 0; i < (int)chain.size(); i++) {
+                const bool pinned = chain[i] == 0 || chain[i] == nb - 1;
+                const bool mark = !pinned && !prev;
+                if (mark) { T[chain[i]] = lv; any = true; } else next.push_back(chain[i]);
+                prev = mark;
+            }
+            if (!any) break;
+            chain = next;
+        }
+    }
+    P->N = nb; P->elim.clear(); P->work.clear(); P->e_off.assign(1, 0); P->w_off.assign(1, 0);
+    orient0->assign(std::max(nb - 1, 1), 0);
+    for (int p = 0; p + 1 < nb; p++) (*orient0)[p] = T[p] < T[p + 1] || (T[p] == NEVER && T[p + 1] == NEVER) ? 1 : 0;      // both pinned (nb == 2): rows on the first
+    std::vector<int> chain(nb), cslot(std::max(nb - 1, 0));
+    for (int i = 0; i < nb; i++) chain[i] = i;
+    for (int p = 0; p + 1 < nb; p++) cslot[p] = p;
+    int nslots = nb - 1;
+    for (int lv = 0;; lv++) {
+        const int k = (int)chain.size();
+        std::vector<char> mark(k, 0);
+        bool any = false;
+        for (int i = 0; i < k; i++) if (T[chain[i]] == lv) { mark[i] = 1; any = true; }
+        if (!any) break;
+        std::vector<int> fill(k, -1);                         // slot of the new coupling through eliminated position i
+        for (int i = 0; i < k; i++) if (mark[i])
+            P->elim.push_back({ chain[i], i > 0 ? chain[i - 1] : -1, i + 1 < k ? chain[i + 1] : -1, i > 0 ? cslot[i - 1] : -1, i + 1 < k ? cslot[i] : -1 });
+        for (int i = 0; i < k; i++) if (!mark[i]) {
+            int a[2] = { -1, -1 }, ye[2] = { -1, -1 }, m = 0;
+            if (i > 0 && mark[i - 1]) { a[m] = cslot[i - 1]; ye[m] = chain[i - 1]; m++; }
+            if (i + 1 < k && mark[i + 1]) { a[m] = cslot[i]; ye[m] = chain[i + 1]; m++; }
+            if (m) P->work.push_back({ chain[i], 0, a[0], -1, a[1], ye[0], ye[1] });
+        }
+        for (int i = 0; i < k; i++) if (mark[i] && i > 0 && i + 1 < k) {
+            const int l = chain[i - 1], r = chain[i + 1];
+            const bool rows_on_l = T[l] < T[r] || (T[l] == NEVER && T[r] == NEVER);
+            fill[i] = nslots++;
+            P->work.push_back({ fill[i], 1, rows_on_l ? cslot[i - 1] : cslot[i], rows_on_l ? cslot[i] : cslot[i - 1], -1, -1, -1 });
+        }
+        std::vector<int> nchain, ncslot;
+        for (int i = 0; i < k; i++) if (!mark[i]) {
+            if (!nchain.empty()) ncslot.push_back(mark[i - 1] ? fill[i - 1] : cslot[i - 1]);
+            nchain.push_back(chain[i]);
+        }
+        P->e_off.push_back((int)P->elim.size()); P->w_off.push_back((int)P->work.size());
+        chain = nchain; cslot = ncslot;
+    }
+    P->nslots = nslots; P->nlev = (int)P->e_off.size() - 1;
+    *fslot = cslot.empty() ? 0 : cslot[0];                    // the chain is (first, last) now
+}
+
+// band rows of this rank's segment -> its diagonal blocks, the couplings inside the segment (orientation per plan), the right-hand
+// side, and - straight into this rank's share of the gather buffer - the coupling to the previous segment's last block (rows on this
+// segment's first block: the band's own orientation).  grid (2 nb, 256): blocks [0, nb) diagonal, [nb, 2nb-1) couplings, 2nb-1: C_prev
+__global__ __launch_bounds__(256) void k_dbcr_extract(const double* __restrict__ A, const double* __restrict__ bs, int n, int bw, int B0, int nb,
+                                                      const uint8_t* __restrict__ orient, double* __restrict__ Dblk, double* __restrict__ Cpl,
+                                                      double* __restrict__ g, double* __restrict__ cprev)
+{
+    const int b = blockIdx.x, r = blockIdx.y, c = threadIdx.x;
+    const size_t LD = (size_t)bw + 1;
+    if (b < nb) {
+        if ((c >> 4) > (r >> 4)) return;                      // tiles above the diagonal are never read
+        const long long R = 256LL * (B0 + b) + r, C = 256LL * (B0 + b) + c;
+        double v = 0.0;
+        if (R < n && C < n) { if (c <= r && r - c <= bw) v = A[R * LD + (C - R + bw)]; }
+        else if (R == C) v = 1.0;
+        Dblk[(size_t)b * BCR_BLK + r * 256 + c] = v;
+        if (c == 0) g[256 * b + r] = R < n ? bs[R] : 0.0;
+    } else if (b < 2 * nb - 1) {
+        const int p = b - nb;
+        const long long R = 256LL * (B0 + p + 1) + r, C = 256LL * (B0 + p) + c;
+        const double v = (R < n && R - C <= bw) ? A[R * LD + (C - R + bw)] : 0.0;
+        Cpl[(size_t)p * BCR_BLK + (orient[p] ? c * 256 + r : r * 256 + c)] = v;
+    } else {
+        const long long R = 256LL * B0 + r, C = 256LL * (B0 - 1) + c;
+        cprev[r * 256 + c] = (B0 > 0 && R < n && R - C <= bw) ? A[R * LD + (C - R + bw)] : 0.0;
+    }
+}
+// the segment's end blocks after the interior is gone -> this rank's share of the gather buffer
+__global__ __launch_bounds__(256) void k_dbcr_pack(const double* __restrict__ Dblk, const double* __restrict__ Cpl, const double* __restrict__ g, int nb, int fslot,
+                                                   double* __restrict__ out)
+{
+    const int which = blockIdx.y;                             // 0 D_first, 1 D_last, 2 F
+    const double* src = which == 0 ? Dblk : (which == 1 ? Dblk + (size_t)(nb - 1) * BCR_BLK : Cpl + (size_t)fslot * BCR_BLK);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    out[(size_t)which * BCR_BLK + i] = src[i];
+    if (which == 0 && i < 256) { out[4 * (size_t)BCR_BLK + i] = g[i]; out[4 * (size_t)BCR_BLK + 256 + i] = g[256 * (size_t)(nb - 1) + i]; }
+}
+// gathered shares -> the chain of 2R blocks in the layout the cyclic-reduction kernels take (coupling p: even p = F of rank p/2,
+// rows on block p; odd p = C_prev of rank (p+1)/2, rows on block p+1)
+__global__ __launch_bounds__(256) void k_dbcr_unpack(const double* __restrict__ gat, int Rk, double* __restrict__ Dblk, double* __restrict__ Cpl, double* __restrict__ g)
+{
+    const int r = blockIdx.z, which = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const double* src = gat + (size_t)r * DBCR_CH;
+    const double v = src[(size_t)which * BCR_BLK + i];
+    if (which == 0) Dblk[(size_t)(2 * r) * BCR_BLK + i] = v;
+    else if (which == 1) Dblk[(size_t)(2 * r + 1) * BCR_BLK + i] = v;
+    else if (which == 2) Cpl[(size_t)(2 * r) * BCR_BLK + i] = v;
+    else if (r > 0) Cpl[(size_t)(2 * r - 1) * BCR_BLK + i] = v;
+    if (which == 0 && i < 256) { g[256 * (size_t)(2 * r) + i] = src[4 * (size_t)BCR_BLK + i]; g[256 * (size_t)(2 * r + 1) + i] = src[4 * (size_t)BCR_BLK + 256 + i]; }
+}
+// solution of the two end blocks -> the segment's padded solution and its output rows
+__global__ __launch_bounds__(256) void k_dbcr_ends(const double* __restrict__ xg, int rank, int nb, double* __restrict__ xp, double* __restrict__ x, int nloc)
+{
+    const int i = threadIdx.x, which = blockIdx.x;
+    const double v = xg[256 * (size_t)(2 * rank + which) + i];
+    const size_t o = which ? 256 * (size_t)(nb - 1) : 0;
+    xp[o + i] = v;
+    if ((long long)(o + i) < nloc) x[o + i] = v;
+}
+
+static int dbcr_carve(bh_ctx* ctx, hipStream_t st, bcr_dev* dv, int N, void* scratch)
+{
+    dv->D = (double*)scratch; dv->C = dv->D + (size_t)N * BCR_BLK; dv->g = dv->C + (size_t)(2 * N + 2) * BCR_BLK;
+    dv->y = dv->g + (size_t)N * 256; dv->xp = dv->y + (size_t)N * 256;
+    dv->elim = (bcr_elim*)(dv->xp + (size_t)N * 256); dv->work = (bcr_work*)(dv->elim + 2 * N + 4);
+    if (dv->plan.nslots > 2 * N + 2 || (int)dv->plan.elim.size() > 2 * N + 4 || (int)dv->plan.work.size() > 2 * N + 4)
+        return bh_set_err(ctx, BH_ERR_CAPACITY, "dbcr: plan larger than its scratch");
+    if (!dv->plan.elim.empty()) BH_HIP(ctx, hipMemcpyAsync(dv->elim, dv->plan.elim.data(), sizeof(bcr_elim) * dv->plan.elim.size(), hipMemcpyHostToDevice, st));
+    if (!dv->plan.work.empty()) BH_HIP(ctx, hipMemcpyAsync(dv->work, dv->plan.work.data(), sizeof(bcr_work) * dv->plan.work.size(), hipMemcpyHostToDevice, st));
     return BH_OK;
 }
 
@@ -2319,6 +2492,7 @@ extern "C" int bh_ba_create(bh_ctx* ctx, const double K[5], bh_ba** out)
 extern "C" void bh_ba_destroy(bh_ba* ba)
 {
     if (!ba) return;
+    dbcr_release(ba->dsol); ba->dsol = nullptr;
     (void)hipSetDevice(ba->ctx->device);
     (void)hipStreamSynchronize(ba->ctx->stream);
     bh_buf* all[] = { &ba->cams[0], &ba->cams[1], &ba->pts[0], &ba->pts[1], &ba->e_cam, &ba->e_pt, &ba->e_meas, &ba->cslot,
@@ -2356,11 +2530,97 @@ static int ba_allreduce(bh_ba* ba, void* dev, long long count, int op)
     const auto t0 = std::chrono::steady_clock::now();
     const int r = ba->ar(ba->ar_user, dev, count, op);
     ba->comm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    ba->comm_bytes += 8 * count;
+    // bytes a rank RECEIVES: all-reduce = the buffer; reduce-scatter (op 2) = its chunk; all-gather (op 3) = the other ranks' chunks
+    const long long rb = op == 2 ? 8 * count / ba->world : (op == 3 ? 8 * count / ba->world * (ba->world - 1) : 8 * count);
+    ba->comm_bytes += rb;
+    if (op < 2) ba->ar_bytes += rb;
+    else if (ba->dsol) { if (op == 2) ba->dsol->bytes_rs += rb; else ba->dsol->bytes_ag += rb; }
     if (r != 0) return bh_set_err(ctx, BH_ERR_INVALID, "global BA: the all-reduce hook failed (%d)", r);
     return BH_OK;
 }
 
+
+static void dbcr_release(dbcr_dev* d)
+{
+    if (!d) return;
+    for (bh_buf* b : { &d->buf_loc, &d->buf_glob, &d->gather, &d->orient_d }) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    if (d->e0) (void)hipEventDestroy(d->e0);
+    if (d->e1) (void)hipEventDestroy(d->e1);
+    delete d;
+}
+
+// decide whether the sharded solve applies (every rank takes the same decision from n, bw and the world size) and set it up
+static int dbcr_setup(bh_ba* ba, int n6, int bw, long long* rows_pad)
+{
+    bh_ctx* ctx = ba->ctx;
+    *rows_pad = n6;
+    if (ba->dsol) ba->dsol->active = 0;
+    const char* ev = getenv("BH_BA_DSOLVE");
+    if (!ba->ar || ba->world < 2 || !ba->chol_bcr || (ev && !strcmp(ev, "0"))) return BH_OK;
+    const int N = (n6 + 255) / 256, R = ba->world, seg = (N + R - 1) / R;
+    if (seg < 2 || N - (R - 1) * seg < 2) return BH_OK;       // a rank would hold fewer than two blocks: the replicated solve stays
+    if (!ba->dsol) ba->dsol = new dbcr_dev();
+    dbcr_dev* d = ba->dsol;
+    d->seg = seg; d->B0 = ba->rank * seg; d->nb = std::min(N, (ba->rank + 1) * seg) - d->B0;
+    dbcr_make_plan(d->nb, &d->loc.plan, &d->orient, &d->fslot);
+    bcr_make_plan(2 * R, &d->glob.plan);
+    hipStream_t st = ctx->stream;
+    BH_TRY(bh_reserve(ctx, &d->buf_loc, BCR_SCRATCH_BYTES(d->nb) + 4096));
+    BH_TRY(bh_reserve(ctx, &d->buf_glob, BCR_SCRATCH_BYTES(2 * R) + sizeof(double) * 512 * (size_t)R + 4096));
+    BH_TRY(bh_reserve(ctx, &d->gather, sizeof(double) * (size_t)R * DBCR_CH));
+    BH_TRY(bh_reserve(ctx, &d->orient_d, d->orient.size() + 16));
+    BH_TRY(dbcr_carve(ctx, st, &d->loc, d->nb, d->buf_loc.p));
+    BH_TRY(dbcr_carve(ctx, st, &d->glob, 2 * R, d->buf_glob.p));
+    BH_HIP(ctx, hipMemcpyAsync(d->orient_d.p, d->orient.data(), d->orient.size(), hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipMemsetAsync(d->gather.p, 0, sizeof(double) * (size_t)R * DBCR_CH, st));
+    if (!d->e0) { BH_HIP(ctx, hipEventCreate(&d->e0)); BH_HIP(ctx, hipEventCreate(&d->e1)); }
+    BH_HIP(ctx, hipStreamSynchronize(st));
+    d->active = 1;
+    *rows_pad = 256LL * seg * R;
+    return BH_OK;
+}
+
+static int ba_allreduce(bh_ba* ba, void* dev, long long count, int op);
+// S: this rank's band rows are summed (after the reduce-scatter); bs: complete on every rank.  x receives the whole step.
+static int dbcr_solve(bh_ba* ba, const double* S, const double* bs, int n, int bw, double* x, ba_state* state)
+{
+    bh_ctx* ctx = ba->ctx;
+    hipStream_t st = ctx->stream;
+    dbcr_dev* d = ba->dsol;
+    const int R = ba->world, nb = d->nb;
+    double* gat = (double*)d->gather.p; double* mine = gat + (size_t)ba->rank * DBCR_CH;
+    double* xg = (double*)((char*)d->buf_glob.p + BCR_SCRATCH_BYTES(2 * R));
+    double* xloc = x + 256 * (size_t)d->B0;
+    const int nloc = std::max(0, std::min(n - 256 * d->B0, 256 * nb));
+    hipLaunchKernelGGL(k_dbcr_extract, dim3(2 * nb, 256), dim3(256), 0, st, S, bs, n, bw, d->B0, nb, (const uint8_t*)d->orient_d.p, d->loc.D, d->loc.C, d->loc.g,
+                       mine + 3 * (size_t)BCR_BLK);
+    bcr_forward(st, &d->loc, state);                          // the interior of the segment goes; its Schur complement lands on the two end blocks
+    hipLaunchKernelGGL(k_dbcr_pack, dim3(256, 3), dim3(256), 0, st, (const double*)d->loc.D, (const double*)d->loc.C, (const double*)d->loc.g, nb, d->fslot, mine);
+    BH_HIP(ctx, hipGetLastError());
+    BH_TRY(ba_allreduce(ba, gat, (long long)R * DBCR_CH, 3));
+    BH_HIP(ctx, hipEventRecord(d->e0, st));                   // the replicated part: the chain of 2R end blocks
+    hipLaunchKernelGGL(k_dbcr_unpack, dim3(256, 4, R), dim3(256), 0, st, (const double*)gat, R, d->glob.D, d->glob.C, d->glob.g);
+    bcr_forward(st, &d->glob, state);
+    bcr_backward(st, &d->glob, xg, 512 * R, state);
+    BH_HIP(ctx, hipEventRecord(d->e1, st));
+    hipLaunchKernelGGL(k_dbcr_ends, dim3(2), dim3(256), 0, st, (const double*)d->glob.xp, ba->rank, nb, d->loc.xp, xloc, nloc);
+    bcr_backward(st, &d->loc, xloc, nloc, state);
+    BH_HIP(ctx, hipGetLastError());
+    BH_TRY(ba_allreduce(ba, x, 256LL * d->seg * R, 3));      // every rank's rows of the step -> everyone
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, d->e0, d->e1) == hipSuccess) { d->ms_replicated += ms; d->n_replicated++; } else (void)hipGetLastError();
+    return BH_OK;
+}
+
+extern "C" int bh_ba_get_comm_detail(bh_ba* ba, double* out)
+{
+    if (!ba || !out) return BH_ERR_INVALID;
+    const dbcr_dev* d = ba->dsol;
+    out[0] = (double)ba->ar_bytes; out[1] = d ? (double)d->bytes_rs : 0.0; out[2] = d ? (double)d->bytes_ag : 0.0;
+    out[3] = d ? d->ms_replicated : 0.0; out[4] = d ? (double)d->n_replicated : 0.0; out[5] = d && d->active ? 1.0 : 0.0;
+    out[6] = d && d->active ? (double)d->nb : 0.0; out[7] = d && d->active ? (double)d->seg : 0.0;
+    return BH_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ problem construction on the device
 // The structure g2o builds in initializeOptimization - which vertices take part, the edges by point and by free camera, the camera
@@ -2827,6 +3087,8 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
         if (!ba->bcr) ba->bcr = new bcr_dev();
         BH_TRY(bcr_prepare(ctx, ctx->stream, ba->bcr, n6i, ba->xch.p));
     }
+    long long rows_pad = n6i;                                  // sharded mode: S and the step are padded to equal row chunks per rank
+    BH_TRY(dbcr_setup(ba, n6i, ba->bw, &rows_pad));
     {
         const char* ev = getenv("BH_BA_CHOL");
         ba->chol_dense = (!ba->chol_window && n6i >= 1 && n6i <= 16 * CD_MAXT && !(ev && !strcmp(ev, "panel"))) ? 1 : 0;
@@ -2849,8 +3111,8 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     BH_TRY(bh_reserve(ctx, &ba->Hpp, sizeof(double) * 36 * ((size_t)Cf + 1))); BH_TRY(bh_reserve(ctx, &ba->bp, sizeof(double) * (n6 + 6)));
     BH_TRY(bh_reserve(ctx, &ba->pdiag, sizeof(double) * (Pa + 1))); BH_TRY(bh_reserve(ctx, &ba->cdiag, sizeof(double) * (Cf + 1)));
     BH_TRY(bh_reserve(ctx, &ba->Dinv, sizeof(double) * 9 * ((size_t)Pa + 1))); BH_TRY(bh_reserve(ctx, &ba->db, sizeof(double) * 3 * ((size_t)Pa + 1)));
-    BH_TRY(bh_reserve(ctx, &ba->S, sizeof(double) * (n6 * (size_t)(ba->bw + 1) + 1))); BH_TRY(bh_reserve(ctx, &ba->bs, sizeof(double) * (n6 + 6)));
-    BH_TRY(bh_reserve(ctx, &ba->dxp, sizeof(double) * (n6 + 6))); BH_TRY(bh_reserve(ctx, &ba->dxl, sizeof(double) * 3 * ((size_t)Pa + 1)));
+    BH_TRY(bh_reserve(ctx, &ba->S, sizeof(double) * ((size_t)rows_pad * (size_t)(ba->bw + 1) + 1))); BH_TRY(bh_reserve(ctx, &ba->bs, sizeof(double) * (n6 + 6)));
+    BH_TRY(bh_reserve(ctx, &ba->dxp, sizeof(double) * ((size_t)rows_pad + 6))); BH_TRY(bh_reserve(ctx, &ba->dxl, sizeof(double) * 3 * ((size_t)Pa + 1)));
     BH_TRY(bh_reserve(ctx, &ba->part, sizeof(double) * 2 * BA_NPART));
     BH_HIP(ctx, hipMemsetAsync(ba->state.p, 0, sizeof(ba_state), ctx->stream));
     BH_HIP(ctx, hipMemsetAsync(ba->err[0].p, 0, sizeof(double) * 2 * (E + 1), ctx->stream));
@@ -2886,7 +3148,8 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
     const bool dist = ba->ar != nullptr;
     double* part = Ea > 16384 ? (double*)ba->part.p : nullptr;       // two-stage sums above this size (one workgroup streams ~50 GB/s: 80 k residuals took 22 + 31 us in k_ba_prep / k_ba_decide)
     const int lead = ba->rank == 0 ? 1 : 0;              // the rank that contributes the replicated camera terms
-    ba->comm_ms = 0; ba->comm_bytes = 0;
+    ba->comm_ms = 0; ba->comm_bytes = 0; ba->ar_bytes = 0;
+    if (ba->dsol) { ba->dsol->bytes_rs = ba->dsol->bytes_ag = 0; ba->dsol->ms_replicated = 0; ba->dsol->n_replicated = 0; }
     const int pblocks = (Pa + 255) / 256, cblocks = (C + 255) / 256;
     int rc = BH_OK;
     for (int it = 0; it < iters; it++) {
@@ -2921,7 +3184,9 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
             ba_cam* cams_t = (ba_cam*)ba->cams[ba->cur ^ 1].p; double* pts_t = (double*)ba->pts[ba->cur ^ 1].p;
             BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_dinv, dim3(pblocks), dim3(256), st, (const double*)Hll, (const double*)bl, Pa, state, Dinv, db);
             if (Cf) {
-                BH_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double) * (size_t)n6 * (ba->bw + 1), st));     // blocks without a common point stay zero
+                const bool dsolve = dist && ba->dsol && ba->dsol->active;
+                const size_t s_rows = dsolve ? 256 * (size_t)ba->dsol->seg * ba->world : (size_t)n6;       // sharded solve: equal row chunks per rank
+                BH_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double) * s_rows * (ba->bw + 1), st));     // blocks without a common point stay zero
                 if (ba->schur_wave)
                     BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<64>), dim3((ba->npairs + 7) / 8 * 8), dim3(64), st, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
                               (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S, ba->npairs);
@@ -2934,13 +3199,15 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                 if (ba->schur_wave)
                     BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_b, dim3(Cf), dim3(256), st, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)db,
                               (const double*)bp, dist ? lead : 1, bs);
-                if (dist) { BH_TRY(ba_allreduce(ba, S, (long long)n6 * (ba->bw + 1), 0)); BH_TRY(ba_allreduce(ba, bs, n6, 0)); }
+                if (dsolve) { BH_TRY(ba_allreduce(ba, S, (long long)s_rows * (ba->bw + 1), 2)); BH_TRY(ba_allreduce(ba, bs, n6, 0)); }      // every rank keeps the sum of ITS rows
+                else if (dist) { BH_TRY(ba_allreduce(ba, S, (long long)n6 * (ba->bw + 1), 0)); BH_TRY(ba_allreduce(ba, bs, n6, 0)); }
                 {
                     const int nbsel = ba->chol_nb, bw = ba->bw;
                     const size_t lds = sizeof(double) * ((size_t)std::min(n6, nbsel + bw) * (nbsel + 1) + 1100);
                     int solve_rc = BH_OK;
                     bh_time_begin(ctx, BH_K_BA_SOLVE);
-                    if (ba->chol_bcr) solve_rc = bcr_solve(ctx, st, ba->bcr, (const double*)S, (const double*)bs, n6, bw, dxp, state);
+                    if (dsolve) solve_rc = dbcr_solve(ba, (const double*)S, (const double*)bs, n6, bw, dxp, state);
+                    else if (ba->chol_bcr) solve_rc = bcr_solve(ctx, st, ba->bcr, (const double*)S, (const double*)bs, n6, bw, dxp, state);
                     else if (ba->chol_window) solve_rc = sw_solve(ctx, st, S, (const double*)bs, n6, bw, dxp, state, ba->chol_split, (double*)ba->xch.p);
                     else if (ba->chol_dense) hipLaunchKernelGGL(k_ba_chol_dense<false>, dim3(1), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, (const double*)S, (const double*)bs, n6, bw, dxp, state,
                                                                  (const bcr_elim*)nullptr, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
@@ -3228,6 +3495,7 @@ extern "C" int bh_ba_get_chi2(bh_ba* ba, double* chi2, int mem)
 extern "C" int bh_ba_solver(bh_ba* ba)
 {
     if (!ba || ba->C <= 0) return BH_ERR_INVALID;
+    if (ba->dsol && ba->dsol->active) return 5;
     if (ba->chol_bcr) return 4;
     if (ba->chol_window) return ba->chol_split ? 3 : 2;
     return ba->chol_dense ? 1 : 0;

@@ -180,7 +180,8 @@ int  bh_ba_get_chi2(bh_ba* ba, double* chi2, int mem);
 int  bh_ba_get_log(bh_ba* ba, double* log, int max_rows);
 /* which reduced-camera-system solver bh_ba_set_problem selected for the current problem (so that a test which claims to
  * compare two of them can assert it): 0 = panel kernel, 1 = whole factor on chip (n <= 288), 2 = on-chip sliding window,
- * 3 = two-way window elimination, 4 = block cyclic reduction over the whole chip; < 0 = no problem set. */
+ * 3 = two-way window elimination, 4 = block cyclic reduction over the whole chip, 5 = the same cut into one segment per rank
+ * (sharded mode: bh_ba_set_allreduce); < 0 = no problem set. */
 int  bh_ba_solver(bh_ba* ba);
 
 /* Batched local BA: W windows, each a bh_ba handle of `ctx` that holds a problem (bh_ba_set_problem; windows may differ in size),
@@ -205,18 +206,30 @@ int  bh_ba_debug_band_solve(bh_ctx* ctx, const double* band, const double* rhs, 
                             long long* clocks);
 
 /* Global BA over several GPUs (BASELINE configs[4]; no counterpart in the reference, whose covisibility_graph.py:186-235
- * optimises on one CPU).  The problem is sharded BY LANDMARK: every rank passes all C poses (same order, same fixed flags)
- * and its own subset of points with all their edges to bh_ba_set_problem.  The library then calls `fn` at the exchange
- * points of every Levenberg trial: sum of the reduced camera system S (lower band, f64[6Cf][bw+1]) and of b~ (f64[6Cf]),
- * sum of Hpp/bp, and a few scalars (chi2, gain-ratio denominator, max diagonal).  The Cholesky of S and the camera update are
- * replicated (identical inputs, deterministic kernel -> identical poses on every rank); landmarks are updated by their owner.
- *   fn(user, dev_buf, count, op): all-reduce `count` f64 at device address `dev_buf` in place; op 0 = sum, 1 = max.
- *   The library's stream is idle when fn is called; fn returns (0 = ok) when the reduced values are visible to the device.
+ * optimises on one CPU).  Landmarks (with all their observations) are dealt out to the ranks; every rank passes all C poses (same
+ * order, same fixed flags) and its own subset of points with their edges to bh_ba_set_problem.  Linearisation and the Schur products
+ * are local.  The reduced camera system S is cut BY KEYFRAME into one contiguous segment of 256-row blocks per rank:
+ *   - the partial S of all ranks is reduce-scattered: a rank receives the sum of its own segment's band rows (S / world bytes);
+ *   - each rank eliminates the interior of its segment (block cyclic reduction on its own chip), leaving its two end blocks;
+ *   - the end blocks (4 x 512 KB per rank) are all-gathered and the chain of 2 x world blocks is solved on every rank - the only
+ *     replicated arithmetic; each rank back-substitutes its segment; the keyframes' step (6Cf f64) is all-gathered;
+ *   - Hpp / bp (1.7 MB at configs[4]), b~ and three scalars per trial are all-reduced as before.
+ * Systems too short for that (fewer than two blocks per rank, or not banded) keep the round-2 scheme: S all-reduced, solve replicated.
+ *   fn(user, dev_buf, count, op) works in place on `count` f64 at device address `dev_buf`:
+ *     op 0 all-reduce sum, op 1 all-reduce max,
+ *     op 2 reduce-scatter sum: the buffer is `world` equal chunks; afterwards chunk `rank` holds the sum over ranks of that chunk,
+ *     op 3 all-gather: chunk `rank` holds this rank's data; afterwards every chunk holds its owner's.
+ *   The library's stream is idle when fn is called; fn returns (0 = ok) when the result is visible to the device.
  * Call before bh_ba_set_problem.  fn == NULL restores the single-GPU behaviour. */
 typedef int (*bh_allreduce_fn)(void* user, void* dev_buf, long long count, int op);
 int  bh_ba_set_allreduce(bh_ba* ba, bh_allreduce_fn fn, void* user, int rank, int world);
 /* wall time spent inside fn and bytes handed to it since the last bh_ba_optimize began */
 int  bh_ba_get_comm(bh_ba* ba, double* ms, long long* bytes);
+/* Sharded mode in detail since the last bh_ba_optimize began, out f64[8]: bytes received through plain all-reduces, through the
+ * reduce-scatter of S (this rank's band rows), through the all-gathers (end blocks of the other segments + their rows of the step);
+ * milliseconds and count of the replicated part of the reduced-camera solves (the chain of 2 x world end blocks); 1 if the
+ * segment-wise solve is active; blocks of 256 rows this rank holds; blocks per rank. */
+int  bh_ba_get_comm_detail(bh_ba* ba, double* out);
 
 /* ---- local-BA window and problem construction ----------------------------------------------
  * Replaces CovisibilityGraph.get_local_map(kf, flag_inner_outer=True, flag_with_input_kf=False) — slam/covisibility_graph.py:51-78

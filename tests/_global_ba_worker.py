@@ -9,7 +9,7 @@ out = sys.argv[1]
 n_kf, n_pts, window, iters = (int(v) for v in sys.argv[2:6])
 dist.init_process_group(backend=os.environ.get("BH_TEST_BACKEND", "gloo"))
 rank = dist.get_rank()
-pr = synth.ba_problem_sequence(n_kf=n_kf, n_pts=n_pts, window=window, seed=3)
+pr = synth.ba_problem_sequence(n_kf=n_kf, n_pts=n_pts, window=window, seed=int(os.environ.get("BH_TEST_SEED", "3")))
 ctx = Context(0)
 s = ba.GlobalBA(ctx, pr["K"], dist)
 s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
@@ -17,7 +17,9 @@ done = s.optimize(iters)
 R, t = s.poses()
 pts = s.points_all()
 ms, nbytes = s.comm()
-np.savez(os.path.join(out, f"rank{rank}.npz"), R=R, t=t, pts=pts, log=s.log()[:done], comm_ms=ms, comm_bytes=nbytes)
+det = s.comm_detail()
+np.savez(os.path.join(out, f"rank{rank}.npz"), R=R, t=t, pts=pts, log=s.log()[:done], comm_ms=ms, comm_bytes=nbytes, solver=s.solver(),
+         **{"det_" + k: v for k, v in det.items()})
 s.close(); ctx.close()
 dist.barrier()
 dist.destroy_process_group()
