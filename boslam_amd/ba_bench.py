@@ -185,5 +185,16 @@ def run_global(ctx, n_kf=5000, n_pts=500000, iters=5, window=20, dist=None, devi
                                      "peak_of_cus_used": round(78.6 * cus / 256, 4), "frac_of_cus_used": round(flops / (ms * 1e-3) / (78.6e12 * cus / 256), 4),
                                      "mfma_flops_per_solve": int(flops),
                                      "note": "two dependency chains of ~%d block columns, one CU each; the dense f64 MFMA peak of 78.6 TFLOP/s is for 256 CUs" % (nblk // cus)}
+    if dist is not None:                                      # the exchange per rank and Levenberg trial, by kind; the replicated part of the solve
+        det = s.comm_detail()
+        tr = max(out["trials"], 1)
+        out["solver"] = s.solver()
+        out["exchange_per_trial_per_rank"] = {
+            "segment_solve": det["segment_solve"], "blocks_of_256_rows_this_rank": det["blocks_this_rank"], "blocks_per_rank": det["blocks_per_rank"],
+            "reduce_scatter_S_mb": round(det["reduce_scatter_bytes"] / tr / 1e6, 3), "all_gather_mb": round(det["all_gather_bytes"] / tr / 1e6, 3),
+            "allreduce_mb": round(det["allreduce_bytes"] / tr / 1e6, 3),
+            "replicated_solve_ms": round(det["replicated_ms"] / max(det["solves"], 1), 4),
+            "note": "bytes RECEIVED by this rank: its own band rows of S (reduce-scatter), the other segments' end blocks and step rows (all-gathers), "
+                    "Hpp / bp / b~ / scalars (all-reduces); replicated_solve_ms = the chain of 2 x world end blocks, the only arithmetic every rank repeats"}
     s.close()
     return out
