@@ -19,7 +19,6 @@
 #include "pnp_small.h"
 
 #define PNP_T 64            // one wave per problem: RANSAC iterations in sequence (as OpenCV runs them), each one wave-parallel
-#define PNP_MAX_HYP 256
 #define PNP_TRACE_HYP 32       // test hook: hypotheses traced per problem
 #define PNP_TRACE_STRIDE 512   // doubles per traced hypothesis
 
@@ -565,7 +564,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
                                                       int* __restrict__ n_inliers, int* __restrict__ ok_out,
                                                       uint8_t* __restrict__ mask_ws, int lm_max, double* trace_all)
 {
-    __shared__ int s_idx[PNP_MAX_HYP * 5];
+    __shared__ int s_idx[5];                                  // the current iteration's sample (drawn lazily: any iterationsCount works)
     __shared__ double s_ws[3 * 144 + 12];
     __shared__ double s_ws2[3 * 36 + 6 + 60 + 6 + 20 + 24];   // + rotation scratch of pj_eig_wave
     __shared__ double s_samp[25];
@@ -581,7 +580,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
     uint8_t* mask = mask_ws + b * (size_t)stride;
     int* out_idx = inliers + b * (size_t)stride;
     if (n < 5) { if (tid == 0) { ok_out[b] = 0; n_inliers[b] = 0; } return; }
-    const int niter0 = n == 5 ? 1 : max(1, min(iterations, PNP_MAX_HYP));
+    const int niter0 = n == 5 ? 1 : max(1, iterations);
     // phase 0: the sample stream of cv::RNG((uint64)-1) is drawn LAZILY, five indices at the start of each iteration, by lane 0 (an
     // accepted model shrinks the iteration budget to one or two on a tracking problem; drawing all `iterations` samples up front was
     // 28 us of a single lane's 64-bit modulo arithmetic per problem)
@@ -595,7 +594,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
         double bR[9], bt[3];
         for (int it = 0; it < niters; it++) {
             if (tid == 0) {
-                int* idx = s_idx + 5 * it;
+                int* idx = s_idx;
                 if (n == 5) { for (int i = 0; i < 5; i++) idx[i] = i; }
                 else
                     for (int i = 0; i < 5;) {
@@ -608,7 +607,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
             double* so = s_samp; double* si = s_samp + 15;      // the sample, in LDS (every lane writes and reads the same values)
             double R[9], t[3];
             for (int i = 0; i < 5; i++) {
-                const int p = s_idx[5 * it + i];
+                const int p = s_idx[i];
                 for (int k = 0; k < 3; k++) so[3 * i + k] = (double)(float)obj[3 * p + k];
                 for (int k = 0; k < 2; k++) si[2 * i + k] = (double)(float)img[2 * p + k];
             }
@@ -629,7 +628,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
                 for (int m = 32; m > 0; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
                 good = cnt;
             }
-            if (trace && tid == 0) { trace[0] = it; for (int i = 0; i < 5; i++) trace[1 + i] = s_idx[5 * it + i]; for (int i = 0; i < 9; i++) trace[469 + i] = R[i]; for (int i = 0; i < 3; i++) trace[478 + i] = t[i]; trace[481] = good; }
+            if (trace && tid == 0) { trace[0] = it; for (int i = 0; i < 5; i++) trace[1 + i] = s_idx[i]; for (int i = 0; i < 9; i++) trace[469 + i] = R[i]; for (int i = 0; i < 3; i++) trace[478 + i] = t[i]; trace[481] = good; }
             if (n == 5 || good > (max_good > 4 ? max_good : 4)) {
                 best = it; max_good = good;
                 for (int k = 0; k < 9; k++) bR[k] = R[k];
@@ -789,7 +788,6 @@ extern "C" int bh_solve_pnp_ransac(bh_ctx* ctx, const double* obj, const double*
     if (!obj || !img || !n || !K || !rvec || !tvec || !inliers || !n_inliers || !ok || B < 0 || stride < 1 ||
         (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE) || !(confidence > 0 && confidence < 1))
         return bh_set_err(ctx, BH_ERR_INVALID, "bh_solve_pnp_ransac: bad argument");
-    if (iterations > PNP_MAX_HYP) return bh_set_err(ctx, BH_ERR_INVALID, "bh_solve_pnp_ransac: iterations > %d not supported", PNP_MAX_HYP);
     if (B == 0) return BH_OK;
     BH_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;

@@ -101,7 +101,11 @@ SOLVEPNP_EPNP = 1
 def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None, rvec=None, tvec=None, useExtrinsicGuess=False,
                    iterationsCount=100, reprojectionError=8.0, confidence=0.99, inliers=None, flags=SOLVEPNP_ITERATIVE, ctx=None):
     """-> (retval, rvec (3,1), tvec (3,1), inliers (k,1) int32 | None), like cv2.  The final pose is the reprojection-error
-    minimiser over the RANSAC inliers for both ITERATIVE and EPNP flags."""
+    minimiser over the RANSAC inliers for both ITERATIVE and EPNP flags.
+
+    NOT cv2 for exactly four points: OpenCV 3.x switches its minimal solver to P3P when n == 4 (5 points and EPnP otherwise); that
+    branch is not built - n == 4 returns (False, zeros, zeros, None).  The reference never gets there: its only live call site needs
+    >= 10 matches first (experiments/pnp_two_way_tracking.py:45,57-61).  Any iterationsCount is accepted."""
     import ctypes as C
     if distCoeffs is not None and np.any(np.asarray(distCoeffs) != 0):
         raise ValueError("non-zero distortion is not supported (the reference always passes zeros, camera.py:82)")

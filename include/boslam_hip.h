@@ -254,8 +254,8 @@ int bh_ba_window_problem(bh_ctx* ctx, int K, const int* nbr_start, const int* nb
  * experiments/pnp_two_way_tracking.py:57-61,68-69 (slam/tracking.py:68-71 is dead code) — for B problems.
  *   obj f64[B][stride][3], img f64[B][stride][2], n int[B] (n >= 5; n == 4, where OpenCV switches to P3P, reports ok = 0)
  *   K = {fx, fy, cx, cy}; distortion is zero in the reference (camera.py:82, config.py:34)
- *   defaults of the reference call: iterations 100, reproj_error 8.0, confidence 0.99; iterations > 256 is BH_ERR_INVALID (the
- *   kernel pre-draws the sample stream of cv::RNG for at most 256 hypotheses)
+ *   defaults of the reference call: iterations 100, reproj_error 8.0, confidence 0.99 (any iterationsCount: the sample stream of
+ *   cv::RNG((uint64)-1) is drawn hypothesis by hypothesis)
  *   the final pose is the Levenberg-Marquardt minimiser of the reprojection error over the RANSAC inliers, started from the RANSAC
  *   model (OpenCV: solvePnP(ITERATIVE) from a DLT guess, CvLevMarq 20 iterations / FLT_EPSILON): same minimum, poses agree to ~1e-6
  *   rvec/tvec f64[B][3] (world -> camera), inliers int[B][stride] ascending, n_inliers int[B], ok int[B] (1/0)

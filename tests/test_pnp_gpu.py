@@ -112,3 +112,17 @@ def test_pnp_hypothesis_trace_matches_oracle_bit_for_bit(ctx):
         assert np.array_equal(tg[0].view(np.uint64), to.view(np.uint64)), np.argwhere(tg[0] != to)[:5]
         assert bool(ok[0]) == o_ok and np.array_equal(inl[0, :ni[0]], oinl)
         assert np.array_equal(rv[0], orv) and np.array_equal(tv[0], otv)
+
+
+def test_pnp_many_iterations_and_hopeless_problems(ctx):
+    """iterationsCount beyond the former cap of 256 (the sample stream is drawn lazily, hypothesis by hypothesis): a problem with 85 %
+    outliers needs hundreds of hypotheses before the iteration budget shrinks; a problem with no consistent model at all runs every one
+    of them.  rvec / tvec / inliers equal the oracle's bit for bit."""
+    rng = np.random.default_rng(21)
+    for n, outl, iters in ((120, 0.85, 700), (60, 1.0, 400), (200, 0.6, 300)):
+        X, uv, _, _ = _problem(rng, n, outliers=outl)
+        ok, rv, tv, inl = cv2_shim.solvePnPRansac(X, uv, KM, None, iterationsCount=iters, ctx=ctx)
+        o_ok, orv, otv, oinl = oracle.solve_pnp_ransac(X, uv, K4, iterations=iters)
+        assert ok == o_ok
+        if ok:
+            assert np.array_equal(inl.ravel(), oinl) and np.array_equal(rv.ravel(), orv) and np.array_equal(tv.ravel(), otv)
