@@ -158,6 +158,55 @@ __global__ __launch_bounds__(256) void k_gray_mask(const uint8_t* __restrict__ i
     }
 }
 
+// The reference call's case (camera.py:141: BGR frame, mask = (depth > 0) * 255) with a width that is a multiple of 4, specialised:
+// the luma (B 1868 + G 9617 + R 4899 + 8192) >> 14 straight from the three packed BGR words by v_dot4_u32_u8 (weights split into
+// high and low bytes: 1868 = 7 x 256 + 76, 9617 = 37 x 256 + 145, 4899 = 19 x 256 + 35; a pixel that straddles two words chains two
+// dot products), the four depth values to a nibble by one packed min per register, frame-uniform 64-bit bases with 32-bit lane
+// offsets.  50 vector instructions per lane where the general kernel above takes 118; both are at the HBM roof on their own, but the
+// front end as a whole is bound by vector-instruction issue, and this kernel runs beside the others.
+__global__ __launch_bounds__(256) void k_gray_bits(const uint8_t* __restrict__ img, const uint16_t* __restrict__ depth, uint8_t* __restrict__ pyr,
+                                                   int W, int H, int pitch, int pyr_stride, uint32_t* __restrict__ mbits, int mpitch, int mstride)
+{
+    const int groups = pitch >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    int y;
+    {   // idx / groups: both multiples of 16 apart from idx's low bits, the divisor at most 4096 / 4; a float quotient off by one is put right
+        const int q = idx >> 4, d = groups >> 4;
+        y = (int)((float)q * __builtin_amdgcn_rcpf((float)d));
+        const int r = q - y * d;
+        y += r >= d ? 1 : (r < 0 ? -1 : 0);
+    }
+    const int x = (idx - y * groups) << 2;
+    if (y >= H) return;                                        // whole rows leave together (groups is a multiple of 16: DPP rows stay whole)
+    const uint8_t* __restrict__ fimg = img + (size_t)blockIdx.y * H * W * 3;
+    const uint16_t* __restrict__ fd = depth + (size_t)blockIdx.y * H * W;
+    uint8_t* __restrict__ fp = pyr + (size_t)blockIdx.y * pyr_stride;
+    uint32_t* __restrict__ fm = mbits + (size_t)blockIdx.y * mstride;
+    uint32_t g4 = 0, nib = 0;
+    if (x < W) {
+        const uint32_t px = (uint32_t)(y * W + x);
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(fimg + px * 3u);
+        const uint32_t a = sp[0], b = sp[1], c = sp[2];       // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        const uint32_t h0 = __builtin_amdgcn_udot4(a, 7u | 37u << 8 | 19u << 16, 0u, false), l0 = __builtin_amdgcn_udot4(a, 76u | 145u << 8 | 35u << 16, 8192u, false);
+        const uint32_t h1 = __builtin_amdgcn_udot4(a, 7u << 24, __builtin_amdgcn_udot4(b, 37u | 19u << 8, 0u, false), false);
+        const uint32_t l1 = __builtin_amdgcn_udot4(a, 76u << 24, __builtin_amdgcn_udot4(b, 145u | 35u << 8, 8192u, false), false);
+        const uint32_t h2 = __builtin_amdgcn_udot4(b, 7u << 16 | 37u << 24, __builtin_amdgcn_udot4(c, 19u, 0u, false), false);
+        const uint32_t l2 = __builtin_amdgcn_udot4(b, 76u << 16 | 145u << 24, __builtin_amdgcn_udot4(c, 35u, 8192u, false), false);
+        const uint32_t h3 = __builtin_amdgcn_udot4(c, 7u << 8 | 37u << 16 | 19u << 24, 0u, false), l3 = __builtin_amdgcn_udot4(c, 76u << 8 | 145u << 16 | 35u << 24, 8192u, false);
+        g4 = __builtin_amdgcn_ubfe((h0 << 8) + l0, 14u, 8u) | __builtin_amdgcn_ubfe((h1 << 8) + l1, 14u, 8u) << 8 |
+             __builtin_amdgcn_ubfe((h2 << 8) + l2, 14u, 8u) << 16 | __builtin_amdgcn_ubfe((h3 << 8) + l3, 14u, 8u) << 24;
+        typedef unsigned short gm_us2 __attribute__((ext_vector_type(2)));
+        const uint2 d = *reinterpret_cast<const uint2*>(fd + px);
+        const gm_us2 one = gm_us2{ 1, 1 };
+        const uint32_t nx = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(gm_us2, d.x), one));      // 1 / 0 in each half
+        const uint32_t ny = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(gm_us2, d.y), one));
+        nib = ((nx | nx >> 15) & 3u) | ((ny | ny >> 15) & 3u) << 2;
+    }
+    *reinterpret_cast<uint32_t*>(fp + (uint32_t)(y * pitch + x)) = g4;
+    const uint32_t wd = nib_gather8(nib, threadIdx.x);
+    if ((threadIdx.x & 7) == 7) fm[(uint32_t)(y * mpitch + (x >> 5))] = wd;
+}
+
 // ------------------------------------------------------------------------------------------------ pyramid level l from l-1
 // INTER_LINEAR_EXACT arithmetic: horizontal 8.8 fixed point, vertical 16.16, round to nearest.
 // One lane produces 4 output pixels.  Its 4 coefficient entries come in one 16-B load; the <= 6 source columns they
@@ -778,7 +827,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __syncthreads();
     const int kk = s_k;
     const size_t lv = (size_t)frame * g.nlevels + level;
+#if defined(FAST_STOP) && FAST_STOP == 5      // diagnostic: no returning global atomic at the tile's end (wrong lists)
+    if (tid == 0 && kk) s_base = 0;
+#else
     if (tid == 0 && kk) s_base = atomicAdd(&ccnt[lv], kk);
+#endif
     __syncthreads();
     if (kk) {
         const int base = s_base;
@@ -1378,8 +1431,12 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         BH_HIP(ctx, hipMemsetAsync(ccnt, 0, sizeof(int) * g.nlevels * chunk, st));
         {
             const int n = (g.lv[0].pitch >> 2) * g.lv[0].h;
-            BH_LAUNCH(ctx, BH_K_GRAY, k_gray_mask, dim3((n + 255) / 256, nb), dim3(256), st, d_img, channels, d_mask, d_depth,
-                               pyr, mpyr, W, H, g.lv[0].pitch, g.pyr_stride, mbits, g.lv[0].mpitch, g.mstride);
+            if (mbits && channels == 3 && (W & 3) == 0 && !getenv("BH_ORB_GRAY_GENERAL"))      // the reference call's case
+                BH_LAUNCH(ctx, BH_K_GRAY, k_gray_bits, dim3((n + 255) / 256, nb), dim3(256), st, d_img, d_depth, pyr, W, H, g.lv[0].pitch, g.pyr_stride, mbits,
+                          g.lv[0].mpitch, g.mstride);
+            else
+                BH_LAUNCH(ctx, BH_K_GRAY, k_gray_mask, dim3((n + 255) / 256, nb), dim3(256), st, d_img, channels, d_mask, d_depth,
+                          pyr, mpyr, W, H, g.lv[0].pitch, g.pyr_stride, mbits, g.lv[0].mpitch, g.mstride);
         }
         for (int l = 1; l < g.nlevels; l++) {
             if (mbits) {
