@@ -139,6 +139,37 @@ class _DeviceF64:
         self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(addr), False), "version": 2}
 
 
+def host_exchange(t, op, dist):
+    """The hook's four exchanges on a HOST tensor (the gloo rehearsal path; also what tests/test_host_cpu.py drives with two CPU ranks).
+    op 0 / 1: all-reduce sum / max; op 2: reduce-scatter sum in place - `world` equal chunks, afterwards chunk `rank` holds the sum (gloo
+    has no reduce-scatter: one reduce per owner); op 3: all-gather in place - chunk `rank` is this rank's contribution."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if op < 2:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+        return t
+    ch = t.numel() // world
+    if op == 2:
+        for dst in range(world):
+            dist.reduce(t[dst * ch:(dst + 1) * ch], dst=dst, op=dist.ReduceOp.SUM)
+    else:
+        parts = [torch.empty(ch, dtype=t.dtype) for _ in range(world)]
+        dist.all_gather(parts, t[rank * ch:(rank + 1) * ch].clone())
+        for r_, p_ in enumerate(parts):
+            t[r_ * ch:(r_ + 1) * ch] = p_
+    return t
+
+
+def segment_blocks(n_unknowns, world):
+    """The keyframe segments of the sharded reduced-camera solve: blocks of 256 rows per rank, or None when a rank would hold fewer
+    than two (then S is all-reduced and the solve replicated) - the decision bh_ba_set_problem takes (ba.hip: dbcr_setup)."""
+    N = (int(n_unknowns) + 255) // 256
+    seg = (N + world - 1) // world
+    if world < 2 or seg < 2 or N - (world - 1) * seg < 2:
+        return None
+    return [(r * seg, min(N, (r + 1) * seg)) for r in range(world)]
+
+
 def make_allreduce_hook(ctx, dist, device=None):
     """bh_allreduce_fn over torch.distributed.  With a device-capable backend ("nccl" = RCCL over xGMI) the library's device
     buffer is reduced in place; with "gloo" it is staged through host memory (CPU rehearsals)."""
@@ -168,19 +199,7 @@ def make_allreduce_hook(ctx, dist, device=None):
                 h = np.empty(count, np.float64)
                 if L.bh_ctx_copy(ctx.h, _lib.ptr(h), C.c_void_p(dev), 8 * count, 0) != 0:
                     return 2
-                t = torch.from_numpy(h)
-                if op < 2:
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
-                else:
-                    ch = count // world
-                    if op == 2:                                              # gloo has no reduce-scatter: one reduce per owner
-                        for dst in range(world):
-                            dist.reduce(t[dst * ch:(dst + 1) * ch], dst=dst, op=dist.ReduceOp.SUM)
-                    else:
-                        parts = [torch.empty(ch, dtype=torch.float64) for _ in range(world)]
-                        dist.all_gather(parts, t[rank * ch:(rank + 1) * ch].clone())
-                        for r_, p_ in enumerate(parts):
-                            t[r_ * ch:(r_ + 1) * ch] = p_
+                host_exchange(torch.from_numpy(h), op, dist)
                 if L.bh_ctx_copy(ctx.h, C.c_void_p(dev), _lib.ptr(h), 8 * count, 1) != 0:
                     return 2
             return 0

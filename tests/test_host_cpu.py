@@ -153,6 +153,20 @@ def local():
 gi, gs = bow.sharded_query(local, a, 6, td)
 ri, rs = oracle.bow_query_l1(db["q_words"], db["q_vals"], db["start"], db["words"], db["vals"], 6)
 assert np.array_equal(gi, ri) and np.array_equal(gs, rs), (gi, ri)
+# the sharded global BA's exchanges (reduce-scatter of S rows, all-gather of end blocks and of the step) on host tensors
+from boslam_amd import ba
+for world_chunks in (3, 64):
+    full = [torch.arange(world * world_chunks, dtype=torch.float64) * (r + 1) + r for r in range(world)]
+    t = full[rank].clone()
+    ba.host_exchange(t, 2, td)
+    want = sum(full)[rank * world_chunks:(rank + 1) * world_chunks]
+    assert torch.equal(t[rank * world_chunks:(rank + 1) * world_chunks], want)
+    g = torch.zeros(world * world_chunks, dtype=torch.float64)
+    g[rank * world_chunks:(rank + 1) * world_chunks] = want
+    ba.host_exchange(g, 3, td)
+    assert torch.equal(g, sum(full))                                   # reduce-scatter + all-gather == all-reduce
+    a2 = full[rank].clone(); ba.host_exchange(a2, 0, td); assert torch.equal(a2, sum(full))
+    m2 = full[rank].clone(); ba.host_exchange(m2, 1, td); assert torch.equal(m2, torch.stack(full).max(0).values)
 td.barrier()
 td.destroy_process_group()
 os.write(1, ("rank %d ok\n" % rank).encode())        # one write(): two ranks share the pipe, print() would interleave
@@ -197,3 +211,17 @@ def test_committed_bench_line_meets_the_contract():
     b = d["bow_query"]["roofline"]
     assert b["frac"] < 0.79 and b["survey_bytes_per_query"] == 3 * (b["bytes_per_query"] - 16 * 100000)   # streamed-bytes fraction stays physical
     assert abs(d["value"] - 1000 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-3
+
+
+def test_segment_plan_of_the_sharded_reduced_camera_solve():
+    """boslam_amd.ba.segment_blocks mirrors the library's decision (ba.hip dbcr_setup): contiguous segments of 256-row blocks, every rank
+    at least two, else the replicated scheme.  configs[4] (4 998 free keyframes = 29 988 unknowns = 118 blocks) on 1 / 2 / 4 / 8 ranks."""
+    from boslam_amd import ba
+    n = 6 * 4998
+    assert ba.segment_blocks(n, 1) is None
+    for world, sizes in ((2, [59, 59]), (4, [30, 30, 30, 28]), (8, [15] * 7 + [13])):
+        seg = ba.segment_blocks(n, world)
+        assert [b - a for a, b in seg] == sizes and seg[0][0] == 0 and seg[-1][1] == 118
+        assert all(seg[i][1] == seg[i + 1][0] for i in range(world - 1))
+    assert ba.segment_blocks(6 * 698, 2) == [(0, 9), (9, 17)] and ba.segment_blocks(6 * 698, 3) == [(0, 6), (6, 12), (12, 17)]
+    assert ba.segment_blocks(6 * 100, 2) is None and ba.segment_blocks(256 * 9, 8) is None      # too short: S all-reduced, solve replicated
