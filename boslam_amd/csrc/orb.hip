@@ -498,6 +498,8 @@ typedef short fs2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ fs2 fswap(fs2 a) { return fs2{ a.y, a.x }; }
 __device__ __forceinline__ fs2 fmn(fs2 a, fs2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ fs2 fmx(fs2 a, fs2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ fs2 fmn3(fs2 a, fs2 b, fs2 c) { fs2 r; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ fs2 fmx3(fs2 a, fs2 b, fs2 c) { fs2 r; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 // LDS fetch-add issued as ONE ds_add_rtn_u32 for all active lanes (the hardware serialises lanes that hit the same address).  The
 // compiler's atomic optimiser would turn a divergent-value atomicAdd into a scalar loop over the active lanes (~8 SALU each).
 __device__ __forceinline__ int lds_add_rtn(int* p, int v)
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // (ds_read_u8_d16 / _d16_hi would fill the halves for free, but with SRAM ECC on - gfx950 - a d16 load clears the other half.)
         const uint8_t* c = px + b + 3 * FROW;
         const uint32_t vc = c[0];
-        const fs2 VV = __builtin_bit_cast(fs2, vc | (vc << 16));
+        const fs2 VV = __builtin_bit_cast(fs2, (vc | (vc << 16)) + 0x01000100u);      // + 256 in both halves (see below)
         fs2 R8[8];
         R8[0] = __builtin_bit_cast(fs2, (uint32_t)c[3 * FROW]      | ((uint32_t)c[-3 * FROW] << 16));
         R8[1] = __builtin_bit_cast(fs2, (uint32_t)c[3 * FROW + 1]  | ((uint32_t)c[-3 * FROW - 1] << 16));
@@ -695,26 +697,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         R8[5] = __builtin_bit_cast(fs2, (uint32_t)c[-FROW + 3]     | ((uint32_t)c[FROW - 3] << 16));
         R8[6] = __builtin_bit_cast(fs2, (uint32_t)c[-2 * FROW + 2] | ((uint32_t)c[2 * FROW - 2] << 16));
         R8[7] = __builtin_bit_cast(fs2, (uint32_t)c[-3 * FROW + 1] | ((uint32_t)c[3 * FROW - 1] << 16));
-        // Packed 16-bit lanes: P[k] = (d[k], d[k+8]); the ring rotated by j is P[k+j], with P[8+i] = swap(P[i]).
+        // Packed 16-bit lanes: P[k] = (d[k], d[k+8]) + 256; the ring rotated by j is P[k+j], with P[8+i] = swap(P[i]).
         // A = max over the 16 arcs of min(d over 9 ring pixels), Bn = min over arcs of max(d): the pixel is a corner iff
         // A > thr or -Bn > thr, and its score (cornerScore<16>) is max(thr, A, -Bn) - 1.
-        fs2 P[8], mn[8], mx[8], t0[8], t1[8];
+        // The biased differences 1..511 are positive f16 DENORMALS as bit patterns, which order like the integers: gfx950's three-input
+        // v_pk_minimum3_f16 / v_pk_maximum3_f16 build a 9-arc as min3 of three min3 of three (16 + 8 packed ops instead of the 40 of the
+        // two-input doubling tree; f16 denormals are never flushed in this build's float mode).
+        fs2 P[8], t3[8], u3[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) P[k] = VV - R8[k];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { const fs2 nx = k < 7 ? P[k + 1] : fswap(P[0]); mn[k] = fmn(P[k], nx); mx[k] = fmx(P[k], nx); }
-#pragma unroll
-        for (int k = 0; k < 8; k++) { t0[k] = fmn(mn[k], k < 6 ? mn[k + 2] : fswap(mn[k - 6])); t1[k] = fmx(mx[k], k < 6 ? mx[k + 2] : fswap(mx[k - 6])); }
-#pragma unroll
-        for (int k = 0; k < 8; k++) { mn[k] = fmn(t0[k], k < 4 ? t0[k + 4] : fswap(t0[k - 4])); mx[k] = fmx(t1[k], k < 4 ? t1[k + 4] : fswap(t1[k - 4])); }
-        fs2 am = fs2{ -32768, -32768 }, bm2 = fs2{ 32767, 32767 };
+        for (int k = 0; k < 8; k++) {
+            const fs2 p1 = k < 7 ? P[k + 1] : fswap(P[0]), p2 = k < 6 ? P[k + 2] : fswap(P[k - 6]);
+            t3[k] = fmn3(P[k], p1, p2); u3[k] = fmx3(P[k], p1, p2);
+        }
+        fs2 a9[8], b9[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const fs2 ninth = fswap(P[k]);                       // (d[k+8], d[k+16]) closes the 9-arc
-            am = fmx(am, fmn(mn[k], ninth));
-            bm2 = fmn(bm2, fmx(mx[k], ninth));
+            const fs2 q1 = k < 5 ? t3[k + 3] : fswap(t3[k - 5]), q2 = k < 2 ? t3[k + 6] : fswap(t3[k - 2]);
+            const fs2 r1 = k < 5 ? u3[k + 3] : fswap(u3[k - 5]), r2 = k < 2 ? u3[k + 6] : fswap(u3[k - 2]);
+            a9[k] = fmn3(t3[k], q1, q2); b9[k] = fmx3(u3[k], r1, r2);
         }
-        const int A = max((int)am.x, (int)am.y), Bn = min((int)bm2.x, (int)bm2.y);
+        const fs2 am = fmx3(fmx3(a9[0], a9[1], a9[2]), fmx3(a9[3], a9[4], a9[5]), fmx(a9[6], a9[7]));
+        const fs2 bm2 = fmn3(fmn3(b9[0], b9[1], b9[2]), fmn3(b9[3], b9[4], b9[5]), fmn(b9[6], b9[7]));
+        const int A = max((int)am.x, (int)am.y) - 256, Bn = min((int)bm2.x, (int)bm2.y) - 256;
         if (!(A > thr || -Bn > thr)) continue;
         const int a0 = max(thr, A);
         const int b0 = min(Bn, -a0);
