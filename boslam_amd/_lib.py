@@ -54,7 +54,9 @@ _SIGS = {
     "bh_ba_get_chi2": (_i, [_vp, _vp, _i]),
     "bh_ba_get_log": (_i, [_vp, _vp, _i]),
     "bh_ba_solver": (_i, [_vp]),
+    "bh_ba_debug_structure": (_i, [_vp, _i, _vp, C.c_longlong, C.POINTER(C.c_longlong)]),
     "bh_ba_batch_create": (_i, [_vp, _i, _vp, _vp]),
+    "bh_ba_batch_set_problems": (_i, [_vp, _i, _vp, _vp]),
     "bh_ba_batch_destroy": (None, [_vp]),
     "bh_ba_batch_optimize": (_i, [_vp, _i, C.c_double, _i, _vp]),
     "bh_ctx_copy": (_i, [_vp, _vp, _vp, C.c_size_t, _i]),

@@ -87,6 +87,23 @@ class LocalBA:
         """Name of the reduced-camera-system solver set_problem selected (bh_ba_solver)."""
         return {0: "panel", 1: "dense", 2: "window", 3: "twoway", 4: "bcr", 5: "bcr-segments"}.get(_lib.lib().bh_ba_solver(self.h), "none")
 
+    def structure(self):
+        """The structural arrays set_problem built (test hook bh_ba_debug_structure): dict name -> int32 array."""
+        names = ("e_pt", "p_start", "p_edges", "c_start", "c_edges", "pairs", "j_start", "join", "cslot")
+        out = {}
+        cap = 1 << 16
+        for w, name in enumerate(names):
+            while True:
+                buf = np.zeros(cap, np.int32); n = C.c_longlong(0)
+                rc = _lib.lib().bh_ba_debug_structure(self.h, w, _lib.ptr(buf), cap, C.byref(n))
+                if rc == -3 and cap < (1 << 28):                               # BH_ERR_CAPACITY: grow and retry
+                    cap *= 4
+                    continue
+                self.ctx.check(rc)
+                out[name] = buf[:n.value].copy()
+                break
+        return out
+
     def close(self):
         if getattr(self, "h", None):
             _lib.lib().bh_ba_destroy(self.h)
@@ -97,6 +114,34 @@ class LocalBA:
             self.close()
         except Exception:
             pass
+
+
+class _Problem(C.Structure):                          # bh_ba_problem
+    _fields_ = [("C", C.c_int), ("R", C.c_void_p), ("t", C.c_void_p), ("fixed", C.c_void_p), ("P", C.c_int), ("points", C.c_void_p),
+                ("E", C.c_int), ("edge_pose", C.c_void_p), ("edge_point", C.c_void_p), ("meas", C.c_void_p)]
+
+
+def set_problems(ctx, windows, problems):
+    """bh_ba_batch_set_problems: LocalBA.set_problem for many windows in one call - the local windows among them are built by one launch
+    (a workgroup each) and one copy in either direction.  problems: sequence of (R, t, fixed, points, edge_pose, edge_point, meas)."""
+    windows = list(windows)
+    assert len(windows) == len(problems)
+    arr = (_Problem * len(windows))()
+    keep = []
+    for w, (win, pr) in enumerate(zip(windows, problems)):
+        R, t, fixed, points, edge_pose, edge_point, meas = pr
+        R = np.ascontiguousarray(R, dtype=np.float64).reshape(-1, 9); t = np.ascontiguousarray(t, dtype=np.float64).reshape(-1, 3)
+        fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+        points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        edge_pose = np.ascontiguousarray(edge_pose, dtype=np.int32); edge_point = np.ascontiguousarray(edge_point, dtype=np.int32)
+        meas = np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 2)
+        keep.append((R, t, fixed, points, edge_pose, edge_point, meas))
+        win.C, win.P, win.E = len(R), len(points), len(edge_pose)
+        win._points_in = points.copy()
+        arr[w] = _Problem(win.C, R.ctypes.data, t.ctypes.data, fixed.ctypes.data, win.P, points.ctypes.data, win.E,
+                          edge_pose.ctypes.data, edge_point.ctypes.data, meas.ctypes.data)
+    hs = (C.c_void_p * len(windows))(*[w.h for w in windows])
+    ctx.check(_lib.lib().bh_ba_batch_set_problems(ctx.h, len(windows), hs, arr))
 
 
 class LocalBABatch:

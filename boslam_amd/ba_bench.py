@@ -76,10 +76,10 @@ def run_batch(ctx, W=64, n_kf=50, n_pts=10000, iters=10, repeats=3, n_distinct=8
     probs = [synth.ba_problem(n_kf=n_kf, n_pts=n_pts, seed=7 + k) for k in range(n_distinct)]
     wins = [ba.LocalBA(ctx, probs[w % n_distinct]["K"]) for w in range(W)]
 
-    def set_all():
-        for w, s in enumerate(wins):
-            pr = probs[w % n_distinct]
-            s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+    args = [tuple(probs[w % n_distinct][k] for k in ("R", "t", "fixed", "pts", "ecam", "ept", "meas")) for w in range(W)]
+
+    def set_all():                                        # bh_ba_batch_set_problems: the local windows are built by one launch, a workgroup each
+        ba.set_problems(ctx, wins, args)
     batch = ba.LocalBABatch(ctx, wins)
     t_set, t_opt, done = [], [], None
     for r in range(repeats + 1):
@@ -90,24 +90,29 @@ def run_batch(ctx, W=64, n_kf=50, n_pts=10000, iters=10, repeats=3, n_distinct=8
         ctx.synchronize(); t2 = time.perf_counter()
         if r:
             t_set.append(t1 - t0); t_opt.append(t2 - t1)
-    # one window at a time, same problems
-    t_one = []
+    # one window at a time, same problems (bh_ba_set_problem + bh_ba_optimize per window)
+    t_one, t_set1 = [], []
     for r in range(2):
-        set_all()
         ctx.synchronize(); t0 = time.perf_counter()
+        for s, a in zip(wins[:8], args[:8]):
+            s.set_problem(*a)
+        ctx.synchronize(); t1 = time.perf_counter()
         for s in wins[:8]:
             s.optimize(iters)
         ctx.synchronize()
         if r:
-            t_one.append((time.perf_counter() - t0) / 8)
+            t_one.append((time.perf_counter() - t1) / 8); t_set1.append((t1 - t0) / 8)
     tot = int(done.sum())
     opt = float(np.median(t_opt)); st = float(np.median(t_set)); one = float(np.median(t_one))
     chi = [float(s.log()[:int(done[w])][-1, 0]) for w, s in enumerate(wins[:n_distinct])]
     out = {"metric": "local_ba_lm_iters_per_sec_batched", "windows": W, "workload": f"{label}: {W} windows of {n_kf} keyframes x {n_pts} landmarks x "
            f"{len(probs[0]['ecam'])} observations, {iters} LM iterations each ({n_distinct} distinct problems)",
            "value": round(tot / opt, 1), "unit": "iters/s", "ms_per_round": round(opt / max(int(done.max()), 1) * 1e3, 3),
-           "value_incl_set_problem": round(tot / (opt + st), 1), "set_problem_ms_per_window": round(st / W * 1e3, 3),
+           "value_incl_set_problem": round(tot / (opt + st), 1), "set_problem_ms_per_window": round(st / W * 1e3, 4),
            "single_window_iters_per_s": round(iters / one, 1), "speedup_vs_one_at_a_time": round((tot / opt) / (iters / one), 1),
+           "single_window_set_problem_ms": round(float(np.median(t_set1)) * 1e3, 3),
+           "single_window_iters_per_s_incl_set_problem": round(iters / (one + float(np.median(t_set1))), 1),
+           "speedup_incl_set_problem": round((tot / (opt + st)) / (iters / (one + float(np.median(t_set1)))), 1),
            "iters_done_min_max": [int(done.min()), int(done.max())], "final_robust_chi2_first_windows": chi}
     batch.close()
     for s in wins:

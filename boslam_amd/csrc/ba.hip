@@ -2936,6 +2936,420 @@ static int ba_build_device(bh_ba* ba, int C, const uint8_t* fixed, int P, const 
     return BH_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// One-workgroup builder for local windows (round 3).  ba_build_device above is ~60 launches (three merge sorts of ~20 kernels each)
+// and four host reads - 0.4 ms for a live window whose seven LM iterations take 0.6 ms, and the part of local mapping that the
+// batched optimiser does not cover.  A window with at most BLD_SF free keyframes is built by ONE 1024-thread workgroup
+// (k_bld_small: slots, edges by point, edges by camera, camera pairs, join offsets) plus one launch of a wave per camera pair
+// (k_bld_join_merge), from user arrays that went up in one copy; what the host needs comes back in one.  Same arrays bit for bit as
+// the general builder and the host loops (test_device_built_problem_equals_host_built runs all three), built without any sort:
+//   p_edges   per-point lists are filled in arbitrary order (integer atomics) and then RANKED inside the point by (camera, input
+//             position) - the keys are unique, so the order is total and nothing depends on the fill order;
+//   c_edges   = the p_edges sequence filtered by camera: a stable partition.  Wave w owns a contiguous chunk; lane s of the wave keeps
+//             camera s's running position in a register (hence <= 64 free cameras), a batch of 64 edges is placed by one ballot per
+//             distinct camera in it;
+//   pairs     counted per (s1, s2) in LDS by integer atomics, compacted in lexicographic order by a block scan; j_start = scan of the counts;
+//   join      camera s1's and s2's lists are both sorted by landmark: a wave per pair walks s1's list, finds each landmark in s2's by
+//             binary search and writes the hits in order (ballot prefix) - landmark order without a sort.
+#define BLD_SF 64                    // free cameras a window may have (lane per camera; 64 x 64 pair counters in LDS)
+#define BLD_SC 1024                  // user cameras
+#define BLD_LE 12288                 // edges: four 16-bit arrays of this length live in LDS
+#define BLD_LP 4096                  // landmarks
+#define BLD_MJ 4096                  // k_bld_join_merge: entries of camera s2's list staged in LDS
+struct bld_view {
+    int C, P, E, all_used;
+    const int* ep; const int* pp; const uint8_t* fixed; const double* points; const double* meas;      // staged user arrays (device)
+    int* e_cam; int* e_pt; double* e_meas; int* cslot; int* pslot;
+    int* p_start; int* p_edges; int* c_start; int* c_edges; int* c_pt;                                  // c_pt: landmark of every c_edges entry (scratch for the join)
+    int2* pairs; int* j_start; int2* join; long long join_cap;
+    double* pts;
+    int* info;                       // out: [0] first bad edge, [1] max |s1 - s2|, [2] Cf, [3] Pa, [4] npairs, [5] c_total, [6] M, [7] refused (1: Cf > BLD_SF, 2: join list too long)
+    int* back_cslot;                 // copy of cslot next to info and pslot: what the host mirrors comes back in ONE read
+    // what bh_ba_set_problem does after the build, here in the same launch: camera blocks, cleared control block / residuals / S / step
+    const ba_cam* cams_src; ba_cam* cams_dst; ba_K K;
+    double* S; double* dxp; double* err0; ba_state* state;
+};
+__host__ __device__ inline size_t bld_lds_bytes(int E, int P)
+{
+    const size_t e2 = ((size_t)E + 1) & ~(size_t)1, p2 = ((size_t)P + 2) & ~(size_t)1;
+    return 2 * (4 * e2 + 3 * p2) + 16;
+}
+
+// exclusive prefix of one int per thread over the 1024-thread workgroup; *total = the sum (s_w: 16 ints of LDS)
+__device__ __forceinline__ int bld_exscan(int v, int* s_w, int* total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    __syncthreads();                                             // s_w may still be read from the previous scan
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const int t = s_w[w]; if (w < wv) base += t; tot += t; }
+    *total = tot;
+    return base + inc - v;
+}
+// 16-bit counters, two per LDS word (LDS atomics are 32 bits wide; a half never reaches 65 536 here)
+__device__ __forceinline__ int bld_add16(uint16_t* a, int i, int v)
+{
+    const unsigned sh = 16u * ((unsigned)i & 1u);
+    const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(a) + (i >> 1), (unsigned)v << sh);
+    return (int)((old >> sh) & 0xffffu);
+}
+
+__global__ __launch_bounds__(1024) void k_bld_small(const bld_view* __restrict__ views)
+{
+    const bld_view V = views[blockIdx.y];
+    if (V.C == 0) return;                                        // a window of the batch that is not a local one
+#ifdef BLD_CLOCKS
+    int clk_i = 0;
+#define BLD_CLK() do { if (threadIdx.x == 0 && clk_i < 10) V.info[8 + clk_i] = (int)wall_clock64(); clk_i++; } while (0)
+#else
+#define BLD_CLK() do {} while (0)
+#endif
+    BLD_CLK();
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_dyn[];
+    __shared__ int8_t s_cs[BLD_SC];                              // user camera -> free slot or -1 (first: used flag)
+    __shared__ int s_jc[BLD_SF * BLD_SF];                        // (s1, s2) -> number of (edge, edge) pairs on a common landmark
+    __shared__ int s_cc[BLD_SF + 1];
+    __shared__ int s_w[16];
+    __shared__ int s_bad, s_bw;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int C = V.C, P = V.P, E = V.E;
+    const int e2 = (E + 1) & ~1, p2 = (P + 2) & ~1;
+    uint16_t* s_ep = s_dyn;                                      // user camera of edge e
+    uint16_t* s_pt = s_ep + e2;                                  // user landmark, then landmark slot
+    uint16_t* s_tmp = s_pt + e2;                                 // per-point lists in fill order
+    uint16_t* s_pe = s_tmp + e2;                                 // p_edges
+    uint16_t* s_ps = s_pe + e2;                                  // user landmark -> slot (0xffff: none); first: used flag
+    uint16_t* s_st = s_ps + p2;                                  // counts, then p_start
+    uint16_t* s_fl = s_st + p2;                                  // fill counters
+    for (int i = tid; i < C; i += 1024) s_cs[i] = 0;
+    for (int i = tid; i < BLD_SF * BLD_SF; i += 1024) s_jc[i] = 0;
+    for (int i = tid; i < 3 * p2 / 2; i += 1024) reinterpret_cast<uint32_t*>(s_ps)[i] = 0;
+    if (tid <= BLD_SF) s_cc[tid] = 0;
+    if (tid == 0) { s_bad = 0x7fffffff; s_bw = 0; }
+    __syncthreads();
+    BLD_CLK();
+    // which vertices take part
+    for (int e = tid; e < E; e += 1024) {
+        const int c = V.ep[e], q = V.pp[e];
+        if (c < 0 || c >= C || q < 0 || q >= P) atomicMin(&s_bad, e);
+        else { s_ep[e] = (uint16_t)c; s_pt[e] = (uint16_t)q; s_cs[c] = 1; s_ps[q] = 1; V.e_cam[e] = c; }
+    }
+    __syncthreads();
+    if (s_bad != 0x7fffffff) { if (tid == 0) { V.info[0] = s_bad; V.info[7] = 0; } return; }
+    BLD_CLK();
+    // slots: rank among the used, non-fixed cameras / among the points that have an edge
+    int Cf, Pa;
+    {
+        const int f = (tid < C && (V.all_used || s_cs[tid]) && !V.fixed[tid]) ? 1 : 0;
+        const int ex = bld_exscan(f, s_w, &Cf);
+        if (tid < C) { const int sl = (f && ex < BLD_SF) ? ex : -1; s_cs[tid] = (int8_t)sl; V.cslot[tid] = f ? ex : -1; V.back_cslot[tid] = f ? ex : -1; }
+    }
+    if (Cf > BLD_SF) { if (tid == 0) { V.info[0] = 0x7fffffff; V.info[7] = 1; } return; }
+    {
+        const int q0 = tid * 4;
+        int fl[4], n = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { fl[i] = (q0 + i < P) ? s_ps[q0 + i] : 0; n += fl[i]; }
+        int run = bld_exscan(n, s_w, &Pa);
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (q0 + i < P) { const int sl = fl[i] ? run : -1; s_ps[q0 + i] = (uint16_t)sl; V.pslot[q0 + i] = sl; run += fl[i]; }
+    }
+    __syncthreads();
+    BLD_CLK();
+    // counts per point and per free camera
+    for (int e = tid; e < E; e += 1024) {
+        const int j = s_ps[s_pt[e]];
+        s_pt[e] = (uint16_t)j; V.e_pt[e] = j;
+        bld_add16(s_st, j, 1);
+        const int sl = s_cs[s_ep[e]];
+        if (sl >= 0) atomicAdd(&s_cc[sl], 1);
+    }
+    __syncthreads();
+    int c_total;
+    {
+        const int j0 = tid * 4;
+        int cn[4], n = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { cn[i] = (j0 + i < Pa) ? s_st[j0 + i] : 0; n += cn[i]; }
+        int tot, run = bld_exscan(n, s_w, &tot);
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (j0 + i <= Pa) { s_st[j0 + i] = (uint16_t)run; V.p_start[j0 + i] = run; run += cn[i]; }
+        if (tid == 0) { s_st[Pa] = (uint16_t)tot; V.p_start[Pa] = tot; }              // (index 4096 has no owner thread)
+        const int cv = tid < Cf ? s_cc[tid] : 0;
+        const int cex = bld_exscan(cv, s_w, &c_total);
+        if (tid <= Cf) { V.c_start[tid] = cex; s_cc[tid] = cex; }
+    }
+    __syncthreads();
+    BLD_CLK();
+    // per-point lists in fill order, then ranked by (camera, input position)
+    for (int e = tid; e < E; e += 1024) {
+        const int j = s_pt[e];
+        const int pos = bld_add16(s_fl, j, 1);
+        s_tmp[s_st[j] + pos] = (uint16_t)e;
+    }
+    __syncthreads();
+    for (int j = tid; j < Pa; j += 1024) {
+        const int a0 = s_st[j], k = s_st[j + 1] - a0;
+        for (int i = 0; i < k; i++) {
+            const int ei = s_tmp[a0 + i], ci = s_ep[ei];
+            int r = 0;
+            for (int i2 = 0; i2 < k; i2++) { const int ex = s_tmp[a0 + i2], c2 = s_ep[ex]; r += (c2 < ci || (c2 == ci && ex < ei)) ? 1 : 0; }
+            s_pe[a0 + r] = (uint16_t)ei;
+        }
+    }
+    __syncthreads();
+    BLD_CLK();
+    for (int k = tid; k < E; k += 1024) V.p_edges[k] = s_pe[k];
+    // camera pairs: how many (edge, edge) pairs of a landmark fall on (s1, s2), s1 <= s2 (a landmark's edges are sorted by camera)
+    for (int j = tid; j < Pa; j += 1024) {
+        const int a0 = s_st[j], a1 = s_st[j + 1];
+        for (int u = a0; u < a1; u++) {
+            const int s1 = s_cs[s_ep[s_pe[u]]]; if (s1 < 0) continue;
+            for (int v = u; v < a1; v++) { const int sb = s_cs[s_ep[s_pe[v]]]; if (sb >= 0) atomicAdd(&s_jc[s1 * Cf + sb], 1); }
+        }
+    }
+    __syncthreads();
+    BLD_CLK();
+    int npairs, M;
+    {   // lexicographic compaction: thread t owns the four cells 4 t .. 4 t + 3 of the Cf x Cf table
+        int fl[4], cn[4], nf = 0, nc = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = 4 * tid + i, s1 = idx < Cf * Cf ? idx / Cf : 0, sb = idx - s1 * Cf;
+            const int c = idx < Cf * Cf ? s_jc[idx] : 0;
+            fl[i] = (idx < Cf * Cf && sb >= s1 && (c > 0 || s1 == sb)) ? 1 : 0; cn[i] = fl[i] ? c : 0;
+            nf += fl[i]; nc += cn[i];
+            if (fl[i] && sb - s1 > 0) atomicMax(&s_bw, sb - s1);
+        }
+        int pi = bld_exscan(nf, s_w, &npairs);
+        int jo = bld_exscan(nc, s_w, &M);
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (fl[i]) {
+            const int idx = 4 * tid + i, s1 = idx / Cf, sb = idx - s1 * Cf;
+            V.pairs[pi] = make_int2(s1, sb); V.j_start[pi] = jo; pi++; jo += cn[i];
+        }
+        if (tid == 0) V.j_start[npairs] = M;
+    }
+    BLD_CLK();
+    // c_edges: stable partition of the p_edges sequence by free camera.  Lane s holds camera s's next position.
+    {
+        const int ch = ((E + 15) / 16 + 63) & ~63, k0 = wv * ch, k1 = min(E, k0 + ch);
+        __syncthreads();                                         // s_jc is dead: it takes the per-wave histograms
+        int* s_wh = s_jc;                                        // [16][BLD_SF]
+        for (int i = tid; i < 16 * BLD_SF; i += 1024) s_wh[i] = 0;
+        __syncthreads();
+        for (int k = k0 + lane; k < k1; k += 64) { const int sl = s_cs[s_ep[s_pe[k]]]; if (sl >= 0) atomicAdd(&s_wh[wv * BLD_SF + sl], 1); }
+        __syncthreads();
+        int run = 0;
+        if (lane < Cf) { run = s_cc[lane]; for (int w = 0; w < wv; w++) run += s_wh[w * BLD_SF + lane]; }
+        for (int kb = k0; kb < k1; kb += 64) {
+            const int k = kb + lane;
+            const int e = k < k1 ? s_pe[k] : 0;
+            const int sl = k < k1 ? s_cs[s_ep[e]] : -1;
+            unsigned long long rem = __ballot(sl >= 0);
+            while (rem) {
+                const int l0 = __ffsll((long long)rem) - 1;
+                const int s0 = __shfl(sl, l0, 64);
+                const unsigned long long m = __ballot(sl == s0);
+                const int base = __shfl(run, s0, 64);
+                if (sl == s0) { const int o = base + __popcll(m & ((1ull << lane) - 1)); V.c_edges[o] = e; V.c_pt[o] = s_pt[e]; }
+                if (lane == s0) run += __popcll(m);
+                rem &= ~m;
+            }
+        }
+    }
+    BLD_CLK();
+    if (tid == 0) {
+        V.info[0] = 0x7fffffff; V.info[1] = s_bw; V.info[2] = Cf; V.info[3] = Pa; V.info[4] = npairs; V.info[5] = c_total; V.info[6] = M;
+        V.info[7] = (long long)M > V.join_cap ? 2 : 0;
+    }
+}
+
+// One workgroup per camera pair: the (edge of s1, edge of s2) pairs on a common landmark, landmarks ascending - both cameras' lists are
+// sorted by landmark, so s1's entries look themselves up in s2's (staged in LDS) and a block scan puts the hits in order.  The
+// workgroups behind the pairs copy the measurements and gather the active landmarks (independent of everything else in the build).
+__global__ __launch_bounds__(256) void k_bld_join_merge(const bld_view* __restrict__ views, int pair_blocks)
+{
+    const bld_view V = views[blockIdx.y];
+    if (V.C == 0 || V.info[0] != 0x7fffffff || V.info[7]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if ((int)blockIdx.x >= pair_blocks) {
+        const int nx = (int)gridDim.x - pair_blocks, i0 = ((int)blockIdx.x - pair_blocks) * 256 + tid, step = nx * 256;
+        for (int i = i0; i < V.E; i += step) { V.e_meas[2 * i] = V.meas[2 * i]; V.e_meas[2 * i + 1] = V.meas[2 * i + 1]; V.err0[2 * i] = 0; V.err0[2 * i + 1] = 0; }
+        for (int i = i0; i < V.P; i += step) {
+            const int sl = V.pslot[i];
+            if (sl >= 0) { V.pts[3 * (size_t)sl] = V.points[3 * (size_t)i]; V.pts[3 * (size_t)sl + 1] = V.points[3 * (size_t)i + 1]; V.pts[3 * (size_t)sl + 2] = V.points[3 * (size_t)i + 2]; }
+        }
+        for (int i = i0; i < V.C; i += step) { V.cams_dst[i] = V.cams_src[i]; d_cam_refresh(&V.cams_dst[i], V.K); }      // (in place, as k_ba_cam_init: the same code, the same bits)
+        // cleared: the LM control block, the residual slot past the last edge, the reduced camera system and the step (as bh_ba_set_problem's memsets)
+        const int n6 = 6 * V.info[2], bw = n6 > 0 ? min(n6 - 1, 6 * V.info[1] + 5) : 0;
+        const long long nS = (long long)n6 * (bw + 1) + 1;
+        for (long long i = i0; i < nS; i += step) V.S[i] = 0;
+        for (int i = i0; i < n6 + 6; i += step) V.dxp[i] = 0;
+        if (i0 < 2) V.err0[2 * (size_t)V.E + i0] = 0;
+        for (int i = i0; i < (int)(sizeof(ba_state) / 4); i += step) reinterpret_cast<int*>(V.state)[i] = 0;
+        return;
+    }
+    const int p = blockIdx.x;
+    if (p >= V.info[4]) return;
+    __shared__ int s_l2[BLD_MJ];
+    __shared__ int s_w[4];
+    const int2 pr = V.pairs[p];
+    const int a0 = V.c_start[pr.x], n1 = V.c_start[pr.x + 1] - a0, b0 = V.c_start[pr.y], n2 = V.c_start[pr.y + 1] - b0;
+    const int* q2 = V.c_pt + b0;                                 // landmarks of s2's list
+    const bool staged = n2 <= BLD_MJ;
+    if (staged) for (int i = tid; i < n2; i += 256) s_l2[i] = q2[i];
+    __syncthreads();
+    const int* l2 = V.c_edges + b0;
+    int out = V.j_start[p];
+    for (int i0 = 0; i0 < n1; i0 += 256) {
+        const int i = i0 + tid;
+        int e1 = 0, first = 0, cnt = 0;
+        if (i < n1) {
+            e1 = V.c_edges[a0 + i];
+            const int j = V.c_pt[a0 + i];
+            int lo = 0, hi = n2;
+            if (staged) {
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_l2[mid] < j) lo = mid + 1; else hi = mid; }
+                if (pr.x == pr.y) while (lo < n2 && s_l2[lo] == j && l2[lo] < e1) lo++;      // the diagonal block takes the pairs u <= v only
+                first = lo;
+                while (lo < n2 && s_l2[lo] == j) lo++;
+            } else {
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (q2[mid] < j) lo = mid + 1; else hi = mid; }
+                if (pr.x == pr.y) while (lo < n2 && q2[lo] == j && l2[lo] < e1) lo++;
+                first = lo;
+                while (lo < n2 && q2[lo] == j) lo++;
+            }
+            cnt = lo - first;
+        }
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        __syncthreads();
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        int base = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const int t = s_w[w]; if (w < wv) base += t; tot += t; }
+        const int wr = out + base + inc - cnt;
+        for (int k = 0; k < cnt; k++) V.join[wr + k] = make_int2(e1, l2[first + k]);
+        out += tot;
+    }
+}
+
+// Host side of the one-workgroup builder, for W windows at once (W = 1: bh_ba_set_problem).  taken[w] = 0: window w is not a local
+// window (or the kernel refused it) and nothing was built for it; taken[w] = 1: structure, measurements, landmarks, camera blocks and
+// the cleared buffers are on the device, out[w] holds the counts.  One copy up, two launches, one copy back, one synchronisation.
+typedef bh_ba_problem ba_prob;
+static void h_quat_from_R(const double* m, double* q);
+static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* pr, ba_build_out* out, int* taken)
+{
+    hipStream_t st = ctx->stream;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    struct lay { size_t ep, pp, fx, pt, ms, cm, back, cpt; int nfree; long long join_cap; size_t maxpairs; };
+    std::vector<lay> L(W);
+    size_t up = al(sizeof(bld_view) * (size_t)W), back = 0, scr = 0;
+    int n_el = 0, max_blocks = 1;
+    size_t max_lds = 0;
+    for (int w = 0; w < W; w++) {
+        taken[w] = 0;
+        const ba_prob& q = pr[w]; bh_ba* ba = bas[w];
+        if (ba->ar || q.C < 1 || q.C > BLD_SC || q.E < 1 || q.E > BLD_LE || q.P < 1 || q.P > BLD_LP) continue;
+        int nfree = 0;
+        for (int i = 0; i < q.C; i++) nfree += q.fixed[i] ? 0 : 1;
+        if (nfree > BLD_SF) continue;
+        lay& l = L[w];
+        l.nfree = nfree;
+        l.join_cap = (long long)q.E * (nfree + 1) / 2 + q.E + 1;                   // exact bound without duplicate edges; the kernel checks
+        l.maxpairs = (size_t)nfree * (nfree + 1) / 2 + 1;
+        l.ep = up; up += al(sizeof(int) * (size_t)q.E); l.pp = up; up += al(sizeof(int) * (size_t)q.E); l.fx = up; up += al((size_t)q.C);
+        l.pt = up; up += al(sizeof(double) * 3 * (size_t)q.P); l.ms = up; up += al(sizeof(double) * 2 * (size_t)q.E); l.cm = up; up += al(sizeof(ba_cam) * (size_t)q.C);
+        l.back = back; back += sizeof(int) * (8 + (size_t)q.C + (size_t)q.P);
+        l.cpt = scr; scr += sizeof(int) * (size_t)q.E;
+        taken[w] = 2;                                                              // staged
+        n_el++;
+        max_blocks = std::max(max_blocks, std::min(64, (std::max(q.E, q.P) + 255) / 256 + 1));      // workgroups behind the pairs (grid-stride copies)
+        max_lds = std::max(max_lds, bld_lds_bytes(q.E, q.P));
+    }
+    if (!n_el) return BH_OK;
+    const size_t back_al = al(back);
+    BH_TRY(bh_pin_reserve(ctx, up + back_al));
+    BH_TRY(bh_reserve(ctx, &ctx->st_a, up));
+    BH_TRY(bh_reserve(ctx, &ctx->st_d, back_al + scr + 256));
+    for (int w = 0; w < W; w++) {                                                  // everything the two kernels write, sized by bounds (Cf <= nfree, Pa <= P)
+        if (!taken[w]) continue;
+        const ba_prob& q = pr[w]; bh_ba* ba = bas[w]; const lay& l = L[w];
+        const size_t E = q.E, P = q.P, C = q.C, n6m = 6 * (size_t)l.nfree;
+        BH_TRY(bh_reserve(ctx, &ba->cslot, sizeof(int) * C));
+        BH_TRY(bh_reserve(ctx, &ba->e_cam, sizeof(int) * E)); BH_TRY(bh_reserve(ctx, &ba->e_pt, sizeof(int) * E));
+        BH_TRY(bh_reserve(ctx, &ba->e_meas, sizeof(double) * 2 * (E + 1)));
+        BH_TRY(bh_reserve(ctx, &ba->p_edges, sizeof(int) * E)); BH_TRY(bh_reserve(ctx, &ba->c_edges, sizeof(int) * E));
+        BH_TRY(bh_reserve(ctx, &ba->p_start, sizeof(int) * (P + 2))); BH_TRY(bh_reserve(ctx, &ba->c_start, sizeof(int) * (C + 2)));
+        BH_TRY(bh_reserve(ctx, &ba->pairs, sizeof(int2) * l.maxpairs)); BH_TRY(bh_reserve(ctx, &ba->j_start, sizeof(int) * (l.maxpairs + 2)));
+        BH_TRY(bh_reserve(ctx, &ba->join, sizeof(int2) * (size_t)l.join_cap));
+        BH_TRY(bh_reserve(ctx, &ba->pts[0], sizeof(double) * 3 * (P + 1)));
+        BH_TRY(bh_reserve(ctx, &ba->cams[0], sizeof(ba_cam) * (C + 1)));
+        BH_TRY(bh_reserve(ctx, &ba->state, sizeof(ba_state)));
+        BH_TRY(bh_reserve(ctx, &ba->err[0], sizeof(double) * 2 * (E + 1)));
+        BH_TRY(bh_reserve(ctx, &ba->S, sizeof(double) * (n6m * n6m + 1))); BH_TRY(bh_reserve(ctx, &ba->dxp, sizeof(double) * (n6m + 6)));
+    }
+    char* hp = (char*)ctx->pin; char* dp = (char*)ctx->st_a.p; char* ds = (char*)ctx->st_d.p;
+    bld_view* hv = (bld_view*)hp;
+    for (int w = 0; w < W; w++) {
+        bld_view V = {};
+        V.info = (int*)ds;                                                         // (a window that is not staged: C = 0 makes both kernels leave at once)
+        if (taken[w]) {
+            const ba_prob& q = pr[w]; bh_ba* ba = bas[w]; const lay& l = L[w];
+            V.C = q.C; V.P = q.P; V.E = q.E; V.all_used = 0;
+            V.ep = (const int*)(dp + l.ep); V.pp = (const int*)(dp + l.pp); V.fixed = (const uint8_t*)(dp + l.fx);
+            V.points = (const double*)(dp + l.pt); V.meas = (const double*)(dp + l.ms); V.cams_src = (const ba_cam*)(dp + l.cm);
+            int* bk = (int*)(ds + l.back);
+            V.info = bk; V.back_cslot = bk + 8; V.pslot = bk + 8 + q.C; V.c_pt = (int*)(ds + back_al + l.cpt);
+            V.e_cam = (int*)ba->e_cam.p; V.e_pt = (int*)ba->e_pt.p; V.e_meas = (double*)ba->e_meas.p; V.cslot = (int*)ba->cslot.p;
+            V.p_start = (int*)ba->p_start.p; V.p_edges = (int*)ba->p_edges.p; V.c_start = (int*)ba->c_start.p; V.c_edges = (int*)ba->c_edges.p;
+            V.pairs = (int2*)ba->pairs.p; V.j_start = (int*)ba->j_start.p; V.join = (int2*)ba->join.p; V.join_cap = l.join_cap;
+            V.pts = (double*)ba->pts[0].p; V.cams_dst = (ba_cam*)ba->cams[0].p; V.K = ba->K;
+            V.S = (double*)ba->S.p; V.dxp = (double*)ba->dxp.p; V.err0 = (double*)ba->err[0].p; V.state = (ba_state*)ba->state.p;
+            memcpy(hp + l.ep, q.edge_pose, sizeof(int) * (size_t)q.E); memcpy(hp + l.pp, q.edge_point, sizeof(int) * (size_t)q.E);
+            memcpy(hp + l.fx, q.fixed, (size_t)q.C); memcpy(hp + l.pt, q.points, sizeof(double) * 3 * (size_t)q.P);
+            memcpy(hp + l.ms, q.meas, sizeof(double) * 2 * (size_t)q.E);
+            ba_cam* hc = (ba_cam*)(hp + l.cm);
+            memset(hc, 0, sizeof(ba_cam) * (size_t)q.C);
+            for (int i = 0; i < q.C; i++) { h_quat_from_R(q.R + 9 * (size_t)i, hc[i].q); for (int k = 0; k < 3; k++) hc[i].t[k] = q.t[3 * (size_t)i + k]; }
+        }
+        hv[w] = V;
+    }
+    BH_HIP(ctx, hipMemcpyAsync(dp, hp, up, hipMemcpyHostToDevice, st));
+    static bool lds_attr = false;                                                  // > 64 KB of dynamic LDS needs the attribute (once per process)
+    if (!lds_attr) { BH_HIP(ctx, hipFuncSetAttribute((const void*)k_bld_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bld_lds_bytes(BLD_LE, BLD_LP))); lds_attr = true; }
+    int max_pairs = 1;
+    for (int w = 0; w < W; w++) if (taken[w]) max_pairs = std::max(max_pairs, (int)L[w].maxpairs);
+    bh_time_begin(ctx, BH_K_BA_OTHER);
+    hipLaunchKernelGGL(k_bld_small, dim3(1, W), dim3(1024), max_lds, st, (const bld_view*)dp);
+    bh_time_end(ctx);
+    BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bld_join_merge, dim3((unsigned)(max_pairs + max_blocks), W), dim3(256), st, (const bld_view*)dp, max_pairs);
+    char* hb0 = hp + up;
+    BH_HIP(ctx, hipMemcpyAsync(hb0, ds, back, hipMemcpyDeviceToHost, st));
+    BH_HIP(ctx, hipGetLastError());
+    BH_HIP(ctx, hipStreamSynchronize(st));
+    for (int w = 0; w < W; w++) {
+        if (!taken[w]) continue;
+        const ba_prob& q = pr[w]; bh_ba* ba = bas[w];
+        const int* hb = (const int*)(hb0 + L[w].back);
+        if (hb[0] != 0x7fffffff) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: edge %d references a missing vertex", hb[0]);
+        if (hb[7]) { taken[w] = 0; continue; }                                     // refused (duplicate-heavy edge list): the general builder takes it
+        out[w].bwb = hb[1]; out[w].Cf = hb[2]; out[w].Pa = hb[3]; out[w].npairs = hb[4]; out[w].c_total = hb[5];
+        ba->cam_slot.assign(hb + 8, hb + 8 + q.C); ba->pt_slot.assign(hb + 8 + q.C, hb + 8 + q.C + q.P);
+        taken[w] = 1;
+    }
+    return BH_OK;
+}
+
 template <typename T>
 static int upload(bh_ctx* ctx, bh_buf* b, const std::vector<T>& v)
 {
@@ -2943,6 +3357,9 @@ static int upload(bh_ctx* ctx, bh_buf* b, const std::vector<T>& v)
     if (!v.empty()) BH_HIP(ctx, hipMemcpyAsync(b->p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, ctx->stream));
     return BH_OK;
 }
+
+static int ba_set_problem_rest(bh_ba* ba, int C, const double* R, const double* t, const uint8_t* fixed, int P, const double* points, int E,
+                               const int* edge_pose, const int* edge_point, const double* meas, bool host_build, int small, ba_build_out bo);
 
 extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double* t, const uint8_t* fixed,
                                  int P, const double* points, int E, const int* edge_pose, const int* edge_point,
@@ -2959,21 +3376,38 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     const char* bmode = getenv("BH_BA_BUILD");
     const bool host_build = bmode && !strcmp(bmode, "host");
     if (ba->ar && E == 0) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: a rank of a sharded problem needs at least one edge");
+    int small = 0;                                           // local windows: one workgroup builds the structure (BH_BA_BUILD=general: the chip-wide builder)
+    ba_build_out bo = {};
+    if (!host_build && !(bmode && !strcmp(bmode, "general"))) {
+        const ba_prob q = { C, R, t, fixed, P, points, E, edge_pose, edge_point, meas };
+        bh_ba* one = ba;
+        BH_TRY(ba_small_many(ctx, 1, &one, &q, &bo, &small));
+    }
+    return ba_set_problem_rest(ba, C, R, t, fixed, P, points, E, edge_pose, edge_point, meas, host_build, small, bo);
+}
+
+// bh_ba_set_problem behind the one-workgroup builder: the chip-wide / host builders for everything that is not a local window, then the
+// solver choice and the working buffers.  small != 0: structure, camera blocks and cleared buffers are already on the device.
+static int ba_set_problem_rest(bh_ba* ba, int C, const double* R, const double* t, const uint8_t* fixed, int P, const double* points, int E,
+                               const int* edge_pose, const int* edge_point, const double* meas, bool host_build, int small, ba_build_out bo)
+{
+    bh_ctx* ctx = ba->ctx;
     int Cf = 0, Pa = 0, bwb = 0, c_total = 0;
-    std::vector<ba_cam> cams(C);
-    for (int i = 0; i < C; i++) {
+    std::vector<ba_cam> cams(small ? 0 : C);
+    for (int i = 0; i < C && !small; i++) {
         memset(&cams[i], 0, sizeof(ba_cam));
         h_quat_from_R(R + 9 * i, cams[i].q);
         for (int k = 0; k < 3; k++) cams[i].t[k] = t[3 * i + k];
     }
     if (!host_build) {
-        ba_build_out bo = {};
         ba->C = C; ba->P = P; ba->E = E; ba->edge_user.clear();
-        BH_TRY(ba_build_device(ba, C, fixed, P, points, E, edge_pose, edge_point, &bo));
+        if (!small) {
+            BH_TRY(ba_build_device(ba, C, fixed, P, points, E, edge_pose, edge_point, &bo));
+            BH_TRY(bh_reserve(ctx, &ba->e_meas, sizeof(double) * 2 * ((size_t)E + 1)));
+            if (E) BH_HIP(ctx, hipMemcpyAsync(ba->e_meas.p, meas, sizeof(double) * 2 * (size_t)E, hipMemcpyHostToDevice, ctx->stream));
+        }
         Cf = bo.Cf; Pa = bo.Pa; bwb = bo.bwb; c_total = bo.c_total; ba->npairs = bo.npairs;
         ba->Cf = Cf; ba->Pa = Pa; ba->Ea = E;
-        BH_TRY(bh_reserve(ctx, &ba->e_meas, sizeof(double) * 2 * ((size_t)E + 1)));
-        if (E) BH_HIP(ctx, hipMemcpyAsync(ba->e_meas.p, meas, sizeof(double) * 2 * (size_t)E, hipMemcpyHostToDevice, ctx->stream));
     } else {
         for (int e = 0; e < E; e++)
             if (edge_pose[e] < 0 || edge_pose[e] >= C || edge_point[e] < 0 || edge_point[e] >= P)
@@ -3102,7 +3536,8 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
         ba->chol_nb = nb;
     }
 
-    BH_TRY(upload(ctx, &ba->cams[0], cams)); BH_TRY(bh_reserve(ctx, &ba->cams[1], sizeof(ba_cam) * (C + 1)));
+    if (!small) BH_TRY(upload(ctx, &ba->cams[0], cams));
+    BH_TRY(bh_reserve(ctx, &ba->cams[1], sizeof(ba_cam) * (C + 1)));
     BH_TRY(bh_reserve(ctx, &ba->pts[1], sizeof(double) * 3 * (Pa + 1)));
     const size_t n6 = 6 * (size_t)Cf;
     for (int k = 0; k < 2; k++) { BH_TRY(bh_reserve(ctx, &ba->err[k], sizeof(double) * 2 * (E + 1))); BH_TRY(bh_reserve(ctx, &ba->chi_e[k], sizeof(double) * (E + 1))); }
@@ -3114,14 +3549,72 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     BH_TRY(bh_reserve(ctx, &ba->S, sizeof(double) * ((size_t)rows_pad * (size_t)(ba->bw + 1) + 1))); BH_TRY(bh_reserve(ctx, &ba->bs, sizeof(double) * (n6 + 6)));
     BH_TRY(bh_reserve(ctx, &ba->dxp, sizeof(double) * ((size_t)rows_pad + 6))); BH_TRY(bh_reserve(ctx, &ba->dxl, sizeof(double) * 3 * ((size_t)Pa + 1)));
     BH_TRY(bh_reserve(ctx, &ba->part, sizeof(double) * 2 * BA_NPART));
-    BH_HIP(ctx, hipMemsetAsync(ba->state.p, 0, sizeof(ba_state), ctx->stream));
-    BH_HIP(ctx, hipMemsetAsync(ba->err[0].p, 0, sizeof(double) * 2 * (E + 1), ctx->stream));
-    BH_HIP(ctx, hipMemsetAsync(ba->S.p, 0, sizeof(double) * (n6 * (size_t)(ba->bw + 1) + 1), ctx->stream));
-    BH_HIP(ctx, hipMemsetAsync(ba->dxp.p, 0, sizeof(double) * (n6 + 6), ctx->stream));
-    if (C) hipLaunchKernelGGL(k_ba_cam_init, dim3((C + 63) / 64), dim3(64), 0, ctx->stream, (ba_cam*)ba->cams[0].p, C, ba->K);
-    BH_HIP(ctx, hipGetLastError());
-    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the host vectors above go out of scope
+    if (!small) {
+        BH_HIP(ctx, hipMemsetAsync(ba->state.p, 0, sizeof(ba_state), ctx->stream));
+        BH_HIP(ctx, hipMemsetAsync(ba->err[0].p, 0, sizeof(double) * 2 * (E + 1), ctx->stream));
+        BH_HIP(ctx, hipMemsetAsync(ba->S.p, 0, sizeof(double) * (n6 * (size_t)(ba->bw + 1) + 1), ctx->stream));
+        BH_HIP(ctx, hipMemsetAsync(ba->dxp.p, 0, sizeof(double) * (n6 + 6), ctx->stream));
+        if (C) hipLaunchKernelGGL(k_ba_cam_init, dim3((C + 63) / 64), dim3(64), 0, ctx->stream, (ba_cam*)ba->cams[0].p, C, ba->K);
+        BH_HIP(ctx, hipGetLastError());
+        BH_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the host vectors above go out of scope
+    }
     ba->cur = 0; ba->have_problem = 1; ba->iters_done = 0; ba->log.clear(); ba->last_err_sel = 0;
+    return BH_OK;
+}
+
+extern "C" int bh_ba_batch_set_problems(bh_ctx* ctx, int W, bh_ba* const* windows, const bh_ba_problem* problems)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (W < 0 || (W && (!windows || !problems))) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_set_problems: bad argument");
+    for (int w = 0; w < W; w++) {
+        const bh_ba_problem& q = problems[w];
+        if (!windows[w] || windows[w]->ctx != ctx) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_set_problems: window %d is not a handle of this context", w);
+        if (q.C < 0 || q.P < 0 || q.E < 0 || (q.C && (!q.R || !q.t || !q.fixed)) || (q.P && !q.points) || (q.E && (!q.edge_pose || !q.edge_point || !q.meas)))
+            return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_set_problems: bad argument (window %d)", w);
+        if (windows[w]->ar && q.E == 0) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: a rank of a sharded problem needs at least one edge");
+    }
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    const char* bmode = getenv("BH_BA_BUILD");
+    const bool host_build = bmode && !strcmp(bmode, "host");
+    std::vector<ba_build_out> bo(W);
+    std::vector<int> taken(W, 0);
+    if (W && !host_build && !(bmode && !strcmp(bmode, "general"))) BH_TRY(ba_small_many(ctx, W, windows, problems, bo.data(), taken.data()));
+    for (int w = 0; w < W; w++) {
+        const bh_ba_problem& q = problems[w];
+        BH_TRY(ba_set_problem_rest(windows[w], q.C, q.R, q.t, q.fixed, q.P, q.points, q.E, q.edge_pose, q.edge_point, q.meas, host_build, taken[w], bo[w]));
+    }
+    return BH_OK;
+}
+
+// Test hook: one structural array of the problem as bh_ba_set_problem left it (tests compare the three builders array by array).
+// which: 0 e_pt[E], 1 p_start[Pa+1], 2 p_edges[E], 3 c_start[Cf+1], 4 c_edges[c_total], 5 pairs[npairs] (int2), 6 j_start[npairs+1],
+// 7 join[M] (int2), 8 cslot[C].  *n_ints = number of 32-bit values written (at most cap_ints).
+extern "C" int bh_ba_debug_structure(bh_ba* ba, int which, int* out, long long cap_ints, long long* n_ints)
+{
+    if (!ba || !out || !n_ints) return BH_ERR_INVALID;
+    bh_ctx* ctx = ba->ctx;
+    if (!ba->have_problem) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_debug_structure: no problem set");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int c_total = 0, M = 0;
+    if (ba->Cf) BH_HIP(ctx, hipMemcpy(&c_total, (int*)ba->c_start.p + ba->Cf, sizeof(int), hipMemcpyDeviceToHost));
+    BH_HIP(ctx, hipMemcpy(&M, (int*)ba->j_start.p + ba->npairs, sizeof(int), hipMemcpyDeviceToHost));
+    const void* src = nullptr; long long n = 0;
+    switch (which) {
+        case 0: src = ba->e_pt.p; n = ba->Ea; break;
+        case 1: src = ba->p_start.p; n = ba->Pa + 1; break;
+        case 2: src = ba->p_edges.p; n = ba->Ea; break;
+        case 3: src = ba->c_start.p; n = ba->Cf + 1; break;
+        case 4: src = ba->c_edges.p; n = c_total; break;
+        case 5: src = ba->pairs.p; n = 2LL * ba->npairs; break;
+        case 6: src = ba->j_start.p; n = ba->npairs + 1; break;
+        case 7: src = ba->join.p; n = 2LL * M; break;
+        case 8: src = ba->cslot.p; n = ba->C; break;
+        default: return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_debug_structure: which = %d", which);
+    }
+    if (n > cap_ints) return bh_set_err(ctx, BH_ERR_CAPACITY, "bh_ba_debug_structure: %lld values, room for %lld", n, cap_ints);
+    if (n) BH_HIP(ctx, hipMemcpy(out, src, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    *n_ints = n;
     return BH_OK;
 }
 

@@ -69,6 +69,8 @@ struct bh_ctx {
     bh_buf      st_img, st_mask, st_depth, st_kps, st_desc, st_nkp;     // host-mode staging
     bh_buf      st_a, st_b, st_c, st_d, st_e, st_f, st_g, st_h;         // generic staging (match / BA)
     bh_buf      tr_w, tr_in;                                              // bh_track_refkf: intermediates (raw matches, gathered BA inputs, chi2), host-mode inputs
+    void*       pin = nullptr;                                            // pinned host staging (grow-only): small problems go up in one copy and come back in one
+    size_t      pin_cap = 0;
     int         last_B = 0;
     int         last_has_mask = 0, last_mask_bits = 0;
     // ---- per-kernel timing ----
@@ -93,6 +95,7 @@ void bh_time_end(bh_ctx* ctx);
 
 int  bh_set_err(bh_ctx* ctx, int code, const char* fmt, ...);
 int  bh_reserve(bh_ctx* ctx, bh_buf* b, size_t bytes);
+int  bh_pin_reserve(bh_ctx* ctx, size_t bytes);     // ctx->pin holds at least `bytes` (synchronises the stream before it grows)
 int  bh_status_ready(bh_ctx* ctx);      // allocates + zeroes the sticky device status word on first use
 
 #define BH_HIP(ctx, call)                                                                          \

@@ -29,6 +29,17 @@ int bh_reserve(bh_ctx* ctx, bh_buf* b, size_t bytes)
     return BH_OK;
 }
 
+int bh_pin_reserve(bh_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->pin_cap) return BH_OK;
+    if (ctx->pin) { BH_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->pin); ctx->pin = nullptr; ctx->pin_cap = 0; }
+    const size_t want = (bytes + (bytes >> 1) + 4095) & ~(size_t)4095;
+    hipError_t e = hipHostMalloc(&ctx->pin, want, hipHostMallocDefault);
+    if (e != hipSuccess) { ctx->pin = nullptr; return bh_set_err(ctx, BH_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+    ctx->pin_cap = want;
+    return BH_OK;
+}
+
 // The device status word is STICKY: kernels OR capacity flags into it, nothing clears it except bh_ctx_status after reading it, so
 // a BH_MEM_DEVICE caller that checks once after many enqueued steps sees every flag raised in between.
 int bh_status_ready(bh_ctx* ctx)
@@ -75,6 +86,7 @@ extern "C" void bh_ctx_destroy(bh_ctx* ctx)
                       &ctx->st_img, &ctx->st_mask, &ctx->st_depth, &ctx->st_kps, &ctx->st_desc, &ctx->st_nkp,
                       &ctx->st_a, &ctx->st_b, &ctx->st_c, &ctx->st_d, &ctx->st_e, &ctx->st_f, &ctx->st_g, &ctx->st_h };
     for (bh_buf* b : all) release(b);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     (void)drain_timing(ctx);
     for (int i = 0; i < ctx->n_epool; i++) (void)hipEventDestroy(ctx->epool[i]);
     free(ctx->epool); free(ctx->trecs);

@@ -183,6 +183,11 @@ int  bh_ba_get_log(bh_ba* ba, double* log, int max_rows);
  * 3 = two-way window elimination, 4 = block cyclic reduction over the whole chip, 5 = the same cut into one segment per rank
  * (sharded mode: bh_ba_set_allreduce); < 0 = no problem set. */
 int  bh_ba_solver(bh_ba* ba);
+/* Test hook: one structural array of the current problem as bh_ba_set_problem built it (the three builders - one workgroup for local
+ * windows, chip-wide kernels, host loops behind BH_BA_BUILD=general|host - must produce the same arrays).  which: 0 e_pt[E],
+ * 1 p_start[Pa+1], 2 p_edges[E], 3 c_start[Cf+1], 4 c_edges[c_total], 5 pairs[npairs] (int2), 6 j_start[npairs+1], 7 join[M] (int2),
+ * 8 cslot[C]; out receives at most cap_ints 32-bit values, *n_ints how many. */
+int  bh_ba_debug_structure(bh_ba* ba, int which, int* out, long long cap_ints, long long* n_ints);
 
 /* Batched local BA: W windows, each a bh_ba handle of `ctx` that holds a problem (bh_ba_set_problem; windows may differ in size),
  * advance together - every kernel of a Levenberg trial is launched once for all of them, gridded over (item, window), and each
@@ -192,6 +197,17 @@ int  bh_ba_solver(bh_ba* ba);
  * the usual getters (bh_ba_get_poses / _points / _chi2 / _log) read each window.  Windows must be local ones (<= 48 free keyframes,
  * not sharded); iters_done (may be NULL) receives int[W]. */
 typedef struct bh_ba_batch bh_ba_batch;
+/* One window's arguments of bh_ba_set_problem (host arrays). */
+typedef struct bh_ba_problem {
+    int C; const double* R; const double* t; const uint8_t* fixed;
+    int P; const double* points;
+    int E; const int* edge_pose; const int* edge_point; const double* meas;
+} bh_ba_problem;
+/* bh_ba_set_problem for W windows of one context at once: what W calls would leave behind, but the local windows among them
+ * (<= 64 free keyframes, <= 12 288 observations, <= 4 096 landmarks) are built together - one copy up, one workgroup per window in ONE
+ * launch (slots, edges by landmark / by keyframe, keyframe pairs, join lists, camera blocks), one copy back - instead of ~60 launches
+ * and four host reads each.  Windows that are not local ones go through bh_ba_set_problem one by one. */
+int  bh_ba_batch_set_problems(bh_ctx* ctx, int W, bh_ba* const* windows, const bh_ba_problem* problems);
 int  bh_ba_batch_create(bh_ctx* ctx, int W, bh_ba* const* windows, bh_ba_batch** out);
 void bh_ba_batch_destroy(bh_ba_batch* batch);
 int  bh_ba_batch_optimize(bh_ba_batch* batch, int iters, double huber_delta, int verbose_errors, int* iters_done);

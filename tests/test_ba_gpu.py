@@ -238,29 +238,46 @@ def test_global_ba_config5_full_size(ctx, monkeypatch):
 
 
 def test_device_built_problem_equals_host_built(ctx, monkeypatch):
-    """bh_ba_set_problem builds the graph structure (slots, edges by point / by camera, camera pairs, band) on the device; the
-    former host loops stay selectable (BH_BA_BUILD=host).  Same problem, both builds: poses, landmarks, per-edge chi2 and the LM
-    log must agree bit for bit - they can only do so if every structural array is identical."""
+    """bh_ba_set_problem builds the graph structure (slots, edges by point / by camera, camera pairs, join lists, band) on the device:
+    local windows (<= 64 free keyframes) by ONE workgroup without any sort, everything else by chip-wide kernels + radix sorts
+    (BH_BA_BUILD=general); the former host loops stay selectable (BH_BA_BUILD=host).  Same problem through all three: every
+    structural array identical, and poses, landmarks, per-edge chi2 and the LM log equal bit for bit."""
     probs = [synth.ba_problem(n_kf=12, n_pts=500, seed=4), synth.ba_problem(n_kf=50, n_pts=10000, seed=7),
-             synth.ba_problem_sequence(n_kf=300, n_pts=9000, window=6, seed=3)]
+             synth.ba_problem_sequence(n_kf=300, n_pts=9000, window=6, seed=3), synth.ba_problem(n_kf=3, n_pts=40, seed=11),
+             synth.ba_problem(n_kf=20, n_pts=1500, seed=9)]
     pr = synth.ba_problem(n_kf=9, n_pts=200, seed=2)                       # unused point, unused camera, fixed camera with edges
     keep = (pr["ecam"] != 4) & (pr["ept"] != 17)
     probs.append(dict(pr, ecam=pr["ecam"][keep], ept=pr["ept"][keep], meas=pr["meas"][keep]))
-    for pr in probs:
-        res = []
-        for mode in ("device", "host"):
-            if mode == "host":
-                monkeypatch.setenv("BH_BA_BUILD", "host")
-            else:
+    pr = synth.ba_problem(n_kf=14, n_pts=300, seed=6)                      # duplicate observations (ties keep the input position), shuffled input
+    rng = np.random.default_rng(1)
+    dup = rng.choice(len(pr["ecam"]), 150, replace=False)
+    ecam = np.concatenate([pr["ecam"], pr["ecam"][dup]]); ept = np.concatenate([pr["ept"], pr["ept"][dup]])
+    meas = np.concatenate([pr["meas"], pr["meas"][dup] + rng.normal(0, 0.3, (150, 2))])
+    sh = rng.permutation(len(ecam))
+    probs.append(dict(pr, ecam=np.ascontiguousarray(ecam[sh]), ept=np.ascontiguousarray(ept[sh]), meas=np.ascontiguousarray(meas[sh])))
+    pr = synth.ba_problem(n_kf=40, n_pts=2500, seed=8)                     # a window with most keyframes fixed (the outer ring of covisibility_graph.py:200-208)
+    fx = pr["fixed"].copy(); fx[8:] = 1
+    probs.append(dict(pr, fixed=fx))
+    for pi, pr in enumerate(probs):
+        res, st = [], []
+        for mode in ("device", "general", "host"):
+            if mode == "device":
                 monkeypatch.delenv("BH_BA_BUILD", raising=False)
+            else:
+                monkeypatch.setenv("BH_BA_BUILD", mode)
             s = ba.LocalBA(ctx, pr["K"])
             s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+            st.append(s.structure())
             done = s.optimize(4)
             res.append((s.poses(), s.points(), s.chi2(), s.log()[:done]))
             s.close()
-        (Rd, td), pd, cd, ld = res[0]; (Rh, th), ph, ch, lh = res[1]
-        assert np.array_equal(ld, lh) and np.array_equal(Rd, Rh) and np.array_equal(td, th)
-        assert np.array_equal(pd, ph, equal_nan=True) and np.array_equal(cd, ch)
+        monkeypatch.delenv("BH_BA_BUILD", raising=False)
+        for other in (1, 2):
+            for name in st[0]:
+                assert np.array_equal(st[0][name], st[other][name]), (pi, name, other)
+            (Rd, td), pd, cd, ld = res[0]; (Rh, th), ph, ch, lh = res[other]
+            assert np.array_equal(ld, lh) and np.array_equal(Rd, Rh) and np.array_equal(td, th)
+            assert np.array_equal(pd, ph, equal_nan=True) and np.array_equal(cd, ch)
 
 
 def test_batched_windows_equal_single_window_runs_bitwise(ctx):
@@ -282,11 +299,16 @@ def test_batched_windows_equal_single_window_runs_bitwise(ctx):
             done = s.optimize(NIT, verbose_errors=verbose)
             single.append((done, s.poses(), s.points().copy(), s.chi2().copy(), s.log()[:done].copy()))
             s.close()
-        wins = []
-        for pr in probs:
-            s = ba.LocalBA(ctx, pr["K"])
-            s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
-            wins.append(s)
+        wins = [ba.LocalBA(ctx, pr["K"]) for pr in probs]
+        # all windows set up by ONE call: the local ones are built together (a workgroup each), the 50-keyframe one goes the general way
+        ba.set_problems(ctx, wins, [(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"]) for pr in probs])
+        if verbose:
+            for pr, s in zip(probs, wins):
+                one = ba.LocalBA(ctx, pr["K"])
+                one.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+                a, b = one.structure(), s.structure()
+                assert all(np.array_equal(a[k], b[k]) for k in a)
+                one.close()
         batch = ba.LocalBABatch(ctx, wins)
         done = batch.optimize(NIT, verbose_errors=verbose)
         assert any(sg[4][:, 2].max() > 1 for sg in single), "no window exercised the retry path"
