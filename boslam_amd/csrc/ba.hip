@@ -2956,6 +2956,8 @@ static int ba_build_device(bh_ba* ba, int C, const uint8_t* fixed, int P, const 
 #define BLD_LE 12288                 // edges: four 16-bit arrays of this length live in LDS
 #define BLD_LP 4096                  // landmarks
 #define BLD_MJ 4096                  // k_bld_join_merge: entries of camera s2's list staged in LDS
+#define BLD_E2 (1 << 18)             // tier 2 (grid-wide kernels, global scratch): edges, landmarks
+#define BLD_P2 (1 << 16)
 struct bld_view {
     int C, P, E, all_used;
     const int* ep; const int* pp; const uint8_t* fixed; const double* points; const double* meas;      // staged user arrays (device)
@@ -2968,6 +2970,9 @@ struct bld_view {
     // what bh_ba_set_problem does after the build, here in the same launch: camera blocks, cleared control block / residuals / S / step
     const ba_cam* cams_src; ba_cam* cams_dst; ba_K K;
     double* S; double* dxp; double* err0; ba_state* state;
+    // tier 2 (a local window too big for LDS: the same steps as grid-wide kernels over zero-initialised global scratch)
+    int tier, nwaves;
+    int* cam_used; int* pcnt; int* pfill; int* ccnt; int* jc; int* wh; int* tmp;
 };
 __host__ __device__ inline size_t bld_lds_bytes(int E, int P)
 {
@@ -2991,6 +2996,23 @@ __device__ __forceinline__ int bld_exscan(int v, int* s_w, int* total)
     *total = tot;
     return base + inc - v;
 }
+// Stable partition step for one batch of 64 entries: lane l holds camera slot sl (or -1) of entry l, and - as camera `lane` - that
+// camera's next output position in `run`.  Returns the output position of the lane's entry and advances the counters.  Six ballots
+// (one per bit of the slot) give every lane the set of lanes with ITS slot and, as a camera, the set of lanes that are its entries.
+__device__ __forceinline__ int bld_place64(int sl, int lane, int& run)
+{
+    const unsigned long long valid = __ballot(sl >= 0);
+    unsigned long long same = valid, mine = valid;
+#pragma unroll
+    for (int b = 0; b < 6; b++) {
+        const unsigned long long mb = __ballot((sl >> b) & 1);
+        same &= ((sl >> b) & 1) ? mb : ~mb;
+        mine &= ((lane >> b) & 1) ? mb : ~mb;
+    }
+    const int base = __shfl(run, sl & 63, 64);
+    run += __popcll(mine);
+    return base + __popcll(same & ((1ull << lane) - 1));
+}
 // 16-bit counters, two per LDS word (LDS atomics are 32 bits wide; a half never reaches 65 536 here)
 __device__ __forceinline__ int bld_add16(uint16_t* a, int i, int v)
 {
@@ -3002,7 +3024,7 @@ __device__ __forceinline__ int bld_add16(uint16_t* a, int i, int v)
 __global__ __launch_bounds__(1024) void k_bld_small(const bld_view* __restrict__ views)
 {
     const bld_view V = views[blockIdx.y];
-    if (V.C == 0) return;                                        // a window of the batch that is not a local one
+    if (V.C == 0 || V.tier != 1) return;                         // a window of the batch that is not a local one, or one too big for LDS
 #ifdef BLD_CLOCKS
     int clk_i = 0;
 #define BLD_CLK() do { if (threadIdx.x == 0 && clk_i < 10) V.info[8 + clk_i] = (int)wall_clock64(); clk_i++; } while (0)
@@ -3151,22 +3173,208 @@ __global__ __launch_bounds__(1024) void k_bld_small(const bld_view* __restrict__
             const int k = kb + lane;
             const int e = k < k1 ? s_pe[k] : 0;
             const int sl = k < k1 ? s_cs[s_ep[e]] : -1;
-            unsigned long long rem = __ballot(sl >= 0);
-            while (rem) {
-                const int l0 = __ffsll((long long)rem) - 1;
-                const int s0 = __shfl(sl, l0, 64);
-                const unsigned long long m = __ballot(sl == s0);
-                const int base = __shfl(run, s0, 64);
-                if (sl == s0) { const int o = base + __popcll(m & ((1ull << lane) - 1)); V.c_edges[o] = e; V.c_pt[o] = s_pt[e]; }
-                if (lane == s0) run += __popcll(m);
-                rem &= ~m;
-            }
+            const int o = bld_place64(sl, lane, run);
+            if (sl >= 0) { V.c_edges[o] = e; V.c_pt[o] = s_pt[e]; }
         }
     }
     BLD_CLK();
     if (tid == 0) {
         V.info[0] = 0x7fffffff; V.info[1] = s_bw; V.info[2] = Cf; V.info[3] = Pa; V.info[4] = npairs; V.info[5] = c_total; V.info[6] = M;
         V.info[7] = (long long)M > V.join_cap ? 2 : 0;
+    }
+}
+
+// ---- tier 2: the steps of k_bld_small as grid-wide kernels (blockIdx.y = window) for local windows that do not fit LDS (configs[2]:
+// 80 k observations).  Scratch is zero-initialised by one memset; info[0] counts as 0x7fffffff - (first bad edge) until k_b2_compact.
+#define B2_CH 512                    // p_edges entries per wave in the camera partition
+#define B2_LIVE(V) ((V).C != 0 && (V).tier == 2 && (V).info[0] == 0 && (V).info[7] == 0)
+__global__ __launch_bounds__(256) void k_b2_mark(const bld_view* __restrict__ views)
+{
+    const bld_view V = views[blockIdx.y];
+    if (V.C == 0 || V.tier != 2) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= V.E) return;
+    const int c = V.ep[e], q = V.pp[e];
+    if (c < 0 || c >= V.C || q < 0 || q >= V.P) { atomicMax(&V.info[0], 0x7fffffff - e); return; }
+    V.cam_used[c] = 1; V.pslot[q] = 1; V.e_cam[e] = c;
+}
+__global__ __launch_bounds__(1024) void k_b2_slots(const bld_view* __restrict__ views)
+{
+    const bld_view V = views[blockIdx.y];
+    if (!B2_LIVE(V)) return;
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, C = V.C, P = V.P;
+    int Cf, Pa;
+    const int f = (tid < C && (V.all_used || V.cam_used[tid]) && !V.fixed[tid]) ? 1 : 0;
+    const int ex = bld_exscan(f, s_w, &Cf);
+    if (tid < C) { V.cslot[tid] = f ? ex : -1; V.back_cslot[tid] = f ? ex : -1; }
+    const int ch = (P + 1023) >> 10, q0 = tid * ch, q1 = min(P, q0 + ch);
+    int n = 0;
+    for (int q = q0; q < q1; q++) n += V.pslot[q];
+    int run = bld_exscan(n, s_w, &Pa);
+    for (int q = q0; q < q1; q++) { const int fl = V.pslot[q]; V.pslot[q] = fl ? run : -1; run += fl; }
+    if (tid == 0) { V.info[2] = Cf; V.info[3] = Pa; if (Cf > BLD_SF) V.info[7] = 1; }
+}
+__global__ __launch_bounds__(256) void k_b2_count(const bld_view* __restrict__ views)
+{
+    const bld_view V = views[blockIdx.y];
+    if (!B2_LIVE(V)) return;
+    __shared__ int s_cc[BLD_SF];
+    if (threadIdx.x < BLD_SF) s_cc[threadIdx.x] = 0;
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < V.E) {
+        const int j = V.pslot[V.pp[e]];
+        V.e_pt[e] = j;
+        atomicAdd(&V.pcnt[j], 1);
+        const int sl = V.cslot[V.ep[e]];
+        if (sl >= 0) atomicAdd(&s_cc[sl], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < BLD_SF) { const int v = s_cc[threadIdx.x]; if (v) atomicAdd(&V.ccnt[threadIdx.x], v); }
+}
+__global__ __launch_bounds__(1024) void k_b2_scan(const bld_view* __restrict__ views)
+{
+    const bld_view V = views[blockIdx.y];
+    if (!B2_LIVE(V)) return;
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, Cf = V.info[2], Pa = V.info[3];
+    const int* __restrict__ cnt = V.pcnt; int* __restrict__ ps = V.p_start;
+    const int ch = (Pa + 1 + 1023) >> 10, j0 = tid * ch, j1 = min(Pa + 1, j0 + ch);
+    int n = 0;
+    for (int j = j0; j < j1; j++) n += cnt[j];
+    int tot, run = bld_exscan(n, s_w, &tot);
+    for (int j = j0; j < j1; j++) { ps[j] = run; run += cnt[j]; }
+    int c_total;
+    const int cv = tid < Cf ? V.ccnt[tid] : 0;
+    const int cex = bld_exscan(cv, s_w, &c_total);
+    if (tid <= Cf) V.c_start[tid] = cex;
+    if (tid == 0) V.info[5] = c_total;
+}
+__global__ __launch_bounds__(256) void k_b2_fill(const bld_view* __restrict__ views)
+{
+    const bld_view V = views[blockIdx.y];
+    if (!B2_LIVE(V)) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= V.E) return;
+    const int j = V.e_pt[e];
+    const int pos = atomicAdd(&V.pfill[j], 1);
+    V.tmp[V.p_start[j] + pos] = e;
+}
+#define B2_MK 16                     // landmark degree up to which k_b2_rank works from an LDS copy of the landmark's list
+__global__ __launch_bounds__(256) void k_b2_rank(const bld_view* __restrict__ views)
+{
+    const bld_view V = views[blockIdx.y];
+    if (!B2_LIVE(V)) return;
+    __shared__ int s_jc[BLD_SF * BLD_SF];
+    __shared__ int s_e[B2_MK][256];                              // [entry][thread]: conflict-free
+    __shared__ uint16_t s_c[B2_MK][256];
+    __shared__ int8_t s_s[B2_MK][256];
+    const int Cf = V.info[2], Pa = V.info[3], tid = threadIdx.x;
+    for (int i = tid; i < Cf * Cf; i += 256) s_jc[i] = 0;
+    __syncthreads();
+    const int j = blockIdx.x * 256 + tid;
+    if (j < Pa) {
+        const int a0 = V.p_start[j], k = V.p_start[j + 1] - a0;
+        const int* __restrict__ tm = V.tmp + a0; const int* __restrict__ ep = V.ep; const int* __restrict__ cs = V.cslot;
+        if (k <= B2_MK) {
+            // three dependent levels of loads for the whole list (entry, camera, slot), then everything from LDS.  A pair of entries
+            // lands on (min slot, max slot): slots grow with the camera index, so no order is needed for the count.
+            for (int i = 0; i < k; i++) s_e[i][tid] = tm[i];
+            for (int i = 0; i < k; i++) s_c[i][tid] = (uint16_t)ep[s_e[i][tid]];
+            for (int i = 0; i < k; i++) s_s[i][tid] = (int8_t)cs[s_c[i][tid]];
+            for (int i = 0; i < k; i++) {
+                const int ei = s_e[i][tid], ci = s_c[i][tid], si = s_s[i][tid];
+                int r = 0;
+                for (int i2 = 0; i2 < k; i2++) { const int ex = s_e[i2][tid], c2 = s_c[i2][tid]; r += (c2 < ci || (c2 == ci && ex < ei)) ? 1 : 0; }
+                V.p_edges[a0 + r] = ei;
+                if (si >= 0) for (int i2 = i; i2 < k; i2++) { const int s2 = s_s[i2][tid]; if (s2 >= 0) atomicAdd(&s_jc[min(si, s2) * Cf + max(si, s2)], 1); }
+            }
+        } else {
+            for (int i = 0; i < k; i++) {
+                const int ei = tm[i], ci = ep[ei];
+                int r = 0;
+                for (int i2 = 0; i2 < k; i2++) { const int ex = tm[i2], c2 = ep[ex]; r += (c2 < ci || (c2 == ci && ex < ei)) ? 1 : 0; }
+                V.p_edges[a0 + r] = ei;
+                const int si = cs[ci];
+                if (si >= 0) for (int i2 = i; i2 < k; i2++) { const int s2 = cs[ep[tm[i2]]]; if (s2 >= 0) atomicAdd(&s_jc[min(si, s2) * Cf + max(si, s2)], 1); }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < Cf * Cf; i += 256) { const int v = s_jc[i]; if (v) atomicAdd(&V.jc[i], v); }
+}
+__global__ __launch_bounds__(1024) void k_b2_compact(const bld_view* __restrict__ views)
+{
+    const bld_view V = views[blockIdx.y];
+    if (V.C == 0 || V.tier != 2) return;
+    const int tid = threadIdx.x;
+    if (V.info[0] != 0 || V.info[7] != 0) { if (tid == 0) V.info[0] = V.info[0] ? 0x7fffffff - V.info[0] : 0x7fffffff; return; }
+    __shared__ int s_w[16];
+    __shared__ int s_bw;
+    if (tid == 0) s_bw = 0;
+    __syncthreads();
+    const int Cf = V.info[2];
+    int fl[4], cn[4], nf = 0, nc = 0, npairs, M;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int idx = 4 * tid + i, s1 = idx < Cf * Cf ? idx / Cf : 0, sb = idx - s1 * Cf;
+        const int c = idx < Cf * Cf ? V.jc[idx] : 0;
+        fl[i] = (idx < Cf * Cf && sb >= s1 && (c > 0 || s1 == sb)) ? 1 : 0; cn[i] = fl[i] ? c : 0;
+        nf += fl[i]; nc += cn[i];
+        if (fl[i] && sb - s1 > 0) atomicMax(&s_bw, sb - s1);
+    }
+    int pi = bld_exscan(nf, s_w, &npairs);
+    int jo = bld_exscan(nc, s_w, &M);
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (fl[i]) {
+        const int idx = 4 * tid + i, s1 = idx / Cf, sb = idx - s1 * Cf;
+        V.pairs[pi] = make_int2(s1, sb); V.j_start[pi] = jo; pi++; jo += cn[i];
+    }
+    if (tid == 0) {
+        V.j_start[npairs] = M;
+        V.info[0] = 0x7fffffff; V.info[1] = s_bw; V.info[4] = npairs; V.info[6] = M; V.info[7] = (long long)M > V.join_cap ? 2 : 0;
+    }
+}
+// camera partition of the p_edges sequence: wave w owns entries [w B2_CH, (w + 1) B2_CH); pass 1 counts per camera, pass 2 places
+__global__ __launch_bounds__(256) void k_b2_chist(const bld_view* __restrict__ views)
+{
+    const bld_view V = views[blockIdx.y];
+    if (V.C == 0 || V.tier != 2 || V.info[0] != 0x7fffffff || V.info[7]) return;
+    __shared__ int s_h[4][BLD_SF];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, w = blockIdx.x * 4 + wv;
+    s_h[wv][lane] = 0;
+    __syncthreads();
+    if (w < V.nwaves) {
+        const int k0 = w * B2_CH, k1 = min(V.E, k0 + B2_CH);
+        for (int k = k0 + lane; k < k1; k += 64) { const int sl = V.cslot[V.ep[V.p_edges[k]]]; if (sl >= 0) atomicAdd(&s_h[wv][sl], 1); }
+    }
+    __syncthreads();
+    if (w < V.nwaves) V.wh[w * BLD_SF + lane] = s_h[wv][lane];
+}
+__global__ __launch_bounds__(256) void k_b2_cplace(const bld_view* __restrict__ views)
+{
+    const bld_view V = views[blockIdx.y];
+    if (V.C == 0 || V.tier != 2 || V.info[0] != 0x7fffffff || V.info[7]) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, w = blockIdx.x * 4 + wv;
+    if (w >= V.nwaves) return;
+    const int Cf = V.info[2];
+    int run = 0;
+    if (lane < Cf) { run = V.c_start[lane]; const int* __restrict__ wh = V.wh; for (int x = 0; x < w; x++) run += wh[x * BLD_SF + lane]; }
+    const int k0 = w * B2_CH, k1 = min(V.E, k0 + B2_CH);
+    constexpr int NB = B2_CH / 64;
+    int e[NB], sl[NB], jp[NB];                                   // all loads of the chunk first (three dependent levels), then the placement
+#pragma unroll
+    for (int i = 0; i < NB; i++) { const int k = k0 + 64 * i + lane; e[i] = k < k1 ? V.p_edges[k] : -1; }
+#pragma unroll
+    for (int i = 0; i < NB; i++) { sl[i] = e[i] >= 0 ? V.ep[e[i]] : -1; jp[i] = e[i] >= 0 ? V.e_pt[e[i]] : 0; }
+#pragma unroll
+    for (int i = 0; i < NB; i++) sl[i] = sl[i] >= 0 ? V.cslot[sl[i]] : -1;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        if (k0 + 64 * i >= k1) break;
+        const int o = bld_place64(sl[i], lane, run);
+        if (sl[i] >= 0) { V.c_edges[o] = e[i]; V.c_pt[o] = jp[i]; }
     }
 }
 
@@ -3251,15 +3459,15 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
 {
     hipStream_t st = ctx->stream;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    struct lay { size_t ep, pp, fx, pt, ms, cm, back, cpt; int nfree; long long join_cap; size_t maxpairs; };
+    struct lay { size_t ep, pp, fx, pt, ms, cm, back, cpt, cu, pc, pf, cc, jc, wh, tm; int nfree, tier, nwaves; long long join_cap; size_t maxpairs; };
     std::vector<lay> L(W);
     size_t up = al(sizeof(bld_view) * (size_t)W), back = 0, scr = 0;
-    int n_el = 0, max_blocks = 1;
+    int n_el = 0, max_blocks = 1, n_t1 = 0, n_t2 = 0, maxE2 = 1, maxP2 = 1, maxW2 = 1;
     size_t max_lds = 0;
     for (int w = 0; w < W; w++) {
         taken[w] = 0;
         const ba_prob& q = pr[w]; bh_ba* ba = bas[w];
-        if (ba->ar || q.C < 1 || q.C > BLD_SC || q.E < 1 || q.E > BLD_LE || q.P < 1 || q.P > BLD_LP) continue;
+        if (ba->ar || q.C < 1 || q.C > BLD_SC || q.E < 1 || q.E > BLD_E2 || q.P < 1 || q.P > BLD_P2) continue;
         int nfree = 0;
         for (int i = 0; i < q.C; i++) nfree += q.fixed[i] ? 0 : 1;
         if (nfree > BLD_SF) continue;
@@ -3271,10 +3479,17 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
         l.pt = up; up += al(sizeof(double) * 3 * (size_t)q.P); l.ms = up; up += al(sizeof(double) * 2 * (size_t)q.E); l.cm = up; up += al(sizeof(ba_cam) * (size_t)q.C);
         l.back = back; back += sizeof(int) * (8 + (size_t)q.C + (size_t)q.P);
         l.cpt = scr; scr += sizeof(int) * (size_t)q.E;
+        l.tier = (q.E <= BLD_LE && q.P <= BLD_LP) ? 1 : 2;
+        l.nwaves = (q.E + B2_CH - 1) / B2_CH;
+        if (l.tier == 2) {
+            l.cu = scr; scr += sizeof(int) * (size_t)q.C; l.pc = scr; scr += sizeof(int) * ((size_t)q.P + 1); l.pf = scr; scr += sizeof(int) * ((size_t)q.P + 1);
+            l.cc = scr; scr += sizeof(int) * BLD_SF; l.jc = scr; scr += sizeof(int) * BLD_SF * BLD_SF; l.wh = scr; scr += sizeof(int) * BLD_SF * (size_t)l.nwaves;
+            l.tm = scr; scr += sizeof(int) * (size_t)q.E;
+            n_t2++; maxE2 = std::max(maxE2, q.E); maxP2 = std::max(maxP2, q.P); maxW2 = std::max(maxW2, l.nwaves);
+        } else { n_t1++; max_lds = std::max(max_lds, bld_lds_bytes(q.E, q.P)); }
         taken[w] = 2;                                                              // staged
         n_el++;
         max_blocks = std::max(max_blocks, std::min(64, (std::max(q.E, q.P) + 255) / 256 + 1));      // workgroups behind the pairs (grid-stride copies)
-        max_lds = std::max(max_lds, bld_lds_bytes(q.E, q.P));
     }
     if (!n_el) return BH_OK;
     const size_t back_al = al(back);
@@ -3310,6 +3525,12 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
             V.points = (const double*)(dp + l.pt); V.meas = (const double*)(dp + l.ms); V.cams_src = (const ba_cam*)(dp + l.cm);
             int* bk = (int*)(ds + l.back);
             V.info = bk; V.back_cslot = bk + 8; V.pslot = bk + 8 + q.C; V.c_pt = (int*)(ds + back_al + l.cpt);
+            V.tier = l.tier; V.nwaves = l.nwaves;
+            if (l.tier == 2) {
+                char* sc = ds + back_al;
+                V.cam_used = (int*)(sc + l.cu); V.pcnt = (int*)(sc + l.pc); V.pfill = (int*)(sc + l.pf); V.ccnt = (int*)(sc + l.cc);
+                V.jc = (int*)(sc + l.jc); V.wh = (int*)(sc + l.wh); V.tmp = (int*)(sc + l.tm);
+            }
             V.e_cam = (int*)ba->e_cam.p; V.e_pt = (int*)ba->e_pt.p; V.e_meas = (double*)ba->e_meas.p; V.cslot = (int*)ba->cslot.p;
             V.p_start = (int*)ba->p_start.p; V.p_edges = (int*)ba->p_edges.p; V.c_start = (int*)ba->c_start.p; V.c_edges = (int*)ba->c_edges.p;
             V.pairs = (int2*)ba->pairs.p; V.j_start = (int*)ba->j_start.p; V.join = (int2*)ba->join.p; V.join_cap = l.join_cap;
@@ -3329,9 +3550,25 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
     if (!lds_attr) { BH_HIP(ctx, hipFuncSetAttribute((const void*)k_bld_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bld_lds_bytes(BLD_LE, BLD_LP))); lds_attr = true; }
     int max_pairs = 1;
     for (int w = 0; w < W; w++) if (taken[w]) max_pairs = std::max(max_pairs, (int)L[w].maxpairs);
-    bh_time_begin(ctx, BH_K_BA_OTHER);
-    hipLaunchKernelGGL(k_bld_small, dim3(1, W), dim3(1024), max_lds, st, (const bld_view*)dp);
-    bh_time_end(ctx);
+    const bld_view* dv = (const bld_view*)dp;
+    if (n_t2) BH_HIP(ctx, hipMemsetAsync(ds, 0, back_al + scr, st));             // tier 2 counts into zero-initialised scratch (tier 1 does not care)
+    if (n_t1) {
+        bh_time_begin(ctx, BH_K_BA_OTHER);
+        hipLaunchKernelGGL(k_bld_small, dim3(1, W), dim3(1024), max_lds, st, dv);
+        bh_time_end(ctx);
+    }
+    if (n_t2) {
+        const dim3 gE((maxE2 + 255) / 256, W), gP((maxP2 + 255) / 256, W), g1(1, W), gW((maxW2 + 3) / 4, W);
+        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_mark, gE, dim3(256), st, dv);
+        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_slots, g1, dim3(1024), st, dv);
+        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_count, gE, dim3(256), st, dv);
+        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_scan, g1, dim3(1024), st, dv);
+        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_fill, gE, dim3(256), st, dv);
+        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_rank, gP, dim3(256), st, dv);
+        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_compact, g1, dim3(1024), st, dv);
+        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_chist, gW, dim3(256), st, dv);
+        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_cplace, gW, dim3(256), st, dv);
+    }
     BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bld_join_merge, dim3((unsigned)(max_pairs + max_blocks), W), dim3(256), st, (const bld_view*)dp, max_pairs);
     char* hb0 = hp + up;
     BH_HIP(ctx, hipMemcpyAsync(hb0, ds, back, hipMemcpyDeviceToHost, st));
