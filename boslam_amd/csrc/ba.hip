@@ -586,10 +586,10 @@ __device__ __forceinline__ bool d_inv3(const double* m, double* o)
 }
 
 // ---- k_ba_dinv: per point (Hll + lambda I)^-1 and Dinv * bl
-__device__ __forceinline__ void ba_dinv_body(const double* __restrict__ Hll, const double* __restrict__ bl, int Pa,
+__device__ __forceinline__ void ba_dinv_body(int bid, const double* __restrict__ Hll, const double* __restrict__ bl, int Pa,
                                                  ba_state* __restrict__ S, double* __restrict__ Dinv, double* __restrict__ db)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = bid * 256 + threadIdx.x;
     if (j >= Pa) return;
     const double lambda = S->lambda;
     double D[9], Di[9];
@@ -605,7 +605,7 @@ __device__ __forceinline__ void ba_dinv_body(const double* __restrict__ Hll, con
 __global__ __launch_bounds__(256) void k_ba_dinv(const double* __restrict__ Hll, const double* __restrict__ bl, int Pa,
                                                  ba_state* __restrict__ S, double* __restrict__ Dinv, double* __restrict__ db)
 {
-    ba_dinv_body(Hll, bl, Pa, S, Dinv, db);
+    ba_dinv_body(blockIdx.x, Hll, bl, Pa, S, Dinv, db);
 }
 
 // ---- k_ba_schur_S: workgroup per camera pair (s1 <= s2): S[s1][s2] = [s1==s2](Hpp + lambda I) - sum_j Hpl_1j Dinv_j Hpl_2j'
@@ -2167,7 +2167,7 @@ static int dbcr_carve(bh_ctx* ctx, hipStream_t st, bcr_dev* dv, int N, void* scr
 }
 
 // ---- k_ba_update: trial state = current state (+) step.  blocks [0, pblocks): points (back-substitution); rest: cameras
-__device__ __forceinline__ void ba_update_body(const ba_cam* __restrict__ cams, ba_cam* __restrict__ cams_t,
+__device__ __forceinline__ void ba_update_body(int bid, const ba_cam* __restrict__ cams, ba_cam* __restrict__ cams_t,
                                                    const double* __restrict__ pts, double* __restrict__ pts_t,
                                                    const int* __restrict__ cslot, int C, int Pa, int pblocks,
                                                    const int* __restrict__ p_start, const int* __restrict__ p_edges,
@@ -2175,8 +2175,8 @@ __device__ __forceinline__ void ba_update_body(const ba_cam* __restrict__ cams, 
                                                    const double* __restrict__ Dinv, const double* __restrict__ bl,
                                                    const double* __restrict__ dxp, double* __restrict__ dxl, ba_K K)
 {
-    if ((int)blockIdx.x < pblocks) {
-        const int j = blockIdx.x * 256 + threadIdx.x;
+    if (bid < pblocks) {
+        const int j = bid * 256 + threadIdx.x;
         if (j >= Pa) return;
         double c[3] = { bl[3 * j], bl[3 * j + 1], bl[3 * j + 2] };
         for (int u = p_start[j]; u < p_start[j + 1]; u++) {
@@ -2197,7 +2197,7 @@ __device__ __forceinline__ void ba_update_body(const ba_cam* __restrict__ cams, 
             pts_t[3 * j + a] = pts[3 * j + a] + dl;
         }
     } else {
-        const int i = (blockIdx.x - pblocks) * 256 + threadIdx.x;
+        const int i = (bid - pblocks) * 256 + threadIdx.x;
         if (i >= C) return;
         ba_cam c = cams[i];
         const int s = cslot[i];
@@ -2213,16 +2213,16 @@ __global__ __launch_bounds__(256) void k_ba_update(const ba_cam* __restrict__ ca
                                                    const double* __restrict__ Dinv, const double* __restrict__ bl,
                                                    const double* __restrict__ dxp, double* __restrict__ dxl, ba_K K)
 {
-    ba_update_body(cams, cams_t, pts, pts_t, cslot, C, Pa, pblocks, p_start, p_edges, e_cam, Hpl, Dinv, bl, dxp, dxl, K);
+    ba_update_body(blockIdx.x, cams, cams_t, pts, pts_t, cslot, C, Pa, pblocks, p_start, p_edges, e_cam, Hpl, Dinv, bl, dxp, dxl, K);
 }
 
 // ---- k_ba_err: per-edge error and robust chi at the trial state
-__device__ __forceinline__ void ba_err_body(const ba_cam* __restrict__ cams, const double* __restrict__ pts,
+__device__ __forceinline__ void ba_err_body(int bid, const ba_cam* __restrict__ cams, const double* __restrict__ pts,
                                                 const int* __restrict__ e_cam, const int* __restrict__ e_pt,
                                                 const double* __restrict__ e_meas, int Ea, double delta,
                                                 double* __restrict__ err, double* __restrict__ chi_e)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = bid * 256 + threadIdx.x;
     if (e >= Ea) return;
     double er[2], r0, r1;
     d_edge_error(cams[e_cam[e]].w2i, pts + 3 * (size_t)e_pt[e], e_meas + 2 * e, er);
@@ -2234,7 +2234,7 @@ __global__ __launch_bounds__(256) void k_ba_err(const ba_cam* __restrict__ cams,
                                                 const double* __restrict__ e_meas, int Ea, double delta,
                                                 double* __restrict__ err, double* __restrict__ chi_e)
 {
-    ba_err_body(cams, pts, e_cam, e_pt, e_meas, Ea, delta, err, chi_e);
+    ba_err_body(blockIdx.x, cams, pts, e_cam, e_pt, e_meas, Ea, delta, err, chi_e);
 }
 
 // ---- k_ba_decide: Levenberg gain ratio and lambda schedule (OptimizationAlgorithmLevenberg::solve)
@@ -2311,6 +2311,17 @@ struct ba_view {
     ba_K K;
 };
 
+// Which (window, block) a workgroup of a (blocks, windows-rounded-up-to-8) grid works on.  Consecutive workgroup ids go round the 8 XCDs,
+// each with its own 4 MB L2; all workgroups of window w are sent to XCD w % 8, so a live window's Hpl blocks (0.7 MB, written by the
+// linearisation, gathered ~36 times by the Schur products) stay in ONE L2 instead of being pulled into all eight: 64 windows x 0.7 MB
+// thrashed every L2 and the Schur launch ran at HBM speed (87 us; the same windows one at a time: 12.5 us each).
+__device__ __forceinline__ bool bb_where(int W, int& w, int& bid)
+{
+    const int nb = gridDim.x, lin = blockIdx.y * nb + blockIdx.x, v = lin >> 3, g = v / nb;
+    w = 8 * g + (lin & 7); bid = v - g * nb;
+    return w < W;
+}
+
 __global__ void k_bb_init(const ba_view* __restrict__ views, int W, int iters, int verbose)
 {
     const int w = blockIdx.x * 64 + threadIdx.x;
@@ -2324,15 +2335,17 @@ __global__ void k_bb_setcur(const ba_view* __restrict__ views, const int* __rest
     if (w < W) views[w].state->b_cur = cur[w];
 }
 
-__global__ __launch_bounds__(256) void k_bb_linearize(const ba_view* __restrict__ views, double delta)
+__global__ __launch_bounds__(256) void k_bb_linearize(const ba_view* __restrict__ views, int W, double delta)
 {
-    const ba_view& V = views[blockIdx.y];
+    int w, bx;
+    if (!bb_where(W, w, bx)) return;
+    const ba_view& V = views[w];
     const ba_state* S = V.state;
     if (S->b_done || !S->b_need_lin) return;
     const int nbp = (V.Pa * BP_G + 255) / 256, cur = S->b_cur;
-    if ((int)blockIdx.x < nbp) ba_point_body(blockIdx.x, V.cams[cur], V.pts[cur], V.e_cam, V.e_meas, V.cslot, V.p_start, V.p_edges, V.Pa, V.K, delta, V.Hpl, V.Hll, V.bl,
+    if (bx < nbp) ba_point_body(bx, V.cams[cur], V.pts[cur], V.e_cam, V.e_meas, V.cslot, V.p_start, V.p_edges, V.Pa, V.K, delta, V.Hpl, V.Hll, V.bl,
                                              V.err[0], V.chi_e[0], V.pdiag);
-    else if ((int)blockIdx.x < nbp + V.Cf) ba_cam_body(blockIdx.x - nbp, V.cams[cur], V.pts[cur], V.e_cam, V.e_pt, V.e_meas, V.c_start, V.c_edges, V.K, delta, V.Hpp, V.bp, V.cdiag);
+    else if (bx < nbp + V.Cf) ba_cam_body(bx - nbp, V.cams[cur], V.pts[cur], V.e_cam, V.e_pt, V.e_meas, V.c_start, V.c_edges, V.K, delta, V.Hpp, V.bp, V.cdiag);
 }
 __global__ __launch_bounds__(1024) void k_bb_partial(const ba_view* __restrict__ views, int trial)
 {
@@ -2353,26 +2366,41 @@ __global__ __launch_bounds__(1024) void k_bb_prep(const ba_view* __restrict__ vi
         if (first && !isfinite(S->max_diag)) { S->b_done = 1; S->b_fail = 1; }          // non-finite Hessian at the initial estimate
     }
 }
-__global__ __launch_bounds__(256) void k_bb_dinv(const ba_view* __restrict__ views)
+__global__ __launch_bounds__(256) void k_bb_dinv(const ba_view* __restrict__ views, int W)
 {
-    const ba_view& V = views[blockIdx.y];
-    if (V.state->b_done || (int)blockIdx.x * 256 >= V.Pa) return;
-    ba_dinv_body(V.Hll, V.bl, V.Pa, V.state, V.Dinv, V.db);
+    int w, bx;
+    if (!bb_where(W, w, bx)) return;
+    const ba_view& V = views[w];
+    if (V.state->b_done || bx * 256 >= V.Pa) return;
+    ba_dinv_body(bx, V.Hll, V.bl, V.Pa, V.state, V.Dinv, V.db);
 }
-__global__ __launch_bounds__(256) void k_bb_zeroS(const ba_view* __restrict__ views)
+__global__ __launch_bounds__(256) void k_bb_zeroS(const ba_view* __restrict__ views, int W)
 {
-    const ba_view& V = views[blockIdx.y];
+    int w, bx;
+    if (!bb_where(W, w, bx)) return;
+    const ba_view& V = views[w];
     if (V.state->b_done) return;
     const size_t n = (size_t)V.n6 * (V.bw + 1);
-    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) V.S[i] = 0.0;
+    for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) V.S[i] = 0.0;
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_bb_schur(const ba_view* __restrict__ views)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_bb_schur(const ba_view* __restrict__ views, int W)
 {
-    const ba_view& V = views[blockIdx.y];
+    int w, bx;
+    if (!bb_where(W, w, bx)) return;
+    const ba_view& V = views[w];
     if (V.state->b_done) return;
     const int ngS = (V.npairs + 7) / 8 * 8;
-    if ((int)blockIdx.x < ngS) ba_schur_S_body<256>(blockIdx.x, ngS, V.pairs, V.j_start, V.join, V.e_pt, V.Hpl, V.Dinv, V.Hpp, V.state, V.bw, 1, V.S, V.npairs);
-    else if ((int)blockIdx.x < ngS + V.Cf) ba_schur_b_body(blockIdx.x - ngS, V.c_start, V.c_edges, V.e_pt, V.Hpl, V.db, V.bp, 1, V.bs);
+    if (bx < ngS) { if (!V.pad) ba_schur_S_body<256>(bx, ngS, V.pairs, V.j_start, V.join, V.e_pt, V.Hpl, V.Dinv, V.Hpp, V.state, V.bw, 1, V.S, V.npairs); }
+    else if (bx < ngS + V.Cf) ba_schur_b_body(bx - ngS, V.c_start, V.c_edges, V.e_pt, V.Hpl, V.db, V.bp, 1, V.bs);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_bb_schur64(const ba_view* __restrict__ views, int W)
+{
+    int w, bx;
+    if (!bb_where(W, w, bx)) return;
+    const ba_view& V = views[w];
+    if (V.state->b_done || !V.pad) return;                       // (pad: the window's Schur products go one wave per camera pair)
+    const int ngS = (V.npairs + 7) / 8 * 8;
+    if (bx < ngS) ba_schur_S_body<64>(bx, ngS, V.pairs, V.j_start, V.join, V.e_pt, V.Hpl, V.Dinv, V.Hpp, V.state, V.bw, 1, V.S, V.npairs);
 }
 __global__ __launch_bounds__(1024) void k_bb_chol(const ba_view* __restrict__ views)
 {
@@ -2380,22 +2408,26 @@ __global__ __launch_bounds__(1024) void k_bb_chol(const ba_view* __restrict__ vi
     if (V.state->b_done || V.Cf == 0) return;
     ba_chol_dense_body<false>(V.S, V.bs, V.n6, V.bw, V.dxp, V.state, nullptr, nullptr, nullptr, nullptr);
 }
-__global__ __launch_bounds__(256) void k_bb_update(const ba_view* __restrict__ views)
+__global__ __launch_bounds__(256) void k_bb_update(const ba_view* __restrict__ views, int W)
 {
-    const ba_view& V = views[blockIdx.y];
+    int w, bx;
+    if (!bb_where(W, w, bx)) return;
+    const ba_view& V = views[w];
     const ba_state* S = V.state;
     const int pblocks = (V.Pa + 255) / 256, cblocks = (V.C + 255) / 256;
-    if (S->b_done || (int)blockIdx.x >= pblocks + cblocks) return;
+    if (S->b_done || bx >= pblocks + cblocks) return;
     const int cur = S->b_cur;
-    ba_update_body(V.cams[cur], V.cams[cur ^ 1], V.pts[cur], V.pts[cur ^ 1], V.cslot, V.C, V.Pa, pblocks, V.p_start, V.p_edges, V.e_cam, V.Hpl, V.Dinv, V.bl, V.dxp, V.dxl, V.K);
+    ba_update_body(bx, V.cams[cur], V.cams[cur ^ 1], V.pts[cur], V.pts[cur ^ 1], V.cslot, V.C, V.Pa, pblocks, V.p_start, V.p_edges, V.e_cam, V.Hpl, V.Dinv, V.bl, V.dxp, V.dxl, V.K);
 }
-__global__ __launch_bounds__(256) void k_bb_err(const ba_view* __restrict__ views, double delta)
+__global__ __launch_bounds__(256) void k_bb_err(const ba_view* __restrict__ views, int W, double delta)
 {
-    const ba_view& V = views[blockIdx.y];
+    int w, bx;
+    if (!bb_where(W, w, bx)) return;
+    const ba_view& V = views[w];
     const ba_state* S = V.state;
-    if (S->b_done || (int)blockIdx.x * 256 >= V.Ea) return;
+    if (S->b_done || bx * 256 >= V.Ea) return;
     const int cur = S->b_cur;
-    ba_err_body(V.cams[cur ^ 1], V.pts[cur ^ 1], V.e_cam, V.e_pt, V.e_meas, V.Ea, delta, V.err[1], V.chi_e[1]);
+    ba_err_body(bx, V.cams[cur ^ 1], V.pts[cur ^ 1], V.e_cam, V.e_pt, V.e_meas, V.Ea, delta, V.err[1], V.chi_e[1]);
 }
 __global__ __launch_bounds__(1024) void k_bb_decide(const ba_view* __restrict__ views, int seq)
 {
@@ -2781,7 +2813,7 @@ __global__ void k_bld_join_unpack(const unsigned long long* __restrict__ val, lo
     if (t < M) join[t] = make_int2((int)(val[t] >> 32), (int)(val[t] & 0xffffffffu));
 }
 
-struct ba_build_out { int Cf, Pa, c_total, npairs, bwb; };
+struct ba_build_out { int Cf, Pa, c_total, npairs, bwb; long long M; };
 
 // Builds every structural array of the problem in ba's device buffers from the uploaded edge list.  scratch: ctx->st_a .. st_g.
 static int ba_build_device(bh_ba* ba, int C, const uint8_t* fixed, int P, const double* points, int E, const int* edge_pose,
@@ -2891,6 +2923,7 @@ static int ba_build_device(bh_ba* ba, int C, const uint8_t* fixed, int P, const 
     }
     // the Schur complement's work list: (edge, edge) pairs per camera pair, landmarks ascending inside a pair (stable sort of the
     // per-landmark enumeration by camera-pair key)
+    long long M_total = 0;
     {
         BH_TRY(bh_reserve(ctx, &ba->j_start, sizeof(int) * ((size_t)npairs + 2)));
         long long M = 0;
@@ -2907,6 +2940,7 @@ static int ba_build_device(bh_ba* ba, int C, const uint8_t* fixed, int P, const 
             BH_HIP(ctx, hipMemcpyAsync(&M, joff + Pa, sizeof(long long), hipMemcpyDeviceToHost, st));
             BH_HIP(ctx, hipStreamSynchronize(st));
             if (M >= (1ll << 31)) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: %lld landmark / camera-pair incidences (limit 2^31)", M);
+            M_total = M;
             BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(unsigned long long) * 4 * (size_t)(M + 1)));
             unsigned long long* jk = (unsigned long long*)ctx->st_b.p; unsigned long long* jk2 = jk + M + 1; unsigned long long* jv = jk2 + M + 1; unsigned long long* jv2 = jv + M + 1;
             hipLaunchKernelGGL(k_bld_join_emit, G(Pa), T, 0, st, (const int*)ba->p_start.p, (const int*)ba->p_edges.p, (const int*)ep, (const int*)cam_slot, Pa, Cf, (const long long*)joff, jk, jv);
@@ -2924,7 +2958,7 @@ static int ba_build_device(bh_ba* ba, int C, const uint8_t* fixed, int P, const 
             BH_HIP(ctx, hipMemsetAsync(ba->j_start.p, 0, sizeof(int) * ((size_t)npairs + 2), st));
         }
     }
-    out->npairs = npairs; out->bwb = bwb; out->c_total = c_total;
+    out->npairs = npairs; out->bwb = bwb; out->c_total = c_total; out->M = M_total;
     // active points in slot order; host mirrors of the slots (get_points / get_poses map back through them)
     BH_TRY(bh_reserve(ctx, &ba->pts[0], sizeof(double) * 3 * ((size_t)Pa + 1)));
     if (P) hipLaunchKernelGGL(k_bld_gather_pts, G(P), T, 0, st, (const double*)ctx->st_c.p, (const int*)pt_slot, P, (double*)ba->pts[0].p);
@@ -3580,7 +3614,7 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
         const int* hb = (const int*)(hb0 + L[w].back);
         if (hb[0] != 0x7fffffff) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: edge %d references a missing vertex", hb[0]);
         if (hb[7]) { taken[w] = 0; continue; }                                     // refused (duplicate-heavy edge list): the general builder takes it
-        out[w].bwb = hb[1]; out[w].Cf = hb[2]; out[w].Pa = hb[3]; out[w].npairs = hb[4]; out[w].c_total = hb[5];
+        out[w].bwb = hb[1]; out[w].Cf = hb[2]; out[w].Pa = hb[3]; out[w].npairs = hb[4]; out[w].c_total = hb[5]; out[w].M = hb[6];
         ba->cam_slot.assign(hb + 8, hb + 8 + q.C); ba->pt_slot.assign(hb + 8 + q.C, hb + 8 + q.C + q.P);
         taken[w] = 1;
     }
@@ -3722,10 +3756,18 @@ static int ba_set_problem_rest(bh_ba* ba, int C, const double* R, const double* 
                     for (int v = u; v < p_start[j + 1]; v++) { const int e2 = p_edges[v], s2 = ba->cam_slot[e_cam[e2]]; if (s2 >= 0) join[fill[pair_of[(size_t)s1 * Cf + s2]]++] = make_int2(e1, e2); }
                 }
             BH_TRY(upload(ctx, &ba->join, join)); BH_TRY(upload(ctx, &ba->j_start, j_start));
+            bo.M = j_start[pairs.size()];
         }
         BH_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the host vectors above go out of scope
     }
     ba->schur_wave = (Cf > 0 && ba->npairs >= 4096 && c_total / Cf < 1024) ? 1 : 0;
+    {   // A/B switch (off by default): a wave per camera pair also for short join lists (BH_BA_SCHUR_WAVE_AVG = largest average list length
+        // that takes it).  Measured at 512: 64 batched live windows +7 % (the 256-thread form keeps 188 VGPRs per lane, two workgroups
+        // per CU, 8 rounds of ~10 us), but one live window -10 % and one configs[2] window -6 %: not kept as the default.
+        int avg_max = 0;
+        if (const char* ev = getenv("BH_BA_SCHUR_WAVE_AVG")) avg_max = atoi(ev);
+        if (Cf > 0 && ba->npairs > 0 && !ba->ar && bo.M / ba->npairs <= avg_max && avg_max > 0) ba->schur_wave = 1;
+    }
     BH_TRY(bh_reserve(ctx, &ba->state, sizeof(ba_state)));
     if (ba->ar) {                                          // the band must be the same everywhere: max over ranks
         double v = (double)bwb;
@@ -4030,17 +4072,17 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
 {
     if (!b) return BH_ERR_INVALID;
     bh_ctx* ctx = b->ctx;
-    const int W = (int)b->win.size();
+    const int W = (int)b->win.size(), W8 = (W + 7) & ~7;          // grids are (blocks, windows rounded up to 8): see bb_where
     BH_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     std::vector<ba_view> hv(W);
     std::vector<int> hcur(W);
-    int g_lin = 1, g_pb = 1, g_schur = 1, g_upd = 1, g_eb = 1, any_part = 0;
+    int g_lin = 1, g_pb = 1, g_schur = 1, g_upd = 1, g_eb = 1, g_s64 = 0, any_part = 0;
     for (int w = 0; w < W; w++) {
         bh_ba* ba = b->win[w];
         if (!ba->have_problem) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_optimize: window %d has no problem set", w);
         if (ba->ar) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_optimize: window %d is a sharded (multi-GPU) problem", w);
-        if (ba->Cf > 0 && (!ba->chol_dense || ba->schur_wave))
+        if (ba->Cf > 0 && !ba->chol_dense)
             return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_optimize: window %d has %d free keyframes; the batch takes local windows (<= %d unknowns): use bh_ba_optimize", w, ba->Cf, 16 * CD_MAXT);
         ba_view& V = hv[w];
         memset(&V, 0, sizeof(V));
@@ -4053,7 +4095,8 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
         V.part = ba->Ea > 16384 ? (double*)ba->part.p : nullptr;              // the same two-stage sums as bh_ba_optimize
         V.pairs = (const int2*)ba->pairs.p; V.j_start = (const int*)ba->j_start.p; V.join = (const int2*)ba->join.p;
         V.state = (ba_state*)ba->state.p; V.hstate = b->hstates + w;
-        V.C = ba->C; V.Cf = ba->Cf; V.Pa = ba->Pa; V.Ea = ba->Ea; V.npairs = ba->npairs; V.bw = ba->bw; V.n6 = 6 * ba->Cf; V.K = ba->K;
+        V.C = ba->C; V.Cf = ba->Cf; V.Pa = ba->Pa; V.Ea = ba->Ea; V.npairs = ba->npairs; V.bw = ba->bw; V.n6 = 6 * ba->Cf; V.K = ba->K; V.pad = ba->schur_wave;
+        if (ba->schur_wave) g_s64 = std::max(g_s64, (ba->npairs + 7) / 8 * 8);
         hcur[w] = ba->cur;
         ba->log.clear(); ba->iters_done = 0;
         g_lin = std::max(g_lin, (ba->Pa * BP_G + 255) / 256 + ba->Cf);
@@ -4078,18 +4121,19 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
     int rc = BH_OK;
     for (int round = 0; active > 0 && round < iters * 10 + 2; round++) {
         if (need_lin) {
-            BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_bb_linearize, dim3(g_lin, W), dim3(256), st, views, huber_delta);
+            BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_bb_linearize, dim3(g_lin, W8), dim3(256), st, views, W, huber_delta);
             if (any_part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_partial, dim3(BA_NPART, W), dim3(1024), st, views, 0);
             BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_prep, dim3(1, W), dim3(1024), st, views);
         }
-        BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_dinv, dim3(g_pb, W), dim3(256), st, views);
-        BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_zeroS, dim3(8, W), dim3(256), st, views);
-        BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_schur, dim3(g_schur, W), dim3(256), st, views);
+        BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_dinv, dim3(g_pb, W8), dim3(256), st, views, W);
+        BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_zeroS, dim3(8, W8), dim3(256), st, views, W);
+        BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_schur, dim3(g_schur, W8), dim3(256), st, views, W);
+        if (g_s64) BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_schur64, dim3(g_s64, W8), dim3(64), st, views, W);
         bh_time_begin(ctx, BH_K_BA_SOLVE);
         hipLaunchKernelGGL(k_bb_chol, dim3(W), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, views);
         bh_time_end(ctx);
-        BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_bb_update, dim3(g_upd, W), dim3(256), st, views);
-        BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_bb_err, dim3(g_eb, W), dim3(256), st, views, huber_delta);
+        BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_bb_update, dim3(g_upd, W8), dim3(256), st, views, W);
+        BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_bb_err, dim3(g_eb, W8), dim3(256), st, views, W, huber_delta);
         if (any_part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_partial, dim3(BA_NPART, W), dim3(1024), st, views, 1);
         const int seq = ++b->seq;
         BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_decide, dim3(1, W), dim3(1024), st, views, seq);
