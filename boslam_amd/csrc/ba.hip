@@ -167,16 +167,67 @@ __device__ __forceinline__ double d_wave_sum(double v)
     return v;
 }
 
+// value of lane ^ M (M = 8, 4, 2, 1) on the vector ALU: DPP row rotate / two bank-masked row shifts / quad permutes
+template <int M> __device__ __forceinline__ int i_xor_dpp(int x)
+{
+    if constexpr (M == 8) return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);                       // row_ror:8
+    else if constexpr (M == 4) { const int t = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);          // row_shl:4 into banks 0, 2
+                                 return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false); }               // row_shr:4 into banks 1, 3
+    else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4e, 0xf, 0xf, false);                    // quad_perm [2,3,0,1]
+    else return __builtin_amdgcn_update_dpp(0, x, 0xb1, 0xf, 0xf, false);                                          // quad_perm [1,0,3,2]
+}
+template <int M> __device__ __forceinline__ double d_xor_dpp(double v)
+{
+    return __hiloint2double(i_xor_dpp<M>(__double2hiint(v)), i_xor_dpp<M>(__double2loint(v)));
+}
+// Wave sums of NV values per lane as a REDUCE-SCATTER: the pairs are those of d_wave_sum's xor butterfly (32, 16, 8, 4, 2, 1), so every
+// sum is the one d_wave_sum gives bit for bit (an IEEE addition commutes), but the first two steps halve the number of values a
+// lane carries - gfx950's v_permlane32_swap / v_permlane16_swap exchange the halves the partner keeps in ONE instruction - and
+// the last four run on DPP.  36 values: 207 vector instructions and no LDS traffic where 36 butterflies were 432 ds_bpermutes plus as
+// many address and add instructions.  Afterwards v[i], i < N2, of a lane in 16-lane row q is value i + N2 (q & 1) + N1 (q >> 1)
+// (N1 = ceil(NV / 2), N2 = ceil(N1 / 2); combinations that run past N1 / NV are padding).
+template <int NV> __device__ __forceinline__ void d_wave_sum_rs(double* v)
+{
+    constexpr int N1 = (NV + 1) / 2, N2 = (N1 + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < N1; i++) {
+        int alo = __double2loint(v[i]), ahi = __double2hiint(v[i]);
+        int blo = i + N1 < NV ? __double2loint(v[i + N1]) : 0, bhi = i + N1 < NV ? __double2hiint(v[i + N1]) : 0;
+        const auto rl = __builtin_amdgcn_permlane32_swap(alo, blo, false, false), rh = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        v[i] = __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < N2; i++) {
+        int alo = __double2loint(v[i]), ahi = __double2hiint(v[i]);
+        int blo = i + N2 < N1 ? __double2loint(v[i + N2]) : 0, bhi = i + N2 < N1 ? __double2hiint(v[i + N2]) : 0;
+        const auto rl = __builtin_amdgcn_permlane16_swap(alo, blo, false, false), rh = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        v[i] = __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < N2; i++) { v[i] += d_xor_dpp<8>(v[i]); v[i] += d_xor_dpp<4>(v[i]); v[i] += d_xor_dpp<2>(v[i]); v[i] += d_xor_dpp<1>(v[i]); }
+}
+// the four lanes 0, 16, 32, 48 of a wave store what d_wave_sum_rs left them: out[value index] (NV doubles)
+template <int NV> __device__ __forceinline__ void d_wave_sum_rs_store(const double* v, double* out)
+{
+    constexpr int N1 = (NV + 1) / 2, N2 = (N1 + 1) / 2;
+    const int lane = threadIdx.x & 63, q = lane >> 4;
+    if (lane & 15) return;
+#pragma unroll
+    for (int i = 0; i < N2; i++) {
+        const int sub = i + N2 * (q & 1), idx = sub + N1 * (q >> 1);
+        if (sub < N1 && idx < NV) out[idx] = v[i];
+    }
+}
+
 // block-wide sum of NV doubles per thread, fixed order; result valid in every thread.  s_red: [NV * nwaves] doubles.
 template <int NV, int NT>
 __device__ void d_block_sum(double* v, double* s_red)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wv = threadIdx.x >> 6;
     constexpr int NW = NT / 64;
-#pragma unroll
-    for (int i = 0; i < NV; i++) v[i] = d_wave_sum(v[i]);
+    d_wave_sum_rs<NV>(v);
     __syncthreads();
-    if (lane == 0) for (int i = 0; i < NV; i++) s_red[wv * NV + i] = v[i];
+    d_wave_sum_rs_store<NV>(v, s_red + wv * NV);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; i++) { double s = 0; for (int w = 0; w < NW; w++) s += s_red[w * NV + i]; v[i] = s; }
@@ -672,12 +723,8 @@ __device__ __forceinline__ void ba_schur_S_body(const int bid, const int ngrid, 
     } else {
         // wave sums, then thread e < 36 adds the waves' partials of element e in wave order (same order as d_block_sum; reading the
         // result as acc[tid] would index the accumulator array dynamically and move all 36 accumulators to scratch memory)
-#pragma unroll
-        for (int i = 0; i < 36; i++) acc[i] = d_wave_sum(acc[i]);
-        if ((tid & 63) == 0) {
-#pragma unroll
-            for (int i = 0; i < 36; i++) s_red[(tid >> 6) * 36 + i] = acc[i];
-        }
+        d_wave_sum_rs<36>(acc);
+        d_wave_sum_rs_store<36>(acc, s_red + (tid >> 6) * 36);
         __syncthreads();
         if (tid < 36)
             for (int w = 0; w < NT / 64; w++) v += s_red[w * 36 + tid];
