@@ -160,13 +160,6 @@ __device__ __forceinline__ double d_readlane(double v, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-__device__ __forceinline__ double d_wave_sum(double v)
-{
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += d_shfl_xor(v, m);
-    return v;
-}
-
 // value of lane ^ M (M = 8, 4, 2, 1) on the vector ALU: DPP row rotate / two bank-masked row shifts / quad permutes
 template <int M> __device__ __forceinline__ int i_xor_dpp(int x)
 {
@@ -180,6 +173,27 @@ template <int M> __device__ __forceinline__ double d_xor_dpp(double v)
 {
     return __hiloint2double(i_xor_dpp<M>(__double2hiint(v)), i_xor_dpp<M>(__double2loint(v)));
 }
+// value of lane ^ 32 / lane ^ 16 by one v_permlane32_swap / v_permlane16_swap of two copies (instead of a ds_bpermute and its address)
+template <int M> __device__ __forceinline__ double d_xor_swap(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (M == 32) {
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        const int lane = threadIdx.x & 63;
+        return lane < 32 ? __hiloint2double(rh[1], rl[1]) : __hiloint2double(rh[0], rl[0]);
+    } else {
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const int lane = threadIdx.x & 63;
+        return (lane & 16) ? __hiloint2double(rh[0], rl[0]) : __hiloint2double(rh[1], rl[1]);
+    }
+}
+__device__ __forceinline__ double d_wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += d_shfl_xor(v, m);
+    return v;
+}
+
 // Wave sums of NV values per lane as a REDUCE-SCATTER: the pairs are those of d_wave_sum's xor butterfly (32, 16, 8, 4, 2, 1), so every
 // sum is the one d_wave_sum gives bit for bit (an IEEE addition commutes), but the first two steps halve the number of values a
 // lane carries - gfx950's v_permlane32_swap / v_permlane16_swap exchange the halves the partner keeps in ONE instruction - and
@@ -496,7 +510,7 @@ __device__ __forceinline__ void ba_point_body(int bid, const ba_cam* __restrict_
         }
     }
 #pragma unroll
-    for (int i = 0; i < 9; i++) { acc[i] += d_shfl_xor(acc[i], 1); acc[i] += d_shfl_xor(acc[i], 2); acc[i] += d_shfl_xor(acc[i], 4); }
+    for (int i = 0; i < 9; i++) { acc[i] += d_xor_dpp<1>(acc[i]); acc[i] += d_xor_dpp<2>(acc[i]); acc[i] += d_xor_dpp<4>(acc[i]); }      // (DPP: 54 ds_bpermutes per wave before)
     if (live && sub == 0) {
         double* H = Hll + 9 * (size_t)j;
         H[0] = acc[0]; H[1] = acc[1]; H[2] = acc[2]; H[3] = acc[1]; H[4] = acc[3]; H[5] = acc[4]; H[6] = acc[2]; H[7] = acc[4]; H[8] = acc[5];
@@ -1212,7 +1226,7 @@ __device__ __forceinline__ void ba_chol_dense_body(const double* __restrict__ A_
                     double v = 0.0;
 #pragma unroll
                     for (int rg = 0; rg < 4; rg++) v = __builtin_fma(Tl[k][rg], sx[16 * i + r0 + 4 * rg], v);      // column `col`, my 4 rows
-                    v += d_shfl_xor(v, 16); v += d_shfl_xor(v, 32);                                               // the other 12 rows
+                    v += d_xor_swap<16>(v); v += d_xor_swap<32>(v);                                               // the other 12 rows
                     if (lane < 16) spart[i * 16 + col] = v;
                 }
                 __syncthreads();
@@ -1633,7 +1647,7 @@ __device__ __forceinline__ void sw_body(double* __restrict__ sm, double* __restr
             double t = 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) t += part[(8 * r0 + i) * 16 + col];
-            t += d_shfl_xor(t, 16); t += d_shfl_xor(t, 32);
+            t += d_xor_swap<16>(t); t += d_xor_swap<32>(t);
             double yl = d_shfl_idx(ycur, col) - t;               // ycur lives in lanes 0..15 of wave 0
             const double myinv = 1.0 / Lc[col * SW_P + col];
 #pragma unroll
@@ -1895,7 +1909,7 @@ __global__ __launch_bounds__(256) void k_bcr_update(const bcr_work* __restrict__
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) red[((wv * 4 + t) * 4 + rg) * 64 + lane] = acc[t][rg];
     if (do_g) {
-        g0 += d_shfl_xor(g0, 16); g0 += d_shfl_xor(g0, 32); g1 += d_shfl_xor(g1, 16); g1 += d_shfl_xor(g1, 32);
+        g0 += d_xor_swap<16>(g0); g0 += d_xor_swap<32>(g0); g1 += d_xor_swap<16>(g1); g1 += d_xor_swap<32>(g1);
         if (lane < 16) { gred[wv][0][col] = g0; gred[wv][1][col] = g1; }
     }
     __syncthreads();
