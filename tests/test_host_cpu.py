@@ -189,9 +189,9 @@ def test_two_rank_gloo_sharded_matching_equals_single_process(tmp_path):
 
 
 def test_committed_bench_line_meets_the_contract():
-    """profiles/r02_bench.json is the JSON line bench.py printed on the MI355X; check the measurement contract's fields."""
+    """profiles/r03_bench.json is the JSON line bench.py printed on the MI355X; check the measurement contract's fields."""
     import json
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench.json")).read().strip().splitlines()[-1])
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                  ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
                  ("cpu_baseline", dict)):
@@ -210,6 +210,10 @@ def test_committed_bench_line_meets_the_contract():
     assert set(d["inputs"]) == {"low_texture", "high_corner_density"}
     b = d["bow_query"]["roofline"]
     assert b["frac"] < 0.79 and b["survey_bytes_per_query"] == 3 * (b["bytes_per_query"] - 16 * 100000)   # streamed-bytes fraction stays physical
+    assert d["bow_query"]["paths_agree_bitwise"] is True and d["bow_query"]["ms_per_query"] < d["bow_query"]["scan_ms_per_query"]
+    lb = d["local_ba"]["batched"]
+    assert lb["live_windows"]["windows"] == 64 and lb["live_windows"]["speedup_vs_one_at_a_time"] > 10
+    assert d["tracking"]["device_resident_chain"]["tracked_pairs"] > 900
     assert abs(d["value"] - 1000 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-3
 
 

@@ -13,7 +13,7 @@ ctx = Context(0)
 rng = np.random.default_rng(int(time.time()) & 0xffff)
 bgr_all, depth_all = synth.render_batch(4)
 t_end = time.time() + budget
-n_fe = n_m = n_b = n_p = n_po = n_lb = n_cap = 0
+n_fe = n_m = n_b = n_p = n_po = n_lb = n_cap = n_bs = 0
 K4 = np.array([synth.FX, synth.FY, synth.CX, synth.CY])
 
 
@@ -127,4 +127,29 @@ while time.time() < t_end:
         if not (done == o["iters_done"] and np.array_equal(lg[:, 2:], o["log"][:, 2:]) and rel(Rb, o["R"]) < 1e-4 and rel(tb, o["t"]) < 1e-4 and rel(pb, o["pts"]) < 1e-4):
             print("LOCAL BA MISMATCH", len(pr["fixed"]), len(pr["pts"])); sys.exit(1)
         n_lb += 1
-print(f"fuzz ok: {n_fe} front-end cases, {n_m} matcher cases, {n_b} solver cases, {n_p} PnP problems, {n_po} pose-only BA problems, {n_lb} local BA problems; {n_cap} noise cases stopped by the documented candidate capacity")
+        # ---- problem structure: the one-workgroup builder (tier 1 / tier 2) against the chip-wide one, with duplicate observations, a
+        # shuffled edge list, unused vertices and a random set of fixed keyframes
+        nk = int(rng.integers(3, 40)); npnt = int(rng.integers(30, 3000))
+        pr = synth.ba_problem(n_kf=nk, n_pts=npnt, seed=int(rng.integers(0, 1 << 30)))
+        ecam, ept, meas = pr["ecam"], pr["ept"], pr["meas"]
+        nd = int(rng.integers(0, 60))
+        if nd:
+            d = rng.integers(0, len(ecam), nd)
+            ecam = np.concatenate([ecam, ecam[d]]); ept = np.concatenate([ept, ept[d]]); meas = np.concatenate([meas, meas[d] + rng.normal(0, 0.2, (nd, 2))])
+        keep = rng.random(len(ecam)) > rng.random() * 0.3
+        sh = rng.permutation(int(keep.sum()))
+        ecam = np.ascontiguousarray(ecam[keep][sh]); ept = np.ascontiguousarray(ept[keep][sh]); meas = np.ascontiguousarray(meas[keep][sh])
+        fixed = (rng.random(nk) < rng.random() * 0.7).astype(np.uint8); fixed[0] = 1
+        sts = []
+        for mode in (None, "general"):
+            if mode:
+                os.environ["BH_BA_BUILD"] = mode
+            else:
+                os.environ.pop("BH_BA_BUILD", None)
+            sb = ba.LocalBA(ctx, pr["K"]); sb.set_problem(pr["R"], pr["t"], fixed, pr["pts"], ecam, ept, meas)
+            sts.append(sb.structure()); sb.close()
+        os.environ.pop("BH_BA_BUILD", None)
+        if not all(np.array_equal(sts[0][k], sts[1][k]) for k in sts[0]):
+            print("BUILDER MISMATCH", nk, npnt, len(ecam), [k for k in sts[0] if not np.array_equal(sts[0][k], sts[1][k])]); sys.exit(1)
+        n_bs += 1
+print(f"fuzz ok: {n_fe} front-end cases, {n_m} matcher cases, {n_b} solver cases, {n_p} PnP problems, {n_po} pose-only BA problems, {n_lb} local BA problems, {n_bs} problem structures (one-workgroup vs chip-wide builder); {n_cap} noise cases stopped by the documented candidate capacity")
