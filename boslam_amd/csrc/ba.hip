@@ -3708,6 +3708,7 @@ extern "C" int bh_ba_set_problem(bh_ba* ba, int C, const double* R, const double
     const char* bmode = getenv("BH_BA_BUILD");
     const bool host_build = bmode && !strcmp(bmode, "host");
     if (ba->ar && E == 0) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: a rank of a sharded problem needs at least one edge");
+    ba->have_problem = 0;                                    // an error below leaves no half-built problem behind
     int small = 0;                                           // local windows: one workgroup builds the structure (BH_BA_BUILD=general: the chip-wide builder)
     ba_build_out bo = {};
     if (!host_build && !(bmode && !strcmp(bmode, "general"))) {
@@ -3914,6 +3915,7 @@ extern "C" int bh_ba_batch_set_problems(bh_ctx* ctx, int W, bh_ba* const* window
         if (windows[w]->ar && q.E == 0) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: a rank of a sharded problem needs at least one edge");
     }
     BH_HIP(ctx, hipSetDevice(ctx->device));
+    for (int w = 0; w < W; w++) windows[w]->have_problem = 0;         // an error below leaves no half-built window behind
     const char* bmode = getenv("BH_BA_BUILD");
     const bool host_build = bmode && !strcmp(bmode, "host");
     std::vector<ba_build_out> bo(W);

@@ -332,3 +332,30 @@ def test_batched_windows_equal_single_window_runs_bitwise(ctx):
     with pytest.raises(Exception, match="local windows"):
         batch.optimize(2)
     batch.close(); s.close()
+
+
+def test_set_problems_mixed_windows_and_errors(ctx):
+    """bh_ba_batch_set_problems with every kind of window in one call: a live window (one-workgroup builder, LDS), a configs[2] window
+    (the same steps as grid-wide kernels), a 300-keyframe sequence (chip-wide builder: more than 64 free keyframes) and an empty one;
+    each must come out as bh_ba_set_problem builds it.  A bad edge in any window fails the call and leaves no window half-built."""
+    probs = [synth.ba_problem(n_kf=10, n_pts=600, seed=21), synth.ba_problem(n_kf=50, n_pts=10000, seed=7),
+             synth.ba_problem_sequence(n_kf=300, n_pts=9000, window=6, seed=3), synth.ba_problem(n_kf=4, n_pts=30, seed=5)]
+    args = [(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"]) for pr in probs]
+    args.append((probs[3]["R"], probs[3]["t"], probs[3]["fixed"], probs[3]["pts"], probs[3]["ecam"][:0], probs[3]["ept"][:0], probs[3]["meas"][:0]))
+    wins = [ba.LocalBA(ctx, probs[0]["K"]) for _ in args]
+    ba.set_problems(ctx, wins, args)
+    for a, s in zip(args, wins):
+        one = ba.LocalBA(ctx, probs[0]["K"])
+        one.set_problem(*a)
+        sa, sb = one.structure(), s.structure()
+        assert all(np.array_equal(sa[k], sb[k]) for k in sa)
+        d1, d2 = one.optimize(3), s.optimize(3)
+        assert d1 == d2 and np.array_equal(one.log()[:d1], s.log()[:d2]) and np.array_equal(one.poses()[1], s.poses()[1])
+        one.close()
+    bad = list(args[0]); e = bad[4].copy(); e[17] = 99; bad[4] = e
+    with pytest.raises(RuntimeError, match="edge 17"):
+        ba.set_problems(ctx, wins[:2], [args[1], tuple(bad)])
+    with pytest.raises(RuntimeError, match="no problem"):
+        wins[0].optimize(1)
+    for s in wins:
+        s.close()
