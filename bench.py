@@ -383,6 +383,37 @@ def run_rank(args):
                                           "tracked_pairs": int((st == 0).sum()), "pairs": int(len(st)),
                                           "mean_matches": float(trk.n_match[1:].float().mean().item()), "mean_inliers": float(trk.n_inlier[1:].float().mean().item())}
             del trk
+            if rank == 0:
+                # the reference's live use: ONE frame per call from HOST memory at camera rate (camera.py:141, slam/tracking.py:54-89), results
+                # back on the host - ORB, back-projection and the tracking step against the previous frame; latency, not throughput
+                from boslam_amd import tracking
+                himg = bgr[:2].cpu().numpy(); hdep = depth[:2].cpu().numpy()
+                prev, lat = None, []
+                for rep in range(24):
+                    k = rep & 1
+                    t0 = time.perf_counter()
+                    kps, desc, nk = frontend.orb_detect_describe(ctx, himg[k][None], depth=hdep[k][None], params=params)
+                    xy, cloud = frontend.kp_backproject(ctx, kps, nk, hdep[k][None], K5[0], K5[1], K5[2], K5[3])
+                    o = tracking.track_refkf(ctx, desc, nk, xy, prev[0], prev[1], prev[2], K5) if prev is not None else None
+                    lat.append(time.perf_counter() - t0)
+                    prev = (desc, nk, cloud)
+                lt = frontend.LiveTracker(ctx, 480, 640, params, K5, torch_device=dev)      # the same loop with the previous frame kept on the device
+                lat2, o2 = [], None
+                for rep in range(24):
+                    t0 = time.perf_counter()
+                    o2 = lt.step(himg[rep & 1], hdep[rep & 1])
+                    if o2 is None:
+                        ctx.synchronize()
+                    lat2.append(time.perf_counter() - t0)
+                lt.close()
+                r["live_single_frame_device_state"] = {"ms_per_frame": round(float(np.median(lat2[4:])) * 1e3, 3), "frames_per_s": round(1.0 / float(np.median(lat2[4:])), 1),
+                                                       "status_last": o2["status"], "n_inlier_last": o2["n_inlier"],
+                                                       "stages": "frontend.LiveTracker: one pinned H2D of the frame, ORB + back-projection + bh_track_refkf against the previous "
+                                                                 "frame's descriptors / cloud kept in HBM, one 112-B verdict back"}
+                r["live_single_frame"] = {"ms_per_frame": round(float(np.median(lat[4:])) * 1e3, 3), "frames_per_s": round(1.0 / float(np.median(lat[4:])), 1),
+                                          "status_last": int(o["status"][0]), "n_inlier_last": int(o["n_inlier"][0]),
+                                          "stages": "host frame (1.5 MB over PCIe) -> ORB -> kp_arr + cloud_kp -> match vs previous frame -> CamOnlyBA -> verdict, "
+                                                    "everything back on the host; three synchronous C-ABI calls per frame"}
             return r
         for name, fn in (("local_ba", local_ba), ("tracking", tracking_stage)):
             stage["name"] = name

@@ -221,6 +221,66 @@ class DeviceTracker:
                                         self.desc.data_ptr(), self.n_kp.data_ptr(), self.cloud.data_ptr(), m, self.B - 1, self.K, out, m)
 
 
+class LiveTracker:
+    """The reference's live loop, one frame per call (camera.py:131-168 -> slam/tracking.py:54-89): the frame goes up once (pinned staging),
+    ORB + back-projection + the tracking step against the PREVIOUS frame's descriptors / cloud (kept on the device, two slots) run on
+    the context's stream, and only the verdict comes back: (status, R, t, n_match, n_inlier).  Nothing else crosses PCIe."""
+
+    def __init__(self, ctx, H, W, params, K, max_kp=None, torch_device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.ctx, self.H, self.W, self.params = ctx, H, W, params
+        self.K = np.ascontiguousarray(K, dtype=np.float64)
+        self.max_kp = m = max_kp or default_max_kp(params)
+        dev = torch_device
+        self.h_bgr = torch.zeros((1, H, W, 3), dtype=torch.uint8).pin_memory(); self.h_depth = torch.zeros((1, H, W), dtype=torch.uint16).pin_memory()
+        self.d_bgr = torch.zeros((1, H, W, 3), dtype=torch.uint8, device=dev); self.d_depth = torch.zeros((1, H, W), dtype=torch.uint16, device=dev)
+        self.kps = torch.zeros((2, m, 6), dtype=torch.float32, device=dev); self.desc = torch.zeros((2, m, 32), dtype=torch.uint8, device=dev)
+        self.n_kp = torch.zeros((2,), dtype=torch.int32, device=dev)
+        self.kp_xy = torch.zeros((2, m, 2), dtype=torch.int64, device=dev); self.cloud = torch.zeros((2, m, 3), dtype=torch.float64, device=dev)
+        self.qidx = torch.zeros((m,), dtype=torch.int32, device=dev); self.tidx = torch.zeros_like(self.qidx); self.dist = torch.zeros_like(self.qidx)
+        self.inlier = torch.zeros((m,), dtype=torch.uint8, device=dev)
+        # verdict block: [status, n_match, n_inlier, pad] as int32 + R (9) + t (3) as float64, fetched with one copy
+        self.verdict = torch.zeros((14,), dtype=torch.float64, device=dev); self.h_verdict = torch.zeros((14,), dtype=torch.float64).pin_memory()
+        self.slot, self.have_prev = 0, False
+        self.stream = torch.cuda.Stream(device=dev)             # ONE stream orders the staging copies and the library's kernels: the library adopts it
+        ctx.set_stream(self.stream.cuda_stream)
+
+    def close(self):
+        if self.stream is not None:
+            self.ctx.synchronize(); self.ctx.set_stream(None); self.stream = None
+
+    def step(self, bgr, depth):
+        """bgr u8[H][W][3], depth u16[H][W] numpy arrays -> dict(status, R, t, n_match, n_inlier) or None for the first frame."""
+        from . import tracking
+        torch, L, c, m = self.torch, _lib.lib(), self.ctx, self.max_kp
+        self.h_bgr[0].numpy()[...] = bgr; self.h_depth[0].numpy()[...] = depth
+        with torch.cuda.stream(self.stream):
+            self.d_bgr.copy_(self.h_bgr, non_blocking=True); self.d_depth.copy_(self.h_depth, non_blocking=True)
+        k, p = self.slot, self.slot ^ 1
+        c.check(L.bh_orb_detect_describe(c.h, _lib.ptr(self.d_bgr), 3, None, _lib.ptr(self.d_depth), 1, self.H, self.W, C.byref(self.params), m,
+                                         C.c_void_p(self.kps.data_ptr() + 24 * m * k), C.c_void_p(self.desc.data_ptr() + 32 * m * k),
+                                         C.c_void_p(self.n_kp.data_ptr() + 4 * k), BH_MEM_DEVICE))
+        c.check(L.bh_kp_backproject(c.h, C.c_void_p(self.kps.data_ptr() + 24 * m * k), C.c_void_p(self.n_kp.data_ptr() + 4 * k), _lib.ptr(self.d_depth), 1,
+                                    self.H, self.W, m, float(self.K[0]), float(self.K[1]), float(self.K[2]), float(self.K[3]),
+                                    C.c_void_p(self.kp_xy.data_ptr() + 16 * m * k), C.c_void_p(self.cloud.data_ptr() + 24 * m * k), BH_MEM_DEVICE))
+        res = None
+        if self.have_prev:
+            v = self.verdict.data_ptr()
+            out = dict(qidx=self.qidx.data_ptr(), tidx=self.tidx.data_ptr(), dist=self.dist.data_ptr(), n_match=v + 4, R=v + 16, t=v + 88,
+                       inlier=self.inlier.data_ptr(), n_inlier=v + 8, status=v)
+            tracking.track_refkf_device(c, self.desc.data_ptr() + 32 * m * k, self.n_kp.data_ptr() + 4 * k, self.kp_xy.data_ptr() + 16 * m * k, m,
+                                        self.desc.data_ptr() + 32 * m * p, self.n_kp.data_ptr() + 4 * p, self.cloud.data_ptr() + 24 * m * p, m, 1, self.K, out, m)
+            with torch.cuda.stream(self.stream):
+                self.h_verdict.copy_(self.verdict, non_blocking=True)
+            c.synchronize()
+            hv = self.h_verdict.numpy()
+            iv = hv[:2].view(np.int32)
+            res = dict(status=int(iv[0]), n_match=int(iv[1]), n_inlier=int(iv[2]), R=hv[2:11].reshape(3, 3).copy(), t=hv[11:14].copy())
+        self.slot, self.have_prev = p, True
+        return res
+
+
 def medoid_descriptors(ctx, desc, k):
     """MapPoint.add_observation's medoid choice (slam/nodes.py:142-154) for a batch: desc u8[M][10][32], k int[M] -> idx int[M]."""
     desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 10, 32)

@@ -73,3 +73,33 @@ def test_track_refkf_verdicts_and_edge_cases(ctx):
     c = tracking.track_refkf(ctx, p["q_desc"], p["nq"], p["q_xy"], p["t_desc"], p["nt"], p["t_pts"], p["K"], inclusive=True)
     _check(p, a, 30, False); _check(p, c, 30, True)
     assert c["n_match"][5] > a["n_match"][5] and (c["dist"][5, :c["n_match"][5]] == 30).any() and not (a["dist"][5, :a["n_match"][5]] == 30).any()
+
+
+def test_live_tracker_equals_the_host_staged_calls(ctx):
+    """frontend.LiveTracker (one frame per call, previous frame's descriptors / cloud kept on the device, one verdict back) against the
+    three host-mode entry points called one after the other on the same rendered frames: same verdict, same pose, bit for bit."""
+    torch = pytest.importorskip("torch")
+    from boslam_amd import frontend
+    bgr, depth = synth.render_batch(5)
+    params = frontend.make_params(nfeatures=600)
+    K = np.array([synth.FX, synth.FY, synth.CX, synth.CY, 0.06])
+    lt = frontend.LiveTracker(ctx, bgr.shape[1], bgr.shape[2], params, K)
+    prev = None
+    try:
+        for i in range(len(bgr)):
+            got = lt.step(bgr[i], depth[i])
+            ctx.synchronize()
+            assert (got is None) == (i == 0)
+            if got is not None:
+                kps, desc, nk = frontend.orb_detect_describe(ctx, bgr[i][None], depth=depth[i][None], params=params)
+                xy, cloud = frontend.kp_backproject(ctx, kps, nk, depth[i][None], K[0], K[1], K[2], K[3])
+                ref = tracking.track_refkf(ctx, desc, nk, xy, prev[0], prev[1], prev[2], K)
+                assert got["status"] == int(ref["status"][0]) and got["n_match"] == int(ref["n_match"][0]) and got["n_inlier"] == int(ref["n_inlier"][0])
+                assert np.array_equal(got["R"], ref["R"][0]) and np.array_equal(got["t"], ref["t"][0])
+                prev = (desc, nk, cloud)
+            else:
+                kps, desc, nk = frontend.orb_detect_describe(ctx, bgr[i][None], depth=depth[i][None], params=params)
+                xy, cloud = frontend.kp_backproject(ctx, kps, nk, depth[i][None], K[0], K[1], K[2], K[3])
+                prev = (desc, nk, cloud)
+    finally:
+        lt.close()
