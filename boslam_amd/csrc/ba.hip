@@ -667,10 +667,14 @@ __device__ __forceinline__ void ba_dinv_body(int bid, const double* __restrict__
 #pragma unroll
     for (int a = 0; a < 3; a++) db[3 * j + a] = Di[3 * a] * bl[3 * j] + Di[3 * a + 1] * bl[3 * j + 1] + Di[3 * a + 2] * bl[3 * j + 2];
 }
+// (the workgroups behind the landmarks clear the reduced camera system of a local window: one launch less per trial than a memset)
 __global__ __launch_bounds__(256) void k_ba_dinv(const double* __restrict__ Hll, const double* __restrict__ bl, int Pa,
-                                                 ba_state* __restrict__ S, double* __restrict__ Dinv, double* __restrict__ db)
+                                                 ba_state* __restrict__ S, double* __restrict__ Dinv, double* __restrict__ db,
+                                                 int pblocks, double* __restrict__ Sm, long long nS)
 {
-    ba_dinv_body(blockIdx.x, Hll, bl, Pa, S, Dinv, db);
+    if ((int)blockIdx.x < pblocks) { ba_dinv_body(blockIdx.x, Hll, bl, Pa, S, Dinv, db); return; }
+    const long long step = (long long)((int)gridDim.x - pblocks) * 256;
+    for (long long i = (long long)((int)blockIdx.x - pblocks) * 256 + threadIdx.x; i < nS; i += step) Sm[i] = 0.0;
 }
 
 // ---- k_ba_schur_S: workgroup per camera pair (s1 <= s2): S[s1][s2] = [s1==s2](Hpp + lambda I) - sum_j Hpl_1j Dinv_j Hpl_2j'
@@ -2432,17 +2436,15 @@ __global__ __launch_bounds__(256) void k_bb_dinv(const ba_view* __restrict__ vie
     int w, bx;
     if (!bb_where(W, w, bx)) return;
     const ba_view& V = views[w];
-    if (V.state->b_done || bx * 256 >= V.Pa) return;
-    ba_dinv_body(bx, V.Hll, V.bl, V.Pa, V.state, V.Dinv, V.db);
-}
-__global__ __launch_bounds__(256) void k_bb_zeroS(const ba_view* __restrict__ views, int W)
-{
-    int w, bx;
-    if (!bb_where(W, w, bx)) return;
-    const ba_view& V = views[w];
     if (V.state->b_done) return;
-    const size_t n = (size_t)V.n6 * (V.bw + 1);
-    for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) V.S[i] = 0.0;
+    const int pb = (int)gridDim.x - 8;                           // the last 8 workgroups of a window clear its reduced camera system (was k_bb_zeroS)
+    if (bx >= pb) {
+        const size_t n = (size_t)V.n6 * (V.bw + 1);
+        for (size_t i = (size_t)(bx - pb) * 256 + threadIdx.x; i < n; i += 8 * 256) V.S[i] = 0.0;
+        return;
+    }
+    if (bx * 256 >= V.Pa) return;
+    ba_dinv_body(bx, V.Hll, V.bl, V.Pa, V.state, V.Dinv, V.db);
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_bb_schur(const ba_view* __restrict__ views, int W)
 {
@@ -4017,11 +4019,14 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
         ba->last_err_sel = 0;
         do {
             ba_cam* cams_t = (ba_cam*)ba->cams[ba->cur ^ 1].p; double* pts_t = (double*)ba->pts[ba->cur ^ 1].p;
-            BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_dinv, dim3(pblocks), dim3(256), st, (const double*)Hll, (const double*)bl, Pa, state, Dinv, db);
+            const bool zero_in_dinv = Cf > 0 && ba->chol_dense && !dist;      // a local window: S is cleared by extra workgroups of k_ba_dinv
+            const long long nS0 = zero_in_dinv ? (long long)n6 * (ba->bw + 1) : 0;
+            BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_dinv, dim3(pblocks + (zero_in_dinv ? 32 : 0)), dim3(256), st, (const double*)Hll, (const double*)bl, Pa, state, Dinv, db,
+                      pblocks, S, nS0);
             if (Cf) {
                 const bool dsolve = dist && ba->dsol && ba->dsol->active;
                 const size_t s_rows = dsolve ? 256 * (size_t)ba->dsol->seg * ba->world : (size_t)n6;       // sharded solve: equal row chunks per rank
-                BH_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double) * s_rows * (ba->bw + 1), st));     // blocks without a common point stay zero
+                if (!zero_in_dinv) BH_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double) * s_rows * (ba->bw + 1), st));     // blocks without a common point stay zero
                 if (ba->schur_wave)
                     BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<64>), dim3((ba->npairs + 7) / 8 * 8), dim3(64), st, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
                               (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S, ba->npairs);
@@ -4188,8 +4193,7 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
             if (any_part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_partial, dim3(BA_NPART, W), dim3(1024), st, views, 0);
             BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_prep, dim3(1, W), dim3(1024), st, views);
         }
-        BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_dinv, dim3(g_pb, W8), dim3(256), st, views, W);
-        BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_zeroS, dim3(8, W8), dim3(256), st, views, W);
+        BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_dinv, dim3(g_pb + 8, W8), dim3(256), st, views, W);
         BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_schur, dim3(g_schur, W8), dim3(256), st, views, W);
         if (g_s64) BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_schur64, dim3(g_s64, W8), dim3(64), st, views, W);
         bh_time_begin(ctx, BH_K_BA_SOLVE);
