@@ -22,3 +22,28 @@ def loop_candidate_detection(dbow, kf, exclude_frame_ids=(), min_score=0.0):
     if fid is None or score < min_score:
         return None, None
     return fid, score
+
+
+def similarity_transformation(ctx, kf, cand, d_hamming_max=30, iterations=200, inlier_thr=0.05, min_matches=15, min_inliers=15):
+    """GlobalMapManager._similiarity_transformation (slam/loop_closing.py:17-19: `-> (R, t)`, body `pass`): "R, t that transforms start of
+    the loop with the end".  kf, cand: objects with .des (u8[N][32]) and .cloud_kp (f64[N][3], the back-projected keypoints of
+    camera.py:90-118) - the current keyframe and the loop candidate loop_candidate_detection returned.  Their descriptors are matched as
+    the tracker matches them (cross-check, `distance < d_hamming_max`, slam/tracking.py:56-57), the matched 3-D points are aligned by
+    bh_align_se3_ransac: cloud_kf ~ R cloud_cand + t.  Returns (R, t, n_inliers) or (None, None, 0) - too few matches / no consistent
+    alignment (a false BoW candidate)."""
+    import numpy as np
+    from . import frontend, align
+    qd = np.ascontiguousarray(kf.des, dtype=np.uint8).reshape(-1, 32); td = np.ascontiguousarray(cand.des, dtype=np.uint8).reshape(-1, 32)
+    if len(qd) == 0 or len(td) == 0:
+        return None, None, 0
+    qi, ti, d, nm = frontend.match_pairs(ctx, qd[None], [len(qd)], td[None], [len(td)])
+    k = int(nm[0])
+    keep = d[0, :k] < d_hamming_max
+    qi, ti = qi[0, :k][keep], ti[0, :k][keep]
+    if len(qi) < min_matches:
+        return None, None, 0
+    P = np.asarray(cand.cloud_kp, dtype=np.float64).reshape(-1, 3)[ti]; Q = np.asarray(kf.cloud_kp, dtype=np.float64).reshape(-1, 3)[qi]
+    o = align.align_se3_ransac_batch(ctx, P[None], Q[None], iterations=iterations, inlier_thr=inlier_thr, min_inliers=min_inliers)
+    if o["status"][0] != align.ALIGN_OK:
+        return None, None, int(o["n_inlier"][0])
+    return o["R"][0], o["t"][0], int(o["n_inlier"][0])

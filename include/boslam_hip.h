@@ -155,6 +155,22 @@ int bh_track_refkf(bh_ctx* ctx, const uint8_t* q_desc, const int* nq, const int6
                    int* qidx, int* tidx, int* dist, int* n_match, double* R, double* t, uint8_t* inlier, int* n_inlier,
                    int* status, int out_stride, int mem);
 
+/* ---- loop-closure verification: rigid alignment of matched 3-D points ---------------------------------------------------
+ * The stage slam/loop_closing.py:17-19 declares - GlobalMapManager._similiarity_transformation(self) -> (R, t), "R, t that
+ * transforms start of the loop with the end" - and leaves as `pass`.  No reference behaviour exists; the
+ * algorithm is specified here: for B independent problems, pairs (p_i, q_i) - e.g. cloud_kp of the loop candidate and of the
+ * current keyframe at the indices of their descriptor matches - find R, t with q ~ R p + t by RANSAC over 3-point minimal sets
+ * (cv::RNG((uint64)-1) sampling stream, OpenCV's adaptive iteration count) + the Horn / Kabsch closed form, then two rounds of
+ * closed form over the inliers (|q - (R p + t)| <= inlier_thr, metres).  Bit-identical to the CPU checker oracle/align_oracle.c.
+ *   P, Q f64[B][stride][3], n int[B] pairs used per problem; R f64[B][9] row-major, t f64[B][3], inlier u8[B][stride], n_inlier[B];
+ *   status[b]: BH_ALIGN_OK | BH_ALIGN_FEW_POINTS (n < 3: R = I, t = 0) | BH_ALIGN_NO_MODEL (no non-degenerate sample reached 3 inliers,
+ *   or fewer than min_inliers inliers: R, t hold the best estimate, or identity). */
+#define BH_ALIGN_OK          0
+#define BH_ALIGN_FEW_POINTS  1
+#define BH_ALIGN_NO_MODEL    2
+int bh_align_se3_ransac(bh_ctx* ctx, const double* P, const double* Q, const int* n, int B, int stride, int iterations, double inlier_thr,
+                        double confidence, int min_inliers, double* R, double* t, uint8_t* inlier, int* n_inlier, int* status, int mem);
+
 /* ---- local bundle adjustment --------------------------------------------------------------------------------------
  * Replaces the g2o graph of BundleAdjustment — slam/optimizer.py:8-79 — as driven by
  * CovisibilityGraph.optimize_local — slam/covisibility_graph.py:186-235.

@@ -315,6 +315,23 @@ def solve_pnp_ransac(obj, img, K4, iterations=100, reproj_error=8.0, confidence=
     return bool(ok), rvec, tvec, inl[:ni.value].copy()
 
 
+def align_se3_ransac(P, Q, iterations=200, thr=0.05, confidence=0.99, min_inliers=15):
+    """q ~ R p + t by 3-point RANSAC + Kabsch (align_oracle.c).  Returns (status, R, t, mask, n_inliers)."""
+    P = np.ascontiguousarray(P, dtype=np.float64).reshape(-1, 3); Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(-1, 3)
+    n = len(P)
+    R = np.zeros((3, 3)); t = np.zeros(3); mask = np.zeros(max(n, 1), np.uint8); ni = C.c_int(0)
+    st = lib().orc_align_se3_ransac(_p(P), _p(Q), n, int(iterations), C.c_double(thr), C.c_double(confidence), int(min_inliers), _p(R), _p(t), _p(mask),
+                                    C.byref(ni))
+    return int(st), R, t, mask[:n].astype(bool), ni.value
+
+
+def se_kabsch(H, pbar, qbar):
+    H = np.ascontiguousarray(H, dtype=np.float64).reshape(9); pbar = np.ascontiguousarray(pbar, dtype=np.float64); qbar = np.ascontiguousarray(qbar, dtype=np.float64)
+    R = np.zeros((3, 3)); t = np.zeros(3)
+    ok = lib().orc_se_kabsch(_p(H), _p(pbar), _p(qbar), _p(R), _p(t))
+    return bool(ok), R, t
+
+
 def voc_transform(voc, desc):
     """voc: dict(child_start, child_idx, node_desc, node_weight, node_word) -> (words u32 ascending, vals f64)."""
     desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)

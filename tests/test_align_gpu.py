@@ -1,0 +1,83 @@
+"""bh_align_se3_ransac (the loop-closure alignment slam/loop_closing.py:17-19 declares and leaves empty) against its CPU checker:
+bit-identical R, t, inlier masks, counts and verdicts; recovery of planted transforms; degenerate inputs."""
+import numpy as np
+import pytest
+
+import oracle
+from boslam_amd import align, loop_closing, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(rng, n, outliers, noise=0.004):
+    R0 = synth._rodrigues(rng.normal(0, 0.6, 3)); t0 = rng.normal(0, 1.0, 3)
+    P = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(0.5, 6, n)], 1)
+    Q = P @ R0.T + t0 + rng.normal(0, noise, (n, 3))
+    bad = rng.random(n) < outliers
+    Q[bad] += rng.normal(0, 1.0, (int(bad.sum()), 3))
+    return P, Q, R0, t0, bad
+
+
+def test_align_matches_oracle_bitwise_and_recovers_the_transform(ctx):
+    rng = np.random.default_rng(7)
+    S = 700
+    cases = [(3, 0.0), (4, 0.0), (17, 0.2), (64, 0.3), (65, 0.5), (300, 0.4), (700, 0.6), (129, 0.0), (500, 0.75)]
+    P = np.zeros((len(cases), S, 3)); Q = np.zeros_like(P); n = np.zeros(len(cases), np.int32); truth = []
+    for b, (nn, out) in enumerate(cases):
+        p, q, R0, t0, bad = _problem(rng, nn, out)
+        P[b, :nn] = p; Q[b, :nn] = q; n[b] = nn; truth.append((R0, t0, bad))
+    for thr, iters, mi in ((0.05, 200, 15), (0.02, 50, 3)):
+        got = align.align_se3_ransac_batch(ctx, P, Q, n, iterations=iters, inlier_thr=thr, min_inliers=mi)
+        for b, (nn, out) in enumerate(cases):
+            st, R, t, m, ni = oracle.align_se3_ransac(P[b, :nn], Q[b, :nn], iters, thr, 0.99, mi)
+            assert got["status"][b] == st and got["n_inlier"][b] == ni, (b, nn, got["status"][b], st)
+            assert np.array_equal(got["R"][b], R) and np.array_equal(got["t"][b], t), (b, nn)
+            assert np.array_equal(got["inlier"][b, :nn], m) and not got["inlier"][b, nn:].any()
+            if st == 0 and nn >= 17:
+                R0, t0, bad = truth[b]
+                assert np.abs(R - R0).max() < 5e-3 and np.abs(t - t0).max() < 2e-2
+                assert abs(np.linalg.det(R) - 1) < 1e-12 and np.abs(R @ R.T - np.eye(3)).max() < 1e-12
+                assert (m & ~bad).sum() >= 0.9 * (~bad).sum()
+
+
+def test_align_degenerate_inputs(ctx):
+    rng = np.random.default_rng(3)
+    line = np.outer(np.linspace(0, 1, 40), [1.0, 2.0, 0.5])                    # collinear points fix no rotation
+    same = np.tile([0.3, -0.2, 2.0], (40, 1))
+    P = np.stack([line, same, rng.uniform(-1, 1, (40, 3)), rng.uniform(-1, 1, (40, 3))]); Q = P.copy()
+    Q[2] = rng.uniform(-1, 1, (40, 3))                                         # unrelated clouds: no consistent alignment
+    n = np.array([40, 40, 40, 2], np.int32)
+    got = align.align_se3_ransac_batch(ctx, P, Q, n, iterations=60, inlier_thr=0.01, min_inliers=10)
+    assert list(got["status"]) == [align.ALIGN_NO_MODEL, align.ALIGN_NO_MODEL, align.ALIGN_NO_MODEL, align.ALIGN_FEW_POINTS]
+    for b in range(4):
+        st, R, t, m, ni = oracle.align_se3_ransac(P[b, :n[b]], Q[b, :n[b]], 60, 0.01, 0.99, 10)
+        assert st == got["status"][b] and np.array_equal(R, got["R"][b]) and np.array_equal(t, got["t"][b]) and ni == got["n_inlier"][b]
+    empty = align.align_se3_ransac_batch(ctx, np.zeros((0, 5, 3)), np.zeros((0, 5, 3)))
+    assert empty["R"].shape == (0, 3, 3)
+
+
+def test_similarity_transformation_between_two_rendered_frames(ctx):
+    """The whole stage on two frames of the synthetic sequence: ORB + back-projection, descriptor matches, alignment.  The recovered
+    motion must agree with the pose-only BA of the tracking step between the same frames (two independent estimators)."""
+    from boslam_amd import frontend, tracking
+    bgr, depth = synth.render_batch(2, start=3)
+    params = frontend.make_params(nfeatures=800)
+    kps, desc, nk = frontend.orb_detect_describe(ctx, bgr, depth=depth, params=params)
+    xy, cloud = frontend.kp_backproject(ctx, kps, nk, depth, synth.FX, synth.FY, synth.CX, synth.CY)
+
+    class F:
+        pass
+    a, b = F(), F()
+    a.des, a.cloud_kp = desc[0, :nk[0]], cloud[0, :nk[0]]
+    b.des, b.cloud_kp = desc[1, :nk[1]], cloud[1, :nk[1]]
+    good = lambda f: np.isfinite(f.cloud_kp).all(1) & (np.abs(f.cloud_kp).sum(1) > 0)
+    a.des, a.cloud_kp = a.des[good(a)], a.cloud_kp[good(a)]
+    b.des, b.cloud_kp = b.des[good(b)], b.cloud_kp[good(b)]
+    R, t, ni = loop_closing.similarity_transformation(ctx, b, a, inlier_thr=0.03)
+    assert R is not None and ni >= 100
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(R) - 1) < 1e-12
+    # a nearly static pair of consecutive frames: small rotation, centimetre-scale translation
+    assert np.abs(R - np.eye(3)).max() < 0.05 and np.abs(t).max() < 0.2
+    class E:
+        des = np.zeros((0, 32), np.uint8); cloud_kp = np.zeros((0, 3))
+    assert loop_closing.similarity_transformation(ctx, b, E()) == (None, None, 0)

@@ -414,3 +414,46 @@ def test_lm_decisions_do_not_depend_on_how_the_cube_is_rounded():
         exact = Fraction(v) ** 3
         got = float(np.float64(v) ** 3)                                        # numpy -> libm pow
         assert abs(Fraction(got) - exact) <= abs(Fraction(np.nextafter(got, np.inf)) - Fraction(got)) * Fraction(51, 100)
+
+
+def test_se3_alignment_oracle_against_numpy():
+    """se3_small.h (shared as text by the alignment kernel and its checker): the closed form against numpy's SVD, the RANSAC wrapper
+    against planted transforms with outliers, degenerate inputs."""
+    rng = np.random.default_rng(11)
+
+    def rot(v):
+        th = np.linalg.norm(v); k = v / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    for trial in range(40):
+        n = int(rng.integers(3, 60))
+        R0 = rot(rng.normal(0, 1.0, 3)); t0 = rng.normal(0, 2, 3)
+        P = rng.normal(0, 1, (n, 3))
+        if trial % 5 == 0:
+            P[:, 2] = 0.0                                                      # coplanar points: H has rank 2, the rotation is still fixed
+        Q = P @ R0.T + t0 + rng.normal(0, 1e-3, (n, 3))
+        pb, qb = P.mean(0), Q.mean(0)
+        H = (P - pb).T @ (Q - qb)
+        ok, R, t = oracle.se_kabsch(H, pb, qb)
+        U, S, Vt = np.linalg.svd(H)
+        D = np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))])
+        Rn = Vt.T @ D @ U.T
+        assert ok and np.abs(R - Rn).max() < 1e-9 and np.abs(t - (qb - Rn @ pb)).max() < 1e-9
+        assert abs(np.linalg.det(R) - 1) < 1e-12 and np.abs(R - R0).max() < 0.05
+    line = np.outer(np.linspace(0, 1, 10), [1.0, 2.0, 3.0])
+    ok, _, _ = oracle.se_kabsch((line - line.mean(0)).T @ (line - line.mean(0)), line.mean(0), line.mean(0))
+    assert not ok                                                              # collinear: no rotation is fixed
+    for n, out in ((30, 0.0), (200, 0.3), (600, 0.6)):
+        R0 = rot(rng.normal(0, 0.7, 3)); t0 = rng.normal(0, 1, 3)
+        P = rng.uniform(-2, 2, (n, 3)); Q = P @ R0.T + t0 + rng.normal(0, 0.004, (n, 3))
+        bad = rng.random(n) < out
+        Q[bad] += rng.normal(0, 1, (int(bad.sum()), 3))
+        st, R, t, m, ni = oracle.align_se3_ransac(P, Q, 200, 0.05, 0.99, 15)
+        assert st == 0 and ni == m.sum() and np.abs(R - R0).max() < 5e-3 and np.abs(t - t0).max() < 2e-2
+        assert (m & ~bad).sum() >= 0.95 * (~bad).sum() and (m & bad).sum() <= 0.05 * n
+        Pi, Qi = P[m], Q[m]                                                    # the returned pose is the least-squares fit of its own inlier set
+        U, S, Vt = np.linalg.svd((Pi - Pi.mean(0)).T @ (Qi - Qi.mean(0)))
+        Rn = Vt.T @ np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))]) @ U.T
+        assert np.abs(R - Rn).max() < 1e-6
+    assert oracle.align_se3_ransac(np.zeros((2, 3)), np.zeros((2, 3)))[0] == 1
+    assert oracle.align_se3_ransac(rng.normal(0, 1, (50, 3)), rng.normal(0, 1, (50, 3)), 50, 0.01, 0.99, 10)[0] == 2
