@@ -166,7 +166,7 @@ extern "C" int bh_align_se3_ransac(bh_ctx* ctx, const double* P, const double* Q
         din = (uint8_t*)ip; ip += al(mb);
         dni = (int*)ip; ip += al(sizeof(int) * B); dst = (int*)ip;
     }
-    BH_LAUNCH(ctx, BH_K_PNP, k_align_se3, dim3(B), dim3(64), st, dP, dQ, dn, stride, iterations, inlier_thr, confidence, min_inliers, dR, dt, din, dni, dst);
+    BH_LAUNCH(ctx, BH_K_ALIGN, k_align_se3, dim3(B), dim3(64), st, dP, dQ, dn, stride, iterations, inlier_thr, confidence, min_inliers, dR, dt, din, dni, dst);
     BH_HIP(ctx, hipGetLastError());
     if (mem == BH_MEM_HOST) {
         BH_HIP(ctx, hipMemcpyAsync(R, dR, sizeof(double) * 9 * B, hipMemcpyDeviceToHost, st));

@@ -44,7 +44,7 @@ struct bh_orb_geom {
 
 // kernel ids for the optional per-kernel hipEvent timing (bh_ctx_timing / bh_ctx_timing_read)
 enum bh_kid { BH_K_GRAY = 0, BH_K_PYR, BH_K_FAST, BH_K_BLUR, BH_K_SELECT, BH_K_BRIEF, BH_K_MATCH, BH_K_BACKPROJ,
-              BH_K_POSE_BA, BH_K_BA_LINEARIZE, BH_K_BA_SCHUR, BH_K_BA_SOLVE, BH_K_BA_UPDATE, BH_K_BA_OTHER, BH_K_GATE, BH_K_BOW_SCAN, BH_K_PNP, BH_K_VOC, BH_K_BOW_INV, BH_K_COUNT };
+              BH_K_POSE_BA, BH_K_BA_LINEARIZE, BH_K_BA_SCHUR, BH_K_BA_SOLVE, BH_K_BA_UPDATE, BH_K_BA_OTHER, BH_K_GATE, BH_K_BOW_SCAN, BH_K_PNP, BH_K_VOC, BH_K_BOW_INV, BH_K_ALIGN, BH_K_COUNT };
 
 struct bh_time_rec { int kid; hipEvent_t e0, e1; };
 

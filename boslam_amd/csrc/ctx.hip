@@ -139,7 +139,7 @@ extern "C" int bh_ctx_status(bh_ctx* ctx)
 // ------------------------------------------------------------------------------------------------ per-kernel timing
 static const char* k_names[BH_K_COUNT] = { "k_gray_mask", "k_pyr_down", "k_fast", "k_blur", "k_select", "k_describe",
                                            "k_match", "k_kp_backproject", "k_pose_ba", "k_ba_linearize", "k_ba_schur",
-                                           "k_ba_solve", "k_ba_update", "k_ba_other", "k_gate", "k_bow_scan", "k_pnp_ransac", "k_voc_transform", "k_bow_inverted" };
+                                           "k_ba_solve", "k_ba_update", "k_ba_other", "k_gate", "k_bow_scan", "k_pnp_ransac", "k_voc_transform", "k_bow_inverted", "k_align_se3" };
 
 static hipEvent_t take_event(bh_ctx* ctx)
 {
