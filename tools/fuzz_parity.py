@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
 import oracle
-from boslam_amd import Context, frontend, synth, _lib, pnp, ba
+from boslam_amd import Context, frontend, synth, _lib, pnp, ba, align
 from test_band_solve_gpu import band_system, scipy_solve, gpu_solve
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -13,7 +13,7 @@ ctx = Context(0)
 rng = np.random.default_rng(int(time.time()) & 0xffff)
 bgr_all, depth_all = synth.render_batch(4)
 t_end = time.time() + budget
-n_fe = n_m = n_b = n_p = n_po = n_lb = n_cap = n_bs = 0
+n_fe = n_m = n_b = n_p = n_po = n_lb = n_cap = n_bs = n_al = 0
 K4 = np.array([synth.FX, synth.FY, synth.CX, synth.CY])
 
 
@@ -152,4 +152,22 @@ while time.time() < t_end:
         if not all(np.array_equal(sts[0][k], sts[1][k]) for k in sts[0]):
             print("BUILDER MISMATCH", nk, npnt, len(ecam), [k for k in sts[0] if not np.array_equal(sts[0][k], sts[1][k])]); sys.exit(1)
         n_bs += 1
-print(f"fuzz ok: {n_fe} front-end cases, {n_m} matcher cases, {n_b} solver cases, {n_p} PnP problems, {n_po} pose-only BA problems, {n_lb} local BA problems, {n_bs} problem structures (one-workgroup vs chip-wide builder); {n_cap} noise cases stopped by the documented candidate capacity")
+        # ---- rigid alignment (loop-closure verification): R, t, masks and verdicts bit for bit
+        Ba, Sa = 6, int(rng.integers(3, 900))
+        Pa_ = np.zeros((Ba, Sa, 3)); Qa_ = np.zeros_like(Pa_); na = np.zeros(Ba, np.int32)
+        for b in range(Ba):
+            nn = int(rng.integers(0, Sa + 1)); na[b] = nn
+            R0 = synth._rodrigues(rng.normal(0, 0.8, 3)); t0 = rng.normal(0, 1.5, 3)
+            p = rng.uniform(-3, 3, (nn, 3)) * ([1, 1, 1] if rng.random() > 0.1 else [1, 1, 0])
+            q = p @ R0.T + t0 + rng.normal(0, rng.random() * 0.01, (nn, 3))
+            bad = rng.random(nn) < rng.random() * 0.8
+            q[bad] += rng.normal(0, 1.0, (int(bad.sum()), 3))
+            Pa_[b, :nn] = p; Qa_[b, :nn] = q
+        thr = float(rng.uniform(0.005, 0.1)); its = int(rng.integers(1, 300)); mi = int(rng.integers(3, 30))
+        g = align.align_se3_ransac_batch(ctx, Pa_, Qa_, na, iterations=its, inlier_thr=thr, min_inliers=mi)
+        for b in range(Ba):
+            st, R, t, m, ni = oracle.align_se3_ransac(Pa_[b, :na[b]], Qa_[b, :na[b]], its, thr, 0.99, mi)
+            if not (st == g["status"][b] and ni == g["n_inlier"][b] and np.array_equal(R, g["R"][b]) and np.array_equal(t, g["t"][b]) and np.array_equal(m, g["inlier"][b, :na[b]])):
+                print("ALIGN MISMATCH", na[b], thr, its, mi); sys.exit(1)
+        n_al += Ba
+print(f"fuzz ok: {n_fe} front-end cases, {n_m} matcher cases, {n_b} solver cases, {n_p} PnP problems, {n_po} pose-only BA problems, {n_lb} local BA problems, {n_bs} problem structures (one-workgroup vs chip-wide builder), {n_al} rigid alignments; {n_cap} noise cases stopped by the documented candidate capacity")
