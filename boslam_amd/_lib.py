@@ -43,6 +43,7 @@ _SIGS = {
     "bh_kp_backproject": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _vp, _i]),
     "bh_match_hamming_crosscheck": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i]),
     "bh_medoid_descriptor": (_i, [_vp, _vp, _vp, _i, _vp, _i]),
+    "bh_mp_add_observation": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "bh_pose_only_ba": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i]),
     "bh_track_refkf": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     "bh_align_se3_ransac": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _i]),

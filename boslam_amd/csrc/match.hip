@@ -216,14 +216,9 @@ extern "C" int bh_match_hamming_crosscheck(bh_ctx* ctx, const uint8_t* q, const 
 // matrix has the smallest median (numpy semantics: mean of the two middle values for even k; first minimum).
 // One lane per map point: 45 xor+popcount distances, a 10-element insertion sort per column, integer compare of 2*median.
 #define MEDOID_K 10
-__global__ __launch_bounds__(256) void k_medoid(const uint8_t* __restrict__ desc, const int* __restrict__ k_arr, int M,
-                                                int* __restrict__ out)
+__device__ __forceinline__ int medoid_index(const uint8_t* __restrict__ desc10, int k)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    const int k = min(k_arr[i], MEDOID_K);
-    if (k <= 0) { out[i] = -1; return; }
-    const uint4* d = reinterpret_cast<const uint4*>(desc + (size_t)i * MEDOID_K * 32);
+    const uint4* d = reinterpret_cast<const uint4*>(desc10);
     int D[MEDOID_K][MEDOID_K];
 #pragma unroll
     for (int a = 0; a < MEDOID_K; a++) {
@@ -260,7 +255,48 @@ __global__ __launch_bounds__(256) void k_medoid(const uint8_t* __restrict__ desc
             if (m2 < best_m2) { best_m2 = m2; best = c; }
         }
     }
-    out[i] = best;
+    return best;
+}
+__global__ __launch_bounds__(256) void k_medoid(const uint8_t* __restrict__ desc, const int* __restrict__ k_arr, int M,
+                                                int* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int k = min(k_arr[i], MEDOID_K);
+    out[i] = k <= 0 ? -1 : medoid_index(desc + (size_t)i * MEDOID_K * 32, k);
+}
+
+// MapPoint.add_observation as a whole - slam/nodes.py:142-156 - for M map points that the new keyframe observes (the loop body of
+// CovisibilityGraph.add_kf, slam/covisibility_graph.py:125-136, for the features already associated with a map point):
+//   n /= norm(n);  n_obs += 1;  if len(obs) < 10: obs.append(feat), feat = obs[argmin(median(dists, axis=0))];
+//   self.n = (n + (n_obs - 1) * self.n) / n_obs
+// One lane per map point; arrays are updated in place.
+__global__ __launch_bounds__(256) void k_mp_add_obs(uint8_t* __restrict__ obs, int* __restrict__ obs_cnt, int* __restrict__ n_obs,
+                                                    double* __restrict__ normal, uint8_t* __restrict__ feat,
+                                                    const uint8_t* __restrict__ new_desc, const double* __restrict__ new_n, int M)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    double n0 = new_n[3 * (size_t)i], n1 = new_n[3 * (size_t)i + 1], n2 = new_n[3 * (size_t)i + 2];
+    const double nrm = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
+    n0 = n0 / nrm; n1 = n1 / nrm; n2 = n2 / nrm;
+    const int no = n_obs[i] + 1;
+    n_obs[i] = no;
+    int k = obs_cnt[i];
+    if (k < MEDOID_K) {
+        uint8_t* slot = obs + ((size_t)i * MEDOID_K + k) * 32;
+        const uint4* src = reinterpret_cast<const uint4*>(new_desc + (size_t)i * 32);
+        reinterpret_cast<uint4*>(slot)[0] = src[0]; reinterpret_cast<uint4*>(slot)[1] = src[1];
+        k++;
+        obs_cnt[i] = k;
+        const int m = medoid_index(obs + (size_t)i * MEDOID_K * 32, k);
+        const uint4* md = reinterpret_cast<const uint4*>(obs + ((size_t)i * MEDOID_K + m) * 32);
+        reinterpret_cast<uint4*>(feat + (size_t)i * 32)[0] = md[0]; reinterpret_cast<uint4*>(feat + (size_t)i * 32)[1] = md[1];
+    }
+    const double w = (double)(no - 1), dn = (double)no;
+    normal[3 * (size_t)i] = (n0 + w * normal[3 * (size_t)i]) / dn;
+    normal[3 * (size_t)i + 1] = (n1 + w * normal[3 * (size_t)i + 1]) / dn;
+    normal[3 * (size_t)i + 2] = (n2 + w * normal[3 * (size_t)i + 2]) / dn;
 }
 
 extern "C" int bh_medoid_descriptor(bh_ctx* ctx, const uint8_t* desc, const int* k, int M, int* medoid_idx, int mem)
@@ -282,6 +318,41 @@ extern "C" int bh_medoid_descriptor(bh_ctx* ctx, const uint8_t* desc, const int*
     BH_HIP(ctx, hipGetLastError());
     if (mem == BH_MEM_HOST) {
         BH_HIP(ctx, hipMemcpyAsync(medoid_idx, d_out, sizeof(int) * M, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipStreamSynchronize(st));
+    }
+    return BH_OK;
+}
+
+extern "C" int bh_mp_add_observation(bh_ctx* ctx, int M, uint8_t* obs_desc, int* obs_cnt, int* n_obs, double* normal, uint8_t* feat,
+                                     const uint8_t* new_desc, const double* new_n, int mem)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (!obs_desc || !obs_cnt || !n_obs || !normal || !feat || !new_desc || !new_n || M < 0 || (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_mp_add_observation: bad argument");
+    if (M == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    uint8_t *d_obs = obs_desc, *d_feat = feat; int *d_cnt = obs_cnt, *d_no = n_obs; double* d_nrm = normal; const uint8_t* d_nd = new_desc; const double* d_nn = new_n;
+    const size_t ob = (size_t)M * MEDOID_K * 32, fb = (size_t)M * 32, ib = sizeof(int) * (size_t)M, nb = sizeof(double) * 3 * (size_t)M;
+    if (mem == BH_MEM_HOST) {
+        for (int i = 0; i < M; i++) if (obs_cnt[i] < 0 || obs_cnt[i] > MEDOID_K) return bh_set_err(ctx, BH_ERR_INVALID, "bh_mp_add_observation: obs_cnt outside [0, 10]");
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        BH_TRY(bh_reserve(ctx, &ctx->st_a, al(ob) + 2 * al(fb) + 2 * al(ib) + 2 * al(nb)));
+        char* p = (char*)ctx->st_a.p;
+        d_obs = (uint8_t*)p; p += al(ob); d_feat = (uint8_t*)p; p += al(fb); uint8_t* nd = (uint8_t*)p; p += al(fb);
+        d_cnt = (int*)p; p += al(ib); d_no = (int*)p; p += al(ib); d_nrm = (double*)p; p += al(nb); double* nn = (double*)p;
+        BH_HIP(ctx, hipMemcpyAsync(d_obs, obs_desc, ob, hipMemcpyHostToDevice, st)); BH_HIP(ctx, hipMemcpyAsync(d_feat, feat, fb, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(nd, new_desc, fb, hipMemcpyHostToDevice, st)); BH_HIP(ctx, hipMemcpyAsync(d_cnt, obs_cnt, ib, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(d_no, n_obs, ib, hipMemcpyHostToDevice, st)); BH_HIP(ctx, hipMemcpyAsync(d_nrm, normal, nb, hipMemcpyHostToDevice, st));
+        BH_HIP(ctx, hipMemcpyAsync(nn, new_n, nb, hipMemcpyHostToDevice, st));
+        d_nd = nd; d_nn = nn;
+    }
+    BH_LAUNCH(ctx, BH_K_MATCH, k_mp_add_obs, dim3((M + 255) / 256), dim3(256), st, d_obs, d_cnt, d_no, d_nrm, d_feat, d_nd, d_nn, M);
+    BH_HIP(ctx, hipGetLastError());
+    if (mem == BH_MEM_HOST) {
+        BH_HIP(ctx, hipMemcpyAsync(obs_desc, d_obs, ob, hipMemcpyDeviceToHost, st)); BH_HIP(ctx, hipMemcpyAsync(feat, d_feat, fb, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(obs_cnt, d_cnt, ib, hipMemcpyDeviceToHost, st)); BH_HIP(ctx, hipMemcpyAsync(n_obs, d_no, ib, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(normal, d_nrm, nb, hipMemcpyDeviceToHost, st));
         BH_HIP(ctx, hipStreamSynchronize(st));
     }
     return BH_OK;

@@ -221,6 +221,17 @@ class DeviceTracker:
                                         self.desc.data_ptr(), self.n_kp.data_ptr(), self.cloud.data_ptr(), m, self.B - 1, self.K, out, m)
 
 
+def mp_add_observations(ctx, obs_desc, obs_cnt, n_obs, normal, feat, new_desc, new_n):
+    """MapPoint.add_observation (slam/nodes.py:142-156) for M map points at once; returns the updated (obs_desc, obs_cnt, n_obs, normal, feat)."""
+    obs_desc = np.array(obs_desc, dtype=np.uint8).reshape(-1, 10, 32); M = len(obs_desc)
+    obs_cnt = np.array(obs_cnt, dtype=np.int32); n_obs = np.array(n_obs, dtype=np.int32)
+    normal = np.array(normal, dtype=np.float64).reshape(M, 3); feat = np.array(feat, dtype=np.uint8).reshape(M, 32)
+    new_desc = np.ascontiguousarray(new_desc, dtype=np.uint8).reshape(M, 32); new_n = np.ascontiguousarray(new_n, dtype=np.float64).reshape(M, 3)
+    ctx.check(_lib.lib().bh_mp_add_observation(ctx.h, M, _lib.ptr(obs_desc), _lib.ptr(obs_cnt), _lib.ptr(n_obs), _lib.ptr(normal), _lib.ptr(feat),
+                                               _lib.ptr(new_desc), _lib.ptr(new_n), BH_MEM_HOST))
+    return obs_desc, obs_cnt, n_obs, normal, feat
+
+
 class LiveTracker:
     """The reference's live loop, one frame per call (camera.py:131-168 -> slam/tracking.py:54-89): the frame goes up once (pinned staging),
     ORB + back-projection + the tracking step against the PREVIOUS frame's descriptors / cloud (kept on the device, two slots) run on

@@ -121,6 +121,14 @@ int bh_match_hamming_crosscheck(bh_ctx* ctx, const uint8_t* q, const int* nq, in
  * slam/nodes.py:142-154: for M map points with k[m] <= 10 stored descriptors each (desc u8[M][10][32]) the index of the
  * descriptor whose column of the uint8 Hamming matrix has the smallest numpy-median (first minimum); -1 when k[m] <= 0. */
 int bh_medoid_descriptor(bh_ctx* ctx, const uint8_t* desc, const int* k, int M, int* medoid_idx, int mem);
+/* MapPoint.add_observation as a whole - slam/nodes.py:142-156, the per-feature body of CovisibilityGraph.add_kf
+ * (slam/covisibility_graph.py:125-136) for features already associated with a map point - for M map points, in place:
+ *   n = new_n / |new_n|;  n_obs += 1;  if fewer than 10 stored observations: the descriptor is appended and feat becomes the medoid
+ *   of the stored descriptors (as bh_medoid_descriptor);  normal = (n + (n_obs - 1) normal) / n_obs.
+ * obs_desc u8[M][10][32], obs_cnt int[M] (0..10), n_obs int[M], normal f64[M][3], feat u8[M][32] are updated; new_desc u8[M][32],
+ * new_n f64[M][3] (not normalised, non-zero: the caller's `norm > 0` test, covisibility_graph.py:128). */
+int bh_mp_add_observation(bh_ctx* ctx, int M, uint8_t* obs_desc, int* obs_cnt, int* n_obs, double* normal, uint8_t* feat,
+                          const uint8_t* new_desc, const double* new_n, int mem);
 
 /* ---- pose-only bundle adjustment ----------------------------------------------------------------------------------
  * Replaces CamOnlyBA(pixels, points, cam, ...) — slam/optimizer.py:82-142, called at slam/tracking.py:73,128 —

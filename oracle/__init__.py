@@ -315,6 +315,25 @@ def solve_pnp_ransac(obj, img, K4, iterations=100, reproj_error=8.0, confidence=
     return bool(ok), rvec, tvec, inl[:ni.value].copy()
 
 
+def mp_add_observation(obs, n_obs, normal, feat, new_desc, new_n):
+    """MapPoint.add_observation, slam/nodes.py:142-156, line by line in numpy as the reference runs it (dbow.distance = Hamming distance
+    of the two descriptors).  obs: list of u8[32] descriptors.  Returns (obs, n_obs, normal, feat)."""
+    n = np.array(new_n, dtype=np.float64)
+    n /= np.linalg.norm(n)
+    n_obs += 1
+    obs = list(obs)
+    if len(obs) < 10:
+        obs.append(np.array(new_desc, dtype=np.uint8))
+        dists = np.zeros((len(obs), len(obs)), dtype=np.uint8)
+        for i1, f1 in enumerate(obs):
+            for i2, f2 in enumerate(obs):
+                if i1 < i2:
+                    dists[i2, i1] = dists[i1, i2] = np.uint8(int(np.unpackbits(np.bitwise_xor(f1, f2)).sum()) & 255)
+        feat = obs[np.argmin(np.median(dists, axis=0))]
+    normal = (n + (n_obs - 1) * np.asarray(normal, dtype=np.float64)) / n_obs
+    return obs, n_obs, normal, feat
+
+
 def align_se3_ransac(P, Q, iterations=200, thr=0.05, confidence=0.99, min_inliers=15):
     """q ~ R p + t by 3-point RANSAC + Kabsch (align_oracle.c).  Returns (status, R, t, mask, n_inliers)."""
     P = np.ascontiguousarray(P, dtype=np.float64).reshape(-1, 3); Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(-1, 3)

@@ -260,3 +260,36 @@ def test_dense_corner_frame_takes_the_rescan_path(ctx):
         assert rc == 0 and n[f] == len(okp) and np.array_equal(desc[f, :n[f]], odesc)
         for fld in ("x", "y", "angle", "response", "octave"):
             assert np.array_equal(kps[fld][f, :n[f]].view(np.uint32), okp[fld].view(np.uint32)), fld
+
+
+def test_mp_add_observation_matches_the_reference_loop(ctx):
+    """bh_mp_add_observation against MapPoint.add_observation (slam/nodes.py:142-156) restated in numpy: stored descriptors, counts,
+    the medoid descriptor exactly; the running mean of the viewing direction to the last bit but one (numpy's norm is a BLAS dot)."""
+    import oracle
+    from boslam_amd import frontend
+    rng = np.random.default_rng(4)
+    M = 300
+    base = rng.integers(0, 256, (M, 32), dtype=np.uint8)
+    cnt = rng.integers(0, 11, M).astype(np.int32)
+    obs = np.zeros((M, 10, 32), np.uint8)
+    for i in range(M):
+        for k in range(cnt[i]):
+            d = base[i].copy(); flip = rng.integers(0, 256, 3); d[flip % 32] ^= (1 << (flip % 8)).astype(np.uint8)
+            obs[i, k] = d
+    cnt[:3] = [0, 9, 10]
+    n_obs = (cnt + rng.integers(0, 5, M)).astype(np.int32)
+    normal = rng.normal(0, 1, (M, 3)); normal /= np.linalg.norm(normal, axis=1)[:, None]
+    feat = base.copy()
+    state = (obs, cnt, n_obs, normal, feat)
+    ref = [([obs[i, k].copy() for k in range(cnt[i])], int(n_obs[i]), normal[i].copy(), feat[i].copy()) for i in range(M)]
+    for step in range(3):                                                       # three keyframes in a row: lists fill up to ten and stay there
+        nd = base ^ rng.integers(0, 2, (M, 32), dtype=np.uint8)
+        nn = rng.normal(0, 2, (M, 3))
+        state = frontend.mp_add_observations(ctx, *state, nd, nn)
+        for i in range(M):
+            o, no, nr, ft = oracle.mp_add_observation(ref[i][0], ref[i][1], ref[i][2], ref[i][3], nd[i], nn[i])
+            ref[i] = (o, no, nr, ft)
+            assert state[1][i] == len(o) and state[2][i] == no
+            assert all(np.array_equal(state[0][i, k], o[k]) for k in range(len(o)))
+            assert np.array_equal(state[4][i], ft), (step, i)
+            assert np.abs(state[3][i] - nr).max() <= 4e-16
