@@ -82,6 +82,7 @@ _SIGS = {
     "bh_voc_destroy": (None, [_vp]),
     "bh_voc_transform": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i]),
     "bh_bow_query_l1": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i]),
+    "bh_bow_query_l1_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "bh_bow_query_l1_subset": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "bh_bow_compare_l1": (_i, [_vp, _i, _i, C.POINTER(_i), C.POINTER(_d)]),
 }

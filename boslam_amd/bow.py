@@ -74,6 +74,19 @@ class BowDatabase:
                                                       _lib.ptr(ids), _lib.ptr(sc), C.byref(n), BH_MEM_HOST))
         return ids[:n.value].copy(), sc[:n.value].copy()
 
+    def query_batch(self, queries, max_results=1):
+        """Many queries in one call (bh_bow_query_l1_batch): queries = sequence of (words, vals).  Returns a list of (ids, scores), each
+        what query() returns for that query; with the inverted file up to 16 queries share every launch."""
+        Q = len(queries)
+        S = max([len(w) for w, _ in queries] + [1])
+        qw = np.zeros((Q, S), np.uint32); qv = np.zeros((Q, S), np.float64); nq = np.zeros(Q, np.int32)
+        for i, (w, v) in enumerate(queries):
+            nq[i] = len(w); qw[i, :len(w)] = w; qv[i, :len(w)] = v
+        ids = np.zeros((Q, max_results), np.int32); sc = np.zeros((Q, max_results), np.float64); n = np.zeros(Q, np.int32)
+        if Q:
+            self.ctx.check(_lib.lib().bh_bow_query_l1_batch(self.h, _lib.ptr(qw), _lib.ptr(qv), _lib.ptr(nq), Q, S, int(max_results), _lib.ptr(ids), _lib.ptr(sc), _lib.ptr(n)))
+        return [(ids[i, :n[i]].copy(), sc[i, :n[i]].copy()) for i in range(Q)]
+
     def set_mode(self, mode):
         """'inverted' (default: inverted-file query, scan as the fallback) or 'scan' (always stream the database)."""
         self.ctx.check(_lib.lib().bh_bow_set_mode(self.h, {"inverted": 0, "scan": 1}[mode]))

@@ -84,6 +84,25 @@ def run_sharded(ctx, dist=None, device="cuda:0", n_entries=100000, repeats=20, k
     (ids_i, sc_i), dt_inv, kt_inv = timed_mode("inverted")
     (ids, sc), dt, kt = timed_mode("scan")
     same = bool(np.array_equal(ids, ids_i) and np.array_equal(sc, sc_i))
+    # a queue of queries handed over together (bh_bow_query_l1_batch): 64 relocalisation-style queries - perturbed copies of 64 different
+    # stored entries of this shard - in rounds of 16 slots; every one must come back as the single-query path answers it
+    batch = None
+    if world == 1:
+        d.set_mode("inverted")
+        hw = words.cpu().numpy().astype(np.uint32).reshape(n_loc, 1000); hv = vals.cpu().numpy().reshape(n_loc, 1000)
+        rng = np.random.default_rng(3)
+        qs = []
+        for e in rng.choice(n_loc, 64, replace=False):
+            keep = rng.random(1000) > 0.2
+            w = hw[e][keep]; qs.append((w, np.full(len(w), 1.0 / len(w))))
+        got = d.query_batch(qs, k)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            got = d.query_batch(qs, k)
+        el_b = (time.perf_counter() - t0) / 5
+        ok = all(np.array_equal(g[0], r[0]) and np.array_equal(g[1], r[1]) for g, r in zip(got[:8], [d.query(w, v, k) for w, v in qs[:8]]))
+        batch = {"queries": 64, "ms_per_batch": round(el_b * 1e3, 3), "queries_per_s": round(64 / el_b, 1), "ms_per_query_amortised": round(el_b / 64 * 1e3, 4),
+                 "equals_single_queries": bool(ok), "note": "16 query slots per round of four launches; per-query scratch"}
     scan_ms = kt["k_bow_scan"][0] / kt["k_bow_scan"][1]
     inv_ms = kt_inv["k_bow_inverted"][0] / kt_inv["k_bow_inverted"][1] if "k_bow_inverted" in kt_inv else None
     hits = int(np.isin(words.cpu().numpy().astype(np.uint32), q_words).sum())             # (entry, word) pairs the query's rows hold on this rank
@@ -102,6 +121,7 @@ def run_sharded(ctx, dist=None, device="cuda:0", n_entries=100000, repeats=20, k
                          "byte_model": "12 B per item of the query words' rows + 24 B per hit record written and read back + row bounds + bucket counters",
                          "kernels_GBps": None if inv_ms is None else round(inv_bytes / (inv_ms * 1e-3) / 1e9, 1),
                          "note": "latency-bound (three dependent launches over ~1 MB): reported in ms, not as a roofline fraction"},
+            "batched": batch,
             "scan_ms_per_query": round(dt * 1e3, 4), "scan_queries_per_s": round(1.0 / dt, 1), "paths_agree_bitwise": same,
             "scan_kernel_ms": round(scan_ms, 4),
             "roofline": {"bound": "hbm", "kernel": "k_bow_scan", "achieved": gbs(streamed), "peak": 8000.0, "unit": "GB/s",

@@ -114,8 +114,11 @@ struct bh_bow {
     int mode = 0;                  // 0 = inverted file where possible, 1 = always scan (bh_bow_set_mode)
     long long inv_nb = 0;          // buckets of 64 entries
     int bcap = 0;                  // hit records a bucket can hold
-    char* hq = nullptr;            // pinned, device-visible: the query going in, the results coming out
+    char* hq = nullptr;            // pinned, device-visible: per query slot the query going in and the results coming out
     size_t hq_cap = 0;
+    int inv_nslots = 1;            // query slots (scratch sets): 1 for bh_bow_query_l1, INV_QSLOTS once bh_bow_query_l1_batch has been used
+    int slots_ready = 0;
+    bh_buf inv_slots, inv_acc;     // device copy of the slot table; the slots' accumulator arrays
 };
 
 // grow a device buffer keeping its first `keep` bytes
@@ -304,7 +307,7 @@ extern "C" void bh_bow_destroy(bh_bow* bow)
     (void)hipSetDevice(bow->ctx->device);
     (void)hipStreamSynchronize(bow->ctx->stream);
     bh_buf* all[] = { &bow->pstart, &bow->words, &bow->vals, &bow->acc, &bow->qw, &bow->qv, &bow->res,
-                      &bow->inv_start, &bow->inv_entry, &bow->inv_val, &bow->inv_tmp, &bow->bcnt, &bow->bkey, &bow->bval, &bow->cand_v, &bow->cand_i };
+                      &bow->inv_start, &bow->inv_entry, &bow->inv_val, &bow->inv_tmp, &bow->bcnt, &bow->bkey, &bow->bval, &bow->cand_v, &bow->cand_i, &bow->inv_slots, &bow->inv_acc };
     for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     if (bow->hq) (void)hipHostFree(bow->hq);
     delete bow;
@@ -406,6 +409,15 @@ extern "C" int bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const doubl
 #define INV_SELCAP 1024                                       // accumulators at or below the threshold
 
 struct inv_ctl { int ovf_cnt, heavy_cnt, flags, pad; int heavy_bk[INV_HEAVY_MAX]; int heavy_n[INV_HEAVY_MAX][INV_NSUB]; };
+// One query slot: its own scratch (bucket lists, overflow list, accumulators, control block) and its pinned in / out block
+//   [int nq][int k][pad 8] [u32 words[BOW_QMAX]] [f64 vals[BOW_QMAX]] [int n][int fallback][f64 scores[INV_KMAX]][int ids[INV_KMAX]].
+// bh_bow_query_l1 uses slot 0; bh_bow_query_l1_batch runs up to INV_QSLOTS queries per launch (blockIdx.y = slot).
+#define INV_QSLOTS 16
+#define INV_PIN_W 16
+#define INV_PIN_V (INV_PIN_W + 4 * BOW_QMAX)
+#define INV_PIN_R (INV_PIN_V + 8 * BOW_QMAX)
+#define INV_PIN_BYTES (INV_PIN_R + 8 + 12 * INV_KMAX + 56)
+struct inv_slot { const int* hdr; const uint32_t* qw; const double* qv; int* bcnt; uint32_t* bkey; double* bval; inv_ctl* ctl; uint32_t* okey; double* oval; double* acc; double* bmin; char* hout; };
 
 __global__ __launch_bounds__(256) void k_inv_count(const uint32_t* __restrict__ pw, long long n, uint32_t* __restrict__ cnt, int* __restrict__ bad)
 {
@@ -436,12 +448,13 @@ __global__ void k_inv_widen(const uint32_t* __restrict__ cnt, long long* __restr
     if (i < n) out[i] = cnt[i];
 }
 
-__global__ __launch_bounds__(256) void k_inv_gather(const uint32_t* __restrict__ qw, const double* __restrict__ qv, int nq,
-                                                    const long long* __restrict__ inv_start, const uint32_t* __restrict__ inv_entry,
-                                                    const double* __restrict__ inv_val, int* __restrict__ bcnt, uint32_t* __restrict__ bkey,
-                                                    double* __restrict__ bval, int scap, inv_ctl* __restrict__ ctl, uint32_t* __restrict__ okey,
-                                                    double* __restrict__ oval)
+__global__ __launch_bounds__(256) void k_inv_gather(const inv_slot* __restrict__ slots, const long long* __restrict__ inv_start,
+                                                    const uint32_t* __restrict__ inv_entry, const double* __restrict__ inv_val, int scap)
 {
+    const inv_slot S = slots[blockIdx.y];
+    const uint32_t* __restrict__ qw = S.qw; const double* __restrict__ qv = S.qv; const int nq = S.hdr[0];
+    int* __restrict__ bcnt = S.bcnt; uint32_t* __restrict__ bkey = S.bkey; double* __restrict__ bval = S.bval; inv_ctl* __restrict__ ctl = S.ctl;
+    uint32_t* __restrict__ okey = S.okey; double* __restrict__ oval = S.oval;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= nq) return;
     const uint32_t w = qw[r];
@@ -498,10 +511,11 @@ __device__ __forceinline__ double inv_wave_min(double v, int lane)
 }
 
 #define INV_LCAP 256                                           // records a light bucket's wave ranks (4 lists x 64)
-__global__ __launch_bounds__(256) void k_inv_reduce(int* __restrict__ bcnt, const uint32_t* __restrict__ bkey, const double* __restrict__ bval, int scap,
-                                                    long long n_entries, const uint8_t* __restrict__ keep, double* __restrict__ acc_out, long long nb,
-                                                    inv_ctl* __restrict__ ctl, double* __restrict__ bmin)
+__global__ __launch_bounds__(256) void k_inv_reduce(const inv_slot* __restrict__ slots, int scap, long long n_entries, const uint8_t* __restrict__ keep, long long nb)
 {
+    const inv_slot S = slots[blockIdx.y];
+    int* __restrict__ bcnt = S.bcnt; const uint32_t* __restrict__ bkey = S.bkey; const double* __restrict__ bval = S.bval;
+    double* __restrict__ acc_out = S.acc; inv_ctl* __restrict__ ctl = S.ctl; double* __restrict__ bmin = S.bmin;
     __shared__ uint32_t s_key[4][INV_LCAP], s_okey[4][INV_LCAP];
     __shared__ double s_val[4][INV_LCAP], s_oval[4][INV_LCAP];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -536,10 +550,11 @@ __global__ __launch_bounds__(256) void k_inv_reduce(int* __restrict__ bcnt, cons
     if (lane == 0) bmin[bk] = bm;
 }
 
-__global__ __launch_bounds__(1024) void k_inv_heavy(const uint32_t* __restrict__ bkey, const double* __restrict__ bval, int scap, long long n_entries,
-                                                    const uint8_t* __restrict__ keep, double* __restrict__ acc_out, inv_ctl* __restrict__ ctl,
-                                                    const uint32_t* __restrict__ okey, const double* __restrict__ oval, double* __restrict__ bmin)
+__global__ __launch_bounds__(1024) void k_inv_heavy(const inv_slot* __restrict__ slots, int scap, long long n_entries, const uint8_t* __restrict__ keep)
 {
+    const inv_slot S = slots[blockIdx.y];
+    const uint32_t* __restrict__ bkey = S.bkey; const double* __restrict__ bval = S.bval; double* __restrict__ acc_out = S.acc; inv_ctl* __restrict__ ctl = S.ctl;
+    const uint32_t* __restrict__ okey = S.okey; const double* __restrict__ oval = S.oval; double* __restrict__ bmin = S.bmin;
     extern __shared__ uint32_t hsm[];
     uint32_t* s_key = hsm; uint32_t* s_okey = hsm + INV_HCAP;
     double* s_val = reinterpret_cast<double*>(hsm + 2 * INV_HCAP); double* s_oval = s_val + INV_HCAP;
@@ -621,9 +636,11 @@ __global__ __launch_bounds__(1024) void k_inv_heavy(const uint32_t* __restrict__
 // results -> pinned host memory: [int n][int fallback][double scores[k]][int ids[k]].  Works from the buckets' minima: the k-th
 // smallest of the 16 wave minima T is an upper bound of the k-th best accumulator (k <= 16 distinct buckets hold a value <= T); only
 // buckets whose minimum is <= T can hold a result, and there are few of them.
-__global__ __launch_bounds__(1024) void k_inv_select(const double* __restrict__ acc, const double* __restrict__ bmin, long long nb, long long n_entries, int k,
-                                                     inv_ctl* __restrict__ ctl, char* __restrict__ hout)
+__global__ __launch_bounds__(1024) void k_inv_select(const inv_slot* __restrict__ slots, long long nb, long long n_entries)
 {
+    const inv_slot S = slots[blockIdx.y];
+    const double* __restrict__ acc = S.acc; const double* __restrict__ bmin = S.bmin; const int k = S.hdr[1]; inv_ctl* __restrict__ ctl = S.ctl;
+    char* __restrict__ hout = S.hout;
     __shared__ double s_wmin[16];
     __shared__ double s_cv[INV_SELCAP];
     __shared__ int s_ci[INV_SELCAP];
@@ -675,9 +692,46 @@ __global__ __launch_bounds__(1024) void k_inv_select(const double* __restrict__ 
         const double v = s_cv[tid]; const int id = s_ci[tid];
         int pos = 0;
         for (int j = 0; j < m; j++) { const double ov = s_cv[j]; pos += (ov < v || (ov == v && s_ci[j] < id)) ? 1 : 0; }
-        if (pos < k) { reinterpret_cast<double*>(hout + 8)[pos] = -v / 2.0; reinterpret_cast<int*>(hout + 8 + 8 * k)[pos] = id; }
+        if (pos < k) { reinterpret_cast<double*>(hout + 8)[pos] = -v / 2.0; reinterpret_cast<int*>(hout + 8 + 8 * INV_KMAX)[pos] = id; }
     }
     if (tid == 0) { hi[0] = min(m, k); hi[1] = ctl->flags; ctl->ovf_cnt = 0; ctl->heavy_cnt = 0; ctl->flags = 0; }      // counters ready for the next query
+}
+
+// Scratch, pinned in / out blocks and the device slot table for `nslots` concurrent queries (sizes follow the current database).
+static int inv_alloc_slots(bh_bow* bow, int nslots)
+{
+    bh_ctx* ctx = bow->ctx;
+    hipStream_t st = ctx->stream;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t nl = (size_t)bow->inv_nb * INV_NSUB;
+    const size_t cb = al(sizeof(int) * (nl + 64) + sizeof(inv_ctl)), kb = al(sizeof(uint32_t) * nl * bow->bcap + 64), vb = al(sizeof(double) * nl * bow->bcap + 64);
+    const size_t ob = al(sizeof(uint32_t) * INV_OVF_CAP), ovb = al(sizeof(double) * (INV_OVF_CAP + (size_t)bow->inv_nb + 8)), ab = al(sizeof(double) * ((size_t)bow->n_entries + 2));
+    BH_TRY(bh_reserve(ctx, &bow->bcnt, cb * nslots)); BH_TRY(bh_reserve(ctx, &bow->bkey, kb * nslots)); BH_TRY(bh_reserve(ctx, &bow->bval, vb * nslots));
+    BH_TRY(bh_reserve(ctx, &bow->cand_i, ob * nslots)); BH_TRY(bh_reserve(ctx, &bow->cand_v, ovb * nslots));      // the overflow lists; bucket minima behind their values
+    BH_TRY(bh_reserve(ctx, &bow->inv_acc, ab * nslots)); BH_TRY(bh_reserve(ctx, &bow->inv_slots, sizeof(inv_slot) * nslots));
+    const size_t need = (size_t)INV_PIN_BYTES * nslots;
+    if (need > bow->hq_cap) {
+        BH_HIP(ctx, hipStreamSynchronize(st));
+        if (bow->hq) (void)hipHostFree(bow->hq);
+        bow->hq = nullptr; bow->hq_cap = 0;
+        if (hipHostMalloc((void**)&bow->hq, need, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); bow->hq = nullptr; bow->inv_usable = 0; return BH_OK; }
+        bow->hq_cap = need;
+    }
+    BH_HIP(ctx, hipMemsetAsync(bow->bcnt.p, 0, cb * nslots, st));
+    std::vector<inv_slot> tab(nslots);
+    for (int q = 0; q < nslots; q++) {
+        inv_slot& S = tab[q];
+        char* hp = bow->hq + (size_t)INV_PIN_BYTES * q;
+        S.hdr = (const int*)hp; S.qw = (const uint32_t*)(hp + INV_PIN_W); S.qv = (const double*)(hp + INV_PIN_V); S.hout = hp + INV_PIN_R;
+        S.bcnt = (int*)((char*)bow->bcnt.p + cb * q); S.ctl = (inv_ctl*)(S.bcnt + nl + 64);
+        S.bkey = (uint32_t*)((char*)bow->bkey.p + kb * q); S.bval = (double*)((char*)bow->bval.p + vb * q);
+        S.okey = (uint32_t*)((char*)bow->cand_i.p + ob * q); S.oval = (double*)((char*)bow->cand_v.p + ovb * q); S.bmin = S.oval + INV_OVF_CAP;
+        S.acc = (double*)((char*)bow->inv_acc.p + ab * q);
+    }
+    BH_HIP(ctx, hipMemcpyAsync(bow->inv_slots.p, tab.data(), sizeof(inv_slot) * nslots, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipStreamSynchronize(st));
+    bow->inv_nslots = nslots;
+    return BH_OK;
 }
 
 static int inv_build(bh_bow* bow)
@@ -711,14 +765,46 @@ static int inv_build(bh_bow* bow)
     const double per_entry = ne ? (double)nel / (double)ne : 0.0;                               // words per entry (padded)
     const long long cap = (long long)(3.0 * 64.0 * per_entry * (double)BOW_QMAX / (double)INV_WORDS / INV_NSUB) + 16;
     bow->bcap = (int)std::min<long long>(INV_LCAP / INV_NSUB, (cap + 15) / 16 * 16);          // per list
-    const size_t nl = (size_t)bow->inv_nb * INV_NSUB;
-    BH_TRY(bh_reserve(ctx, &bow->bcnt, sizeof(int) * (nl + 64) + sizeof(inv_ctl)));
-    BH_TRY(bh_reserve(ctx, &bow->bkey, sizeof(uint32_t) * nl * bow->bcap + 64)); BH_TRY(bh_reserve(ctx, &bow->bval, sizeof(double) * nl * bow->bcap + 64));
-    BH_TRY(bh_reserve(ctx, &bow->cand_v, sizeof(double) * (INV_OVF_CAP + (size_t)bow->inv_nb + 8))); BH_TRY(bh_reserve(ctx, &bow->cand_i, sizeof(uint32_t) * INV_OVF_CAP));      // the overflow list; bucket minima behind its values
-    BH_HIP(ctx, hipMemsetAsync(bow->bcnt.p, 0, sizeof(int) * (nl + 64) + sizeof(inv_ctl), st));
-    BH_HIP(ctx, hipStreamSynchronize(st));
+    BH_TRY(inv_alloc_slots(bow, bow->inv_nslots));
     bow->inv_ready = 1;
     return BH_OK;
+}
+
+// The four launches of the inverted-file path for the first G slots (grid.y = slot), then one synchronisation.
+static int inv_launch(bh_bow* bow, int G, int max_nq, const uint8_t* keep)
+{
+    bh_ctx* ctx = bow->ctx;
+    hipStream_t st = ctx->stream;
+    static bool heavy_attr = false;
+    const size_t hlds = (sizeof(uint32_t) + sizeof(double)) * 2 * INV_HCAP + sizeof(uint32_t) * (4096 + 4096 + 64);
+    if (!heavy_attr) { BH_HIP(ctx, hipFuncSetAttribute((const void*)k_inv_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds)); heavy_attr = true; }
+    const inv_slot* slots = (const inv_slot*)bow->inv_slots.p;
+    bh_time_begin(ctx, BH_K_BOW_INV);
+    hipLaunchKernelGGL(k_inv_gather, dim3((max_nq + 3) / 4, G), dim3(256), 0, st, slots, (const long long*)bow->inv_start.p, (const uint32_t*)bow->inv_entry.p,
+                       (const double*)bow->inv_val.p, bow->bcap);
+    hipLaunchKernelGGL(k_inv_reduce, dim3((unsigned)((bow->inv_nb + 3) / 4), G), dim3(256), 0, st, slots, bow->bcap, bow->n_entries, keep, bow->inv_nb);
+    hipLaunchKernelGGL(k_inv_heavy, dim3(INV_HEAVY_MAX, G), dim3(1024), hlds, st, slots, bow->bcap, bow->n_entries, keep);
+    hipLaunchKernelGGL(k_inv_select, dim3(1, G), dim3(1024), 0, st, slots, bow->inv_nb, bow->n_entries);
+    bh_time_end(ctx);
+    BH_HIP(ctx, hipGetLastError());
+    BH_HIP(ctx, hipStreamSynchronize(st));
+    return BH_OK;
+}
+static void inv_fill_slot(bh_bow* bow, int q, const uint32_t* q_words, const double* q_vals, int nq, int k)
+{
+    char* hp = bow->hq + (size_t)INV_PIN_BYTES * q;
+    reinterpret_cast<int*>(hp)[0] = nq; reinterpret_cast<int*>(hp)[1] = k;
+    memcpy(hp + INV_PIN_W, q_words, sizeof(uint32_t) * (size_t)nq); memcpy(hp + INV_PIN_V, q_vals, sizeof(double) * (size_t)nq);
+}
+static int inv_read_slot(bh_bow* bow, int q, int* ids, double* scores, int* n_results)      // 1: answered, 0: the scan must
+{
+    const char* hr = bow->hq + (size_t)INV_PIN_BYTES * q + INV_PIN_R;
+    const int nres = reinterpret_cast<const int*>(hr)[0], fallback = reinterpret_cast<const int*>(hr)[1];
+    if (fallback) return 0;                                    // something did not fit this query
+    *n_results = nres;
+    memcpy(scores, hr + 8, sizeof(double) * (size_t)nres);
+    memcpy(ids, hr + 8 + 8 * INV_KMAX, sizeof(int) * (size_t)nres);
+    return 1;
 }
 
 // The inverted-file query, host arrays in and out.  Returns BH_OK with *used = 1 when it answered, *used = 0 when the scan must.
@@ -730,17 +816,8 @@ static int inv_query(bh_bow* bow, const uint32_t* q_words, const double* q_vals,
     *used = 0;
     if (max_results > INV_KMAX) return BH_OK;
     if (!bow->inv_ready) BH_TRY(inv_build(bow));
-    if (!bow->inv_usable) return BH_OK;
-    // pinned, device-visible block: the query in, the results out - no staging copies, one synchronisation
-    const size_t qoff_v = ((sizeof(uint32_t) * (size_t)nq + 15) & ~(size_t)15), roff = qoff_v + sizeof(double) * (size_t)nq, need = roff + 8 + 12 * (size_t)max_results + 64;
-    if (need > bow->hq_cap) {
-        if (bow->hq) (void)hipHostFree(bow->hq);
-        bow->hq = nullptr; bow->hq_cap = 0;
-        const size_t want = std::max<size_t>(need, 64 * 1024);
-        if (hipHostMalloc((void**)&bow->hq, want, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); bow->hq = nullptr; return BH_OK; }
-        bow->hq_cap = want;
-    }
-    memcpy(bow->hq, q_words, sizeof(uint32_t) * (size_t)nq); memcpy(bow->hq + qoff_v, q_vals, sizeof(double) * (size_t)nq);
+    if (!bow->inv_usable || !bow->hq) return BH_OK;
+    inv_fill_slot(bow, 0, q_words, q_vals, nq, max_results);  // pinned, device-visible block: the query in, the results out - no staging copies, one synchronisation
     const uint8_t* keep = nullptr;
     if (n_subset > 0) {
         BH_TRY(bh_reserve(ctx, &ctx->st_g, (size_t)bow->n_entries + sizeof(int) * (size_t)n_subset + 16));
@@ -750,30 +827,8 @@ static int inv_query(bh_bow* bow, const uint32_t* q_words, const double* q_vals,
         hipLaunchKernelGGL(k_bow_flag_set, dim3((n_subset + 255) / 256), dim3(256), 0, st, (const int*)d_sub, n_subset, bow->n_entries, flag);
         keep = flag;
     }
-    const int k = max_results;
-    static bool heavy_attr = false;
-    const size_t hlds = (sizeof(uint32_t) + sizeof(double)) * 2 * INV_HCAP + sizeof(uint32_t) * (4096 + 4096 + 64);
-    if (!heavy_attr) { BH_HIP(ctx, hipFuncSetAttribute((const void*)k_inv_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds)); heavy_attr = true; }
-    const size_t nl = (size_t)bow->inv_nb * INV_NSUB;
-    inv_ctl* ctl = (inv_ctl*)((int*)bow->bcnt.p + nl + 64);
-    uint32_t* okey = (uint32_t*)bow->cand_i.p; double* oval = (double*)bow->cand_v.p; double* bmin = oval + INV_OVF_CAP;
-    bh_time_begin(ctx, BH_K_BOW_INV);
-    hipLaunchKernelGGL(k_inv_gather, dim3((nq + 3) / 4), dim3(256), 0, st, (const uint32_t*)bow->hq, (const double*)(bow->hq + qoff_v), nq, (const long long*)bow->inv_start.p,
-                       (const uint32_t*)bow->inv_entry.p, (const double*)bow->inv_val.p, (int*)bow->bcnt.p, (uint32_t*)bow->bkey.p, (double*)bow->bval.p, bow->bcap, ctl, okey, oval);
-    hipLaunchKernelGGL(k_inv_reduce, dim3((unsigned)((bow->inv_nb + 3) / 4)), dim3(256), 0, st, (int*)bow->bcnt.p, (const uint32_t*)bow->bkey.p, (const double*)bow->bval.p, bow->bcap,
-                       bow->n_entries, keep, (double*)bow->acc.p, bow->inv_nb, ctl, bmin);
-    hipLaunchKernelGGL(k_inv_heavy, dim3(INV_HEAVY_MAX), dim3(1024), hlds, st, (const uint32_t*)bow->bkey.p, (const double*)bow->bval.p, bow->bcap, bow->n_entries, keep,
-                       (double*)bow->acc.p, ctl, (const uint32_t*)okey, (const double*)oval, bmin);
-    hipLaunchKernelGGL(k_inv_select, dim3(1), dim3(1024), 0, st, (const double*)bow->acc.p, (const double*)bmin, bow->inv_nb, bow->n_entries, k, ctl, bow->hq + roff);
-    bh_time_end(ctx);
-    BH_HIP(ctx, hipGetLastError());
-    BH_HIP(ctx, hipStreamSynchronize(st));
-    const int nres = reinterpret_cast<const int*>(bow->hq + roff)[0], fallback = reinterpret_cast<const int*>(bow->hq + roff)[1];
-    if (fallback) return BH_OK;                                // something did not fit this query: the scan answers
-    *n_results = nres;
-    memcpy(scores, bow->hq + roff + 8, sizeof(double) * (size_t)nres);
-    memcpy(ids, bow->hq + roff + 8 + 8 * (size_t)max_results, sizeof(int) * (size_t)nres);
-    *used = 1;
+    BH_TRY(inv_launch(bow, 1, nq, keep));
+    *used = inv_read_slot(bow, 0, ids, scores, n_results);
     return BH_OK;
 }
 
@@ -942,5 +997,41 @@ extern "C" int bh_bow_erase_entry(bh_bow* bow, int entry_id)
     if (e > a) BH_HIP(ctx, hipMemsetAsync((uint32_t*)bow->words.p + a, 0xff, sizeof(uint32_t) * (size_t)(e - a), ctx->stream));
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     bow->inv_ready = 0;
+    return BH_OK;
+}
+
+// Q queries at once through the inverted file: up to INV_QSLOTS per round of four launches (blockIdx.y = query slot, every slot with its
+// own scratch), so the ~0.1 ms of launch / dependency latency a single query pays is shared.  A loop closer or relocaliser that works
+// through a queue of keyframes (slam/loop_closing.py:29-30 takes them one by one from bow_queue) can hand them over together.
+extern "C" int bh_bow_query_l1_batch(bh_bow* bow, const uint32_t* q_words, const double* q_vals, const int* nq, int Q, int q_stride, int max_results,
+                                     int* ids, double* scores, int* n_results)
+{
+    if (!bow) return BH_ERR_INVALID;
+    bh_ctx* ctx = bow->ctx;
+    if (!q_words || !q_vals || !nq || !ids || !scores || !n_results || Q < 0 || q_stride < 1 || max_results < 1 || max_results > 1024)
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_query_l1_batch: bad argument");
+    for (int q = 0; q < Q; q++) {
+        if (nq[q] < 0 || nq[q] > q_stride || nq[q] > BOW_QMAX) return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_query_l1_batch: query %d has %d words (stride %d, limit %d)", q, nq[q], q_stride, BOW_QMAX);
+        const uint32_t* w = q_words + (size_t)q * q_stride;
+        for (int i = 1; i < nq[q]; i++) if (w[i] <= w[i - 1]) return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_query_l1: query words must be strictly ascending");
+    }
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<char> done(Q, 0);
+    if (bow->mode == 0 && max_results <= INV_KMAX && bow->n_entries > 0 && Q > 0) {
+        if (!bow->inv_ready) BH_TRY(inv_build(bow));
+        if (bow->inv_usable && bow->inv_nslots < INV_QSLOTS) BH_TRY(inv_alloc_slots(bow, INV_QSLOTS));
+        if (bow->inv_usable && bow->hq) {
+            for (int g0 = 0; g0 < Q; g0 += INV_QSLOTS) {
+                const int G = std::min(INV_QSLOTS, Q - g0);
+                int max_nq = 1;
+                for (int s = 0; s < G; s++) { const int q = g0 + s; inv_fill_slot(bow, s, q_words + (size_t)q * q_stride, q_vals + (size_t)q * q_stride, nq[q], max_results); max_nq = std::max(max_nq, nq[q]); }
+                BH_TRY(inv_launch(bow, G, max_nq, nullptr));
+                for (int s = 0; s < G; s++) { const int q = g0 + s; if (nq[q] > 0) done[q] = (char)inv_read_slot(bow, s, ids + (size_t)q * max_results, scores + (size_t)q * max_results, n_results + q); }
+            }
+        }
+    }
+    for (int q = 0; q < Q; q++)                                 // whatever the inverted file could not answer (or scan mode): one by one
+        if (!done[q]) BH_TRY(bow_query_impl(bow, q_words + (size_t)q * q_stride, q_vals + (size_t)q * q_stride, nq[q], nullptr, 0, max_results,
+                                            ids + (size_t)q * max_results, scores + (size_t)q * max_results, n_results + q, BH_MEM_HOST));
     return BH_OK;
 }

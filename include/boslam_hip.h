@@ -340,6 +340,13 @@ int  bh_bow_set_db(bh_bow* bow, long long n_entries, const int64_t* start, const
 int  bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, int max_results,
                      int* ids, double* scores, int* n_results, int mem);
 
+/* Q queries in one call (host arrays): q_words u32[Q][q_stride], q_vals f64[Q][q_stride], nq int[Q]; ids int[Q][max_results],
+ * scores f64[Q][max_results], n_results int[Q] - each query answered exactly as bh_bow_query_l1 answers it.  With the inverted
+ * file (the default mode, max_results <= 16) up to 16 queries share every launch: a loop closer or relocaliser working through a
+ * queue of keyframes (slam/loop_closing.py:29-30 takes them from bow_queue one by one) pays the launch latency once per 16. */
+int  bh_bow_query_l1_batch(bh_bow* bow, const uint32_t* q_words, const double* q_vals, const int* nq, int Q, int q_stride, int max_results,
+                           int* ids, double* scores, int* n_results);
+
 /* The fork's Database::query(features, target_inds, max_results, max_id) with a non-empty target_inds — slam/bow_db.py:37-39 ->
  * dbow3.cpp:147-152: only the entries listed in `subset` can appear in the result (host arrays). */
 int  bh_bow_query_l1_subset(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, const int* subset, int n_subset,

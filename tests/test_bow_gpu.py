@@ -239,3 +239,37 @@ def test_dbow_from_file_subset_query_and_compare_frames(ctx, tmp_path):
     res = D.query(frames[6].des, [], 1, -1)
     assert len(res) == 1 and res[0].Id == 6 and abs(res[0].Score - 1.0) < 1e-12
     assert [r.Id for r in D.query(frames[6].des, [], 3, 5)] == [int(i) for i in oracle.bow_query_l1_subset(qw, qv, start, words, vals, range(6), 3)[0]]
+
+
+def test_bow_query_batch_equals_single_queries(ctx):
+    """bh_bow_query_l1_batch: 37 queries (more than two rounds of 16 slots; near-duplicates of stored entries, unrelated word sets, an
+    empty query, one that shares nothing) against the same queries one at a time and against the oracle - ids and score bits equal,
+    in both modes, and single queries keep working afterwards (slot 0 of the enlarged scratch)."""
+    db = synth.bow_database(n_entries=6000, words_per_entry=400, query_entry=2000, seed=9)
+    d = bow.BowDatabase(ctx)
+    d.set_db(db["start"], db["words"], db["vals"])
+    rng = np.random.default_rng(2)
+    queries = [(db["q_words"], db["q_vals"])]
+    for e in rng.integers(0, 6000, 20):                                        # perturbed copies of stored entries
+        a, b = db["start"][e], db["start"][e + 1]
+        w = db["words"][a:b].copy(); v = db["vals"][a:b].copy()
+        keep = rng.random(len(w)) > 0.2
+        queries.append((w[keep], v[keep] / v[keep].sum()))
+    for _ in range(14):                                                        # random word sets
+        w = np.unique(rng.integers(0, 1 << 20, int(rng.integers(1, 900)))).astype(np.uint32)
+        v = rng.random(len(w)); queries.append((w, v / v.sum()))
+    queries.append((np.zeros(0, np.uint32), np.zeros(0)))
+    queries.append((np.array([(1 << 20) - 1], np.uint32), np.array([1.0])))
+    for mode in ("inverted", "scan"):
+        d.set_mode(mode)
+        for k in (1, 7):
+            got = d.query_batch(queries, k)
+            assert len(got) == len(queries)
+            for (w, v), (ids, sc) in zip(queries, got):
+                i1, s1 = d.query(w, v, k) if len(w) else (np.zeros(0, np.int32), np.zeros(0))
+                assert np.array_equal(ids, i1) and np.array_equal(sc.view(np.uint64), s1.view(np.uint64)), mode
+                if len(w):
+                    oi, os_ = oracle.bow_query_l1(w, v, db["start"], db["words"], db["vals"], k)
+                    assert np.array_equal(ids, oi) and np.array_equal(sc.view(np.uint64), os_.view(np.uint64))
+    assert d.query_batch([], 3) == []
+    d.close()
