@@ -3612,6 +3612,7 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
     }
     char* hp = (char*)ctx->pin; char* dp = (char*)ctx->st_a.p; char* ds = (char*)ctx->st_d.p;
     bld_view* hv = (bld_view*)hp;
+    bool all_piecewise = true;
     for (int w = 0; w < W; w++) {
         bld_view V = {};
         V.info = (int*)ds;                                                         // (a window that is not staged: C = 0 makes both kernels leave at once)
@@ -3633,16 +3634,27 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
             V.pairs = (int2*)ba->pairs.p; V.j_start = (int*)ba->j_start.p; V.join = (int2*)ba->join.p; V.join_cap = l.join_cap;
             V.pts = (double*)ba->pts[0].p; V.cams_dst = (ba_cam*)ba->cams[0].p; V.K = ba->K;
             V.S = (double*)ba->S.p; V.dxp = (double*)ba->dxp.p; V.err0 = (double*)ba->err[0].p; V.state = (ba_state*)ba->state.p;
-            memcpy(hp + l.ep, q.edge_pose, sizeof(int) * (size_t)q.E); memcpy(hp + l.pp, q.edge_point, sizeof(int) * (size_t)q.E);
-            memcpy(hp + l.fx, q.fixed, (size_t)q.C); memcpy(hp + l.pt, q.points, sizeof(double) * 3 * (size_t)q.P);
-            memcpy(hp + l.ms, q.meas, sizeof(double) * 2 * (size_t)q.E);
+            // a big window (configs[2]: 2.2 MB) goes up array by array, each copy enqueued as soon as its array is packed - the transfer of
+            // one runs under the packing of the next; small windows wait for the one copy of everything below
+            const bool piecewise = l.tier == 2;
+            auto put = [&](size_t off, const void* src, size_t bytes) -> int {
+                memcpy(hp + off, src, bytes);
+                if (piecewise) BH_HIP(ctx, hipMemcpyAsync(dp + off, hp + off, bytes, hipMemcpyHostToDevice, st));
+                return BH_OK;
+            };
+            BH_TRY(put(l.ep, q.edge_pose, sizeof(int) * (size_t)q.E)); BH_TRY(put(l.pp, q.edge_point, sizeof(int) * (size_t)q.E));
+            BH_TRY(put(l.fx, q.fixed, (size_t)q.C)); BH_TRY(put(l.pt, q.points, sizeof(double) * 3 * (size_t)q.P));
+            BH_TRY(put(l.ms, q.meas, sizeof(double) * 2 * (size_t)q.E));
             ba_cam* hc = (ba_cam*)(hp + l.cm);
             memset(hc, 0, sizeof(ba_cam) * (size_t)q.C);
             for (int i = 0; i < q.C; i++) { h_quat_from_R(q.R + 9 * (size_t)i, hc[i].q); for (int k = 0; k < 3; k++) hc[i].t[k] = q.t[3 * (size_t)i + k]; }
+            if (piecewise) BH_HIP(ctx, hipMemcpyAsync(dp + l.cm, hp + l.cm, sizeof(ba_cam) * (size_t)q.C, hipMemcpyHostToDevice, st));
+            all_piecewise &= piecewise;
         }
         hv[w] = V;
     }
-    BH_HIP(ctx, hipMemcpyAsync(dp, hp, up, hipMemcpyHostToDevice, st));
+    if (all_piecewise) BH_HIP(ctx, hipMemcpyAsync(dp, hp, al(sizeof(bld_view) * (size_t)W), hipMemcpyHostToDevice, st));      // only the view table is left
+    else BH_HIP(ctx, hipMemcpyAsync(dp, hp, up, hipMemcpyHostToDevice, st));
     static bool lds_attr = false;                                                  // > 64 KB of dynamic LDS needs the attribute (once per process)
     if (!lds_attr) { BH_HIP(ctx, hipFuncSetAttribute((const void*)k_bld_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bld_lds_bytes(BLD_LE, BLD_LP))); lds_attr = true; }
     int max_pairs = 1;
