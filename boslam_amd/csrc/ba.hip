@@ -2241,19 +2241,27 @@ __device__ __forceinline__ void ba_update_body(int bid, const ba_cam* __restrict
                                                    const double* __restrict__ dxp, double* __restrict__ dxl, ba_K K)
 {
     if (bid < pblocks) {
-        const int j = bid * 256 + threadIdx.x;
-        if (j >= Pa) return;
-        double c[3] = { bl[3 * j], bl[3 * j + 1], bl[3 * j + 2] };
-        for (int u = p_start[j]; u < p_start[j + 1]; u++) {
-            const int e = p_edges[u];
-            const int s = cslot[e_cam[e]];
-            if (s < 0) continue;
-            const double* B = Hpl + 18 * (size_t)e; const double* d = dxp + 6 * s;
+        // BP_G lanes per landmark (as the linearisation): a lane takes every BP_G-th edge - one thread per landmark walked its ~8 edges one
+        // dependent load chain after the other (k_ba_update: 25 us at configs[2], 13 us for a live window) - and the partial sums of
+        // Hpl' dx meet in an xor tree on DPP; lane 0 of the group finishes the landmark
+        const int j = (bid * 256 + (int)threadIdx.x) / BP_G, sub = threadIdx.x & (BP_G - 1);
+        const bool live = j < Pa;
+        double acc[3] = { 0, 0, 0 };
+        if (live)
+            for (int u = p_start[j] + sub; u < p_start[j + 1]; u += BP_G) {
+                const int e = p_edges[u];
+                const int s = cslot[e_cam[e]];
+                if (s < 0) continue;
+                const double* B = Hpl + 18 * (size_t)e; const double* d = dxp + 6 * s;
 #pragma unroll
-            for (int bb = 0; bb < 3; bb++)
+                for (int bb = 0; bb < 3; bb++)
 #pragma unroll
-                for (int a = 0; a < 6; a++) c[bb] -= B[3 * a + bb] * d[a];
-        }
+                    for (int a = 0; a < 6; a++) acc[bb] += B[3 * a + bb] * d[a];
+            }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { acc[i] += d_xor_dpp<1>(acc[i]); acc[i] += d_xor_dpp<2>(acc[i]); acc[i] += d_xor_dpp<4>(acc[i]); }
+        if (!live || sub) return;
+        const double c[3] = { bl[3 * j] - acc[0], bl[3 * j + 1] - acc[1], bl[3 * j + 2] - acc[2] };
         const double* Di = Dinv + 9 * (size_t)j;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
@@ -2477,7 +2485,7 @@ __global__ __launch_bounds__(256) void k_bb_update(const ba_view* __restrict__ v
     if (!bb_where(W, w, bx)) return;
     const ba_view& V = views[w];
     const ba_state* S = V.state;
-    const int pblocks = (V.Pa + 255) / 256, cblocks = (V.C + 255) / 256;
+    const int pblocks = (V.Pa * BP_G + 255) / 256, cblocks = (V.C + 255) / 256;
     if (S->b_done || bx >= pblocks + cblocks) return;
     const int cur = S->b_cur;
     ba_update_body(bx, V.cams[cur], V.cams[cur ^ 1], V.pts[cur], V.pts[cur ^ 1], V.cslot, V.C, V.Pa, pblocks, V.p_start, V.p_edges, V.e_cam, V.Hpl, V.Dinv, V.bl, V.dxp, V.dxl, V.K);
@@ -4070,7 +4078,8 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                     BH_TRY(solve_rc);                       // a failed launch inside the multi-kernel solvers (the error text is set there)
                 }
             }
-            BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_update, dim3(pblocks + cblocks), dim3(256), st, cams, cams_t, pts, pts_t, cslot, C, Pa, pblocks,
+            const int upblocks = (Pa * BP_G + 255) / 256;       // the update's landmark workgroups: BP_G lanes per landmark
+            BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_update, dim3(upblocks + cblocks), dim3(256), st, cams, cams_t, pts, pts_t, cslot, C, Pa, upblocks,
                       p_start, p_edges, e_cam, (const double*)Hpl, (const double*)Dinv, (const double*)bl, (const double*)dxp, dxl, ba->K);
             BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_err, dim3((Ea + 255) / 256), dim3(256), st, (const ba_cam*)cams_t, (const double*)pts_t, e_cam, e_pt,
                       e_meas, Ea, huber_delta, (double*)ba->err[1].p, (double*)ba->chi_e[1].p);
@@ -4182,7 +4191,7 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
         g_lin = std::max(g_lin, (ba->Pa * BP_G + 255) / 256 + ba->Cf);
         g_pb = std::max(g_pb, (ba->Pa + 255) / 256);
         g_schur = std::max(g_schur, (ba->npairs + 7) / 8 * 8 + ba->Cf);
-        g_upd = std::max(g_upd, (ba->Pa + 255) / 256 + (ba->C + 255) / 256);
+        g_upd = std::max(g_upd, (ba->Pa * BP_G + 255) / 256 + (ba->C + 255) / 256);
         g_eb = std::max(g_eb, (ba->Ea + 255) / 256);
         any_part |= V.part != nullptr;
         if (iters_done) iters_done[w] = 0;
