@@ -2574,15 +2574,18 @@ static void h_quat_from_R(const double* m, double* q)
     for (int a = 0; a < 4; a++) q[a] /= n;
 }
 
+static void ba_builder_attr();
 extern "C" int bh_ba_create(bh_ctx* ctx, const double K[5], bh_ba** out)
 {
     if (!ctx || !K || !out) return BH_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);                         // the attributes below belong to the context's device
     (void)hipFuncSetAttribute((const void*)k_ba_chol<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute((const void*)k_ba_chol<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute((const void*)k_ba_chol<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute((const void*)k_ba_chol_dense<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
     (void)hipFuncSetAttribute((const void*)k_ba_chol_dense<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
     (void)hipFuncSetAttribute((const void*)k_ba_chol_sw, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    ba_builder_attr();                                       // (k_bld_small: > 64 KB of dynamic LDS)
     bh_ba* ba = new bh_ba();
     ba->ctx = ctx; ba->K = { K[0], K[1], K[2], K[3] };
     (void)hipSetDevice(ctx->device);
@@ -3555,6 +3558,8 @@ __global__ __launch_bounds__(256) void k_bld_join_merge(const bld_view* __restri
     }
 }
 
+static void ba_builder_attr() { (void)hipFuncSetAttribute((const void*)k_bld_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bld_lds_bytes(BLD_LE, BLD_LP)); }
+
 // Host side of the one-workgroup builder, for W windows at once (W = 1: bh_ba_set_problem).  taken[w] = 0: window w is not a local
 // window (or the kernel refused it) and nothing was built for it; taken[w] = 1: structure, measurements, landmarks, camera blocks and
 // the cleared buffers are on the device, out[w] holds the counts.  One copy up, two launches, one copy back, one synchronisation.
@@ -3663,8 +3668,6 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
     }
     if (all_piecewise) BH_HIP(ctx, hipMemcpyAsync(dp, hp, al(sizeof(bld_view) * (size_t)W), hipMemcpyHostToDevice, st));      // only the view table is left
     else BH_HIP(ctx, hipMemcpyAsync(dp, hp, up, hipMemcpyHostToDevice, st));
-    static bool lds_attr = false;                                                  // > 64 KB of dynamic LDS needs the attribute (once per process)
-    if (!lds_attr) { BH_HIP(ctx, hipFuncSetAttribute((const void*)k_bld_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bld_lds_bytes(BLD_LE, BLD_LP))); lds_attr = true; }
     int max_pairs = 1;
     for (int w = 0; w < W; w++) if (taken[w]) max_pairs = std::max(max_pairs, (int)L[w].maxpairs);
     const bld_view* dv = (const bld_view*)dp;
