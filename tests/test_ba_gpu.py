@@ -318,6 +318,16 @@ def test_batched_windows_equal_single_window_runs_bitwise(ctx):
             R, t = s.poses()
             assert np.array_equal(R, R0) and np.array_equal(t, t0) and np.array_equal(s.points(), p0, equal_nan=True)
             assert np.array_equal(s.chi2(), c0) and np.array_equal(s.log()[:d0], l0)
+        if verbose:                                                         # a window count that is not a multiple of 8 (the grids are padded to 8 windows)
+            three = [ba.LocalBA(ctx, pr["K"]) for pr in probs[:3]]
+            ba.set_problems(ctx, three, [(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"]) for pr in probs[:3]])
+            b3 = ba.LocalBABatch(ctx, three)
+            d3 = b3.optimize(NIT, verbose_errors=verbose)
+            for w, s3 in enumerate(three):
+                assert d3[w] == single[w][0] and np.array_equal(s3.poses()[1], single[w][1][1]) and np.array_equal(s3.points(), single[w][2], equal_nan=True)
+            b3.close()
+            for s3 in three:
+                s3.close()
         # a second run on the same handles continues from the optimised state exactly like the single-window path does
         done2 = batch.optimize(2, verbose_errors=verbose)
         assert (done2 >= 1).all()
