@@ -533,7 +533,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // staging array reuses the pixel tile, which is dead once phase 2 and the blur are through.
     __shared__ __attribute__((aligned(16))) uint32_t s_px[FPX_H * FPW + 8];      // +8: the last k-block of the blur reads 15 bytes past the last row (zero taps)
     __shared__ uint32_t s_mask[TILE_H * (TILE_W / 32)];         // the tile of the bit-packed mask (no HBM round trip in phase 3)
-    __shared__ uint32_t s_scw[FITEMS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_scw[FITEMS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_k1[4];   // 16 constant bytes: the blur's "+128" rides through spare k slots of its second product
     __shared__ uint16_t s_list[FLIST_CAP];
     __shared__ uint32_t s_vm[FPW];
     __shared__ uint16_t s_cl[FCL_CAP];                          // the candidates phase 2 found to be corners: phase 3 walks these, not the whole candidate list
@@ -558,22 +559,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t pw[NLD];
     const int lr0 = tid / FRW, lc = tid - lr0 * FRW;
     const bool ldl = tid < 7 * FRW;
-    const bool interior = x0 >= 4 && x0 + TILE_W + 4 <= L.w && y0 >= 4 && y0 + TILE_H + 4 <= L.h;      // 37 % of the tiles at 640 x 480
-    if (interior) {                                              // halo and all inside the level: plain aligned word loads
-        const uint8_t* org = img + (size_t)(y0 - 4) * L.pitch + (x0 - 4) + 4 * lc;
+    const bool yin = y0 >= 4 && y0 + TILE_H + 4 <= L.h;          // rows y0-4 .. y0+35 all inside the level: no reflection per row
+    const bool interior = yin && x0 >= 4 && x0 + TILE_W + 4 <= L.w;      // 37 % of the tiles at 640 x 480
+    // Every lane loads from an address clamped into its row (level base + 32-bit offset: scalar base + vector offset form, no 64-bit
+    // multiply per load, no predicate): a word further than 8 px beyond the border is never read with a non-zero weight, the words that
+    // straddle the border are overwritten by the fix lanes below.
+    const uint32_t xwc = (uint32_t)min(max(x0 - 4 + 4 * lc, 0), L.pitch - 4);
+    if (yin) {
+        const uint8_t* org = img + (uint32_t)((y0 - 4) * L.pitch);
 #pragma unroll
         for (int j = 0; j < NLD; j++) {
             const int r = min(lr0 + 7 * j, FPX_H - 1);
-            pw[j] = *reinterpret_cast<const uint32_t*>(org + r * L.pitch);
+            pw[j] = *reinterpret_cast<const uint32_t*>(org + ((uint32_t)(r * L.pitch) + xwc));
         }
     } else
 #pragma unroll
     for (int j = 0; j < NLD; j++) {
-        const int r = lr0 + 7 * j;
-        const int y = y0 - 4 + r, x = x0 - 4 + lc * 4;
-        uint32_t v = 0;
-        if (ldl && r < FPX_H && y < L.h + 8 && x >= 0 && x + 3 < L.w) v = *reinterpret_cast<const uint32_t*>(img + (size_t)reflect101(y, L.h) * L.pitch + x);
-        pw[j] = v;
+        const int ry = reflect101(y0 - 4 + lr0 + 7 * j, L.h);
+        pw[j] = *reinterpret_cast<const uint32_t*>(img + ((uint32_t)(ry * L.pitch) + xwc));
     }
     // The words that straddle or lie just beyond the left / right border (one on the left, at most three on the right, per row) are
     // gathered byte by byte with reflection - by 160 dedicated lanes, once: as a branch of the loop above, every wave of a border tile
@@ -601,13 +604,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int xlo = max(max(3, et - 1), x0 - 1), xhi = min(min(L.w - 4, L.w - et), x0 + TILE_W);
     const int ylo = max(3, et - 1), yhi = min(L.h - 4, L.h - et);
     if (tid < TILE_H * (TILE_W / 32)) s_mask[tid] = mw;
-    if (tid == 0) { s_n = 0; s_k = 0; s_c = 0; }
+    if (tid == 0) { s_n = 0; s_k = 0; s_c = 0; s_k1[0] = 0x80808181u; s_k1[1] = 0x80808080u; s_k1[2] = 0x80808080u; s_k1[3] = 0x80808080u; }
     if (tid < FPW) {                                             // per tile word: 0x80 in the bytes whose pixel is in [xlo, xhi]; pads 0
         const int xb = x0 - 8 + 4 * tid;
         const int lo = min(max(xlo - xb, 0), 4), hi = min(max(xhi - xb + 1, 0), 4);
         s_vm[tid] = (tid >= 1 && tid <= FRW) ? (uint32_t)((0x80808080ull << (8 * lo)) & (0x80808080ull >> (8 * (4 - hi)))) : 0u;
     }
-    for (int i = tid; i < FITEMS; i += 256) s_scw[i] = 0;
+    {
+        static_assert(FITEMS % 4 == 0 && FITEMS / 4 <= 512, "score tile is zeroed by two 16-byte stores per lane");
+        uint4* z = reinterpret_cast<uint4*>(s_scw);
+        z[tid] = make_uint4(0, 0, 0, 0);
+        if (tid < FITEMS / 4 - 256) z[256 + tid] = make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < NLD; j++) {
         const int r = lr0 + 7 * j;
@@ -631,12 +639,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const fs2 T = fs2{ (short)thr, (short)thr };
         const int sy0 = tid / FPW, w = tid - sy0 * FPW;
         const uint32_t vmw = tid < 7 * FPW ? s_vm[w] : 0u;
+        // rows: the tile's score rows y0-1 .. y0+32 all inside [ylo, yhi] (every tile but those of the level's first and last tile rows):
+        // no row test per round; a band of 7 rows with no row inside (edgeThreshold = 31 leaves the first 29 rows of a level unscored)
+        // is skipped by the whole workgroup.
+        const bool allrows = y0 - 1 >= ylo && y0 + TILE_H <= yhi;
+        const bool anycol = xlo <= xhi;
         uint32_t M = 0;
 #pragma unroll
         for (int it = 0; it < (FSC_H + 6) / 7; it++) {
+            const int yb0 = y0 - 1 + 7 * it, yb1 = y0 - 1 + min(7 * it + 6, FSC_H - 1);      // the band's rows (uniform)
+            if (!(anycol && yb1 >= ylo && yb0 <= yhi)) continue;
             const int sy = sy0 + 7 * it;
-            const int y = y0 - 1 + sy;
-            const uint32_t vm = (sy < FSC_H && y >= ylo && y <= yhi) ? vmw : 0u;
+            uint32_t vm = (7 * it + 6 < FSC_H || sy < FSC_H) ? vmw : 0u;
+            if (!allrows) { const int y = y0 - 1 + sy; vm = (y >= ylo && y <= yhi) ? vm : 0u; }
             const uint32_t* cw = s_px + min(sy, FSC_H - 1) * FPW + w + 3 * FPW;
             const uint32_t W0 = cw[0], Wm = cw[-1], Wp = cw[1], U = cw[-3 * FPW], D = cw[3 * FPW];
             // packed 16-bit operand pairs: pixels (0,1) and (2,3) of the word; left = pixel - 3, right = pixel + 3
@@ -647,20 +662,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const fs2 R0 = fpk(Wp, W0, 0x0c040c03u), R1 = fpk(0, Wp, 0x0c020c01u);
             const fs2 dk0 = fmx(fmn(D0, U0), fmn(R0, L0)), br0 = fmn(fmx(D0, U0), fmx(R0, L0));
             const fs2 dk1 = fmx(fmn(D1, U1), fmn(R1, L1)), br1 = fmn(fmx(D1, U1), fmx(R1, L1));
-            const fs2 m0 = ((dk0 + T) - C0) | ((C0 + T) - br0);    // negative <=> darker pair below v - thr, or brighter pair above v + thr
-            const fs2 m1 = ((dk1 + T) - C1) | ((C1 + T) - br1);
+            const fs2 m0 = T - fmx(C0 - dk0, br0 - C0);             // negative <=> darker pair below v - thr, or brighter pair above v + thr
+            const fs2 m1 = T - fmx(C1 - dk1, br1 - C1);
             const uint32_t P = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, m1), __builtin_bit_cast(uint32_t, m0), 0x07050301u) & vm;
             M |= P >> (7 - it);                                      // vm leaves only the sign bits 7, 15, 23, 31
         }
         if (M) {
-            int pos = lds_add_rtn(&s_n, __popc(M));
-            const int b0 = 4 * (sy0 * FPW + w);
-            do {
-                const int q = __ffs(M) - 1;
-                M &= M - 1;
-                if (pos < FLIST_CAP) s_list[pos] = (uint16_t)(b0 + (q & 7) * (4 * 7 * FPW) + (q >> 3));      // byte index into the score tile
-                pos++;
-            } while (M);
+            const int cnt = __popc(M);
+            int pos = lds_add_rtn(&s_n, cnt);
+            if (pos + cnt <= FLIST_CAP) {                            // (a list that overflows is dropped as a whole below: s_n > FLIST_CAP)
+                const int b0 = 4 * (sy0 * FPW + w);
+                do {
+                    const int q = __ffs(M) - 1;
+                    M &= M - 1;
+                    s_list[pos++] = (uint16_t)(b0 + (q & 7) * (4 * 7 * FPW) + (q >> 3));      // byte index into the score tile
+                } while (M);
+            }
         }
     }
     __syncthreads();
@@ -761,9 +778,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
             for (int rb = 0; rb < 2; rb++) {
                 const uint8_t* rp = pxb + min(32 * rb + n, FPX_H - 1) * FROW + 32 * wv + 16 * h;
-                fv4 a0 = *reinterpret_cast<const fv4*>(rp), a1 = *reinterpret_cast<const fv4*>(rp + 32);
+                // k slots 48 .. 63 of the second product (lane half 1) only meet zero taps: they carry the constant bytes (1, 1, 0, ..)
+                // against taps (64, 64, 0, ..) instead - the "+ 128" without sixteen accumulator moves
+                fv4 a0 = *reinterpret_cast<const fv4*>(rp), a1 = *reinterpret_cast<const fv4*>(h ? reinterpret_cast<const uint8_t*>(s_k1) : rp + 32);
                 a0 ^= (int)0x80808080u; a1 ^= (int)0x80808080u;
-                fv16 acc = { 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128 };
+                fv16 acc = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, P1B0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, P1B1, acc, 0, 0, 0);
 #pragma unroll
@@ -781,26 +800,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         accH = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi[0], P2B0, accH, 0, 0, 0);
         accH = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi[1], P2B1, accH, 0, 0, 0);
         const int CI = 257 * (128 + 32768) + 32768;
-        fv16 accL = { CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI };
+        fv16 accL;                                                 // 256 sum g hi + the constant is the C operand of the low product: no constant fill, no combine afterwards
+#pragma unroll
+        for (int i = 0; i < 16; i++) accL[i] = (accH[i] << 8) + CI;
         accL = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo[0], P2B0, accL, 0, 0, 0);
         accL = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo[1], P2B1, accL, 0, 0, 0);
-        // lane = output row n; registers 4 g .. 4 g + 3 = columns 32 w + 8 g + 4 h + (0..3): byte 2 of the clamped sums
+        // lane = output row n; registers 4 g .. 4 g + 3 = columns 32 w + 8 g + 4 h + (0..3): bits 16 .. 24 of the sums, clamped to 255
         uint32_t* s_o = s_px;                                      // 32 rows x 33 words
         __syncthreads();                                           // every wave has read its pixels
 #pragma unroll
         for (int g2 = 0; g2 < 4; g2++) {
-            uint32_t v[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) v[m] = min((uint32_t)((accH[4 * g2 + m] << 8) + accL[4 * g2 + m]), 0xffffffu);
-            const uint32_t p01 = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), p23 = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u);
-            s_o[n * 33 + 8 * wv + 2 * g2 + h] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            const us2 lim = us2{ 255, 255 };
+            const us2 p01 = __builtin_elementwise_min(__builtin_bit_cast(us2, __builtin_amdgcn_perm((uint32_t)accL[4 * g2 + 1], (uint32_t)accL[4 * g2], 0x07060302u)), lim);
+            const us2 p23 = __builtin_elementwise_min(__builtin_bit_cast(us2, __builtin_amdgcn_perm((uint32_t)accL[4 * g2 + 3], (uint32_t)accL[4 * g2 + 2], 0x07060302u)), lim);
+            s_o[n * 33 + 8 * wv + 2 * g2 + h] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
         }
         __syncthreads();
+        {   // whole 128-byte row segments; tile base in scalar registers, one 32-bit offset per lane
+            const int wd = tid & 31, r0 = tid >> 5;
+            uint8_t* bt = blur + fbase + (uint32_t)(y0 * L.pitch + x0);
+            const bool xin = x0 + 4 * wd < L.w;
+            const uint32_t o0 = (uint32_t)(r0 * L.pitch + 4 * wd);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int idx = tid + 256 * k, row = idx >> 5, wd = idx & 31;
-            const int xs = x0 + 4 * wd, y = y0 + row;
-            if (xs < L.w && y < L.h) *reinterpret_cast<uint32_t*>(blur + fbase + (size_t)y * L.pitch + xs) = s_o[row * 33 + wd];
+            for (int k = 0; k < 4; k++) {
+                const int row = r0 + 8 * k;
+                if (xin && y0 + row < L.h) *reinterpret_cast<uint32_t*>(bt + (o0 + (uint32_t)(8 * k * L.pitch))) = s_o[row * 33 + wd];
+            }
         }
     }
     __syncthreads();                                            // the pixel tile is dead from here on: s_out takes its place
@@ -1308,7 +1334,7 @@ static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
                     const int n = lane & 31, hh = lane >> 5;
                     const int t1 = 32 * kb + 16 * hh + j - n - 5;                                    // pass 1: k = byte offset in the LDS row, n = output column
                     const int t2 = 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hh - n - 1;                // pass 2: k = tile row (accumulator order), n = output row
-                    gt[((0 + kb) * 64 + lane) * 16 + j] = (int8_t)((t1 >= 0 && t1 <= 6) ? gk[t1] : 0);
+                    gt[((0 + kb) * 64 + lane) * 16 + j] = (int8_t)((t1 >= 0 && t1 <= 6) ? gk[t1] : ((kb == 1 && hh == 1 && j < 2) ? 64 : 0));      // + the bias slots (k_fast, pass 1)
                     gt[((2 + kb) * 64 + lane) * 16 + j] = (int8_t)((t2 >= 0 && t2 <= 6) ? gk[t2] : 0);
                 }
     }
