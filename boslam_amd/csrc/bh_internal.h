@@ -48,6 +48,10 @@ enum bh_kid { BH_K_GRAY = 0, BH_K_PYR, BH_K_FAST, BH_K_BLUR, BH_K_SELECT, BH_K_B
 
 struct bh_time_rec { int kid; hipEvent_t e0, e1; };
 
+// k_pyr_mfma's host-built tables for one pyramid level (offsets in u32 words into bh_ctx::rtab): window start per 32-column block,
+// tap fragments of the two passes, the mask's run masks per 32-pixel word, the per-tile lists of special mask positions
+struct bh_pm_level { int xinfo, xtap, yinfo, ytap, mtab, mwb, fidx, fix, tiles_x, tiles_y; };
+
 struct bh_orb_ws { bh_buf pyr, mpyr, clist, blur, hist, sel_xy, sel_resp, sel_cnt; };   // one chunk pipeline's workspace
 
 struct bh_ctx {
@@ -65,6 +69,9 @@ struct bh_ctx {
     int         ws_frames = 0;       // frames the pyramid workspace holds
     bh_orb_ws   ows[BH_MAX_PIPES];
     bh_buf      tab, status;
+    bh_buf      rtab;                // matrix-core resize tables (k_pyr_mfma)
+    bh_pm_level pm[BH_MAX_LEVELS] = {};
+    int         pm_ok = 0;           // every level's windows fit the kernel's tile (else k_pyr_down_bits)
     int         last_pipe = 0;
     bh_buf      st_img, st_mask, st_depth, st_kps, st_desc, st_nkp;     // host-mode staging
     bh_buf      st_a, st_b, st_c, st_d, st_e, st_f, st_g, st_h;         // generic staging (match / BA)

@@ -384,6 +384,164 @@ __global__ __launch_bounds__(256) void k_pyr_down_bits(uint8_t* __restrict__ pyr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ pyramid level l from l-1 on the matrix cores
+// The resize is a separable linear map with at most two taps per output and axis, i.e. two products with banded matrices, and the
+// arithmetic of INTER_LINEAR_EXACT (8.8 horizontal, 16.16 vertical, one rounding at the end) is exact in int32 in any order.  The
+// vector-ALU form above spends ~0.53 wave-instructions per output pixel (the front end is bound by vector issue, tools/valu_rate.hip);
+// here one wave makes a 32-column x 24-row output block with 8 v_mfma_i32_32x32x32_i8:
+//   pass H   Hs[r][c'] = sum_k (-cx[k][c']) (127 - px[r][k]) - 1 = H - 32513  for the block's 32 source rows (24 x 1.3 + 2 <= 32) and a
+//            64-byte source window starting at a multiple of 16 (32 outputs span <= 43 columns): A = the rows' bytes as they lie in
+//            memory (xor 0x7f), B = tap fragments built on the host per column block.  A tap is 0 .. 256 - nine bits - so it enters as
+//            two int8 halves (two products into one accumulator), and NEGATED, because 256 = 128 + 128 has no int8 form but -256 has;
+//            the operand is negated with it (127 - px = -(px - 128) - 1, the -1 is a constant since the taps of an output sum to 256).
+//   pass V   the accumulator tile is the next product's A operand (k = source row, in accumulator order; the host builds the row taps
+//            in that order): Hs = 256 hi + lo8 -> (-hi - 1), (127 - lo8) as int8, 256 x (sum over hi) + constant is the C operand of
+//            the lo product, whose result is the rounded sum; byte 2 is the pixel.
+// The bit-packed mask (binary: depth > 0) follows the reference's resize + threshold(254) by bit logic: away from a sparse, static set
+// of "special" positions the output bit is the AND of its four taps - per 32-pixel output word: AND the two taps' windows, then
+// gather the bits by the runs of equal (source - destination) distance (six shift-and-mask steps per 16 outputs, masks from the
+// host).  Where a tap weighs <= 128 of 65 536 (3.4 % of the positions; a property of the coefficients alone) the reference result is a
+// 16-entry truth table of the four taps, built on the host: those positions are patched in LDS from a per-tile list.
+#define PM_TW 128
+#define PM_TH 24
+
+#define PM_MH 64             // rows of a mask workgroup (4 words x 64 rows: one 32-pixel output word per lane)
+#define PM_MSR 88            // source mask rows staged for them (64 x 1.3 + 2 <= 88)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pyr_mfma(uint8_t* __restrict__ pyr, bh_orb_geom g, int level,
+                                                  const uint32_t* __restrict__ tab, const uint32_t* __restrict__ rtab, bh_pm_level T, uint32_t* __restrict__ mbits)
+{
+    typedef int fv4 __attribute__((ext_vector_type(4)));
+    typedef int fv16 __attribute__((ext_vector_type(16)));
+    __shared__ uint32_t s_o[4 * 32 * 9];                          // image: per wave 32 rows x (8 + 1) words; mask: the staged source rows (88 x 8)
+    __shared__ __attribute__((aligned(16))) uint32_t s_mt[64];    // mask: run masks of the tile's four output words
+    __shared__ uint32_t s_m[256];                                 // mask: the tile's output words
+    static_assert(PM_MSR * 8 <= 4 * 32 * 9, "the mask rows share the image's LDS");
+    const bh_level_geom S = g.lv[level - 1], D = g.lv[level];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 31, h = lane >> 5;
+    const int x0 = blockIdx.x * PM_TW;
+
+    if ((int)blockIdx.y < T.tiles_y) {
+        // ---- image: a wave makes its 32 x 24 block alone - no workgroup barrier, the transposition for the row stores goes through a
+        // wave-private piece of LDS.  Every global load is issued before the first use.
+        const int y0 = blockIdx.y * PM_TH;
+        if (!(x0 + 32 * wv < D.w)) return;                        // wave-uniform
+        const uint8_t* __restrict__ src = pyr + (size_t)blockIdx.z * g.pyr_stride + S.off;
+        uint8_t* __restrict__ dst = pyr + (size_t)blockIdx.z * g.pyr_stride + D.off;
+        const int cb = blockIdx.x * 4 + wv;
+        const int r0 = (int)rtab[T.yinfo + blockIdx.y], ws = (int)rtab[T.xinfo + cb];
+        const uint8_t* rp = src + (uint32_t)(min(r0 + n, S.h - 1) * S.pitch + ws + 16 * h);
+        fv4 a0 = *reinterpret_cast<const fv4*>(rp), a1 = *reinterpret_cast<const fv4*>(rp + 32);
+        const fv4* xt = reinterpret_cast<const fv4*>(rtab + (uint32_t)(T.xtap + 1024 * cb)) + lane;      // [column block][k-block][half][lane]
+        const fv4 X00 = xt[0], X01 = xt[64], X10 = xt[128], X11 = xt[192];
+        const fv4* yt = reinterpret_cast<const fv4*>(rtab + (uint32_t)(T.ytap + 512 * blockIdx.y)) + lane;      // [row block][half][lane]
+        const fv4 Y0 = yt[0], Y1 = yt[64];
+        a0 ^= (int)0x7f7f7f7fu; a1 ^= (int)0x7f7f7f7fu;
+        fv16 acc = { -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1 };
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, X00, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, X01, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, X10, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, X11, acc, 0, 0, 0);
+        fv4 Al, Ah;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t q01 = __builtin_amdgcn_perm((uint32_t)acc[4 * d + 1], (uint32_t)acc[4 * d], 0x05010400u);      // (r0.b0, r1.b0, r0.b1, r1.b1)
+            const uint32_t q23 = __builtin_amdgcn_perm((uint32_t)acc[4 * d + 3], (uint32_t)acc[4 * d + 2], 0x05010400u);
+            Al[d] = (int)(__builtin_amdgcn_perm(q23, q01, 0x05040100u) ^ 0x7f7f7f7fu);      // 127 - lo8
+            Ah[d] = (int)~__builtin_amdgcn_perm(q23, q01, 0x07060302u);                      // -hi - 1
+        }
+        fv16 accH = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        accH = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, Y0, accH, 0, 0, 0);
+        accH = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ah, Y1, accH, 0, 0, 0);
+        const int KC = 256 * 32384 + 32768;                        // 256 (-256 + 127 + 32513) + the rounding
+        fv16 accL;
+#pragma unroll
+        for (int i = 0; i < 16; i++) accL[i] = (accH[i] << 8) + KC;
+        accL = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, Y0, accL, 0, 0, 0);
+        accL = __builtin_amdgcn_mfma_i32_32x32x32_i8(Al, Y1, accL, 0, 0, 0);
+        // lane = output row n; registers 4 q .. 4 q + 3 = columns 8 q + 4 h + (0..3) of the block: byte 2 of the sums
+        uint32_t* so = s_o + wv * (32 * 9);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)accL[4 * q + 1], (uint32_t)accL[4 * q], 0x0c0c0602u);
+            const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)accL[4 * q + 3], (uint32_t)accL[4 * q + 2], 0x0c0c0602u);
+            so[n * 9 + 2 * q + h] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // LDS exchange inside one wave: ordered by the hardware, the fences keep the compiler from moving the reads up
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {   // 32-byte row segments (the four waves of the workgroup fill the 128-byte lines together); padding columns stay zero
+            const int wd = lane & 7, r0s = lane >> 3, x = x0 + 32 * wv + 4 * wd;
+            const int over = min(max(x + 4 - D.w, 0), 4);
+            const uint32_t keep = over == 4 ? 0u : (0xffffffffu >> (8 * over));
+            uint8_t* bt = dst + (uint32_t)(y0 * D.pitch + x0 + 32 * wv);
+            const uint32_t o0 = (uint32_t)(r0s * D.pitch + 4 * wd);
+#pragma unroll
+            for (int k = 0; k < PM_TH / 8; k++) {
+                const int rr = r0s + 8 * k;
+                if (x < D.pitch && y0 + rr < D.h) *reinterpret_cast<uint32_t*>(bt + (o0 + (uint32_t)(8 * k * D.pitch))) = so[rr * 9 + wd] & keep;
+            }
+        }
+        return;
+    }
+
+    // ---- mask: 4 output words x 64 rows per workgroup, one word per lane.  The source rows the block needs (<= 88, 8 words from the
+    // tile's first source word) are staged in LDS by coalesced loads; the per-lane windows and the special positions read LDS.
+    uint32_t* s_ms = s_o;
+    const uint32_t* __restrict__ ms = mbits + (size_t)blockIdx.z * g.mstride + S.moff;
+    uint32_t* __restrict__ md = mbits + (size_t)blockIdx.z * g.mstride + D.moff;
+    const int by = blockIdx.y - T.tiles_y, y0 = by * PM_MH;
+    const int r0 = (int)(tab[D.taby_off + y0] >> 16), mwb = (int)rtab[T.mwb + blockIdx.x];
+    const int tile = by * T.tiles_x + blockIdx.x;
+    const int f0 = (int)rtab[T.fidx + tile], f1 = (int)rtab[T.fidx + tile + 1];
+    // special positions of this block: entry = (x in tile | y in block << 7 | truth table << 13, source column | source row << 16)
+    uint2 fe0 = make_uint2(0, 0), fe1 = fe0;
+    if (f0 + tid < f1) fe0 = *reinterpret_cast<const uint2*>(rtab + (uint32_t)(T.fix + 2 * (f0 + tid)));
+    if (f0 + 256 + tid < f1) fe1 = *reinterpret_cast<const uint2*>(rtab + (uint32_t)(T.fix + 2 * (f0 + 256 + tid)));
+    uint32_t msw[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int idx = min(tid + 256 * k, PM_MSR * 8 - 1);
+        msw[k] = ms[(uint32_t)(min(r0 + (idx >> 3), S.h - 1) * S.mpitch + min(mwb + (idx & 7), S.mpitch - 1))];
+    }
+    uint32_t mtw = 0;
+    if (tid < 64) mtw = rtab[(uint32_t)(T.mtab + 64 * blockIdx.x) + tid];
+    const int mrow = tid >> 2, mw = tid & 3, mX = x0 + 32 * mw, my = y0 + mrow;
+    const bool mact = mX < D.pitch && my < D.h;
+    const uint32_t mty = tab[(uint32_t)(D.taby_off + min(my, D.h - 1))];
+#pragma unroll
+    for (int k = 0; k < 3; k++) if (tid + 256 * k < PM_MSR * 8) s_ms[tid + 256 * k] = msw[k];
+    if (tid < 64) s_mt[tid] = mtw;
+    __syncthreads();
+    {
+        const uint32_t* pa = s_ms + ((int)(mty >> 16) - r0) * 8 - mwb;
+        const uint4* mt = reinterpret_cast<const uint4*>(s_mt + 16 * mw);
+        const uint4 t0 = mt[0], t1 = mt[1], t2 = mt[2], t3 = mt[3];      // s0 s1 m0[0] m0[1] | m0[2..5] | m1[0..3] | m1[4] m1[5] - -
+        uint32_t res[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            const uint32_t st = hf ? t0.y : t0.x, wi = st >> 5, sh = st & 31u;
+            const uint32_t wa = __builtin_amdgcn_alignbit(pa[wi + 1], pa[wi], sh), wb = __builtin_amdgcn_alignbit(pa[wi + 9], pa[wi + 8], sh);
+            const uint32_t Q = wa & (wa >> 1) & wb & (wb >> 1);
+            const uint32_t m0 = hf ? t2.x : t0.z, m1 = hf ? t2.y : t0.w, m2 = hf ? t2.z : t1.x, m3 = hf ? t2.w : t1.y, m4 = hf ? t3.x : t1.z, m5 = hf ? t3.y : t1.w;
+            res[hf] = (Q & m0) | ((Q >> 1) & m1) | ((Q >> 2) & m2) | ((Q >> 3) & m3) | ((Q >> 4) & m4) | ((Q >> 5) & m5);
+        }
+        s_m[tid] = res[0] | (res[1] << 16);
+    }
+    __syncthreads();
+    for (int i = f0 + tid, k = 0; i < f1; i += 256, k++) {
+        uint2 e = k == 0 ? fe0 : fe1;
+        if (k >= 2) e = *reinterpret_cast<const uint2*>(rtab + (uint32_t)(T.fix + 2 * i));
+        const int xr = e.x & 127u, yr = (e.x >> 7) & 63u;
+        const int ox = e.y & 0xffffu, ri = (int)(e.y >> 16) - r0, wi = (ox >> 5) - mwb;
+        const uint32_t* pa = s_ms + (ri * 8 + wi);
+        const uint32_t a2 = __builtin_amdgcn_alignbit(pa[1], pa[0], ox & 31) & 3u, b2 = __builtin_amdgcn_alignbit(pa[9], pa[8], ox & 31) & 3u;
+        uint32_t* wp = &s_m[yr * 4 + (xr >> 5)];
+        if (((e.x >> 13) >> (a2 | (b2 << 2))) & 1u) atomicOr(wp, 1u << (xr & 31)); else atomicAnd(wp, ~(1u << (xr & 31)));
+    }
+    __syncthreads();
+    if (mact) md[(uint32_t)(my * D.mpitch + (mX >> 5))] = s_m[tid];
+}
+
 __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, uint8_t* __restrict__ mpyr,
                                                   bh_orb_geom g, int level, const uint32_t* __restrict__ tab)
 {
@@ -540,6 +698,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ uint16_t s_cl[FCL_CAP];                          // the candidates phase 2 found to be corners: phase 3 walks these, not the whole candidate list
     uint32_t* const s_out = s_px;                               // kept corners (phase 3): strict 3x3 maxima, at most one per 2x2 block = 1024 <= FPX_H * FPW
     __shared__ int s_n, s_k, s_base, s_c;
+#ifdef FAST_LDS_PAD                                              // diagnostic builds: fewer workgroups per CU (does a co-running kernel of another stream fill the gap?)
+    __shared__ uint32_t s_pad[FAST_LDS_PAD];
+    if (status[0] == 0xfffffff1u) { s_pad[threadIdx.x] = clist[threadIdx.x].x; __syncthreads(); if (s_pad[(threadIdx.x * 7) % FAST_LDS_PAD] == 7u) status[1] = 1; }
+#endif
 
     const int tid = threadIdx.x;
     const uint32_t tt = tile_tab[blockIdx.x];                   // level | tile column << 4 | tile row << 16 (host-built: no per-wave level search / division)
@@ -1304,6 +1466,119 @@ static void gauss7_coeffs(int* k)
     for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i] * sum); k[i] = round_even_f(cf[i] * 256.f); }
 }
 
+// Tables of k_pyr_mfma for every level (see the kernel).  False: some window does not fit the kernel's tile (then k_pyr_down_bits runs).
+static bool build_pm_tables(const bh_orb_geom& g, const uint32_t* tab, std::vector<uint32_t>& out, bh_pm_level* pm)
+{
+    out.clear();
+    auto align4 = [&]() { while (out.size() & 3) out.push_back(0); };
+    auto put_taps = [&](const int* w /*[64 lanes][16]*/) {          // one fragment pair (c >> 1, c - (c >> 1)), negated, [half][lane][16 bytes]
+        const size_t base = out.size(); out.resize(base + 2 * 64 * 4, 0);
+        int8_t* b = reinterpret_cast<int8_t*>(out.data() + base);
+        for (int i = 0; i < 64 * 16; i++) { const int c = w[i], s0 = c >> 1, s1 = c - s0; b[i] = (int8_t)-s0; b[64 * 16 + i] = (int8_t)-s1; }
+    };
+    for (int l = 1; l < g.nlevels; l++) {
+        const bh_level_geom& S = g.lv[l - 1]; const bh_level_geom& D = g.lv[l];
+        const uint32_t* tx = tab + D.tabx_off; const uint32_t* ty = tab + D.taby_off;
+        bh_pm_level& P = pm[l];
+        P.tiles_x = (D.w + PM_TW - 1) / PM_TW; P.tiles_y = (D.h + PM_TH - 1) / PM_TH;
+        const int ncb = P.tiles_x * 4;
+        // ---- columns: window start + tap fragments per 32-column block
+        std::vector<int> wsv(ncb, 0);
+        align4(); P.xinfo = (int)out.size(); out.resize(out.size() + ncb, 0);
+        align4(); P.xtap = (int)out.size();
+        for (int cb = 0; cb < ncb; cb++) {
+            const int c0 = 32 * cb;
+            int W[32][64]; memset(W, 0, sizeof(W));
+            if (c0 < D.w) {
+                wsv[cb] = (int)(tx[c0] >> 16) & ~15;
+                for (int c = 0; c < 32 && c0 + c < D.w; c++) {
+                    const int ofs = (int)(tx[c0 + c] >> 16) - wsv[cb], c1 = (int)(tx[c0 + c] & 0xffffu);
+                    if (ofs < 0 || ofs + (c1 ? 1 : 0) > 63 || c1 > 256) return false;
+                    W[c][ofs] += 256 - c1; if (c1) W[c][ofs + 1] += c1;
+                }
+            }
+            out[P.xinfo + cb] = (uint32_t)wsv[cb];
+            for (int kb = 0; kb < 2; kb++) {
+                int frag[64 * 16];
+                for (int lane = 0; lane < 64; lane++) for (int j = 0; j < 16; j++) frag[lane * 16 + j] = W[lane & 31][32 * kb + 16 * (lane >> 5) + j];
+                put_taps(frag);
+            }
+        }
+        // ---- rows: first source row + tap fragments (k in accumulator order) per 24-row block
+        align4(); P.yinfo = (int)out.size(); out.resize(out.size() + P.tiles_y, 0);
+        align4(); P.ytap = (int)out.size();
+        for (int rb = 0; rb < P.tiles_y; rb++) {
+            const int yb = PM_TH * rb, r0 = (int)(ty[yb] >> 16);
+            int W[32][32]; memset(W, 0, sizeof(W));
+            for (int r = 0; r < PM_TH && yb + r < D.h; r++) {
+                const int ofs = (int)(ty[yb + r] >> 16) - r0, c1 = (int)(ty[yb + r] & 0xffffu);
+                if (ofs < 0 || ofs + (c1 ? 1 : 0) > 31 || c1 > 256) return false;
+                W[r][ofs] += 256 - c1; if (c1) W[r][ofs + 1] += c1;
+            }
+            out[P.yinfo + rb] = (uint32_t)r0;
+            int frag[64 * 16];
+            for (int lane = 0; lane < 64; lane++) for (int j = 0; j < 16; j++) frag[lane * 16 + j] = W[lane & 31][(j & 3) + 8 * (j >> 2) + 4 * (lane >> 5)];
+            put_taps(frag);
+        }
+        // ---- mask: per 32-pixel output word the two half windows' first source column and the run masks (source - destination distance 0 .. 5)
+        align4(); P.mtab = (int)out.size();
+        for (int wc = 0; wc < ncb; wc++) {
+            uint32_t e[16]; memset(e, 0, sizeof(e));
+            for (int hf = 0; hf < 2; hf++) {
+                const int X = 32 * wc + 16 * hf;
+                if (X >= D.w) { if (PM_TW * (wc / 4) < D.w) e[hf] = (tx[PM_TW * (wc / 4)] >> 16) & ~31u; continue; }      // empty half: window at the tile's first staged word, no run
+                const int s = (int)(tx[X] >> 16);
+                e[hf] = (uint32_t)s;
+                for (int i = 0; i < 16 && X + i < D.w; i++) {
+                    const int d = (int)(tx[X + i] >> 16) - s, k = d - i;
+                    if (k < 0 || k > 5 || d + 1 > 31) return false;
+                    e[hf ? 8 + k : 2 + k] |= 1u << i;
+                }
+            }
+            out.insert(out.end(), e, e + 16);
+        }
+        // first source word of a tile's mask window (8 words per row are staged); every window of the tile must lie inside it
+        P.mwb = (int)out.size();
+        for (int t = 0; t < P.tiles_x; t++) {
+            const int xa = PM_TW * t, xb = (xa + PM_TW < D.w ? xa + PM_TW : D.w) - 1;
+            const int wb0 = (int)(tx[xa] >> 16) >> 5;
+            if ((((int)(tx[xb] >> 16) + 1) >> 5) - wb0 + 1 > 7) return false;      // + the funnel shift's second word
+            out.push_back((uint32_t)wb0);
+        }
+        // ---- mask: special positions (some tap weighs <= 128 of 65 536): truth table of the reference rule T >= 65 408 over the four taps
+        const int mty_n = (D.h + PM_MH - 1) / PM_MH;
+        for (int b = 0; b < mty_n; b++) {                          // the rows a mask block reads must fit its staging area
+            const int ya = PM_MH * b, yb = (ya + PM_MH < D.h ? ya + PM_MH : D.h) - 1;
+            if ((int)(ty[yb] >> 16) + 1 - (int)(ty[ya] >> 16) > PM_MSR - 1) return false;
+        }
+        std::vector<std::vector<uint32_t>> lists((size_t)P.tiles_x * mty_n);
+        for (int y = 0; y < D.h; y++) {
+            const int cy = (int)(ty[y] & 0xffffu);
+            for (int x = 0; x < D.w; x++) {
+                const int cx = (int)(tx[x] & 0xffffu);
+                const int w4[4] = { (256 - cx) * (256 - cy), cx * (256 - cy), (256 - cx) * cy, cx * cy };      // (ra, ox), (ra, ox+1), (rb, ox), (rb, ox+1)
+                uint32_t tt = 0;
+                for (int pat = 0; pat < 16; pat++) {
+                    int sum = 0;
+                    for (int b = 0; b < 4; b++) if (pat >> b & 1) sum += w4[b];
+                    if (sum >= 65408) tt |= 1u << pat;
+                }
+                if (tt != 0x8000u) {
+                    std::vector<uint32_t>& v = lists[(size_t)(y / PM_MH) * P.tiles_x + x / PM_TW];
+                    v.push_back((uint32_t)(x % PM_TW) | (uint32_t)(y % PM_MH) << 7 | tt << 13);
+                    v.push_back((tx[x] >> 16) | (ty[y] >> 16) << 16);
+                }
+            }
+        }
+        P.fidx = (int)out.size();
+        { const size_t nt = lists.size(); out.resize(out.size() + nt + 1, 0); uint32_t acc = 0; for (size_t t = 0; t < nt; t++) { out[P.fidx + t] = acc; acc += (uint32_t)(lists[t].size() / 2); } out[P.fidx + nt] = acc; }
+        while (out.size() & 1) out.push_back(0);
+        P.fix = (int)out.size();
+        for (auto& v : lists) out.insert(out.end(), v.begin(), v.end());
+    }
+    return true;
+}
+
 static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
 {
     if (ctx->geom_valid && memcmp(&ctx->geom_params, p, sizeof(*p)) == 0 && ctx->geom.H == H && ctx->geom.W == W)
@@ -1351,6 +1626,21 @@ static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
         hipError_t e = hipMemcpyAsync(ctx->tab.p, tab, sizeof(uint32_t) * tab_words, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = bh_set_err(ctx, BH_ERR_HIP, "coefficient table upload failed: %s", hipGetErrorString(e));
+    }
+    if (rc == BH_OK) {
+        std::vector<uint32_t> rt;
+        // k_pyr_mfma is bit-identical and issues 40 % fewer vector instructions than k_pyr_down_bits, but its strided 16-byte row loads and
+        // tap fragments keep the texture address path busier than the ALUs were: 0.98 - 1.01 against 0.92 ms per 1000 frames,
+        // so it runs on request only
+        ctx->pm_ok = getenv("BH_ORB_PYR_MFMA") && build_pm_tables(g, tab, rt, ctx->pm) ? 1 : 0;
+        if (ctx->pm_ok && !rt.empty()) {
+            rc = bh_reserve(ctx, &ctx->rtab, sizeof(uint32_t) * rt.size());
+            if (rc == BH_OK) {
+                hipError_t e = hipMemcpyAsync(ctx->rtab.p, rt.data(), sizeof(uint32_t) * rt.size(), hipMemcpyHostToDevice, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) rc = bh_set_err(ctx, BH_ERR_HIP, "resize table upload failed: %s", hipGetErrorString(e));
+            }
+        }
     }
     free(tab);
     if (rc != BH_OK) return rc;
@@ -1471,7 +1761,10 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
                           pyr, mpyr, W, H, g.lv[0].pitch, g.pyr_stride, mbits, g.lv[0].mpitch, g.mstride);
         }
         for (int l = 1; l < g.nlevels; l++) {
-            if (mbits) {
+            if (mbits && ctx->pm_ok) {
+                BH_LAUNCH(ctx, BH_K_PYR, k_pyr_mfma, dim3(ctx->pm[l].tiles_x, ctx->pm[l].tiles_y + (g.lv[l].h + PM_MH - 1) / PM_MH, nb), dim3(256), st, pyr, g, l, (const uint32_t*)ctx->tab.p,
+                          (const uint32_t*)ctx->rtab.p, ctx->pm[l], mbits);
+            } else if (mbits) {
                 const int n = (g.lv[l].pitch >> 2) * ((g.lv[l].h + PD_R - 1) / PD_R);
                 BH_LAUNCH(ctx, BH_K_PYR, k_pyr_down_bits, dim3((n + 255) / 256, nb), dim3(256), st, pyr, g, l, (const uint32_t*)ctx->tab.p, mbits);
             } else {

@@ -71,6 +71,41 @@ def test_depth_masks_take_the_bit_packed_pyramid(ctx, H, W):
     assert n.sum() > 0
 
 
+@pytest.mark.parametrize("H,W", [(480, 640), (241, 322), (97, 129)])
+def test_matrix_core_pyramid_is_bit_identical(monkeypatch, H, W):
+    """BH_ORB_PYR_MFMA=1 selects k_pyr_mfma (resize as two int8 matrix-core products, mask by run gathers + truth-table patches) instead of
+    k_pyr_down_bits: every level of the image and of the mask pyramid, and everything downstream, must equal the oracle all the same."""
+    from boslam_amd import Context
+    monkeypatch.setenv("BH_ORB_PYR_MFMA", "1")
+    c = Context(0)                                               # the choice is made when a context builds its geometry tables
+    try:
+        rng = np.random.default_rng(H * 3 + W)
+        bgr, _ = synth.render_batch(2)
+        crop = np.ascontiguousarray(bgr[:, :H, :W])
+        depth = rng.integers(1, 5000, size=(2, H, W)).astype(np.uint16)
+        depth[0][rng.random((H, W)) < 0.15] = 0
+        for _ in range(12):
+            y, x, hh, ww = rng.integers(0, H - 8), rng.integers(0, W - 8), rng.integers(4, 60), rng.integers(4, 90)
+            depth[1, y:y + hh, x:x + ww] = 0
+        params = frontend.make_params(nfeatures=400)
+        kps, desc, n = frontend.orb_detect_describe(c, crop, depth=depth, params=params)
+        mask = (depth > 0).astype(np.uint8) * 255
+        for f in range(2):
+            ok, od, rc, dbg = oracle.orb_detect_describe(crop[f], mask[f], oracle.orb_params(nfeatures=400), max_kp=4 * 400 + 256, debug=True)
+            dev = frontend.orb_debug_fetch(c, f, H, W, params)
+            for name in ("pyr", "mask"):
+                for l in range(params.nlevels):
+                    w, h, p, o = int(dev["w"][l]), int(dev["h"][l]), int(dev["pitch"][l]), int(dev["off"][l])
+                    got = dev[name][o:o + p * h].reshape(h, p)[:, :w]
+                    ro = int(dbg["off"][l])
+                    bad = np.argwhere(got != dbg[name][ro:ro + w * h].reshape(h, w))
+                    assert len(bad) == 0, (name, f, l, len(bad), bad[:3])
+            assert rc == 0 and n[f] == len(ok)
+            assert np.array_equal(desc[f, :n[f]], od)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("nlevels", [1, 3, 12])
 def test_depth_masks_at_other_pyramid_depths(ctx, nlevels):
     """The bit-packed mask path with no resize at all (one level), a short pyramid, and levels smaller than the border."""
