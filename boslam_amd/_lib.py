@@ -2,6 +2,7 @@
 missing every entry point raises."""
 import ctypes as C
 import os
+import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -118,20 +119,26 @@ def _preload_hip_runtime():
             return
 
 
+_LIB_LOCK = threading.Lock()
+
+
 def lib():
     global _LIB
-    if _LIB is None:
-        if not os.path.exists(LIB_PATH):
-            raise BhError(BH_ERR_HIP, f"{LIB_PATH} is not built (run __graft_entry__.build()); there is no CPU fallback")
-        _preload_hip_runtime()
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGS.items():
-            fn = getattr(L, name, None)
-            if fn is None:                     # tests/test_host_cpu.py asserts this never happens
-                MISSING.append(name)
-                continue
-            fn.restype, fn.argtypes = res, args
-        _LIB = L
+    if _LIB is not None:
+        return _LIB
+    with _LIB_LOCK:                            # the tracker and the local-mapping thread may both make the first call
+        if _LIB is None:
+            if not os.path.exists(LIB_PATH):
+                raise BhError(BH_ERR_HIP, f"{LIB_PATH} is not built (run __graft_entry__.build()); there is no CPU fallback")
+            _preload_hip_runtime()
+            L = C.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGS.items():
+                fn = getattr(L, name, None)
+                if fn is None:                     # tests/test_host_cpu.py asserts this never happens
+                    MISSING.append(name)
+                    continue
+                fn.restype, fn.argtypes = res, args
+            _LIB = L
     return _LIB
 
 
@@ -194,11 +201,14 @@ class Context:
 
 
 _DEFAULT = {}
+_DEFAULT_LOCK = threading.Lock()
 
 
 def default_context(device=0):
-    import threading
+    """The calling thread's own context on `device` (the reference calls from two threads, slam/main.py:37-47: one bh_ctx each)."""
     key = (threading.get_ident(), device)
-    if key not in _DEFAULT:
-        _DEFAULT[key] = Context(device)
-    return _DEFAULT[key]
+    with _DEFAULT_LOCK:
+        c = _DEFAULT.get(key)
+        if c is None:
+            c = _DEFAULT[key] = Context(device)
+        return c

@@ -6,6 +6,43 @@ import numpy as np
 from . import ba, synth
 
 
+_PMC_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_ba_pmc.json")
+
+
+def _pmc(workload):
+    """Per-launch hardware counters of the BA kernels (rocprofv3 --pmc, tools/prof_r04.sh -> tools/ba_pmc.py; the committed summary).
+    bench.py cannot run the profiler inside its timed run: the counters per launch are a property of the kernel and the workload, the
+    durations next to them are measured live."""
+    try:
+        import json
+        with open(_PMC_FILE) as f:
+            return json.load(f).get(workload, {})
+    except (OSError, ValueError):
+        return {}
+
+
+def _counter_block(pm, names, live_ms):
+    """Counter flops / bytes of the named kernels (per launch, summed over `names` = (kernel, launches per iteration)) against the live time."""
+    fl = rd = rdu = wr = busy = 0.0
+    have = False
+    for k, n in names:
+        e = pm.get(k)
+        if not e:
+            continue
+        have = True
+        d = e["derived"]
+        fl += n * d.get("mfma_f64_flops", 0.0); rd += n * d.get("hbm_read_bytes", 0.0); rdu += n * d.get("hbm_read_bytes_uncorrected", 0.0)
+        wr += n * d.get("hbm_write_bytes", 0.0); busy += n * e["counters"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+    if not have or live_ms <= 0:
+        return None
+    t = live_ms * 1e-3
+    return {"source": "profiles/r04_ba_pmc.json (rocprofv3 --pmc, counters per launch) over the live kernel time",
+            "mfma_f64_flops": int(fl), "mfma_tflops": round(fl / t / 1e12, 5), "mfma_frac_of_peak": round(fl / t / 78.6e12, 6),
+            "mfma_busy_simds": round(busy / (t * 2.4e9), 3),
+            "hbm_bytes": int(rd + wr), "hbm_bytes_fetch_uncorrected": int(rdu + wr), "hbm_gbps": round((rd + wr) / t / 1e9, 1),
+            "hbm_frac_of_peak": round((rd + wr) / t / 8e12, 4)}
+
+
 def run(ctx, dev=None, repeats=5):
     pr = synth.ba_problem()
     s = ba.LocalBA(ctx, pr["K"])
@@ -66,6 +103,22 @@ def run(ctx, dev=None, repeats=5):
                                  "peak": 78.6, "frac": round(flops / (ms * 1e-3) / 78.6e12, 7), "cus_used": 1,
                                  "frac_of_cus_used": round(flops / (ms * 1e-3) / (78.6e12 / 256), 4), "mfma_flops_per_solve": int(flops),
                                  "note": note}
+        pm = _pmc("local")
+        cb = _counter_block(pm, [(kname, 1)], ms)
+        if cb:
+            out["solve_roofline"]["counters"] = cb
+    # the Schur complement (S = Hpp - sum Hpl Hll^-1 Hpl', b~): the iteration's HBM-side stage.  Algorithmic bytes: per edge the 6 x 3 Hpl
+    # block (144 B), per landmark Hll^-1 and bl (96 B), S out once; the counter bytes say how much of the gathered re-reads reach the fabric.
+    sms = out["kernel_ms_per_iter"].get("k_ba_schur", 0.0)
+    if sms > 0:
+        E, P = len(pr["ecam"]), len(pr["pts"])
+        alg = E * 144 + P * 96 + n6 * n6 * 8
+        out["schur_roofline"] = {"bound": "hbm", "kernel": "k_ba_dinv + k_ba_schur_Sb", "algorithmic_bytes": int(alg), "ms": sms,
+                                 "achieved": round(alg / (sms * 1e-3) / 1e9, 1), "unit": "GB/s", "peak": 8000, "frac": round(alg / (sms * 1e-3) / 8e12, 5)}
+        cb = _counter_block(_pmc("local"), [("k_ba_dinv", 1), ("k_ba_schur_Sb", 1)], sms)
+        if cb:
+            out["schur_roofline"]["counters"] = cb
+            out["schur_roofline"]["traffic_over_algorithmic"] = round(cb["hbm_bytes"] / alg, 2)
     s.close()
     return out
 
@@ -114,6 +167,14 @@ def run_batch(ctx, W=64, n_kf=50, n_pts=10000, iters=10, repeats=3, n_distinct=8
            "single_window_iters_per_s_incl_set_problem": round(iters / (one + float(np.median(t_set1))), 1),
            "speedup_incl_set_problem": round((tot / (opt + st)) / (iters / (one + float(np.median(t_set1)))), 1),
            "iters_done_min_max": [int(done.min()), int(done.max())], "final_robust_chi2_first_windows": chi}
+    pmb = _pmc("batch") if (W == 64 and n_kf == 50) else {}
+    if "k_bb_schur" in pmb:                              # the round's largest kernel: how much of its gathered Hpl traffic reaches the fabric (profile run, 64 windows)
+        e = pmb["k_bb_schur"]; d = e["derived"]
+        out["schur_counters"] = {"source": "profiles/r04_ba_pmc.json", "kernel": "k_bb_schur", "us_per_round": e["mean_us"],
+                                 "hbm_bytes_per_round": int(d["hbm_read_bytes"] + d["hbm_write_bytes"]),
+                                 "hbm_bytes_per_round_fetch_uncorrected": int(d["hbm_read_bytes_uncorrected"] + d["hbm_write_bytes"]),
+                                 "hbm_gbps": d["hbm_gbps"], "hbm_frac_of_peak": round(d["hbm_gbps"] / 8000.0, 4),
+                                 "algorithmic_bytes_per_round": int(W * (len(probs[0]["ecam"]) * 144 + n_pts * 96))}
     batch.close()
     for s in wins:
         s.close()
@@ -190,6 +251,29 @@ def run_global(ctx, n_kf=5000, n_pts=500000, iters=5, window=20, dist=None, devi
                                      "peak_of_cus_used": round(78.6 * cus / 256, 4), "frac_of_cus_used": round(flops / (ms * 1e-3) / (78.6e12 * cus / 256), 4),
                                      "mfma_flops_per_solve": int(flops),
                                      "note": "two dependency chains of ~%d block columns, one CU each; the dense f64 MFMA peak of 78.6 TFLOP/s is for 256 CUs" % (nblk // cus)}
+    pm = _pmc("global") if dist is None else {}
+    if pm and "solve_roofline" in out and "k_bcr" in out["solve_roofline"]["kernel"]:
+        # launches per solve from the profile itself: dispatches of each kernel over the dispatches of k_ba_prep (one per trial)
+        trials_prof = max(pm.get("k_ba_prep", {}).get("dispatches", 0), 1)
+        names = [(k, pm[k]["dispatches"] / trials_prof) for k in ("k_ba_chol_dense<true>", "k_bcr_trsm", "k_bcr_update", "k_bcr_back", "k_bcr_extract") if k in pm]
+        cb = _counter_block(pm, names, ms)
+        if cb:
+            out["solve_roofline"]["counters"] = cb
+    sms = out["kernel_ms_per_iter"].get("k_ba_schur", 0.0)
+    if sms > 0:
+        E, P = len(pr["ecam"]), len(pr["pts"])
+        alg = E * 144 + P * 96 + n6 * (bw + 1) * 8
+        out["schur_roofline"] = {"bound": "hbm", "kernel": "k_ba_dinv + k_ba_schur_S<64> + k_ba_schur_b", "algorithmic_bytes": int(alg), "ms": sms,
+                                 "achieved": round(alg / (sms * 1e-3) / 1e9, 1), "unit": "GB/s", "peak": 8000, "frac": round(alg / (sms * 1e-3) / 8e12, 5)}
+        cb = _counter_block(pm, [("k_ba_dinv", 1), ("k_ba_schur_S<64>", 1), ("k_ba_schur_b", 1)], sms) if pm else None
+        if cb:
+            out["schur_roofline"]["counters"] = cb
+            out["schur_roofline"]["traffic_over_algorithmic"] = round(cb["hbm_bytes"] / alg, 2)
+    lms = out["kernel_ms_per_iter"].get("k_ba_linearize", 0.0)
+    if lms > 0 and pm:
+        cb = _counter_block(pm, [("k_ba_linearize", 1)], lms)
+        if cb:
+            out["linearize_counters"] = cb
     if dist is not None:                                      # the exchange per rank and Levenberg trial, by kind; the replicated part of the solve
         det = s.comm_detail()
         tr = max(out["trials"], 1)

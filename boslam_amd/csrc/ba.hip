@@ -4100,8 +4100,11 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
             BH_HIP(ctx, hipGetLastError());
             bool polled = false;
             if (hpin) {                                  // poll the pinned verdict: a copy + stream sync costs ~40 us of wake-up per trial
-                for (long spin = 0; spin < 200000000L; spin++)
+                const auto tpoll = std::chrono::steady_clock::now();
+                for (long spin = 0; ; spin++) {              // bounded by time, not by a spin count (a slow trial is not a fault: the copy + sync path below takes over)
                     if (__atomic_load_n(&hpin->pad, __ATOMIC_ACQUIRE) == seq) { polled = true; break; }
+                    if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - tpoll > std::chrono::milliseconds(200)) break;
+                }
                 if (polled) memcpy(&hs, hpin, sizeof(hs));
             }
             if (!polled) {                               // a kernel fault never delivers the verdict: the stream reports it here
@@ -4233,12 +4236,24 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
         for (int w = 0; w < W; w++) {
             if (done[w]) continue;
             ba_state* hp = b->hstates + w;
+            // Poll the pinned verdict for a bounded TIME (a spin count would turn a round that is merely slow - many or large windows, a
+            // profiler attached, a busy host core - into an error); after that the stream itself decides: a successful synchronise means
+            // the round has finished, so the verdict must be there; only a failing synchronise, or a verdict that is still missing after
+            // it, is a fault.  No window may be read back after such an exit (the device may have flipped its ping-pong state).
             bool got = false;
-            for (long spin = 0; spin < 400000000L; spin++)
+            const auto tpoll = std::chrono::steady_clock::now();
+            for (long spin = 0; !got; spin++) {
                 if (__atomic_load_n(&hp->pad, __ATOMIC_ACQUIRE) == seq) { got = true; break; }
-            if (!got) {                                          // a kernel fault never delivers the verdict: the stream reports it
-                BH_HIP(ctx, hipStreamSynchronize(st));
-                return bh_set_err(ctx, BH_ERR_HIP, "bh_ba_batch_optimize: no verdict from window %d", w);
+                if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - tpoll > std::chrono::milliseconds(200)) break;
+            }
+            if (!got) {
+                const hipError_t e = hipStreamSynchronize(st);
+                got = e == hipSuccess && __atomic_load_n(&hp->pad, __ATOMIC_ACQUIRE) == seq;
+                if (!got) {
+                    for (int v = 0; v < W; v++) b->win[v]->have_problem = 0;
+                    if (e != hipSuccess) return bh_set_err(ctx, BH_ERR_HIP, "bh_ba_batch_optimize: %s", hipGetErrorString(e));
+                    return bh_set_err(ctx, BH_ERR_HIP, "bh_ba_batch_optimize: no verdict from window %d", w);
+                }
             }
             ba_state hs; memcpy(&hs, hp, sizeof(hs));
             bh_ba* ba = b->win[w];

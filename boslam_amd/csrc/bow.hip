@@ -294,9 +294,17 @@ __global__ __launch_bounds__(1024) void k_bow_topk(double* __restrict__ acc, lon
     if (tid == 0) *n_res = found;
 }
 
+#define BOW_SCAN_LDS  (BOW_BITS / 8 + BOW_QMAX * (sizeof(uint32_t) + sizeof(double)))
+#define INV_HEAVY_LDS ((sizeof(uint32_t) + sizeof(double)) * 2 * INV_HCAP + sizeof(uint32_t) * (4096 + 4096 + 64))
+static int bow_set_func_attrs(bh_ctx* ctx);      // (defined below the kernels it names)
+
 extern "C" int bh_bow_create(bh_ctx* ctx, bh_bow** out)
 {
     if (!ctx || !out) return BH_ERR_INVALID;
+    // The large-LDS attributes of k_bow_scan / k_inv_heavy are per DEVICE: set them here, on this context's device, for every handle (a
+    // process-wide "already set" flag left a second GPU of the same process without them and let two threads race on the flag).
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    BH_TRY(bow_set_func_attrs(ctx));
     bh_bow* b = new bh_bow(); b->ctx = ctx; *out = b;
     return BH_OK;
 }
@@ -759,7 +767,7 @@ static int inv_build(bh_bow* bow)
                        ne, (const long long*)bow->inv_start.p, cnt, (uint32_t*)bow->inv_entry.p, (double*)bow->inv_val.p);
     BH_HIP(ctx, hipGetLastError());
     BH_HIP(ctx, hipStreamSynchronize(st));
-    bow->inv_usable = hbad ? 0 : 1;
+    bow->inv_usable = (hbad || ne > (1ll << 21)) ? 0 : 1;      // overflow records pack (entry << 11 | rank) into 32 bits: entry ids stay below 2^21, beyond that the scan answers
     // buckets of 64 entries, INV_NSUB lists each: a list holds 3 x the hits a full 1536-word query expects of it, 16 .. 64
     bow->inv_nb = (ne + 63) / 64;
     const double per_entry = ne ? (double)nel / (double)ne : 0.0;                               // words per entry (padded)
@@ -775,9 +783,7 @@ static int inv_launch(bh_bow* bow, int G, int max_nq, const uint8_t* keep)
 {
     bh_ctx* ctx = bow->ctx;
     hipStream_t st = ctx->stream;
-    static bool heavy_attr = false;
-    const size_t hlds = (sizeof(uint32_t) + sizeof(double)) * 2 * INV_HCAP + sizeof(uint32_t) * (4096 + 4096 + 64);
-    if (!heavy_attr) { BH_HIP(ctx, hipFuncSetAttribute((const void*)k_inv_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds)); heavy_attr = true; }
+    const size_t hlds = INV_HEAVY_LDS;
     const inv_slot* slots = (const inv_slot*)bow->inv_slots.p;
     bh_time_begin(ctx, BH_K_BOW_INV);
     hipLaunchKernelGGL(k_inv_gather, dim3((max_nq + 3) / 4, G), dim3(256), 0, st, slots, (const long long*)bow->inv_start.p, (const uint32_t*)bow->inv_entry.p,
@@ -869,9 +875,7 @@ static int bow_query_impl(bh_bow* bow, const uint32_t* q_words, const double* q_
         d_qw = (const uint32_t*)bow->qw.p; d_qv = (const double*)bow->qv.p;
         d_sc = (double*)bow->res.p; d_ids = (int*)(d_sc + max_results); d_n = d_ids + max_results;
     }
-    const size_t lds = BOW_BITS / 8 + BOW_QMAX * (sizeof(uint32_t) + sizeof(double));
-    static bool attr_set = false;
-    if (!attr_set) { BH_HIP(ctx, hipFuncSetAttribute((const void*)k_bow_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    const size_t lds = BOW_SCAN_LDS;
     int grid = 256;                                            // one persistent workgroup per CU (LDS-limited to 1/CU anyway)
     const long long need = (bow->n_entries + BOW_T / 64 - 1) / (BOW_T / 64);
     if (need < grid) grid = (int)need;
@@ -1033,5 +1037,12 @@ extern "C" int bh_bow_query_l1_batch(bh_bow* bow, const uint32_t* q_words, const
     for (int q = 0; q < Q; q++)                                 // whatever the inverted file could not answer (or scan mode): one by one
         if (!done[q]) BH_TRY(bow_query_impl(bow, q_words + (size_t)q * q_stride, q_vals + (size_t)q * q_stride, nq[q], nullptr, 0, max_results,
                                             ids + (size_t)q * max_results, scores + (size_t)q * max_results, n_results + q, BH_MEM_HOST));
+    return BH_OK;
+}
+
+static int bow_set_func_attrs(bh_ctx* ctx)
+{
+    BH_HIP(ctx, hipFuncSetAttribute((const void*)k_bow_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BOW_SCAN_LDS));
+    BH_HIP(ctx, hipFuncSetAttribute((const void*)k_inv_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INV_HEAVY_LDS));
     return BH_OK;
 }

@@ -284,7 +284,10 @@ class LiveTracker:
                                         self.desc.data_ptr() + 32 * m * p, self.n_kp.data_ptr() + 4 * p, self.cloud.data_ptr() + 24 * m * p, m, 1, self.K, out, m)
             with torch.cuda.stream(self.stream):
                 self.h_verdict.copy_(self.verdict, non_blocking=True)
-            c.synchronize()
+        # every call ends synchronised - also the first one, which has no verdict to wait for: the next step() overwrites the single
+        # pinned staging pair (h_bgr / h_depth), and this frame's host-to-device copy must have left it by then
+        c.synchronize()
+        if self.have_prev:
             hv = self.h_verdict.numpy()
             iv = hv[:2].view(np.int32)
             res = dict(status=int(iv[0]), n_match=int(iv[1]), n_inlier=int(iv[2]), R=hv[2:11].reshape(3, 3).copy(), t=hv[11:14].copy())

@@ -356,7 +356,8 @@ int  bh_bow_query_l1_subset(bh_bow* bow, const uint32_t* q_words, const double* 
 int  bh_bow_compare_l1(bh_bow* bow, int entry_i, int entry_j, int* n_common, double* score);
 /* How host-side queries are answered: 0 (default) = through the inverted file (word -> (entry, weight) rows, DBoW3's own structure,
  * built on the device after the database changed; ~1 MB touched per query of configs[3]) with the streaming scan as the fallback
- * (word ids >= 2^20, max_results > 16, a query that overflows a bucket's hit list); 1 = always the scan (400 MB streamed per query).
+ * (word ids >= 2^20, more than 2^21 database entries, max_results > 16, a query that overflows a bucket's hit list); 1 = always the
+ * scan (400 MB streamed per query).
  * Both give bit-identical ids and scores.  BH_MEM_DEVICE queries always scan. */
 int  bh_bow_set_mode(bh_bow* bow, int mode);
 

@@ -87,8 +87,7 @@ def test_live_tracker_equals_the_host_staged_calls(ctx):
     prev = None
     try:
         for i in range(len(bgr)):
-            got = lt.step(bgr[i], depth[i])
-            ctx.synchronize()
+            got = lt.step(bgr[i], depth[i])                      # (the class synchronises on every step itself: its pinned staging pair is reused)
             assert (got is None) == (i == 0)
             if got is not None:
                 kps, desc, nk = frontend.orb_detect_describe(ctx, bgr[i][None], depth=depth[i][None], params=params)
