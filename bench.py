@@ -323,6 +323,26 @@ def run_rank(args):
                     "path_achieved": round(fps / world * ALG_BYTES_PER_FRAME / 1e9, 2),
                     "path_frac": round(fps / world * ALG_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 5),
                     "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(ktimes.items())}}
+        # The front end is bound by vector-instruction ISSUE, not by HBM: price the dominant kernel on that too.
+        # peak = what tools/valu_rate.hip measured on this chip for the instruction class the kernel is made of (packed 16-bit, v_perm,
+        # three-operand integer ops: 4 cycles per wave64 instruction; only a handful of plain 32-bit ops issue in 2); achieved = the
+        # kernel's SQ_INSTS_VALU per launch (profiles/r04_pmc_summary.json, launches of 128 frames) over the live launch time.
+        try:
+            vr = json.load(open(os.path.join(ROOT, "profiles", "r04_valu_rate.json")))["results"]
+            ps = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_summary.json")))
+            cls = ["PERM", "PKADD", "PKSUB", "PKMIN", "PKMAX", "PKMIN3", "PKMAX3", "LSHLOR", "LSHLADD", "MAD24", "ALIGNBIT", "DOT4", "DOT2", "BFE", "MINU", "MAXI"]
+            peak4 = float(np.median([vr[k]["w8"]["chip_winstr_per_s"] for k in cls if k in vr]))
+            peak2 = float(np.median([vr[k]["w8"]["chip_winstr_per_s"] for k in ("XOR", "SUB", "OR", "AND", "LSHR", "ASHR", "MOV", "FMA") if k in vr]))
+            e = ps[{"k_gray_mask": "k_gray_bits", "k_pyr_down": "k_pyr_down_bits"}.get(dom, dom)]
+            instr = e["SQ_INSTS_VALU"] * frames_per_launch / 128.0
+            roofline["valu"] = {"peak_wave_instr_per_s": round(peak4, 0), "achieved": round(instr / avg_s, 0), "frac": round(instr / avg_s / peak4, 4),
+                                "wave_instr_per_launch": int(instr), "valu_per_wave": e.get("derived", {}).get("valu_per_wave"),
+                                "peak_two_cycle_class_wave_instr_per_s": round(peak2, 0),
+                                "note": "tools/valu_rate.hip (profiles/r04_valu_rate.json): packed-16 / v_perm / min3 / dot / three-operand integer ops issue one wave64 "
+                                        "instruction per 4 cycles per SIMD at any occupancy; v_add/sub/and/or/xor/lshr/mov and f32 add/mul/fma reach 2.4 - 2.8 cycles "
+                                        "only in unbroken runs (alternating the two classes: 3.8)"}
+        except Exception:                                           # noqa: BLE001 (profiles absent: the line goes out without the block)
+            pass
         out.update({"value": round(fps, 1), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                     "config": {"workload": "configs[1]: batched ORB detect+describe + BF-Hamming cross-check match, "
@@ -382,6 +402,22 @@ def run_rank(args):
                                           "stages": "ORB detect+describe -> kp_arr + cloud_kp -> match(i, i-1) -> distance < 30 -> CamOnlyBA -> >= 15 inliers",
                                           "tracked_pairs": int((st == 0).sum()), "pairs": int(len(st)),
                                           "mean_matches": float(trk.n_match[1:].float().mean().item()), "mean_inliers": float(trk.n_inlier[1:].float().mean().item())}
+            # ... and the second stage behind it: Tracker._track_local_map (slam/tracking.py:91-136, bh_track_local_map) on the pose the first stage
+            # produced.  Local map of frame i = the back-projected keypoints of frames i-1 and i-2 in frame i-1's coordinates (their descriptors as the
+            # medoids, normals facing the camera): ~2 000 candidates per frame, the live system's order of magnitude
+            m_ = trk.max_kp
+            prev2 = torch.cat([trk.cloud[:1], trk.cloud[:-1]], 0); prev2d = torch.cat([trk.desc[:1], trk.desc[:-1]], 0)
+            mp_pts = torch.cat([torch.cat([trk.cloud[:1], trk.cloud[:-1]], 0), torch.cat([prev2[:1], prev2[:-1]], 0)], 1)      # row i: clouds of i-1, i-2
+            mp_feat = torch.cat([torch.cat([trk.desc[:1], trk.desc[:-1]], 0), torch.cat([prev2d[:1], prev2d[:-1]], 0)], 1)
+            mp_nrm = torch.zeros_like(mp_pts); mp_nrm[..., 2] = -1.0
+            trk.set_local_map(mp_pts, mp_nrm, mp_feat, torch.full((B,), 2 * m_, dtype=torch.int32, device=dev))
+            el2 = timed(trk, bgr, depth, 5, 2)
+            lo = trk.lm["out"]; st2 = lo["status"][1:].cpu().numpy()
+            r["local_map_chain"] = {"frames_per_s": round(B * 5 / el2, 1), "ms_per_step": round(el2 / 5 * 1e3, 3), "frames": B, "candidates_per_frame": 2 * m_,
+                                    "stages": "the chain above -> visibility gate over the local map -> gather of the survivors' descriptors / points -> match `<= 30` -> "
+                                              "CamOnlyBA -> >= 15 inliers (Tracker.update's two tracking stages, no host hop)",
+                                    "tracked_frames": int((st2 == 0).sum()), "mean_gated": float(lo["n_gate"][1:].float().mean().item()),
+                                    "mean_matches": float(lo["n_match"][1:].float().mean().item()), "mean_inliers": float(lo["n_inlier"][1:].float().mean().item())}
             del trk
             if rank == 0:
                 # the reference's live use: ONE frame per call from HOST memory at camera rate (camera.py:141, slam/tracking.py:54-89), results

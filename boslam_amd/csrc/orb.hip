@@ -1477,7 +1477,7 @@ static bool build_pm_tables(const bh_orb_geom& g, const uint32_t* tab, std::vect
         for (int i = 0; i < 64 * 16; i++) { const int c = w[i], s0 = c >> 1, s1 = c - s0; b[i] = (int8_t)-s0; b[64 * 16 + i] = (int8_t)-s1; }
     };
     for (int l = 1; l < g.nlevels; l++) {
-        const bh_level_geom& S = g.lv[l - 1]; const bh_level_geom& D = g.lv[l];
+        const bh_level_geom& D = g.lv[l];
         const uint32_t* tx = tab + D.tabx_off; const uint32_t* ty = tab + D.taby_off;
         bh_pm_level& P = pm[l];
         P.tiles_x = (D.w + PM_TW - 1) / PM_TW; P.tiles_y = (D.h + PM_TH - 1) / PM_TH;

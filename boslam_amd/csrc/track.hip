@@ -144,3 +144,129 @@ extern "C" int bh_track_refkf(bh_ctx* ctx, const uint8_t* q_desc, const int* nq,
     }
     return BH_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ the local-map half of Tracker.update
+// Tracker._track_local_map (slam/tracking.py:91-162) with no host hop: visibility gate over the local map's (keyframe, map point)
+// candidates -> ordered gather of the survivors' medoid descriptors and points into the matcher's train layout -> the chain of
+// bh_track_refkf with the `<=` distance test of :121 -> the candidate index of every match (what ids_matching_mps[inds] needs).
+
+// see_vector of a frame whose pose has just been set (camera.py:26-29 on a fresh Frame: R (0, 0, 1) normalised)
+__global__ void k_tlm_see(const double* __restrict__ R, double* __restrict__ see, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double x = R[9 * b + 2], y = R[9 * b + 5], z = R[9 * b + 8];
+    const double n = sqrt(x * x + y * y + z * z);
+    see[3 * b] = x / n; see[3 * b + 1] = y / n; see[3 * b + 2] = z / n;
+}
+
+__global__ __launch_bounds__(256) void k_tlm_gather(const int* __restrict__ gate_idx, const int* __restrict__ n_gate, int m_stride,
+                                                    const uint8_t* __restrict__ mp_feat, const double* __restrict__ mp_pts,
+                                                    uint8_t* __restrict__ g_desc, double* __restrict__ g_pts)
+{
+    const size_t b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= min(n_gate[b], m_stride)) return;
+    const size_t j = b * m_stride + (size_t)gate_idx[b * m_stride + i], o = b * m_stride + i;
+    const uint4* src = reinterpret_cast<const uint4*>(mp_feat + j * 32);
+    uint4* dst = reinterpret_cast<uint4*>(g_desc + o * 32);
+    dst[0] = src[0]; dst[1] = src[1];
+    g_pts[3 * o] = mp_pts[3 * j]; g_pts[3 * o + 1] = mp_pts[3 * j + 1]; g_pts[3 * o + 2] = mp_pts[3 * j + 2];
+}
+
+__global__ __launch_bounds__(256) void k_tlm_finish(const int* __restrict__ gate_idx, const int* __restrict__ n_gate, int m_stride,
+                                                    const int* __restrict__ tidx, const int* __restrict__ n_match, int out_stride,
+                                                    int* __restrict__ cand, int* __restrict__ status)
+{
+    const size_t b = blockIdx.x;
+    const int n = min(n_match[b], out_stride);
+    for (int i = threadIdx.x; i < n; i += 256) cand[b * out_stride + i] = gate_idx[b * m_stride + tidx[b * out_stride + i]];
+    if (threadIdx.x == 0 && n_gate[b] == 0) status[b] = BH_TRACK_NO_CANDIDATES;       // `if len(feats) == 0: return False` (:116-117)
+}
+
+extern "C" int bh_track_local_map(bh_ctx* ctx, const uint8_t* q_desc, const int* nq, const int64_t* q_xy, int q_stride,
+                                  const double* R_in, const double* t_in, const double* see,
+                                  const double* mp_pts, const double* mp_normals, const uint8_t* mp_feat, const int* M, int m_stride, int B,
+                                  int width, int height, double cos_thr, int d_max, int min_matches, int min_inliers,
+                                  const double K[5], int iters, double huber_delta, double chi2_thr,
+                                  int* gate_idx, int* n_gate, int* qidx, int* tidx, int* cand, int* dist, int* n_match,
+                                  double* R, double* t, uint8_t* inlier, int* n_inlier, int* status, int out_stride, int mem)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (!q_desc || !nq || !q_xy || !R_in || !t_in || !mp_pts || !mp_normals || !mp_feat || !M || !K || !gate_idx || !n_gate || !qidx || !tidx || !cand ||
+        !dist || !n_match || !R || !t || !inlier || !n_inlier || !status || B < 0 || q_stride < 1 || m_stride < 1 || out_stride < 1 ||
+        (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_track_local_map: bad argument");
+    if (B == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t nm = (size_t)B * m_stride, no = (size_t)B * out_stride, nqs = (size_t)B * q_stride;
+    // workspace: gathered train descriptors / points, the see vectors when the caller leaves them to the pose
+    BH_TRY(bh_reserve(ctx, &ctx->tl_w, al(nm * 32) + al(sizeof(double) * 3 * nm) + al(sizeof(double) * 3 * B)));
+    char* wp = (char*)ctx->tl_w.p;
+    uint8_t* g_desc = (uint8_t*)wp; wp += al(nm * 32);
+    double* g_pts = (double*)wp; wp += al(sizeof(double) * 3 * nm);
+    double* d_see_w = (double*)wp;
+    const uint8_t* d_q = q_desc; const int* d_nq = nq; const long long* d_xy = (const long long*)q_xy; const double* d_Ri = R_in; const double* d_ti = t_in;
+    const double* d_see = see; const double* d_mp = mp_pts; const double* d_mn = mp_normals; const uint8_t* d_mf = mp_feat; const int* d_M = M;
+    int *d_gi = gate_idx, *d_ng = n_gate, *d_qi = qidx, *d_ti2 = tidx, *d_ca = cand, *d_di = dist, *d_nm = n_match, *d_ni = n_inlier, *d_st = status;
+    double *d_R = R, *d_t = t; uint8_t* d_in = inlier;
+    if (mem == BH_MEM_HOST) {
+        for (int b = 0; b < B; b++) if (nq[b] < 0 || nq[b] > q_stride || M[b] < 0 || M[b] > m_stride) return bh_set_err(ctx, BH_ERR_INVALID, "bh_track_local_map: count outside [0, stride]");
+        const size_t in_b = al(nqs * 32) + al(sizeof(long long) * 2 * nqs) + al(sizeof(int) * 2 * B) + al(sizeof(double) * 15 * B) + 2 * al(sizeof(double) * 3 * nm) + al(nm * 32);
+        const size_t out_b = al(sizeof(int) * nm) + 4 * al(sizeof(int) * no) + 4 * al(sizeof(int) * B) + al(sizeof(double) * 12 * B) + al(no);
+        BH_TRY(bh_reserve(ctx, &ctx->tl_in, in_b + out_b));
+        char* ip = (char*)ctx->tl_in.p;
+        auto up = [&](const void* src, size_t bytes) -> char* { char* d = ip; ip += al(bytes); return hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, st) == hipSuccess ? d : nullptr; };
+        char* p;
+        if (!(p = up(q_desc, nqs * 32))) return bh_set_err(ctx, BH_ERR_HIP, "bh_track_local_map: upload failed"); d_q = (const uint8_t*)p;
+        if (!(p = up(q_xy, sizeof(long long) * 2 * nqs))) return bh_set_err(ctx, BH_ERR_HIP, "bh_track_local_map: upload failed"); d_xy = (const long long*)p;
+        {   // nq and M side by side
+            char* d = ip; ip += al(sizeof(int) * 2 * B);
+            BH_HIP(ctx, hipMemcpyAsync(d, nq, sizeof(int) * B, hipMemcpyHostToDevice, st)); BH_HIP(ctx, hipMemcpyAsync(d + sizeof(int) * B, M, sizeof(int) * B, hipMemcpyHostToDevice, st));
+            d_nq = (const int*)d; d_M = d_nq + B;
+        }
+        {   // R, t, see
+            double* d = (double*)ip; ip += al(sizeof(double) * 15 * B);
+            BH_HIP(ctx, hipMemcpyAsync(d, R_in, sizeof(double) * 9 * B, hipMemcpyHostToDevice, st)); BH_HIP(ctx, hipMemcpyAsync(d + 9 * (size_t)B, t_in, sizeof(double) * 3 * B, hipMemcpyHostToDevice, st));
+            if (see) BH_HIP(ctx, hipMemcpyAsync(d + 12 * (size_t)B, see, sizeof(double) * 3 * B, hipMemcpyHostToDevice, st));
+            d_Ri = d; d_ti = d + 9 * (size_t)B; if (see) d_see = d + 12 * (size_t)B;
+        }
+        if (!(p = up(mp_pts, sizeof(double) * 3 * nm))) return bh_set_err(ctx, BH_ERR_HIP, "bh_track_local_map: upload failed"); d_mp = (const double*)p;
+        if (!(p = up(mp_normals, sizeof(double) * 3 * nm))) return bh_set_err(ctx, BH_ERR_HIP, "bh_track_local_map: upload failed"); d_mn = (const double*)p;
+        if (!(p = up(mp_feat, nm * 32))) return bh_set_err(ctx, BH_ERR_HIP, "bh_track_local_map: upload failed"); d_mf = (const uint8_t*)p;
+        d_gi = (int*)ip; ip += al(sizeof(int) * nm);
+        d_qi = (int*)ip; ip += al(sizeof(int) * no); d_ti2 = (int*)ip; ip += al(sizeof(int) * no); d_ca = (int*)ip; ip += al(sizeof(int) * no); d_di = (int*)ip; ip += al(sizeof(int) * no);
+        d_ng = (int*)ip; ip += al(sizeof(int) * B); d_nm = (int*)ip; ip += al(sizeof(int) * B); d_ni = (int*)ip; ip += al(sizeof(int) * B); d_st = (int*)ip; ip += al(sizeof(int) * B);
+        d_R = (double*)ip; d_t = d_R + 9 * (size_t)B; ip += al(sizeof(double) * 12 * B);
+        d_in = (uint8_t*)ip;
+    }
+    if (!d_see) {                                                  // the frame's see_vector follows from the pose the first half has just set
+        hipLaunchKernelGGL(k_tlm_see, dim3((B + 63) / 64), dim3(64), 0, st, d_Ri, d_see_w, B);
+        d_see = d_see_w;
+    }
+    BH_TRY(bh_visibility_gate(ctx, d_mp, d_mn, d_M, B, m_stride, d_Ri, d_ti, d_see, K[0], K[2], K[3], width, height, cos_thr, d_gi, d_ng, BH_MEM_DEVICE));
+    BH_LAUNCH(ctx, BH_K_GATE, k_tlm_gather, dim3((m_stride + 255) / 256, B), dim3(256), st, (const int*)d_gi, (const int*)d_ng, m_stride, d_mf, d_mp, g_desc, g_pts);
+    BH_TRY(bh_track_refkf(ctx, d_q, d_nq, (const int64_t*)d_xy, q_stride, g_desc, d_ng, g_pts, m_stride, B, d_max, 1, min_matches, min_inliers, K, iters, huber_delta, chi2_thr,
+                          d_qi, d_ti2, d_di, d_nm, d_R, d_t, d_in, d_ni, d_st, out_stride, BH_MEM_DEVICE));
+    BH_LAUNCH(ctx, BH_K_GATE, k_tlm_finish, dim3(B), dim3(256), st, (const int*)d_gi, (const int*)d_ng, m_stride, (const int*)d_ti2, (const int*)d_nm, out_stride, d_ca, d_st);
+    BH_HIP(ctx, hipGetLastError());
+    if (mem == BH_MEM_HOST) {
+        BH_HIP(ctx, hipMemcpyAsync(gate_idx, d_gi, sizeof(int) * nm, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(n_gate, d_ng, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(qidx, d_qi, sizeof(int) * no, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(tidx, d_ti2, sizeof(int) * no, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(cand, d_ca, sizeof(int) * no, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(dist, d_di, sizeof(int) * no, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(n_match, d_nm, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(n_inlier, d_ni, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(status, d_st, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(R, d_R, sizeof(double) * 9 * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(t, d_t, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(inlier, d_in, no, hipMemcpyDeviceToHost, st));
+        return bh_ctx_status(ctx);
+    }
+    return BH_OK;
+}
+

@@ -203,6 +203,22 @@ class DeviceTracker:
         self.n_match = torch.zeros((B,), dtype=torch.int32, device=dev); self.n_inlier = torch.zeros_like(self.n_match); self.status = torch.zeros_like(self.n_match)
         self.R = torch.zeros((B, 9), dtype=torch.float64, device=dev); self.t = torch.zeros((B, 3), dtype=torch.float64, device=dev)
         self.inlier = torch.zeros((B, m), dtype=torch.uint8, device=dev)
+        self.lm = None
+
+    def set_local_map(self, mp_pts, mp_normals, mp_feat, M):
+        """Device tensors of the local map's candidates per frame, in the loop order of slam/tracking.py:97-99: mp_pts / mp_normals f64[B][Sm][3],
+        mp_feat u8[B][Sm][32], M int32[B].  From then on run() chains Tracker._track_local_map (bh_track_local_map) behind the reference-keyframe
+        step of every frame i >= 1, on the pose that step produced - the whole of Tracker.update's two tracking stages without a host hop."""
+        torch, B, m, dev = self.torch, self.B, self.max_kp, mp_pts.device
+        Sm = mp_pts.shape[1]
+        o = dict(gate_idx=torch.zeros((B, Sm), dtype=torch.int32, device=dev), n_gate=torch.zeros((B,), dtype=torch.int32, device=dev))
+        for k in ("qidx", "tidx", "cand", "dist"):
+            o[k] = torch.zeros((B, m), dtype=torch.int32, device=dev)
+        for k in ("n_match", "n_inlier", "status"):
+            o[k] = torch.zeros((B,), dtype=torch.int32, device=dev)
+        o["R"] = torch.zeros((B, 9), dtype=torch.float64, device=dev); o["t"] = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+        o["inlier"] = torch.zeros((B, m), dtype=torch.uint8, device=dev)
+        self.lm = dict(pts=mp_pts.contiguous(), nrm=mp_normals.contiguous(), feat=mp_feat.contiguous(), M=M.contiguous(), Sm=Sm, out=o)
 
     def run(self, bgr, depth):
         """Enqueues ORB, the back-projection and the B - 1 tracking problems; does not synchronise.  Pair i (frame i vs i-1) at row i."""
@@ -219,6 +235,12 @@ class DeviceTracker:
                        status=self.status.data_ptr() + 4)
             tracking.track_refkf_device(c, self.desc.data_ptr() + 32 * m, self.n_kp.data_ptr() + 4, self.kp_xy.data_ptr() + 16 * m, m,
                                         self.desc.data_ptr(), self.n_kp.data_ptr(), self.cloud.data_ptr(), m, self.B - 1, self.K, out, m)
+            if self.lm is not None:                              # _track_local_map on the pose _track_wrt_refkf has just set (frame.setPose, tracking.py:87)
+                lm, Sm = self.lm, self.lm["Sm"]
+                o = {k: v.data_ptr() + v.element_size() * (v.numel() // self.B) for k, v in lm["out"].items()}      # row 1 onwards
+                tracking.track_local_map_device(c, self.desc.data_ptr() + 32 * m, self.n_kp.data_ptr() + 4, self.kp_xy.data_ptr() + 16 * m, m,
+                                                self.R.data_ptr() + 72, self.t.data_ptr() + 24, None, lm["pts"].data_ptr() + 24 * Sm, lm["nrm"].data_ptr() + 24 * Sm,
+                                                lm["feat"].data_ptr() + 32 * Sm, lm["M"].data_ptr() + 4, Sm, self.B - 1, self.K, o, m, width=self.W, height=self.H)
 
 
 def mp_add_observations(ctx, obs_desc, obs_cnt, n_obs, normal, feat, new_desc, new_n):

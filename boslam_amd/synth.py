@@ -193,6 +193,51 @@ def tracking_pairs(B=8, n_ref=600, n_frame=600, seed=5, frac_seen=0.7, flip_bits
     return dict(q_desc=q_desc, nq=nq, q_xy=q_xy, t_desc=t_desc, nt=nt, t_pts=t_pts, K=np.array([FX, FY, CX, CY, BASELINE]), R=np.stack(Rs), t=np.stack(ts))
 
 
+def local_map_frames(B=6, n_frame=600, n_mp=900, seed=9, dup_frac=0.35, flip_bits=6, outlier_frac=0.1, away_frac=0.2):
+    """B frames shaped like Tracker._track_local_map's inputs (slam/tracking.py:91-136): the local map's candidates in loop order - every
+    (local keyframe, its map point) pair, so `dup_frac` of the n_mp map points appear two or three times - with medoid descriptors, points
+    and viewing normals (a share `away_frac` faces away from the camera and fails the cos60 test, some points lie outside the image);
+    the frame re-observes a part of the map (descriptors with a few flipped bits, int pixels, some wrong pixels) from a pose near identity.
+    Returns q_desc, nq, q_xy, R, t (frame.R, frame.t), mp_pts, mp_normals, mp_feat, mp_id (the map point of each candidate), M, K."""
+    rng = np.random.default_rng(seed)
+    Sm = int(n_mp * (1 + 2 * dup_frac)) + 8
+    q_desc = rng.integers(0, 256, (B, n_frame, 32), dtype=np.uint8)
+    q_xy = rng.integers(0, 480, (B, n_frame, 2)).astype(np.int64)
+    mp_pts = np.zeros((B, Sm, 3)); mp_nrm = np.zeros((B, Sm, 3)); mp_feat = np.zeros((B, Sm, 32), np.uint8); mp_id = -np.ones((B, Sm), np.int64)
+    nq = np.zeros(B, np.int32); M = np.zeros(B, np.int32)
+    Rs, ts = [], []
+    for b in range(B):
+        nq[b] = n_frame - (b % 4) * 5
+        R = _rodrigues(rng.normal(0, 0.02, 3)); t = rng.normal(0, 0.04, 3)
+        X = np.stack([rng.uniform(-2.5, 2.5, n_mp), rng.uniform(-1.8, 1.8, n_mp), rng.uniform(1.0, 4.0, n_mp)], axis=1)
+        feat = rng.integers(0, 256, (n_mp, 32), dtype=np.uint8)
+        see = R @ np.array([0.0, 0.0, 1.0]); see /= np.linalg.norm(see)
+        nrm = -see + rng.normal(0, 0.35, (n_mp, 3))
+        away = rng.random(n_mp) < away_frac
+        nrm[away] = see + rng.normal(0, 0.2, (int(away.sum()), 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        reps = np.ones(n_mp, np.int64); dup = rng.random(n_mp) < dup_frac; reps[dup] = rng.integers(2, 4, int(dup.sum()))
+        order = rng.permutation(np.repeat(np.arange(n_mp), reps))[:Sm]           # loop order: keyframe by keyframe, a map point wherever its keyframes come up
+        M[b] = len(order)
+        mp_pts[b, :M[b]] = X[order]; mp_nrm[b, :M[b]] = nrm[order]; mp_feat[b, :M[b]] = feat[order]; mp_id[b, :M[b]] = order
+        uv, _ = project(R, t, X)
+        uv = uv + rng.normal(0, 0.7, uv.shape)
+        seen = rng.permutation(n_mp)[:int(0.6 * min(nq[b], n_mp))]
+        slots = rng.permutation(int(nq[b]))[:len(seen)]
+        d = feat[seen].copy()
+        for k in range(len(seen)):
+            for bit in rng.integers(0, 256, rng.integers(0, flip_bits + 1)):
+                d[k, bit >> 3] ^= np.uint8(1 << (bit & 7))
+        q_desc[b, slots] = d
+        px = uv[seen].copy()
+        bad = rng.random(len(seen)) < outlier_frac
+        px[bad] += rng.normal(0, 60.0, (int(bad.sum()), 2))
+        q_xy[b, slots] = np.trunc(px).astype(np.int64)
+        Rs.append(R); ts.append(t)
+    return dict(q_desc=q_desc, nq=nq, q_xy=q_xy, R=np.stack(Rs), t=np.stack(ts), mp_pts=mp_pts, mp_normals=mp_nrm, mp_feat=mp_feat, mp_id=mp_id, M=M,
+                K=np.array([FX, FY, CX, CY, BASELINE]))
+
+
 def ba_problem_frontal(n_kf=6, n_pts=120, seed=21, pix_noise=0.7):
     """Local-window flavour of the live system: keyframes a few cm / degrees from identity looking down +z at points
     2..5 m away (so the reference's 640x480 admission gate, optimizer.py:52-54, admits most edges); int pixels."""

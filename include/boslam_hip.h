@@ -156,12 +156,36 @@ int bh_pose_only_ba(bh_ctx* ctx, const double* pix, const double* pts, const int
 #define BH_TRACK_FEW_MATCHES  1
 #define BH_TRACK_BA_FAILED    2
 #define BH_TRACK_FEW_INLIERS  3
+#define BH_TRACK_NO_CANDIDATES 4   /* bh_track_local_map: no map point passed the gate (`if len(feats) == 0: return False`, tracking.py:116-117) */
 int bh_track_refkf(bh_ctx* ctx, const uint8_t* q_desc, const int* nq, const int64_t* q_xy, int q_stride,
                    const uint8_t* t_desc, const int* nt, const double* t_pts, int t_stride, int B,
                    int d_max, int inclusive, int min_matches, int min_inliers,
                    const double K[5], int iters, double huber_delta, double chi2_thr,
                    int* qidx, int* tidx, int* dist, int* n_match, double* R, double* t, uint8_t* inlier, int* n_inlier,
                    int* status, int out_stride, int mem);
+
+/* ---- the local-map half of Tracker.update on the device ------------------------------------------------------------------
+ * Tracker._track_local_map (slam/tracking.py:91-162) for B frames with no host hop: the visibility gate over the local map's
+ * candidates (:97-111) -> feats / pts3d of the survivors stacked in loop order (:119-120) -> matcher.match(frame.des, feats) with
+ * `distance <= d_max` (:121) -> need >= min_matches (:123) -> CamOnlyBA(frame.kp_arr[inds_frame], pts3d[inds], cam) (:128) -> need
+ * >= min_inliers (:136).
+ * Inputs: q_desc u8[B][q_stride][32], nq[B], q_xy i64[B][q_stride][2] (frame.des, frame.kp_arr); R_in f64[B][9], t_in f64[B][3] (frame.R,
+ *   frame.t: the pose the first half set); see f64[B][3] (frame.see_vector) or NULL = R (0,0,1) normalised, what Frame.setPose leaves
+ *   on a fresh frame (camera.py:26-29); the candidates in the loop order of :97-99 - every (local keyframe, its map point) pair, so a map
+ *   point seen from several keyframes appears several times, as in the reference: mp_pts / mp_normals f64[B][m_stride][3] (mp.pt3d,
+ *   mp.nf()), mp_feat u8[B][m_stride][32] (mp.featf()), M[B]; K = {fx, fy, cx, cy, baseline} (the gate uses fx, cx, cy like cam_map).
+ * Outputs: gate_idx int[B][m_stride], n_gate[B]: the candidates that pass the gate, in order (ids_matching_kfs / ids_matching_mps are the
+ *   caller's id arrays at these indices; num_frames_visible_increment applies to them); qidx / tidx / dist / n_match as bh_track_refkf
+ *   (tidx indexes the GATED list, like `inds`); cand int[B][out_stride] = gate_idx[tidx]: the candidate index of each match, so
+ *   ids_matching_mps[inds[inliers]] = mp_ids[cand[inlier]]; R, t, inlier, n_inlier as bh_track_refkf;
+ *   status[b] = BH_TRACK_OK | BH_TRACK_NO_CANDIDATES | BH_TRACK_FEW_MATCHES | BH_TRACK_BA_FAILED | BH_TRACK_FEW_INLIERS. */
+int bh_track_local_map(bh_ctx* ctx, const uint8_t* q_desc, const int* nq, const int64_t* q_xy, int q_stride,
+                       const double* R_in, const double* t_in, const double* see,
+                       const double* mp_pts, const double* mp_normals, const uint8_t* mp_feat, const int* M, int m_stride, int B,
+                       int width, int height, double cos_thr, int d_max, int min_matches, int min_inliers,
+                       const double K[5], int iters, double huber_delta, double chi2_thr,
+                       int* gate_idx, int* n_gate, int* qidx, int* tidx, int* cand, int* dist, int* n_match,
+                       double* R, double* t, uint8_t* inlier, int* n_inlier, int* status, int out_stride, int mem);
 
 /* ---- loop-closure verification: rigid alignment of matched 3-D points ---------------------------------------------------
  * The stage slam/loop_closing.py:17-19 declares - GlobalMapManager._similiarity_transformation(self) -> (R, t), "R, t that

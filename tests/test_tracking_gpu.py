@@ -102,3 +102,62 @@ def test_live_tracker_equals_the_host_staged_calls(ctx):
                 prev = (desc, nk, cloud)
     finally:
         lt.close()
+
+
+def _oracle_local_map(p, b, d_max=30, min_matches=15, min_inliers=15, see=None):
+    """slam/tracking.py:91-136 as the composition of the parts' oracles: gate -> stacked feats / pts3d -> match `<=` -> CamOnlyBA -> verdict."""
+    M = int(p["M"][b]); R, t = p["R"][b], p["t"][b]
+    sv = see if see is not None else (R @ np.array([0.0, 0.0, 1.0])) / np.linalg.norm(R @ np.array([0.0, 0.0, 1.0]))
+    g = oracle.visibility_gate(p["mp_pts"][b, :M], p["mp_normals"][b, :M], R, t, synth.FX, synth.CX, synth.CY, 640, 480, sv)
+    out = dict(gate=g)
+    if len(g) == 0:
+        return dict(out, status=tracking.TRACK_NO_CANDIDATES, n_match=0, n_inlier=0)
+    nq = int(p["nq"][b])
+    qi, ti, d = oracle.match_crosscheck(p["q_desc"][b, :nq], p["mp_feat"][b, g])
+    keep = d <= d_max
+    qi, ti, d = qi[keep], ti[keep], d[keep]
+    out.update(qidx=qi, tidx=ti, dist=d, n_match=len(qi), cand=g[ti])
+    if len(qi) < min_matches:
+        return dict(out, status=tracking.TRACK_FEW_MATCHES, n_inlier=0)
+    o = oracle.pose_only_ba(p["q_xy"][b][qi].astype(np.float64), p["mp_pts"][b, g][ti], p["K"])
+    ninl = int(o["inlier"].sum())
+    return dict(out, R=o["R"], t=o["t"], inlier=o["inlier"], n_inlier=ninl,
+                status=tracking.TRACK_BA_FAILED if o["rc"] != 0 else (tracking.TRACK_FEW_INLIERS if ninl < min_inliers else tracking.TRACK_OK))
+
+
+def _check_local_map(p, got, see=None):
+    for b in range(len(p["nq"])):
+        ref = _oracle_local_map(p, b, see=None if see is None else see[b])
+        assert got["n_gate"][b] == len(ref["gate"]) and np.array_equal(got["gate_idx"][b, :len(ref["gate"])], ref["gate"]), b
+        assert got["status"][b] == ref["status"], (b, got["status"][b], ref["status"])
+        n = ref["n_match"]
+        assert got["n_match"][b] == n and got["n_inlier"][b] == ref["n_inlier"], b
+        if n:
+            assert np.array_equal(got["qidx"][b, :n], ref["qidx"]) and np.array_equal(got["tidx"][b, :n], ref["tidx"]) and np.array_equal(got["dist"][b, :n], ref["dist"])
+            assert np.array_equal(got["cand"][b, :n], ref["cand"])
+        if ref["status"] in (tracking.TRACK_OK, tracking.TRACK_FEW_INLIERS, tracking.TRACK_BA_FAILED):
+            assert np.array_equal(got["inlier"][b, :n], ref["inlier"])
+            assert np.abs(got["R"][b] - ref["R"]).max() < 1e-9 and np.abs(got["t"][b] - ref["t"]).max() < 1e-9
+
+
+def test_track_local_map_matches_oracle_composition(ctx):
+    """bh_track_local_map (slam/tracking.py:91-136): indices, masks and verdicts exact, pose to 1e-9, every early return forced."""
+    p = synth.local_map_frames(B=7, n_frame=600, n_mp=900, seed=9)
+    p["M"][1] = 0                                                                 # no candidates at all
+    p["mp_normals"][2] = np.array([0.0, 0.0, 1.0])                                # every normal along the viewing direction: the cos60 test leaves nothing
+    p["q_desc"][3] = synth.random_descriptors(123, 600)                           # nothing re-observed: chance matches only -> too few
+    bad = p["q_xy"][4].copy(); bad[:] = np.random.default_rng(3).integers(0, 480, bad.shape); p["q_xy"][4] = bad      # matches fine, geometry garbage
+    got = tracking.track_local_map(ctx, p["q_desc"], p["nq"], p["q_xy"], p["R"], p["t"], p["mp_pts"], p["mp_normals"], p["mp_feat"], p["M"], p["K"])
+    _check_local_map(p, got)
+    st = got["status"]
+    assert st[1] == st[2] == tracking.TRACK_NO_CANDIDATES and st[3] == tracking.TRACK_FEW_MATCHES
+    assert st[4] in (tracking.TRACK_FEW_INLIERS, tracking.TRACK_BA_FAILED) and st[0] == st[5] == st[6] == tracking.TRACK_OK
+    # duplicates are real: some matched candidate's map point also sits elsewhere in the candidate list, and the ids come out through `cand`
+    b = 0
+    n = got["n_match"][b]
+    ids = p["mp_id"][b][got["cand"][b, :n]]
+    assert len(np.unique(p["mp_id"][b, :p["M"][b]])) < p["M"][b] and (ids >= 0).all()
+    # an explicit see_vector (a frame whose pose was set more than once, camera.py:26-29) instead of the one derived from R
+    see = np.tile(np.array([0.05, -0.02, 1.0]) / np.linalg.norm([0.05, -0.02, 1.0]), (7, 1))
+    got2 = tracking.track_local_map(ctx, p["q_desc"], p["nq"], p["q_xy"], p["R"], p["t"], p["mp_pts"], p["mp_normals"], p["mp_feat"], p["M"], p["K"], see=see)
+    _check_local_map(p, got2, see=see)
