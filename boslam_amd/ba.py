@@ -215,6 +215,31 @@ def segment_blocks(n_unknowns, world):
     return [(r * seg, min(N, (r + 1) * seg)) for r in range(world)]
 
 
+DBCR_CH = 4 * 65536 + 512            # doubles a rank contributes to the gathered end blocks (ba.hip: DBCR_CH)
+
+
+def exchange_bytes_per_trial(n_unknowns, bw, world, segments=True):
+    """Bytes a rank RECEIVES per Levenberg trial for the reduced camera system, by kind - the arithmetic of ba.hip's own accounting
+    (ba_allreduce: an all-reduce counts its buffer, a reduce-scatter the rank's chunk, an all-gather the other ranks' chunks):
+      segments=True   the keyframe-segment scheme (dbcr_solve): S reduce-scattered over 256 seg world padded rows, b~ all-reduced, the
+                      segments' end blocks all-gathered (DBCR_CH doubles per rank), the step's rows all-gathered;
+      segments=False  the round-2 scheme: S and b~ all-reduced, the solve replicated.
+    Returns dict(reduce_scatter, all_gather, allreduce, total) in bytes, or None when segments are asked for but a rank would hold fewer
+    than two blocks (segment_blocks)."""
+    n, w = int(n_unknowns), int(world)
+    if not segments or w < 2:
+        ar = 8 * n * (bw + 1) + 8 * n
+        return dict(reduce_scatter=0, all_gather=0, allreduce=ar, total=ar)
+    if segment_blocks(n, w) is None:
+        return None
+    N = (n + 255) // 256; seg = (N + w - 1) // w
+    rows_pad = 256 * seg * w
+    rs = 8 * rows_pad * (bw + 1) // w
+    ag = 8 * DBCR_CH * (w - 1) + 8 * 256 * seg * (w - 1)
+    ar = 8 * n
+    return dict(reduce_scatter=rs, all_gather=ag, allreduce=ar, total=rs + ag + ar)
+
+
 def make_allreduce_hook(ctx, dist, device=None):
     """bh_allreduce_fn over torch.distributed.  With a device-capable backend ("nccl" = RCCL over xGMI) the library's device
     buffer is reduced in place; with "gloo" it is staged through host memory (CPU rehearsals)."""

@@ -271,32 +271,134 @@ __global__ __launch_bounds__(256) void k_medoid(const uint8_t* __restrict__ desc
 //   n /= norm(n);  n_obs += 1;  if len(obs) < 10: obs.append(feat), feat = obs[argmin(median(dists, axis=0))];
 //   self.n = (n + (n_obs - 1) * self.n) / n_obs
 // One lane per map point; arrays are updated in place.
-__global__ __launch_bounds__(256) void k_mp_add_obs(uint8_t* __restrict__ obs, int* __restrict__ obs_cnt, int* __restrict__ n_obs,
-                                                    double* __restrict__ normal, uint8_t* __restrict__ feat,
-                                                    const uint8_t* __restrict__ new_desc, const double* __restrict__ new_n, int M)
+// row i of the map-point arrays takes the observation (descriptor nd, viewing direction (n0, n1, n2), not normalised); obs_kf (may be
+// null) records the observing keyframe beside the stored descriptor, as self.obs does
+__device__ __forceinline__ void mp_add_obs_row(size_t i, uint8_t* __restrict__ obs, int* __restrict__ obs_kf, int* __restrict__ obs_cnt, int* __restrict__ n_obs,
+                                               double* __restrict__ normal, uint8_t* __restrict__ feat, const uint8_t* __restrict__ nd,
+                                               double n0, double n1, double n2, int kf_id)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    double n0 = new_n[3 * (size_t)i], n1 = new_n[3 * (size_t)i + 1], n2 = new_n[3 * (size_t)i + 2];
     const double nrm = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
     n0 = n0 / nrm; n1 = n1 / nrm; n2 = n2 / nrm;
     const int no = n_obs[i] + 1;
     n_obs[i] = no;
     int k = obs_cnt[i];
     if (k < MEDOID_K) {
-        uint8_t* slot = obs + ((size_t)i * MEDOID_K + k) * 32;
-        const uint4* src = reinterpret_cast<const uint4*>(new_desc + (size_t)i * 32);
+        uint8_t* slot = obs + (i * MEDOID_K + k) * 32;
+        const uint4* src = reinterpret_cast<const uint4*>(nd);
         reinterpret_cast<uint4*>(slot)[0] = src[0]; reinterpret_cast<uint4*>(slot)[1] = src[1];
+        if (obs_kf) obs_kf[i * MEDOID_K + k] = kf_id;
         k++;
         obs_cnt[i] = k;
-        const int m = medoid_index(obs + (size_t)i * MEDOID_K * 32, k);
-        const uint4* md = reinterpret_cast<const uint4*>(obs + ((size_t)i * MEDOID_K + m) * 32);
-        reinterpret_cast<uint4*>(feat + (size_t)i * 32)[0] = md[0]; reinterpret_cast<uint4*>(feat + (size_t)i * 32)[1] = md[1];
+        const int m = medoid_index(obs + i * MEDOID_K * 32, k);
+        const uint4* md = reinterpret_cast<const uint4*>(obs + (i * MEDOID_K + m) * 32);
+        reinterpret_cast<uint4*>(feat + i * 32)[0] = md[0]; reinterpret_cast<uint4*>(feat + i * 32)[1] = md[1];
     }
     const double w = (double)(no - 1), dn = (double)no;
-    normal[3 * (size_t)i] = (n0 + w * normal[3 * (size_t)i]) / dn;
-    normal[3 * (size_t)i + 1] = (n1 + w * normal[3 * (size_t)i + 1]) / dn;
-    normal[3 * (size_t)i + 2] = (n2 + w * normal[3 * (size_t)i + 2]) / dn;
+    normal[3 * i] = (n0 + w * normal[3 * i]) / dn;
+    normal[3 * i + 1] = (n1 + w * normal[3 * i + 1]) / dn;
+    normal[3 * i + 2] = (n2 + w * normal[3 * i + 2]) / dn;
+}
+__global__ __launch_bounds__(256) void k_mp_add_obs(uint8_t* __restrict__ obs, int* __restrict__ obs_cnt, int* __restrict__ n_obs,
+                                                    double* __restrict__ normal, uint8_t* __restrict__ feat,
+                                                    const uint8_t* __restrict__ new_desc, const double* __restrict__ new_n, int M)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    mp_add_obs_row((size_t)i, obs, nullptr, obs_cnt, n_obs, normal, feat, new_desc + (size_t)i * 32, new_n[3 * (size_t)i], new_n[3 * (size_t)i + 1], new_n[3 * (size_t)i + 2], 0);
+}
+
+// ------------------------------------------------------------------------------------------------ add_kf: the per-feature loop as a whole
+// CovisibilityGraph.add_kf (slam/covisibility_graph.py:123-136) for ONE keyframe against a device-resident map-point table whose row index
+// is the map point's id (MapPoint.cnt, slam/nodes.py:106-110):
+//   for i_feat, (feat, d3, id_mp) in enumerate(zip(kf.des, kf.cloud_kp, kf.des2mp)):
+//       n = frame.t - d3; norm = |n|; if norm > 0:
+//           id_mp == -1 or id_mp not in self.mps -> MapPoint(feat, d3, n / norm, kf.id): id = cnt++, des2mp[i_feat] = id
+//           else                                 -> self.mps[id_mp].add_observation(feat, n, kf.id)
+// One workgroup: the creations take their ids in feature order (a block-wide scan of the create flags), and two features tied to the SAME
+// existing map point (a map point reaches the tracker's candidate list once per keyframe that sees it) are applied one after the other,
+// in feature order: occurrence r of an id runs in round r.
+#define KFA_T 1024
+__global__ __launch_bounds__(KFA_T) void k_kf_add(int kf_id, double t0, double t1, double t2, int N, const uint8_t* __restrict__ des, const double* __restrict__ cloud,
+                                                  int* __restrict__ des2mp, int cap, int next_id, uint8_t* __restrict__ alive, double* __restrict__ pt3d,
+                                                  double* __restrict__ normal, uint8_t* __restrict__ feat, uint8_t* __restrict__ obs, int* __restrict__ obs_kf,
+                                                  int* __restrict__ obs_cnt, int* __restrict__ n_obs, int* __restrict__ first_kf, int* __restrict__ action,
+                                                  int* __restrict__ out /* n_created, capacity flag */, int* __restrict__ ids /* scratch int[N] */)
+{
+    __shared__ int s_w[KFA_T / 64], s_carry, s_maxr, s_ovf;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { s_carry = 0; s_maxr = 0; s_ovf = 0; }
+    __syncthreads();
+    // ---- pass 1: classify, create (ids in feature order)
+    for (int i0 = 0; i0 < N; i0 += KFA_T) {
+        const int i = i0 + tid;
+        bool valid = false, create = false;
+        double n0 = 0, n1 = 0, n2 = 0, nrm = 0;
+        int id = -1;
+        if (i < N) {
+            n0 = t0 - cloud[3 * (size_t)i]; n1 = t1 - cloud[3 * (size_t)i + 1]; n2 = t2 - cloud[3 * (size_t)i + 2];
+            nrm = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
+            valid = nrm > 0.0;
+            id = des2mp[i];
+            create = valid && (id < 0 || id >= cap || !alive[id]);
+        }
+        const unsigned long long bm = __ballot(create);
+        const int before = __popcll(bm & ((1ull << lane) - 1ull));
+        if (lane == 0) s_w[wv] = __popcll(bm);
+        __syncthreads();
+        int off = s_carry, tot = 0;
+        for (int w = 0; w < KFA_T / 64; w++) { const int c = s_w[w]; if (w < wv) off += c; tot += c; }
+        if (i < N) {
+            int act = 0, keep_id = -1;
+            if (create) {
+                const int nid = next_id + off + before;
+                if (nid < cap) {
+                    const size_t r = (size_t)nid;
+                    // MapPoint.__init__ normalises the direction it is handed once more: n = (n / norm) / |n / norm|
+                    double a0 = n0 / nrm, a1 = n1 / nrm, a2 = n2 / nrm;
+                    const double m2 = sqrt((a0 * a0 + a1 * a1) + a2 * a2);
+                    normal[3 * r] = a0 / m2; normal[3 * r + 1] = a1 / m2; normal[3 * r + 2] = a2 / m2;
+                    pt3d[3 * r] = cloud[3 * (size_t)i]; pt3d[3 * r + 1] = cloud[3 * (size_t)i + 1]; pt3d[3 * r + 2] = cloud[3 * (size_t)i + 2];
+                    const uint4* src = reinterpret_cast<const uint4*>(des + (size_t)i * 32);
+                    reinterpret_cast<uint4*>(feat + r * 32)[0] = src[0]; reinterpret_cast<uint4*>(feat + r * 32)[1] = src[1];
+                    reinterpret_cast<uint4*>(obs + r * MEDOID_K * 32)[0] = src[0]; reinterpret_cast<uint4*>(obs + r * MEDOID_K * 32)[1] = src[1];
+                    obs_kf[r * MEDOID_K] = kf_id; obs_cnt[r] = 1; n_obs[r] = 1; first_kf[r] = kf_id; alive[r] = 1;
+                    des2mp[i] = nid; act = 1;
+                } else s_ovf = 1;                                    // table full: reported, the feature keeps its old association
+            } else if (valid) { act = 2; keep_id = id; }
+            action[i] = act;
+            ids[i] = keep_id;                                        // >= 0: an observation of that map point is due
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+    // ---- pass 2: observations; occurrence rank of each feature among the earlier features with the same id
+    for (int i0 = 0; i0 < N; i0 += KFA_T) {
+        const int i = i0 + tid;
+        if (i < N && ids[i] >= 0) {
+            const int id = ids[i];
+            int r = 0;
+            for (int j = 0; j < i; j++) r += ids[j] == id ? 1 : 0;
+            action[i] = 2 | (r << 8);
+            atomicMax(&s_maxr, r);
+        }
+    }
+    __syncthreads();
+    const int maxr = s_maxr;
+    for (int r = 0; r <= maxr; r++) {
+        for (int i0 = 0; i0 < N; i0 += KFA_T) {
+            const int i = i0 + tid;
+            if (i < N && ids[i] >= 0 && (action[i] >> 8) == r) {
+                const size_t ci = (size_t)i;
+                mp_add_obs_row((size_t)ids[i], obs, obs_kf, obs_cnt, n_obs, normal, feat, des + ci * 32,
+                               t0 - cloud[3 * ci], t1 - cloud[3 * ci + 1], t2 - cloud[3 * ci + 2], kf_id);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int i0 = 0; i0 < N; i0 += KFA_T) { const int i = i0 + tid; if (i < N) action[i] &= 255; }
+    if (tid == 0) { out[0] = min(s_carry, max(cap - next_id, 0)); out[1] = s_ovf; }
 }
 
 extern "C" int bh_medoid_descriptor(bh_ctx* ctx, const uint8_t* desc, const int* k, int M, int* medoid_idx, int mem)
@@ -357,3 +459,58 @@ extern "C" int bh_mp_add_observation(bh_ctx* ctx, int M, uint8_t* obs_desc, int*
     }
     return BH_OK;
 }
+
+extern "C" int bh_kf_add_map_points(bh_ctx* ctx, int kf_id, const double frame_t[3], int N, const uint8_t* des, const double* cloud_kp, int* des2mp,
+                                    int cap, int next_id, uint8_t* alive, double* pt3d, double* normal, uint8_t* feat, uint8_t* obs_desc, int* obs_kf,
+                                    int* obs_cnt, int* n_obs, int* first_kf, int* action, int* n_created, int mem)
+{
+    if (!ctx) return BH_ERR_INVALID;
+    if (!frame_t || !des || !cloud_kp || !des2mp || !alive || !pt3d || !normal || !feat || !obs_desc || !obs_kf || !obs_cnt || !n_obs || !first_kf || !action ||
+        !n_created || N < 0 || cap < 1 || next_id < 0 || next_id > cap || (mem != BH_MEM_HOST && mem != BH_MEM_DEVICE))
+        return bh_set_err(ctx, BH_ERR_INVALID, "bh_kf_add_map_points: bad argument");
+    *n_created = 0;
+    if (N == 0) return BH_OK;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t c = (size_t)cap, n = (size_t)N;
+    // per-call scratch: the pending-observation ids and the two result words (+ in host mode everything else)
+    const size_t tab_b = al(c) + 2 * al(sizeof(double) * 3 * c) + al(c * 32) + al(c * MEDOID_K * 32) + al(sizeof(int) * MEDOID_K * c) + 3 * al(sizeof(int) * c);
+    const size_t in_b = al(n * 32) + al(sizeof(double) * 3 * n) + 2 * al(sizeof(int) * n);
+    BH_TRY(bh_reserve(ctx, &ctx->st_b, al(sizeof(int) * n) + 256 + (mem == BH_MEM_HOST ? tab_b + in_b : 0)));
+    char* p = (char*)ctx->st_b.p;
+    int* ids = (int*)p; p += al(sizeof(int) * n);
+    int* d_out = (int*)p; p += 256;
+    const uint8_t* d_des = des; const double* d_cl = cloud_kp; int* d_d2m = des2mp; int* d_act = action;
+    uint8_t *d_alive = alive, *d_feat = feat, *d_obs = obs_desc; double *d_pt = pt3d, *d_nr = normal; int *d_okf = obs_kf, *d_oc = obs_cnt, *d_no = n_obs, *d_fk = first_kf;
+    if (mem == BH_MEM_HOST) {                                      // (test / small-map convenience: the whole table goes up and comes back; the live use keeps it on the device)
+        for (int i = 0; i < N; i++) if (des2mp[i] < -1) return bh_set_err(ctx, BH_ERR_INVALID, "bh_kf_add_map_points: des2mp entries are -1 or ids");
+        auto up = [&](const void* src, size_t bytes) -> char* { char* d = p; p += al(bytes); return hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, st) == hipSuccess ? d : nullptr; };
+        char* q;
+#define KFA_UP(dst, type, src, bytes) if (!(q = up(src, bytes))) return bh_set_err(ctx, BH_ERR_HIP, "bh_kf_add_map_points: upload failed"); dst = (type)q
+        KFA_UP(d_des, const uint8_t*, des, n * 32); KFA_UP(d_cl, const double*, cloud_kp, sizeof(double) * 3 * n); KFA_UP(d_d2m, int*, des2mp, sizeof(int) * n);
+        d_act = (int*)p; p += al(sizeof(int) * n);
+        KFA_UP(d_alive, uint8_t*, alive, c); KFA_UP(d_pt, double*, pt3d, sizeof(double) * 3 * c); KFA_UP(d_nr, double*, normal, sizeof(double) * 3 * c);
+        KFA_UP(d_feat, uint8_t*, feat, c * 32); KFA_UP(d_obs, uint8_t*, obs_desc, c * MEDOID_K * 32); KFA_UP(d_okf, int*, obs_kf, sizeof(int) * MEDOID_K * c);
+        KFA_UP(d_oc, int*, obs_cnt, sizeof(int) * c); KFA_UP(d_no, int*, n_obs, sizeof(int) * c); KFA_UP(d_fk, int*, first_kf, sizeof(int) * c);
+#undef KFA_UP
+    }
+    BH_LAUNCH(ctx, BH_K_MATCH, k_kf_add, dim3(1), dim3(KFA_T), st, kf_id, frame_t[0], frame_t[1], frame_t[2], N, d_des, d_cl, d_d2m, cap, next_id, d_alive, d_pt, d_nr, d_feat,
+              d_obs, d_okf, d_oc, d_no, d_fk, d_act, d_out, ids);
+    BH_HIP(ctx, hipGetLastError());
+    int ho[2] = { 0, 0 };
+    BH_HIP(ctx, hipMemcpyAsync(ho, d_out, sizeof(ho), hipMemcpyDeviceToHost, st));
+    if (mem == BH_MEM_HOST) {
+        BH_HIP(ctx, hipMemcpyAsync(des2mp, d_d2m, sizeof(int) * n, hipMemcpyDeviceToHost, st)); BH_HIP(ctx, hipMemcpyAsync(action, d_act, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(alive, d_alive, c, hipMemcpyDeviceToHost, st)); BH_HIP(ctx, hipMemcpyAsync(pt3d, d_pt, sizeof(double) * 3 * c, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(normal, d_nr, sizeof(double) * 3 * c, hipMemcpyDeviceToHost, st)); BH_HIP(ctx, hipMemcpyAsync(feat, d_feat, c * 32, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(obs_desc, d_obs, c * MEDOID_K * 32, hipMemcpyDeviceToHost, st)); BH_HIP(ctx, hipMemcpyAsync(obs_kf, d_okf, sizeof(int) * MEDOID_K * c, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(obs_cnt, d_oc, sizeof(int) * c, hipMemcpyDeviceToHost, st)); BH_HIP(ctx, hipMemcpyAsync(n_obs, d_no, sizeof(int) * c, hipMemcpyDeviceToHost, st));
+        BH_HIP(ctx, hipMemcpyAsync(first_kf, d_fk, sizeof(int) * c, hipMemcpyDeviceToHost, st));
+    }
+    BH_HIP(ctx, hipStreamSynchronize(st));                      // the count of new map points is the caller's next MapPoint.cnt
+    *n_created = ho[0];
+    if (ho[1]) return bh_set_err(ctx, BH_ERR_CAPACITY, "bh_kf_add_map_points: the map-point table is full (%d rows)", cap);
+    return BH_OK;
+}
+

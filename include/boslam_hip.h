@@ -130,6 +130,22 @@ int bh_medoid_descriptor(bh_ctx* ctx, const uint8_t* desc, const int* k, int M, 
 int bh_mp_add_observation(bh_ctx* ctx, int M, uint8_t* obs_desc, int* obs_cnt, int* n_obs, double* normal, uint8_t* feat,
                           const uint8_t* new_desc, const double* new_n, int mem);
 
+/* The per-feature loop of CovisibilityGraph.add_kf as a whole - slam/covisibility_graph.py:123-136 - for ONE keyframe against a map-point
+ * table whose row index is the map point's id (MapPoint.cnt, slam/nodes.py:106-110), in place:
+ *   for every feature i (des u8[N][32], cloud_kp f64[N][3], des2mp int[N]): n = frame_t - cloud_kp[i]; if |n| > 0:
+ *     des2mp[i] == -1 or not a live row -> a new map point: id = next_id, next_id + 1, ... in FEATURE ORDER; row = MapPoint(feat, d3, n / |n|,
+ *                                          kf_id) (nodes.py:105-123: direction normalised once more, n_obs = 1, obs = [(kf_id, feat)]); des2mp[i] = id
+ *     else                              -> MapPoint.add_observation(feat, n, kf_id) on that row (as bh_mp_add_observation, plus the observing
+ *                                          keyframe in obs_kf); several features tied to one map point are applied in feature order.
+ * Table (capacity cap rows): alive u8[cap], pt3d / normal f64[cap][3], feat u8[cap][32], obs_desc u8[cap][10][32], obs_kf int[cap][10],
+ * obs_cnt / n_obs / first_kf int[cap].  action int[N]: 0 = skipped (|n| == 0), 1 = created, 2 = observed - what add_edge_to_cg (:136)
+ * and KeyFrame.make_mp2kp (nodes.py:36-39: {des2mp[i]: kp_arr[i]}) need, both of which stay with the host's graph.
+ * *n_created: the new map points (the caller's next MapPoint.cnt = next_id + *n_created).  BH_ERR_CAPACITY when the table is full.
+ * BH_MEM_HOST copies the whole table up and back (tests, small maps); the live use keeps the table in HBM (BH_MEM_DEVICE). */
+int bh_kf_add_map_points(bh_ctx* ctx, int kf_id, const double frame_t[3], int N, const uint8_t* des, const double* cloud_kp, int* des2mp,
+                         int cap, int next_id, uint8_t* alive, double* pt3d, double* normal, uint8_t* feat, uint8_t* obs_desc, int* obs_kf,
+                         int* obs_cnt, int* n_obs, int* first_kf, int* action, int* n_created, int mem);
+
 /* ---- pose-only bundle adjustment ----------------------------------------------------------------------------------
  * Replaces CamOnlyBA(pixels, points, cam, ...) — slam/optimizer.py:82-142, called at slam/tracking.py:73,128 —
  * for B independent problems (one free VertexCam initialised to identity, n fixed points, EdgeProjectP2MC,

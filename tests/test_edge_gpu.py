@@ -328,3 +328,64 @@ def test_mp_add_observation_matches_the_reference_loop(ctx):
             assert all(np.array_equal(state[0][i, k], o[k]) for k in range(len(o)))
             assert np.array_equal(state[4][i], ft), (step, i)
             assert np.abs(state[3][i] - nr).max() <= 4e-16
+
+
+def test_kf_add_map_points_matches_the_reference_loop(ctx):
+    """bh_kf_add_map_points against the per-feature loop of CovisibilityGraph.add_kf (slam/covisibility_graph.py:123-136) and MapPoint.__init__ /
+    add_observation (slam/nodes.py:105-123, 142-156) restated in numpy, three keyframes in a row: ids in feature order, stored descriptors,
+    observing keyframes, counts and the medoid exactly; directions to 4e-16 (numpy's norm is a BLAS dot); features tied to the same map point
+    are applied in feature order; erased map points are re-created; a feature at the camera centre is skipped."""
+    import oracle
+    from boslam_amd import map_points
+    rng = np.random.default_rng(8)
+    tab = map_points.MapPointTable(4096)
+    ref = {}                                                         # id -> dict(obs, obs_kf, n_obs, normal, feat, pt3d, first_kf)
+    cnt = 0
+    for kf_id, N in ((10, 500), (11, 600), (12, 550)):
+        t = rng.normal(0, 0.1, 3)
+        des = rng.integers(0, 256, (N, 32), dtype=np.uint8)
+        cloud = np.stack([rng.uniform(-2, 2, N), rng.uniform(-1.5, 1.5, N), rng.uniform(1, 5, N)], 1)
+        d2m = -np.ones(N, np.int32)
+        if cnt:
+            tied = rng.random(N) < 0.6
+            d2m[tied] = rng.integers(0, cnt, int(tied.sum()))        # with replacement: several features per map point do occur
+            for i in np.nonzero(tied)[0][:40]:
+                des[i] = ref[int(d2m[i])]["feat"] ^ rng.integers(0, 2, 32).astype(np.uint8) if int(d2m[i]) in ref else des[i]
+        cloud[7] = t                                                 # |n| == 0: skipped (covisibility_graph.py:128)
+        if kf_id == 12:
+            for dead in (3, 17, 300):
+                tab.erase(dead); ref.pop(dead, None)
+            d2m[20] = 3; d2m[21] = 17                                 # tied to erased map points: re-created as new ones
+        want_d2m = d2m.copy(); want_act = np.zeros(N, np.int32)
+        for i in range(N):                                           # the reference loop
+            n = t - cloud[i]
+            norm = np.linalg.norm(n)
+            if norm > 0.0:
+                id_mp = int(d2m[i])
+                if id_mp == -1 or id_mp not in ref:
+                    nn = n / norm
+                    ref[cnt] = dict(obs=[des[i].copy()], obs_kf=[kf_id], n_obs=1, normal=nn / np.linalg.norm(nn), feat=des[i].copy(), pt3d=cloud[i].copy(), first_kf=kf_id)
+                    want_d2m[i] = cnt; want_act[i] = 1; cnt += 1
+                else:
+                    r = ref[id_mp]
+                    had = len(r["obs"])
+                    r["obs"], r["n_obs"], r["normal"], r["feat"] = oracle.mp_add_observation(r["obs"], r["n_obs"], r["normal"], r["feat"], des[i], n)
+                    if len(r["obs"]) > had:
+                        r["obs_kf"].append(kf_id)
+                    want_act[i] = 2
+        got_d2m, act = tab.add_kf(ctx, kf_id, t, des, cloud, d2m)
+        assert np.array_equal(got_d2m, want_d2m) and np.array_equal(act, want_act) and tab.cnt == cnt
+        for mid, r in ref.items():
+            k = len(r["obs"])
+            assert tab.alive[mid] == 1 and tab.obs_cnt[mid] == k and tab.n_obs[mid] == r["n_obs"] and tab.first_kf[mid] == r["first_kf"], mid
+            assert all(np.array_equal(tab.obs_desc[mid, j], r["obs"][j]) for j in range(k)) and list(tab.obs_kf[mid, :k]) == r["obs_kf"], mid
+            assert np.array_equal(tab.feat[mid], r["feat"]) and np.array_equal(tab.pt3d[mid], r["pt3d"]), mid
+            assert np.abs(tab.normal[mid] - r["normal"]).max() <= 4e-16, mid
+        kp_arr = rng.integers(0, 480, (N, 2))
+        m2k = map_points.make_mp2kp(got_d2m, kp_arr)
+        assert all(np.array_equal(m2k[int(m)], kp_arr[np.nonzero(got_d2m == m)[0][-1]]) for m in np.unique(got_d2m))
+    assert (np.bincount(want_d2m[want_act == 2]).max() > 1)           # the duplicate case was exercised
+    small = map_points.MapPointTable(8)
+    with pytest.raises(Exception):
+        small.add_kf(ctx, 1, np.zeros(3), rng.integers(0, 256, (20, 32), dtype=np.uint8), rng.uniform(1, 2, (20, 3)))
+    assert small.alive.sum() == 8                                    # the table filled up to its capacity before the call reported it

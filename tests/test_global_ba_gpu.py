@@ -119,9 +119,15 @@ def test_segment_wise_solve_matches_single_gpu(ctx, tmp_path, world, window):
     assert float(a["det_reduce_scatter_bytes"]) / trials <= 1.35 * s_bytes / world            # its own rows of S (+ chunk padding)
     assert per_trial <= 1.35 * s_bytes / world + (world - 1) * (4 * 65536 + 512) * 8 + 8.0 * (n6 + 256 * world * 2)
     assert int(a["det_solves"]) == trials and float(a["det_replicated_ms"]) > 0
+    # the library's own accounting equals the plan arithmetic tests/test_host_cpu.py uses for configs[4] (the bytes are deterministic)
+    from boslam_amd import ba as ba_mod
+    model = ba_mod.exchange_bytes_per_trial(n6, bw, world)
+    assert float(a["det_reduce_scatter_bytes"]) == model["reduce_scatter"] * trials and float(a["det_all_gather_bytes"]) == model["all_gather"] * trials
     if world == 2:                                            # the round-2 scheme stays selectable and agrees
         old = _run_ranks(tmp_path, world, n_kf, n_pts, window, iters, {"BH_BA_DSOLVE": "0"})
         assert str(old[0]["solver"]) == "bcr" and not bool(old[0]["det_segment_solve"])
         assert np.array_equal(old[0]["log"][:, 2:], lg0[:, 2:]) and np.abs(old[0]["t"] - t0).max() < 1e-9
+        old_model = ba_mod.exchange_bytes_per_trial(n6, bw, world, segments=False)
+        assert float(old[0]["det_allreduce_bytes"]) >= old_model["total"] * trials                   # S + b~ per trial (+ Hpp, bp, scalars per iteration)
         # (bytes: at this size - S is 2.6 MB, an end-block share 2.1 MB - the old scheme moves less; at configs[4], S = 59 MB on 8 ranks, it
         #  is 59 MB against 7.4 + 14.7 + 0.2 MB per rank and trial: DESIGN.md section 7)

@@ -229,3 +229,27 @@ def test_segment_plan_of_the_sharded_reduced_camera_solve():
         assert all(seg[i][1] == seg[i + 1][0] for i in range(world - 1))
     assert ba.segment_blocks(6 * 698, 2) == [(0, 9), (9, 17)] and ba.segment_blocks(6 * 698, 3) == [(0, 6), (6, 12), (12, 17)]
     assert ba.segment_blocks(6 * 100, 2) is None and ba.segment_blocks(256 * 9, 8) is None      # too short: S all-reduced, solve replicated
+
+
+def test_exchange_bytes_of_the_segment_scheme_at_configs4():
+    """at configs[4] (4 998 free keyframes -> 29 988 unknowns, band 245) the keyframe-segment scheme must move fewer
+    bytes per rank and trial than the round-2 scheme (S all-reduced, solve replicated) on 2, 4 and 8 ranks - and the figures DESIGN.md
+    section 7 quotes follow from the library's own accounting rule, which boslam_amd.ba.exchange_bytes_per_trial restates (checked against
+    bh_ba_get_comm_detail in tests/test_global_ba_gpu.py).  At the small size of that GPU test the inequality is the other way round."""
+    from boslam_amd import ba
+    n, bw = 6 * 4998, 6 * 40 + 5
+    old = ba.exchange_bytes_per_trial(n, bw, 8, segments=False)
+    assert old["total"] == 8 * n * (bw + 1) + 8 * n and abs(old["total"] / 1e6 - 59.3) < 0.2        # the 59 MB of DESIGN.md
+    prev = None
+    for world in (2, 4, 8):
+        new = ba.exchange_bytes_per_trial(n, bw, world)
+        assert new is not None and new["total"] < old["total"], (world, new, old)
+        assert new["reduce_scatter"] <= 1.02 * 8 * n * (bw + 1) / world + 8 * 256 * (bw + 1)         # its own rows of S (+ padding to whole blocks)
+        assert prev is None or new["reduce_scatter"] < prev["reduce_scatter"]
+        prev = new
+    e8 = ba.exchange_bytes_per_trial(n, bw, 8)
+    assert abs(e8["reduce_scatter"] / 1e6 - 7.6) < 0.3 and abs(e8["all_gather"] / 1e6 - 14.9) < 0.3        # 7.4 + 14.7 MB in DESIGN.md section 7
+    small = ba.exchange_bytes_per_trial(6 * 698, 6 * 12 + 5, 2)
+    assert small["total"] > ba.exchange_bytes_per_trial(6 * 698, 6 * 12 + 5, 2, segments=False)["total"]      # the size of the 2-rank GPU test: the old scheme moves less
+    assert ba.exchange_bytes_per_trial(6 * 100, 77, 2) is None
+
