@@ -47,3 +47,27 @@ def similarity_transformation(ctx, kf, cand, d_hamming_max=30, iterations=200, i
     if o["status"][0] != align.ALIGN_OK:
         return None, None, int(o["n_inlier"][0])
     return o["R"][0], o["t"][0], int(o["n_inlier"][0])
+
+
+def loop_fusion(ctx, feat_a, pt_a, nobs_a, feat_b, pt_b, nobs_b, R, t, d_hamming_max=30, radius=0.05):
+    """GlobalMapManager._loop_fusion(R, t) (slam/loop_closing.py:21-26: "finds duplicated mappoints and fuses them together", body `pass`; the
+    behaviour is this project's specification, include/boslam_hip.h): side A = map points around the current keyframe, side B = around the loop
+    candidate, (R, t) from similarity_transformation.  Returns (pair_a, pair_b, keep_a): indices into the two sides and which point survives;
+    the caller re-points the graph's edges (edges_kf2mps / edges_mp2kfs) from the loser to the survivor."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    feat_a = np.ascontiguousarray(feat_a, dtype=np.uint8).reshape(-1, 32); feat_b = np.ascontiguousarray(feat_b, dtype=np.uint8).reshape(-1, 32)
+    Na, Nb = len(feat_a), len(feat_b)
+    if Na == 0 or Nb == 0:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, bool)
+    pt_a = np.ascontiguousarray(pt_a, dtype=np.float64).reshape(Na, 3); pt_b = np.ascontiguousarray(pt_b, dtype=np.float64).reshape(Nb, 3)
+    nobs_a = np.ascontiguousarray(nobs_a, dtype=np.int32).reshape(Na); nobs_b = np.ascontiguousarray(nobs_b, dtype=np.int32).reshape(Nb)
+    Rm = np.ascontiguousarray(R, dtype=np.float64).reshape(9); tv = np.ascontiguousarray(t, dtype=np.float64).reshape(3)
+    cap = min(Na, Nb)
+    pa = np.zeros(cap, np.int32); pb = np.zeros(cap, np.int32); ka = np.zeros(cap, np.uint8); n = C.c_int(0)
+    ctx.check(_lib.lib().bh_loop_fuse_pairs(ctx.h, _lib.ptr(feat_a), _lib.ptr(pt_a), _lib.ptr(nobs_a), Na, _lib.ptr(feat_b), _lib.ptr(pt_b), _lib.ptr(nobs_b), Nb,
+                                            _lib.ptr(Rm), _lib.ptr(tv), int(d_hamming_max), float(radius), _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(ka), C.byref(n), cap, 0))
+    k = n.value
+    return pa[:k], pb[:k], ka[:k].astype(bool)
+

@@ -219,6 +219,18 @@ int bh_track_local_map(bh_ctx* ctx, const uint8_t* q_desc, const int* nq, const 
 int bh_align_se3_ransac(bh_ctx* ctx, const double* P, const double* Q, const int* n, int B, int stride, int iterations, double inlier_thr,
                         double confidence, int min_inliers, double* R, double* t, uint8_t* inlier, int* n_inlier, int* status, int mem);
 
+/* ---- loop closure: duplicate map points of the loop's two ends ------------------------------------------------------------
+ * GlobalMapManager._loop_fusion(R, t) - slam/loop_closing.py:21-26, "finds duplicated mappoints and fuses them together", body `pass`:
+ * PARITY UNPINNED BY CONSTRUCTION (no reference behaviour; specified by this project, checked against oracle.loop_fuse_pairs).
+ * Side A = the map points around the current keyframe (feat_a u8[Na][32], pt_a f64[Na][3], nobs_a int[Na] = MapPoint.n_obs), side B = those
+ * around the loop candidate, (R, t) from bh_align_se3_ransac (a ~ R b + t).  (i, j) is a duplicate when the cross-check Hamming matcher
+ * pairs feat_a[i] with feat_b[j] with distance < d_max and |pt_a[i] - (R pt_b[j] + t)| <= radius.  Out: pair_a / pair_b int[cap] in
+ * ascending i, keep_a u8[cap] (1: the A point survives - it has at least as many observations), *n_pairs. */
+int bh_loop_fuse_pairs(bh_ctx* ctx, const uint8_t* feat_a, const double* pt_a, const int* nobs_a, int Na,
+                       const uint8_t* feat_b, const double* pt_b, const int* nobs_b, int Nb,
+                       const double R[9], const double t[3], int d_max, double radius,
+                       int* pair_a, int* pair_b, uint8_t* keep_a, int* n_pairs, int cap, int mem);
+
 /* ---- local bundle adjustment --------------------------------------------------------------------------------------
  * Replaces the g2o graph of BundleAdjustment — slam/optimizer.py:8-79 — as driven by
  * CovisibilityGraph.optimize_local — slam/covisibility_graph.py:186-235.

@@ -403,3 +403,25 @@ def window_problem(nbr_start, nbr_id, nbr_common, obs_start, obs_mp, obs_px, kf,
     return dict(win_kf=np.array(chain, np.int32), win_fixed=np.array(fixed, bool), n_inner=len(inner), n_outer=len(outer),
                 pt_mp=np.array(pt_mp, np.int32), edge_pose=np.array(e_pose, np.int32), edge_point=np.array(e_pt, np.int32),
                 edge_px=np.array(e_px, np.int64).reshape(-1, 2))
+
+
+def loop_fuse_pairs(feat_a, pt_a, nobs_a, feat_b, pt_b, nobs_b, R, t, d_max=30, radius=0.05):
+    """The project's specification of GlobalMapManager._loop_fusion (slam/loop_closing.py:21-26; the reference body is `pass`: parity unpinned
+    by construction): cross-check Hamming matches of the two sides' map-point descriptors with distance < d_max whose 3-D points agree under
+    a ~ R b + t to within `radius`; the point with at least as many observations survives.  Returns (pair_a, pair_b, keep_a)."""
+    feat_a = np.ascontiguousarray(feat_a, dtype=np.uint8).reshape(-1, 32); feat_b = np.ascontiguousarray(feat_b, dtype=np.uint8).reshape(-1, 32)
+    pt_a = np.asarray(pt_a, dtype=np.float64).reshape(-1, 3); pt_b = np.asarray(pt_b, dtype=np.float64).reshape(-1, 3)
+    R = np.asarray(R, dtype=np.float64).reshape(3, 3); t = np.asarray(t, dtype=np.float64).reshape(3)
+    if len(feat_a) == 0 or len(feat_b) == 0:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, bool)
+    qi, ti, d = match_crosscheck(feat_a, feat_b)
+    pa, pb, ka = [], [], []
+    for a, b, dist in zip(qi, ti, d):
+        if dist >= d_max:
+            continue
+        x = pt_b[b]
+        diff = [pt_a[a][k] - (((R[k, 0] * x[0]) + (R[k, 1] * x[1])) + (R[k, 2] * x[2]) + t[k]) for k in range(3)]
+        if ((diff[0] * diff[0]) + (diff[1] * diff[1])) + (diff[2] * diff[2]) <= radius * radius:
+            pa.append(a); pb.append(b); ka.append(nobs_a[a] >= nobs_b[b])
+    return np.array(pa, np.int32), np.array(pb, np.int32), np.array(ka, bool)
+

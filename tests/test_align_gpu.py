@@ -81,3 +81,35 @@ def test_similarity_transformation_between_two_rendered_frames(ctx):
     class E:
         des = np.zeros((0, 32), np.uint8); cloud_kp = np.zeros((0, 3))
     assert loop_closing.similarity_transformation(ctx, b, E()) == (None, None, 0)
+
+
+def test_loop_fusion_pairs_match_the_specification(ctx):
+    """bh_loop_fuse_pairs (GlobalMapManager._loop_fusion, slam/loop_closing.py:21-26; reference body `pass`, behaviour specified by this project)
+    against its numpy restatement oracle.loop_fuse_pairs: pairs, order and survivor flags exact; the planted duplicates are found, look-alike
+    descriptors at the wrong place and true duplicates with too different descriptors are not."""
+    import oracle
+    from boslam_amd import loop_closing, synth
+    rng = np.random.default_rng(12)
+    Na, Nb = 1400, 1100
+    R = synth._rodrigues(np.array([0.2, -0.1, 0.15])); t = np.array([0.5, -0.2, 0.3])
+    feat_a = rng.integers(0, 256, (Na, 32), dtype=np.uint8); feat_b = rng.integers(0, 256, (Nb, 32), dtype=np.uint8)
+    pt_b = np.stack([rng.uniform(-3, 3, Nb), rng.uniform(-2, 2, Nb), rng.uniform(1, 6, Nb)], 1)
+    pt_a = np.stack([rng.uniform(-3, 3, Na), rng.uniform(-2, 2, Na), rng.uniform(1, 6, Na)], 1)
+    dup = rng.permutation(min(Na, Nb))[:500]
+    for k, j in enumerate(dup):                                      # A[k] duplicates B[j]
+        d = feat_b[j].copy()
+        for bit in rng.integers(0, 256, rng.integers(0, 9)):
+            d[bit >> 3] ^= np.uint8(1 << (bit & 7))
+        feat_a[k] = d
+        pt_a[k] = R @ pt_b[j] + t + rng.normal(0, 0.01, 3)
+    pt_a[:40] += 0.5                                                  # same descriptor, wrong place: not a duplicate
+    feat_a[40:80] = rng.integers(0, 256, (40, 32), dtype=np.uint8)   # right place, unrelated descriptor: not matched
+    nobs_a = rng.integers(1, 12, Na).astype(np.int32); nobs_b = rng.integers(1, 12, Nb).astype(np.int32)
+    pa, pb, ka = loop_closing.loop_fusion(ctx, feat_a, pt_a, nobs_a, feat_b, pt_b, nobs_b, R, t)
+    ra, rb, rk = oracle.loop_fuse_pairs(feat_a, pt_a, nobs_a, feat_b, pt_b, nobs_b, R, t)
+    assert np.array_equal(pa, ra) and np.array_equal(pb, rb) and np.array_equal(ka, rk)
+    assert 380 <= len(pa) <= 420 and not (pa < 80).any() and (np.diff(pa) > 0).all()
+    assert all(dup[a] == b for a, b in zip(pa, pb))
+    assert np.array_equal(ka, nobs_a[pa] >= nobs_b[pb]) and 0 < ka.sum() < len(ka)
+    e = loop_closing.loop_fusion(ctx, feat_a[:0], pt_a[:0], nobs_a[:0], feat_b, pt_b, nobs_b, R, t)
+    assert len(e[0]) == 0
