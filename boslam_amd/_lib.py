@@ -47,6 +47,7 @@ _SIGS = {
     "bh_mp_add_observation": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "bh_pose_only_ba": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i]),
     "bh_track_refkf": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
+    "bh_pose_graph_optimize": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, C.POINTER(_i), C.POINTER(_i)]),
     "bh_loop_fuse_pairs": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _i, _i]),
     "bh_kf_add_map_points": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _i]),
     "bh_track_local_map": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _i, _i, _i, _vp, _i, _d, _d,

@@ -71,3 +71,22 @@ def loop_fusion(ctx, feat_a, pt_a, nobs_a, feat_b, pt_b, nobs_b, R, t, d_hamming
     k = n.value
     return pa[:k], pb[:k], ka[:k].astype(bool)
 
+
+def essential_graph_optimization(ctx, R, t, fixed, ei, ej, Zr, Zt, w=None, iters=10):
+    """GlobalMapManager._essential_graph_optimization (slam/loop_closing.py:28-29, body `pass`; behaviour specified by this project,
+    include/boslam_hip.h: bh_pose_graph_optimize).  R f64[K][3][3], t f64[K][3] keyframe poses (camera in world), fixed bool[K]; edges (ei, ej)
+    with measured relative poses Zr f64[E][3][3], Zt f64[E][3] ~ T_i^-1 T_j and weights w.  Returns (R, t, cost_log, steps_kept, cg_iterations)."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    R = np.array(R, dtype=np.float64).reshape(-1, 9); K = len(R)
+    t = np.array(t, dtype=np.float64).reshape(K, 3)
+    fx = np.ascontiguousarray(fixed, dtype=np.uint8).reshape(K)
+    ei = np.ascontiguousarray(ei, dtype=np.int32); ej = np.ascontiguousarray(ej, dtype=np.int32); E = len(ei)
+    Zr = np.ascontiguousarray(Zr, dtype=np.float64).reshape(E, 9); Zt = np.ascontiguousarray(Zt, dtype=np.float64).reshape(E, 3)
+    w = np.ones(E) if w is None else np.ascontiguousarray(w, dtype=np.float64).reshape(E)
+    log = np.zeros(iters + 1); kept = C.c_int(0); cg = C.c_int(0)
+    ctx.check(_lib.lib().bh_pose_graph_optimize(ctx.h, K, _lib.ptr(R), _lib.ptr(t), _lib.ptr(fx), E, _lib.ptr(ei), _lib.ptr(ej), _lib.ptr(Zr), _lib.ptr(Zt),
+                                                _lib.ptr(w), int(iters), _lib.ptr(log), C.byref(kept), C.byref(cg)))
+    return R.reshape(K, 3, 3), t, log[:kept.value + 1], kept.value, cg.value
+

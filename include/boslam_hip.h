@@ -231,6 +231,17 @@ int bh_loop_fuse_pairs(bh_ctx* ctx, const uint8_t* feat_a, const double* pt_a, c
                        const double R[9], const double t[3], int d_max, double radius,
                        int* pair_a, int* pair_b, uint8_t* keep_a, int* n_pairs, int cap, int mem);
 
+/* ---- loop closure: essential-graph optimisation -----------------------------------------------------------------------------
+ * GlobalMapManager._essential_graph_optimization - slam/loop_closing.py:28-29, body `pass`: PARITY UNPINNED BY CONSTRUCTION (specified by
+ * this project, checked against oracle.pose_graph_optimize).  K keyframe poses R f64[K][9], t f64[K][3] (camera in world, updated in place),
+ * fixed u8[K] (at least one: the gauge); E edges (ei, ej) with the measured relative pose Zr f64[E][9], Zt f64[E][3] ~ T_i^-1 T_j and a
+ * weight w f64[E] - the spanning tree and strong covisibility edges as they were before the loop closed, plus the loop edge from
+ * bh_align_se3_ransac.  Minimises sum_e w_e |(t_E, log R_E)|^2, E = Z^-1 T_i^-1 T_j, by `iters` Gauss-Newton steps (each: conjugate
+ * gradients with a 6 x 6 block-Jacobi preconditioner to 1e-10; a step is kept only if the cost falls).  cost_log f64[iters + 1]: the cost
+ * at the start and after every kept step (0 beyond); *steps_kept, *cg_iters.  Host arrays only (one call per closed loop). */
+int bh_pose_graph_optimize(bh_ctx* ctx, int K, double* R, double* t, const uint8_t* fixed, int E, const int* ei, const int* ej,
+                           const double* Zr, const double* Zt, const double* w, int iters, double* cost_log, int* steps_kept, int* cg_iters);
+
 /* ---- local bundle adjustment --------------------------------------------------------------------------------------
  * Replaces the g2o graph of BundleAdjustment — slam/optimizer.py:8-79 — as driven by
  * CovisibilityGraph.optimize_local — slam/covisibility_graph.py:186-235.

@@ -425,3 +425,84 @@ def loop_fuse_pairs(feat_a, pt_a, nobs_a, feat_b, pt_b, nobs_b, R, t, d_max=30, 
             pa.append(a); pb.append(b); ka.append(nobs_a[a] >= nobs_b[b])
     return np.array(pa, np.int32), np.array(pb, np.int32), np.array(ka, bool)
 
+
+# ---- essential-graph optimisation: the project's specification of GlobalMapManager._essential_graph_optimization (slam/loop_closing.py:28-29;
+# the reference body is `pass`: parity unpinned by construction).  Poses (R_i, t_i) camera-in-world, edges Z_ij ~ T_i^-1 T_j, residual
+# r = (t_E, log R_E) of E = Z^-1 T_i^-1 T_j, update T <- T (+) d: R <- R Exp(d_w), t <- t + R d_v.
+def _so3_log(R):
+    c = min(1.0, max(-1.0, 0.5 * (np.trace(R) - 1.0)))
+    th = np.arccos(c)
+    k = 0.5 + th * th / 12.0 if th < 1e-7 else th / (2.0 * np.sin(th))
+    return k * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+
+
+def _hat(w):
+    return np.array([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def _so3_exp(w):
+    th2 = float(w @ w); th = np.sqrt(th2)
+    a = 1.0 - th2 / 6.0 if th < 1e-7 else np.sin(th) / th
+    b = 0.5 - th2 / 24.0 if th < 1e-7 else (1.0 - np.cos(th)) / th2
+    W = _hat(w)
+    return np.eye(3) + a * W + b * (W @ W)
+
+
+def _jr_inv(w):
+    th2 = float(w @ w); th = np.sqrt(th2)
+    c = 1.0 / 12.0 + th2 / 720.0 if th < 1e-4 else 1.0 / th2 - (1.0 + np.cos(th)) / (2.0 * th * np.sin(th))
+    W = _hat(w)
+    return np.eye(3) + 0.5 * W + c * (W @ W)
+
+
+def pose_graph_edge(Ri, ti, Rj, tj, Zr, Zt, jac=True):
+    """Residual r (6) and the Jacobians A = dr/d(d_i), B = dr/d(d_j) (6 x 6, columns (d_v, d_w)) of one edge."""
+    RE = Zr.T @ Ri.T @ Rj
+    a = Ri.T @ (tj - ti)
+    tE = Zr.T @ (a - Zt)
+    ph = _so3_log(RE)
+    r = np.concatenate([tE, ph])
+    if not jac:
+        return r, None, None
+    Ji = _jr_inv(ph)
+    A = np.zeros((6, 6)); B = np.zeros((6, 6))
+    A[:3, :3] = -Zr.T; A[:3, 3:] = Zr.T @ _hat(a); A[3:, 3:] = -Ji @ RE.T @ Zr.T
+    B[:3, :3] = RE; B[3:, 3:] = Ji
+    return r, A, B
+
+
+def pose_graph_optimize(R, t, fixed, ei, ej, Zr, Zt, w, iters=10):
+    """Gauss-Newton over the free poses, every step the exact solution of (J'WJ + 1e-9 I) d = -J'W r (dense, numpy), kept only if it lowers
+    the cost.  Returns (R, t, cost_log, steps_kept)."""
+    R = np.array(R, dtype=np.float64).reshape(-1, 3, 3); t = np.array(t, dtype=np.float64).reshape(-1, 3)
+    K, E = len(R), len(ei)
+    free = [n for n in range(K) if not fixed[n]]
+    col = {n: 6 * k for k, n in enumerate(free)}
+
+    def cost_of(Rc, tc):
+        return sum(w[e] * float(np.sum(pose_graph_edge(Rc[ei[e]], tc[ei[e]], Rc[ej[e]], tc[ej[e]], Zr[e], Zt[e], False)[0] ** 2)) for e in range(E))
+    log = [cost_of(R, t)]
+    kept = 0
+    for it in range(iters):
+        H = np.zeros((6 * len(free), 6 * len(free))); g = np.zeros(6 * len(free))
+        for e in range(E):
+            i, j = int(ei[e]), int(ej[e])
+            r, A, B = pose_graph_edge(R[i], t[i], R[j], t[j], Zr[e], Zt[e])
+            for n, J in ((i, A), (j, B)):
+                if n in col:
+                    g[col[n]:col[n] + 6] -= w[e] * (J.T @ r)
+                    for m, J2 in ((i, A), (j, B)):
+                        if m in col:
+                            H[col[n]:col[n] + 6, col[m]:col[m] + 6] += w[e] * (J.T @ J2)
+        d = np.linalg.solve(H + 1e-9 * np.eye(len(H)), g) if len(H) else np.zeros(0)
+        Rn, tn = R.copy(), t.copy()
+        for n in free:
+            dv, dw = d[col[n]:col[n] + 3], d[col[n] + 3:col[n] + 6]
+            tn[n] = t[n] + R[n] @ dv; Rn[n] = R[n] @ _so3_exp(dw)
+        c = cost_of(Rn, tn)
+        if not c < log[-1]:
+            break
+        R, t = Rn, tn
+        log.append(c); kept += 1
+    return R, t, np.array(log), kept
+

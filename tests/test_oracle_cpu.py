@@ -457,3 +457,29 @@ def test_se3_alignment_oracle_against_numpy():
         assert np.abs(R - Rn).max() < 1e-6
     assert oracle.align_se3_ransac(np.zeros((2, 3)), np.zeros((2, 3)))[0] == 1
     assert oracle.align_se3_ransac(rng.normal(0, 1, (50, 3)), rng.normal(0, 1, (50, 3)), 50, 0.01, 0.99, 10)[0] == 2
+
+
+def test_pose_graph_edge_jacobians_by_finite_differences():
+    """oracle.pose_graph_edge (the specification bh_pose_graph_optimize is checked against; the reference stage is `pass`): the analytic
+    Jacobians of r = (t_E, log R_E) under T <- T (+) d against central differences - the device restates the same formulas, so a slip in
+    them could otherwise cancel."""
+    import oracle
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        Ri, Rj, Zr = (oracle._so3_exp(rng.normal(0, 0.8, 3)) for _ in range(3))
+        ti, tj, Zt = rng.normal(0, 1, 3), rng.normal(0, 1, 3), rng.normal(0, 1, 3)
+        if trial % 2:                                               # a small error transform, the working point of a real graph
+            Zr = Ri.T @ Rj @ oracle._so3_exp(rng.normal(0, 0.02, 3)); Zt = Ri.T @ (tj - ti) + rng.normal(0, 0.02, 3)
+        r, A, B = oracle.pose_graph_edge(Ri, ti, Rj, tj, Zr, Zt)
+        h = 1e-6
+        for side, J in ((0, A), (1, B)):
+            num = np.zeros((6, 6))
+            for k in range(6):
+                rs = []
+                for sgn in (1, -1):
+                    d = np.zeros(6); d[k] = sgn * h
+                    R2, t2 = (Ri, ti) if side == 0 else (Rj, tj)
+                    Rn = R2 @ oracle._so3_exp(d[3:]); tn = t2 + R2 @ d[:3]
+                    rs.append(oracle.pose_graph_edge(Rn if side == 0 else Ri, tn if side == 0 else ti, Rn if side == 1 else Rj, tn if side == 1 else tj, Zr, Zt, False)[0])
+                num[:, k] = (rs[0] - rs[1]) / (2 * h)
+            assert np.abs(num - J).max() < 1e-6, (trial, side, np.abs(num - J).max())
