@@ -74,6 +74,13 @@ class BowDatabase:
                                                       _lib.ptr(ids), _lib.ptr(sc), C.byref(n), BH_MEM_HOST))
         return ids[:n.value].copy(), sc[:n.value].copy()
 
+    def query_device(self, q_words, q_vals, nq, max_results, ids, scores, n_results):
+        """A device-resident query (bh_bow_query_l1, BH_MEM_DEVICE): every argument but nq / max_results is a device address (int) - words u32
+        strictly ascending, weights f64; ids int32[max_results], scores f64[max_results], n_results int32[1].  Enqueued on the context's
+        stream, no synchronisation; the inverted file answers when it can, the scan otherwise (set_mode as for host queries)."""
+        v = C.c_void_p
+        self.ctx.check(_lib.lib().bh_bow_query_l1(self.h, v(q_words), v(q_vals), int(nq), int(max_results), v(ids), v(scores), v(n_results), _lib.BH_MEM_DEVICE))
+
     def query_batch(self, queries, max_results=1):
         """Many queries in one call (bh_bow_query_l1_batch): queries = sequence of (words, vals).  Returns a list of (ids, scores), each
         what query() returns for that query; with the inverted file up to 16 queries share every launch."""

@@ -119,6 +119,8 @@ struct bh_bow {
     int inv_nslots = 1;            // query slots (scratch sets): 1 for bh_bow_query_l1, INV_QSLOTS once bh_bow_query_l1_batch has been used
     int slots_ready = 0;
     bh_buf inv_slots, inv_acc;     // device copy of the slot table; the slots' accumulator arrays
+    bh_buf dq;                     // device-resident queries (BH_MEM_DEVICE): a slot of their own (slot 0's scratch, the caller's query arrays), its in / out block and the "answered" flag
+    char   slot0_host[128] = {0};  // host copy of slot 0 (an inv_slot), the template of that slot
 };
 
 // grow a device buffer keeping its first `keep` bytes
@@ -161,8 +163,9 @@ __device__ __forceinline__ double bow_shfl(double v, int src)
 __global__ __launch_bounds__(BOW_T) void k_bow_scan(const long long* __restrict__ pstart, const uint32_t* __restrict__ pw,
                                                     const double* __restrict__ pv, long long n_entries,
                                                     const uint32_t* __restrict__ qw, const double* __restrict__ qv, int nq,
-                                                    double* __restrict__ acc_out)
+                                                    double* __restrict__ acc_out, const int* __restrict__ skip)
 {
+    if (skip && *skip) return;                                 // a device-resident query the inverted file has already answered (uniform)
     extern __shared__ uint32_t smem[];
     uint32_t* s_bits = smem;                                   // BOW_BITS / 32 words
     uint32_t* s_qw = smem + BOW_BITS / 32;                     // BOW_QMAX
@@ -228,8 +231,9 @@ __global__ __launch_bounds__(BOW_T) void k_bow_scan(const long long* __restrict_
 #define TOPK_SLICE 8192
 #define TOPK_MAXK 64
 __global__ __launch_bounds__(1024) void k_bow_topk_slices(const double* __restrict__ acc, long long n_entries, int k,
-                                                          double* __restrict__ cand_v, long long* __restrict__ cand_i)
+                                                          double* __restrict__ cand_v, long long* __restrict__ cand_i, const int* __restrict__ skip)
 {
+    if (skip && *skip) return;
     __shared__ double s_v[16];
     __shared__ long long s_i[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -261,8 +265,9 @@ __global__ __launch_bounds__(1024) void k_bow_topk_slices(const double* __restri
 // single workgroup: k rounds of argmin (ties -> smaller id), results best first.  cand_i == NULL: over the accumulators themselves
 // (entry id = index); else over stage-1 candidates (entry id = cand_i[index], -1 = empty).
 __global__ __launch_bounds__(1024) void k_bow_topk(double* __restrict__ acc, long long n_entries, int k, const long long* __restrict__ cand_i,
-                                                   int* __restrict__ ids, double* __restrict__ scores, int* __restrict__ n_res)
+                                                   int* __restrict__ ids, double* __restrict__ scores, int* __restrict__ n_res, const int* __restrict__ skip)
 {
+    if (skip && *skip) return;
     __shared__ double s_v[16];
     __shared__ long long s_i[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -315,7 +320,7 @@ extern "C" void bh_bow_destroy(bh_bow* bow)
     (void)hipSetDevice(bow->ctx->device);
     (void)hipStreamSynchronize(bow->ctx->stream);
     bh_buf* all[] = { &bow->pstart, &bow->words, &bow->vals, &bow->acc, &bow->qw, &bow->qv, &bow->res,
-                      &bow->inv_start, &bow->inv_entry, &bow->inv_val, &bow->inv_tmp, &bow->bcnt, &bow->bkey, &bow->bval, &bow->cand_v, &bow->cand_i, &bow->inv_slots, &bow->inv_acc };
+                      &bow->inv_start, &bow->inv_entry, &bow->inv_val, &bow->inv_tmp, &bow->bcnt, &bow->bkey, &bow->bval, &bow->cand_v, &bow->cand_i, &bow->inv_slots, &bow->inv_acc, &bow->dq };
     for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     if (bow->hq) (void)hipHostFree(bow->hq);
     delete bow;
@@ -738,6 +743,8 @@ static int inv_alloc_slots(bh_bow* bow, int nslots)
     }
     BH_HIP(ctx, hipMemcpyAsync(bow->inv_slots.p, tab.data(), sizeof(inv_slot) * nslots, hipMemcpyHostToDevice, st));
     BH_HIP(ctx, hipStreamSynchronize(st));
+    static_assert(sizeof(inv_slot) <= sizeof(bow->slot0_host), "slot template");
+    memcpy(bow->slot0_host, &tab[0], sizeof(inv_slot));
     bow->inv_nslots = nslots;
     return BH_OK;
 }
@@ -779,12 +786,12 @@ static int inv_build(bh_bow* bow)
 }
 
 // The four launches of the inverted-file path for the first G slots (grid.y = slot), then one synchronisation.
-static int inv_launch(bh_bow* bow, int G, int max_nq, const uint8_t* keep)
+static int inv_launch(bh_bow* bow, int G, int max_nq, const uint8_t* keep, const inv_slot* dev_slot = nullptr)
 {
     bh_ctx* ctx = bow->ctx;
     hipStream_t st = ctx->stream;
     const size_t hlds = INV_HEAVY_LDS;
-    const inv_slot* slots = (const inv_slot*)bow->inv_slots.p;
+    const inv_slot* slots = dev_slot ? dev_slot : (const inv_slot*)bow->inv_slots.p;      // dev_slot: one device-resident query, nothing read back here
     bh_time_begin(ctx, BH_K_BOW_INV);
     hipLaunchKernelGGL(k_inv_gather, dim3((max_nq + 3) / 4, G), dim3(256), 0, st, slots, (const long long*)bow->inv_start.p, (const uint32_t*)bow->inv_entry.p,
                        (const double*)bow->inv_val.p, bow->bcap);
@@ -793,8 +800,16 @@ static int inv_launch(bh_bow* bow, int G, int max_nq, const uint8_t* keep)
     hipLaunchKernelGGL(k_inv_select, dim3(1, G), dim3(1024), 0, st, slots, bow->inv_nb, bow->n_entries);
     bh_time_end(ctx);
     BH_HIP(ctx, hipGetLastError());
-    BH_HIP(ctx, hipStreamSynchronize(st));
+    if (!dev_slot) BH_HIP(ctx, hipStreamSynchronize(st));
     return BH_OK;
+}
+// results of a device-resident query: out of the slot's block into the caller's device arrays, if the inverted file could answer
+__global__ void k_inv_export(const char* __restrict__ hout, int* __restrict__ ids, double* __restrict__ scores, int* __restrict__ n_results, int* __restrict__ answered)
+{
+    const int* hi = reinterpret_cast<const int*>(hout);
+    const int n = hi[0], fb = hi[1], i = threadIdx.x;
+    if (!fb && i < n) { scores[i] = reinterpret_cast<const double*>(hout + 8)[i]; ids[i] = reinterpret_cast<const int*>(hout + 8 + 8 * INV_KMAX)[i]; }
+    if (i == 0) { if (!fb) n_results[0] = n; answered[0] = fb ? 0 : 1; }
 }
 static void inv_fill_slot(bh_bow* bow, int q, const uint32_t* q_words, const double* q_vals, int nq, int k)
 {
@@ -865,6 +880,26 @@ static int bow_query_impl(bh_bow* bow, const uint32_t* q_words, const double* q_
         BH_TRY(inv_query(bow, q_words, q_vals, nq, subset, n_subset, max_results, ids, scores, n_results, &used));
         if (used) return BH_OK;
     }
+    const int* skip = nullptr;
+    if (mem == BH_MEM_DEVICE && bow->mode == 0 && n_subset == 0 && max_results <= INV_KMAX) {
+        // A device-resident query through the inverted file too (a relocaliser that keeps its BoW vectors in HBM): the four kernels run on a
+        // slot whose query arrays are the caller's, k_inv_export moves the results into the caller's arrays and raises `answered`; the
+        // scan that follows is enqueued all the same and returns at once when the flag is up - no host decision, no synchronisation.
+        if (!bow->inv_ready) BH_TRY(inv_build(bow));
+        if (bow->inv_usable && bow->hq) {
+            const size_t off_hdr = 256, off_out = 512, off_flag = 512 + 1024;
+            BH_TRY(bh_reserve(ctx, &bow->dq, 2048));
+            inv_slot S; memcpy(&S, bow->slot0_host, sizeof(S));
+            char* dq = (char*)bow->dq.p;
+            S.hdr = (const int*)(dq + off_hdr); S.qw = q_words; S.qv = q_vals; S.hout = dq + off_out;
+            const int hdr[2] = { nq, max_results };
+            BH_HIP(ctx, hipMemcpyAsync(dq, &S, sizeof(S), hipMemcpyHostToDevice, st));
+            BH_HIP(ctx, hipMemcpyAsync(dq + off_hdr, hdr, sizeof(hdr), hipMemcpyHostToDevice, st));
+            BH_TRY(inv_launch(bow, 1, nq, nullptr, (const inv_slot*)dq));
+            hipLaunchKernelGGL(k_inv_export, dim3(1), dim3(64), 0, st, (const char*)(dq + off_out), ids, scores, n_results, (int*)(dq + off_flag));
+            skip = (const int*)(dq + off_flag);
+        }
+    }
     const uint32_t* d_qw = q_words; const double* d_qv = q_vals; int* d_ids = ids; double* d_sc = scores; int* d_n = n_results;
     if (mem == BH_MEM_HOST) {
         for (int i = 1; i < nq; i++) if (q_words[i] <= q_words[i - 1]) return bh_set_err(ctx, BH_ERR_INVALID, "bh_bow_query_l1: query words must be strictly ascending");
@@ -881,7 +916,7 @@ static int bow_query_impl(bh_bow* bow, const uint32_t* q_words, const double* q_
     if (need < grid) grid = (int)need;
     bh_time_begin(ctx, BH_K_BOW_SCAN);
     hipLaunchKernelGGL(k_bow_scan, dim3(grid), dim3(BOW_T), lds, st, (const long long*)bow->pstart.p, (const uint32_t*)bow->words.p,
-                       (const double*)bow->vals.p, bow->n_entries, d_qw, d_qv, nq, (double*)bow->acc.p);
+                       (const double*)bow->vals.p, bow->n_entries, d_qw, d_qv, nq, (double*)bow->acc.p, skip);
     bh_time_end(ctx);
     if (n_subset > 0) {                                        // restrict to target_inds: everything else becomes "no common word"
         BH_TRY(bh_reserve(ctx, &ctx->st_g, (size_t)bow->n_entries + sizeof(int) * (size_t)n_subset + 16));
@@ -895,10 +930,10 @@ static int bow_query_impl(bh_bow* bow, const uint32_t* q_words, const double* q_
         const int ns = (int)((bow->n_entries + TOPK_SLICE - 1) / TOPK_SLICE);
         BH_TRY(bh_reserve(ctx, &ctx->st_f, (sizeof(double) + sizeof(long long)) * (size_t)ns * max_results));
         double* cv = (double*)ctx->st_f.p; long long* ci = (long long*)(cv + (size_t)ns * max_results);
-        hipLaunchKernelGGL(k_bow_topk_slices, dim3(ns), dim3(1024), 0, st, (const double*)bow->acc.p, bow->n_entries, max_results, cv, ci);
-        hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, st, cv, (long long)ns * max_results, max_results, (const long long*)ci, d_ids, d_sc, d_n);
+        hipLaunchKernelGGL(k_bow_topk_slices, dim3(ns), dim3(1024), 0, st, (const double*)bow->acc.p, bow->n_entries, max_results, cv, ci, skip);
+        hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, st, cv, (long long)ns * max_results, max_results, (const long long*)ci, d_ids, d_sc, d_n, skip);
     } else
-        hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, st, (double*)bow->acc.p, bow->n_entries, max_results, (const long long*)nullptr, d_ids, d_sc, d_n);
+        hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, st, (double*)bow->acc.p, bow->n_entries, max_results, (const long long*)nullptr, d_ids, d_sc, d_n, skip);
     BH_HIP(ctx, hipGetLastError());
     if (mem == BH_MEM_HOST) {
         BH_HIP(ctx, hipMemcpyAsync(scores, d_sc, sizeof(double) * max_results, hipMemcpyDeviceToHost, st));

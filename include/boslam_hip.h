@@ -421,7 +421,10 @@ int  bh_bow_compare_l1(bh_bow* bow, int entry_i, int entry_j, int* n_common, dou
  * built on the device after the database changed; ~1 MB touched per query of configs[3]) with the streaming scan as the fallback
  * (word ids >= 2^20, more than 2^21 database entries, max_results > 16, a query that overflows a bucket's hit list); 1 = always the
  * scan (400 MB streamed per query).
- * Both give bit-identical ids and scores.  BH_MEM_DEVICE queries always scan. */
+ * Both give bit-identical ids and scores.  BH_MEM_DEVICE queries (bh_bow_query_l1 with device pointers; words strictly ascending is the
+ * caller's promise there) take the inverted file too: its kernels run on the caller's query arrays, the results go straight into the
+ * caller's device arrays, and the scan that is enqueued behind them returns at once when a device-side flag says the query has been
+ * answered - no host decision, no synchronisation. */
 int  bh_bow_set_mode(bh_bow* bow, int mode);
 
 /* Database::add at the BoW-vector level — slam/bow_db.py:26 -> dbow3.cpp:138-140: appends one entry (host arrays, words

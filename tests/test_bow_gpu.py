@@ -273,3 +273,31 @@ def test_bow_query_batch_equals_single_queries(ctx):
                     assert np.array_equal(ids, oi) and np.array_equal(sc.view(np.uint64), os_.view(np.uint64))
     assert d.query_batch([], 3) == []
     d.close()
+
+
+def test_device_resident_queries_take_the_inverted_file(ctx):
+    """bh_bow_query_l1 with BH_MEM_DEVICE: the query arrays and the result arrays live in HBM, nothing is synchronised by the
+    call; the inverted file answers (same ids, scores bit-identical to the host paths), the predicated scan stays out of the way - and takes
+    over when the inverted file cannot answer (max_results > 16, scan mode)."""
+    torch = pytest.importorskip("torch")
+    db = synth.bow_database(n_entries=20000, words_per_entry=600, query_entry=777, seed=21)
+    d = bow.BowDatabase(ctx)
+    d.set_db(db["start"], db["words"], db["vals"])
+    qw = torch.from_numpy(db["q_words"].astype(np.int64)).to(torch.int32).cuda(); qv = torch.from_numpy(db["q_vals"]).cuda()      # u32 word ids < 2^31 as int32 bits
+    for k, modes in ((5, ("inverted", "scan")), (16, ("inverted",)), (40, ("inverted",))):
+        oi, os_ = oracle.bow_query_l1(db["q_words"], db["q_vals"], db["start"], db["words"], db["vals"], k)
+        for mode in modes:
+            d.set_mode(mode)
+            ids = torch.full((k,), -7, dtype=torch.int32, device="cuda"); sc = torch.zeros(k, dtype=torch.float64, device="cuda"); n = torch.zeros(1, dtype=torch.int32, device="cuda")
+            for rep in range(3):                                          # back to back on the stream: the slot's counters are reset by each query
+                d.query_device(qw.data_ptr(), qv.data_ptr(), len(db["q_words"]), k, ids.data_ptr(), sc.data_ptr(), n.data_ptr())
+            ctx.synchronize()
+            m = int(n.item())
+            assert m == len(oi) and np.array_equal(ids[:m].cpu().numpy(), oi), (k, mode)
+            assert np.array_equal(sc[:m].cpu().numpy().view(np.uint64), os_.view(np.uint64)), (k, mode)
+    # host queries after device queries on the same handle (shared slot scratch) still agree
+    d.set_mode("inverted")
+    i2, s2 = d.query(db["q_words"], db["q_vals"], 5)
+    oi, os_ = oracle.bow_query_l1(db["q_words"], db["q_vals"], db["start"], db["words"], db["vals"], 5)
+    assert np.array_equal(i2, oi) and np.array_equal(s2, os_)
+    d.close()
