@@ -110,6 +110,7 @@ struct bh_bow {
     // inverted file (DBoW3's own structure: word -> (entry, weight) rows), rebuilt lazily after the database changed
     bh_buf inv_start, inv_entry, inv_val, inv_tmp, bcnt, bkey, bval, cand_v, cand_i;
     int inv_ready = 0;             // rows are current
+    int dirty_queries = 0;         // queries answered by the scan since the database last changed (see inv_ensure)
     int inv_usable = 1;            // every word id < 2^20 (else only the scan can answer)
     int mode = 0;                  // 0 = inverted file where possible, 1 = always scan (bh_bow_set_mode)
     long long inv_nb = 0;          // buckets of 64 entries
@@ -348,7 +349,7 @@ extern "C" int bh_bow_set_db(bh_bow* bow, long long n_entries, const int64_t* st
     }
     const long long nel = hstart[n_entries] - hstart[0], npad = pst[n_entries];
     bow->n_entries = n_entries; bow->n_elems = npad; bow->h_pstart = pst;
-    bow->inv_ready = 0;
+    bow->inv_ready = 0; bow->dirty_queries = 1 << 20;          // a bulk load: the first query builds the inverted file
     BH_TRY(bh_reserve(ctx, &bow->pstart, sizeof(long long) * (n_entries + 1)));
     BH_TRY(bh_reserve(ctx, &bow->words, sizeof(uint32_t) * (npad + 4))); BH_TRY(bh_reserve(ctx, &bow->vals, sizeof(double) * (npad + 4)));
     BH_TRY(bh_reserve(ctx, &bow->acc, sizeof(double) * (n_entries + 1)));
@@ -828,6 +829,21 @@ static int inv_read_slot(bh_bow* bow, int q, int* ids, double* scores, int* n_re
     return 1;
 }
 
+// The inverted file after the database changed.  The reference alternates add and query per keyframe (covisibility_graph.add_kf ->
+// dbow.add, then the loop closer queries from bow_queue): rebuilding the file - an O(database) count / scan / scatter, 1 - 2 ms at configs[3] -
+// for every such query would cost more than the streaming scan it replaces (0.29 ms).  So while the file is stale the scan answers, and the
+// file is rebuilt once INV_DIRTY_QUERIES queries in a row have found the database unchanged (a phase of pure querying pays one rebuild).
+#define INV_DIRTY_QUERIES 3
+static int inv_ensure(bh_bow* bow, int* ready)
+{
+    *ready = 1;
+    if (bow->inv_ready) return BH_OK;
+    if (bow->dirty_queries < INV_DIRTY_QUERIES) { bow->dirty_queries++; *ready = 0; return BH_OK; }
+    BH_TRY(inv_build(bow));
+    bow->dirty_queries = 0;
+    return BH_OK;
+}
+
 // The inverted-file query, host arrays in and out.  Returns BH_OK with *used = 1 when it answered, *used = 0 when the scan must.
 static int inv_query(bh_bow* bow, const uint32_t* q_words, const double* q_vals, int nq, const int* subset, int n_subset, int max_results,
                      int* ids, double* scores, int* n_results, int* used)
@@ -836,8 +852,9 @@ static int inv_query(bh_bow* bow, const uint32_t* q_words, const double* q_vals,
     hipStream_t st = ctx->stream;
     *used = 0;
     if (max_results > INV_KMAX) return BH_OK;
-    if (!bow->inv_ready) BH_TRY(inv_build(bow));
-    if (!bow->inv_usable || !bow->hq) return BH_OK;
+    int ready = 0;
+    BH_TRY(inv_ensure(bow, &ready));
+    if (!ready || !bow->inv_usable || !bow->hq) return BH_OK;
     inv_fill_slot(bow, 0, q_words, q_vals, nq, max_results);  // pinned, device-visible block: the query in, the results out - no staging copies, one synchronisation
     const uint8_t* keep = nullptr;
     if (n_subset > 0) {
@@ -885,8 +902,9 @@ static int bow_query_impl(bh_bow* bow, const uint32_t* q_words, const double* q_
         // A device-resident query through the inverted file too (a relocaliser that keeps its BoW vectors in HBM): the four kernels run on a
         // slot whose query arrays are the caller's, k_inv_export moves the results into the caller's arrays and raises `answered`; the
         // scan that follows is enqueued all the same and returns at once when the flag is up - no host decision, no synchronisation.
-        if (!bow->inv_ready) BH_TRY(inv_build(bow));
-        if (bow->inv_usable && bow->hq) {
+        int ready = 0;
+        BH_TRY(inv_ensure(bow, &ready));
+        if (ready && bow->inv_usable && bow->hq) {
             const size_t off_hdr = 256, off_out = 512, off_flag = 512 + 1024;
             BH_TRY(bh_reserve(ctx, &bow->dq, 2048));
             inv_slot S; memcpy(&S, bow->slot0_host, sizeof(S));
@@ -1019,7 +1037,7 @@ extern "C" int bh_bow_add_entry(bh_bow* bow, const uint32_t* words, const double
     bow->h_pstart.push_back(a + npad);
     if (entry_id) *entry_id = (int)bow->n_entries;
     bow->n_entries += 1; bow->n_elems = a + npad;
-    bow->inv_ready = 0;
+    bow->inv_ready = 0; bow->dirty_queries = 0;
     return BH_OK;
 }
 
@@ -1035,7 +1053,7 @@ extern "C" int bh_bow_erase_entry(bh_bow* bow, int entry_id)
     const long long a = bow->h_pstart[entry_id], e = bow->h_pstart[entry_id + 1];
     if (e > a) BH_HIP(ctx, hipMemsetAsync((uint32_t*)bow->words.p + a, 0xff, sizeof(uint32_t) * (size_t)(e - a), ctx->stream));
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    bow->inv_ready = 0;
+    bow->inv_ready = 0; bow->dirty_queries = 0;
     return BH_OK;
 }
 
@@ -1057,9 +1075,11 @@ extern "C" int bh_bow_query_l1_batch(bh_bow* bow, const uint32_t* q_words, const
     BH_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<char> done(Q, 0);
     if (bow->mode == 0 && max_results <= INV_KMAX && bow->n_entries > 0 && Q > 0) {
-        if (!bow->inv_ready) BH_TRY(inv_build(bow));
-        if (bow->inv_usable && bow->inv_nslots < INV_QSLOTS) BH_TRY(inv_alloc_slots(bow, INV_QSLOTS));
-        if (bow->inv_usable && bow->hq) {
+        int ready = 0;
+        if (!bow->inv_ready && Q >= 2 * INV_DIRTY_QUERIES) bow->dirty_queries = INV_DIRTY_QUERIES;      // a queue of queries is a querying phase by itself
+        BH_TRY(inv_ensure(bow, &ready));
+        if (ready && bow->inv_usable && bow->inv_nslots < INV_QSLOTS) BH_TRY(inv_alloc_slots(bow, INV_QSLOTS));
+        if (ready && bow->inv_usable && bow->hq) {
             for (int g0 = 0; g0 < Q; g0 += INV_QSLOTS) {
                 const int G = std::min(INV_QSLOTS, Q - g0);
                 int max_nq = 1;

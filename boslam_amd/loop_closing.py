@@ -90,3 +90,42 @@ def essential_graph_optimization(ctx, R, t, fixed, ei, ej, Zr, Zt, w=None, iters
                                                 _lib.ptr(w), int(iters), _lib.ptr(log), C.byref(kept), C.byref(cg)))
     return R.reshape(K, 3, 3), t, log[:kept.value + 1], kept.value, cg.value
 
+
+class GlobalMapManager:
+    """Mirror of slam/loop_closing.py:8-39 with every stage filled in over the C ABI (the reference has a body only for the first one):
+        update(kf) = _loop_candidate_detection -> _similiarity_transformation -> _loop_fusion -> _essential_graph_optimization.
+    The map itself stays with the caller's graph; the manager is handed what the stages need:
+      dbow        bow.Dbow (mirror of slam/bow_db.py)
+      get_kf      frame id -> object with .des, .cloud_kp (the loop candidate's keyframe)
+      local_ids   kf -> frame ids of kf's local window (CovisibilityGraph.get_local_map), excluded from the candidates
+      map_points  kf -> (ids, feat u8[N][32], pt3d f64[N][3], n_obs int[N]) of the map points seen around kf (both ends of the loop)
+      pose_graph  () -> (frame ids, R f64[K][3][3], t f64[K][3], fixed bool[K], ei, ej, Zr, Zt, w): the essential graph as it stands
+    update returns None when no loop is accepted, else dict(candidate, R, t, n_inliers, fused = [(survivor id, loser id)], poses = (ids, R, t))."""
+
+    def __init__(self, ctx, dbow, get_kf, local_ids, map_points, pose_graph, min_score=0.05, loop_weight=25.0):
+        self.ctx, self.dbow, self.get_kf, self.local_ids, self.map_points, self.pose_graph = ctx, dbow, get_kf, local_ids, map_points, pose_graph
+        self.min_score, self.loop_weight = min_score, loop_weight
+
+    def update(self, kf):
+        import numpy as np
+        fid, score = loop_candidate_detection(self.dbow, kf, self.local_ids(kf), self.min_score)
+        if fid is None:
+            return None
+        cand = self.get_kf(fid)
+        R, t, n_inl = similarity_transformation(self.ctx, kf, cand)
+        if R is None:
+            return None
+        ids_a, feat_a, pt_a, nobs_a = self.map_points(kf)
+        ids_b, feat_b, pt_b, nobs_b = self.map_points(cand)
+        pa, pb, ka = loop_fusion(self.ctx, feat_a, pt_a, nobs_a, feat_b, pt_b, nobs_b, R, t)
+        fused = [((ids_a[a], ids_b[b]) if k else (ids_b[b], ids_a[a])) for a, b, k in zip(pa, pb, ka)]
+        ids, Rk, tk, fixed, ei, ej, Zr, Zt, w = self.pose_graph()
+        ids = list(ids)
+        # the loop edge: candidate -> current keyframe.  cloud_kf ~ R cloud_cand + t relates the two CAMERA frames, i.e. T_kf^-1 T_cand = (R, t)
+        ei = list(ei) + [ids.index(kf.id)]; ej = list(ej) + [ids.index(fid)]
+        Zr = np.concatenate([np.asarray(Zr, dtype=np.float64).reshape(-1, 3, 3), np.asarray(R)[None]], 0)
+        Zt = np.concatenate([np.asarray(Zt, dtype=np.float64).reshape(-1, 3), np.asarray(t)[None]], 0)
+        w = list(w) + [self.loop_weight]
+        Ro, to, log, kept, cg = essential_graph_optimization(self.ctx, Rk, tk, fixed, ei, ej, Zr, Zt, w)
+        return dict(candidate=fid, score=score, R=R, t=t, n_inliers=n_inl, fused=fused, poses=(ids, Ro, to), cost_log=log)
+
