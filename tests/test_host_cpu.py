@@ -189,9 +189,9 @@ def test_two_rank_gloo_sharded_matching_equals_single_process(tmp_path):
 
 
 def test_committed_bench_line_meets_the_contract():
-    """profiles/r03_bench.json is the JSON line bench.py printed on the MI355X; check the measurement contract's fields."""
+    """profiles/r04_bench.json is the JSON line bench.py printed on the MI355X; check the measurement contract's fields."""
     import json
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench.json")).read().strip().splitlines()[-1])
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                  ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
                  ("cpu_baseline", dict)):
@@ -214,6 +214,15 @@ def test_committed_bench_line_meets_the_contract():
     lb = d["local_ba"]["batched"]
     assert lb["live_windows"]["windows"] == 64 and lb["live_windows"]["speedup_vs_one_at_a_time"] > 10
     assert d["tracking"]["device_resident_chain"]["tracked_pairs"] > 900
+    # round 4: the issue-bound view of the dominant kernel, the counter blocks of the BA kernels, the second tracking stage, the device BoW entry
+    v = r["valu"]
+    assert 0.5 < v["frac"] < 1.0 and abs(v["frac"] - v["achieved"] / v["peak_wave_instr_per_s"]) < 1e-3 and v["peak_two_cycle_class_wave_instr_per_s"] > v["peak_wave_instr_per_s"]
+    sc = d["local_ba"]["solve_roofline"]["counters"]
+    assert sc["mfma_f64_flops"] == d["local_ba"]["solve_roofline"]["mfma_flops_per_solve"]          # counter flops = analytic flops of the dense factorisation
+    assert d["local_ba"]["schur_roofline"]["traffic_over_algorithmic"] > 1 and d["global_ba"]["schur_roofline"]["counters"]["hbm_frac_of_peak"] < 1
+    assert 0.05 < d["global_ba"]["solve_roofline"]["counters"]["mfma_frac_of_peak"] < 0.5
+    assert d["tracking"]["local_map_chain"]["tracked_frames"] > 900 and d["tracking"]["local_map_chain"]["candidates_per_frame"] > 2000
+    assert d["bow_query"]["device_resident_query"]["equals_host_query"] is True and d["bow_query"]["interleaved_add_query"]["last_query_found_the_added_entry"] is True
     assert abs(d["value"] - 1000 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-3
 
 
