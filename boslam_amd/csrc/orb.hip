@@ -1268,13 +1268,15 @@ __constant__ __attribute__((aligned(4))) signed char c_pattern[1024] = {
 //            (64 contiguous 24-B structs);
 //   phase C  wave per keypoint: steered BRIEF, lane l evaluates tests l, 64+l, 128+l, 192+l (its 16 pattern coordinates are
 //            converted to float once per wave and reused for all 16 keypoints); four ballots give the 32 descriptor bytes.
+#ifndef DS_KPW
 #define DS_KPW 16
+#endif
 #define DS_PR 37               // BRIEF window: the pattern's largest radius is 18.385, so a rotated, rounded coordinate is within +-18
 #define DS_PH 18
 #define DS_NL ((DS_PR * 10 + 63) / 64)   // staging loads per lane (6)
 #define DS_PW 10               // words per window row (37 bytes + up to 3 of alignment = 40 B)
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                  bh_orb_geom g, const uint32_t* __restrict__ ic_mask, float patch_size, int sel_cap, int max_kp,
+                                                  bh_orb_geom g, const uint32_t* __restrict__ ic_mask, float patch_size, int sel_cap, int max_kp, int nframes,
                                                   const uint32_t* __restrict__ sel_xy, const float* __restrict__ sel_resp,
                                                   const int* __restrict__ sel_cnt, bh_kp* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int* __restrict__ n_kp,
@@ -1285,13 +1287,16 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     __shared__ float s_a[64], s_b[64], s_resp[64], s_scale[BH_MAX_LEVELS];
     __shared__ uint32_t s_patch[4][2][DS_PR * DS_PW];            // per wave: the blurred 37 x 37 windows of two keypoints (rows of 10 words)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the level lookups stay scalar
-    const size_t f = blockIdx.y;
-    const int* cnt = sel_cnt + f * g.nlevels;
-    int tot = 0;
-    for (int l = 0; l < g.nlevels; l++) { tot += cnt[l]; if (tid == l) s_scale[l] = g.lv[l].scale; }
-    if (blockIdx.x == 0 && tid == 0) { n_kp[f] = min(tot, max_kp); if (tot > max_kp) atomicOr(status, BH_ST_KP_OVERFLOW); }
-    const int nk = min(tot, max_kp), kbase = blockIdx.x * 64 + wv * DS_KPW;
-    if (blockIdx.x * 64 >= nk) return;
+    // Which keypoints a workgroup takes.  Its 64 items are 4 CONSECUTIVE keypoints (one per wave) of each of 16 FRAMES (a wave's 16 steps),
+    // and the frames of one workgroup - and of every workgroup whose launch index is equal mod 8 - are f = x + 8 n: workgroups b and b + 8
+    // share an XCD and its 4 MiB L2 (observed placement - speed only, any placement is correct).  So at any moment the waves of an XCD work on
+    // the same few frames, whose pyramid / blurred levels (0.6 MB each) stay in that L2: a keypoint's window is 32 + 37 rows of one or two
+    // 128-B lines, neighbouring keypoints share most of them, and with 16 frames per XCD in flight at once (a wave per 16 keypoints of ONE
+    // frame, the layout until round 4) two thirds of the lines came from HBM a second and a third time (tools/vmem_rate.hip: a line from HBM
+    // costs a CU 13-16 cycles, from L2 3.4).
+    const int lin = blockIdx.x, xcd = lin & 7, nb4 = (max_kp + 3) >> 2, jb = lin >> 3, fc = jb / nb4, kq = (jb - fc * nb4) * 4;
+    const int fbase = xcd + 8 * DS_KPW * fc;                     // item i of a wave: frame fbase + 8 i, keypoint kq + wv
+    if (tid < g.nlevels) s_scale[tid] = g.lv[tid].scale;
     // ---- phase A: intensity-centroid sums.  Lane = (row parity, column u): step `it` visits row v = 2 it + (lane >> 5) - 15.  Which steps
     // fall inside the disc is a per-lane constant (ic_mask, built on the host from the reference's umax table), and with S = sum I,
     // T = sum it*I over a lane's in-disc pixels: m10 = u S, m01 = 2 T + ((lane >> 5) - 15) S (integers, exact).
@@ -1301,16 +1306,22 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     // keypoints are in flight together (a wave that walks its keypoints one dependent load chain at a time leaves the memory system
     // idle: the kernel was 4 % slower than one wave per keypoint with 40 % fewer instructions)
     uint32_t my_loc = 0xffffffffu; float my_resp = 0.f;
-    if (lane < DS_KPW && kbase + lane < nk) {
-        const int k = kbase + lane;
-        int level = 0, slot = 0, t2 = 0;
+    if (lane < DS_KPW && fbase + 8 * lane < nframes) {
+        const size_t f = fbase + 8 * lane;
+        const int* cnt = sel_cnt + f * g.nlevels;
+        const int k = kq + wv;
+        int level = -1, slot = 0, t2 = 0;
         for (int l = 0; l < g.nlevels; l++) { const int c = cnt[l]; if (k >= t2 && k < t2 + c) { level = l; slot = k - t2; } t2 += c; }
-        const size_t si = (f * g.nlevels + level) * (size_t)sel_cap + slot;
-        const uint32_t xy = sel_xy[si];
-        my_loc = ((uint32_t)level << 28) | ((xy >> 16) << 14) | (xy & 0xffffu);
-        my_resp = sel_resp[si];
+        if (kq == 0 && wv == 0) { n_kp[f] = min(t2, max_kp); if (t2 > max_kp) atomicOr(status, BH_ST_KP_OVERFLOW); }
+        if (level >= 0 && k < max_kp) {
+            const size_t si = (f * g.nlevels + level) * (size_t)sel_cap + slot;
+            const uint32_t xy = sel_xy[si];
+            my_loc = ((uint32_t)level << 28) | ((xy >> 16) << 14) | (xy & 0xffffu);
+            my_resp = sel_resp[si];
+        }
     }
     if (lane < DS_KPW) { s_loc[wv * DS_KPW + lane] = my_loc; s_resp[wv * DS_KPW + lane] = my_resp; }
+    if (!__syncthreads_or(my_loc != 0xffffffffu)) return;       // no keypoint 4 q .. 4 q + 3 in any of the 16 frames
 #pragma unroll
     for (int i0 = 0; i0 < DS_KPW; i0 += 4) {
         int I[4][16];
@@ -1320,7 +1331,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             loc[q] = (uint32_t)__builtin_amdgcn_readlane((int)my_loc, i0 + q);
             if (loc[q] == 0xffffffffu) continue;                 // wave-uniform
             const bh_level_geom L = g.lv[loc[q] >> 28];
-            const uint8_t* __restrict__ lvl = pyr + f * g.pyr_stride + L.off;           // wave-uniform base, 32-bit lane offsets
+            const uint8_t* __restrict__ lvl = pyr + (size_t)(fbase + 8 * (i0 + q)) * g.pyr_stride + L.off;           // wave-uniform base, 32-bit lane offsets
             const uint32_t o = (uint32_t)(((int)((loc[q] >> 14) & 0x3fffu) + vb) * L.pitch + (int)(loc[q] & 0x3fffu) + u);
 #pragma unroll
             for (int it = 0; it < 16; it++) I[q][it] = lvl[o + (uint32_t)(it * 2 * L.pitch)];      // unconditional (v <= 16, |u| <= 16: inside the level's 31-px border)
@@ -1337,7 +1348,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     }
     __syncthreads();
     // ---- phase B: one lane per keypoint
-    if (tid < 64 && s_loc[tid] != 0xffffffffu) {
+    if (tid < 4 * DS_KPW && s_loc[tid] != 0xffffffffu) {
         const uint32_t loc = s_loc[tid];
         const int level = loc >> 28, cx = loc & 0x3fffu, cy = (loc >> 14) & 0x3fffu;
         const float scale = s_scale[level];
@@ -1345,7 +1356,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         bh_kp kp;
         kp.x = (float)cx * scale; kp.y = (float)cy * scale;
         kp.size = patch_size * scale; kp.angle = angle_deg; kp.response = s_resp[tid]; kp.octave = level;
-        kps[f * max_kp + blockIdx.x * 64 + tid] = kp;
+        kps[(size_t)(fbase + 8 * (tid % DS_KPW)) * max_kp + kq + tid / DS_KPW] = kp;
         // the BRIEF centre is recomputed from the scaled float coordinates, as the reference does
         const float inv = 1.f / scale;
         const int bx = __float2int_rn(kp.x * inv), by = __float2int_rn(kp.y * inv);
@@ -1382,15 +1393,15 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int j = wv * DS_KPW + i0 + q;
-            have[q] = kbase + i0 + q < nk;
-            if (!have[q]) continue;
             const uint32_t loc = s_loc[j], bxy = s_bxy[j];
+            have[q] = loc != 0xffffffffu;                       // wave-uniform
+            if (!have[q]) continue;
             const int level = __builtin_amdgcn_readfirstlane((int)(loc >> 28));
             const bh_level_geom L = g.lv[level];
             pa[q] = s_a[j]; pb[q] = s_b[j];
             const int bx = (int)(bxy & 0xffffu) - DS_PH, by = (int)(bxy >> 16) - DS_PH;
             sh[q] = bx & 3;
-            const uint8_t* org = blur + f * g.pyr_stride + L.off + (size_t)by * L.pitch + (bx & ~3);
+            const uint8_t* org = blur + (size_t)(fbase + 8 * (i0 + q)) * g.pyr_stride + L.off + (size_t)by * L.pitch + (bx & ~3);
 #pragma unroll
             for (int m = 0; m < DS_NL; m++) wq[q][m] = *reinterpret_cast<const uint32_t*>(org + (uint32_t)((int)(stg[m] & 63u) * L.pitch + (int)((stg[m] >> 6) & 63u)));
         }
@@ -1417,7 +1428,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             }
             if (lane < 4) {
                 unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-                reinterpret_cast<unsigned long long*>(desc + (f * max_kp + kbase + i0 + q) * 32)[lane] = v;
+                reinterpret_cast<unsigned long long*>(desc + ((size_t)(fbase + 8 * (i0 + q)) * max_kp + kq + wv) * 32)[lane] = v;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1777,8 +1788,8 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
                   (const uint32_t*)ctx->tab.p + align_up(g.tab_len + 4 + g.ntiles + 64, 4));
         BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, clist, ccnt, g, sel_cap, (uint32_t*)Wk.sel_xy.p,
                   (float*)Wk.sel_resp.p, (int*)Wk.sel_cnt.p, (uint32_t*)ctx->status.p);
-        BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3((max_kp + 63) / 64, nb), dim3(256), st, pyr, blur, g, (const uint32_t*)ctx->tab.p + g.tab_len + 4 + g.ntiles,
-                  (float)params->patchSize, sel_cap, max_kp, (const uint32_t*)Wk.sel_xy.p, (const float*)Wk.sel_resp.p,
+        BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3(8 * ((max_kp + 3) / 4) * ((nb + 8 * DS_KPW - 1) / (8 * DS_KPW))), dim3(256), st, pyr, blur, g,
+                  (const uint32_t*)ctx->tab.p + g.tab_len + 4 + g.ntiles, (float)params->patchSize, sel_cap, max_kp, nb, (const uint32_t*)Wk.sel_xy.p, (const float*)Wk.sel_resp.p,
                   (const int*)Wk.sel_cnt.p, d_kps, d_desc, d_nkp, (uint32_t*)ctx->status.p);
         BH_HIP(ctx, hipGetLastError());
         if (mem == BH_MEM_HOST) {

@@ -3,7 +3,7 @@
 # Passes (default: all).  One counter group per pass (gfx950 slot limits); --pmc never together with the hip / hsa trace domains; the
 # program goes directly after "--".
 #   stats                      rocprofv3 --kernel-trace --stats of the front-end bench with ONE chunk pipeline (what bench.py's roofline pass times)
-#   sq1 sq2 fetch write grbm   PMC passes of the front end
+#   sq1 sq2 fetch write grbm   PMC passes of the front end;  ta1 tcp1 tcc1: texture-address / L1 / L2 counters (not in the default set);  list: rocprofv3 -L
 #   ba_local ba_global ba_batch            kernel stats of the local, the global and the batched local BA
 #   ba_mfma_{local,global,batch}           SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES GRBM-free
 #   ba_fetch_{local,global,batch} ba_write_{...}   FETCH_SIZE / WRITE_SIZE (separate passes; x2 rule for wide loads in tools/ba_pmc.py)
@@ -28,6 +28,10 @@ for p in $PASSES; do
     fetch) pmc fetch FETCH_SIZE $B $FE ;;
     write) pmc write WRITE_SIZE $B $FE ;;
     grbm)  pmc grbm GRBM_GUI_ACTIVE $B $FE ;;
+    ta1)   pmc ta1 "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" $B $FE ;;
+    tcp1)  pmc tcp1 "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" $B $FE ;;
+    tcc1)  pmc tcc1 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" $B $FE ;;
+    list)  rocprofv3 -L > $KEEP/counters.txt 2>&1 || true ;;
     ba_local)  kst ba_local python3 $T/ba_only.py ;;
     ba_global) kst ba_global python3 $T/ba_global.py ;;
     ba_batch)  kst ba_batch python3 $T/ba_batch.py 64 ;;
