@@ -1302,6 +1302,9 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     // T = sum it*I over a lane's in-disc pixels: m10 = u S, m01 = 2 T + ((lane >> 5) - 15) S (integers, exact).
     const int u = (lane & 31) - 15, vb = (lane >> 5) - 15;
     const uint32_t msk = ic_mask[lane];
+    uint32_t kc[16];                                             // per step: in the disc ? 1 | it << 16 : 0
+#pragma unroll
+    for (int it = 0; it < 16; it++) { kc[it] = (msk >> it) & 1u ? (1u | ((uint32_t)it << 16)) : 0u; asm volatile("" : "+v"(kc[it])); }      // (opaque: the compiler would split the multiply into and + shifts again)
     // lane i < 16 looks up keypoint i of this wave (level, position, response) - one round trip for all sixteen; the patch loads of FOUR
     // keypoints are in flight together (a wave that walks its keypoints one dependent load chain at a time leaves the memory system
     // idle: the kernel was 4 % slower than one wave per keypoint with 40 % fewer instructions)
@@ -1333,15 +1336,18 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             const bh_level_geom L = g.lv[loc[q] >> 28];
             const uint8_t* __restrict__ lvl = pyr + (size_t)(fbase + 8 * (i0 + q)) * g.pyr_stride + L.off;           // wave-uniform base, 32-bit lane offsets
             const uint32_t o = (uint32_t)(((int)((loc[q] >> 14) & 0x3fffu) + vb) * L.pitch + (int)(loc[q] & 0x3fffu) + u);
+            // buffer loads: the lane offset stays one VGPR, the row step rides in the scalar offset (16 address adds per keypoint saved)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(lvl), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-            for (int it = 0; it < 16; it++) I[q][it] = lvl[o + (uint32_t)(it * 2 * L.pitch)];      // unconditional (v <= 16, |u| <= 16: inside the level's 31-px border)
+            for (int it = 0; it < 16; it++) I[q][it] = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)o, it * 2 * L.pitch, 0);      // unconditional (v <= 16, |u| <= 16: inside the level's 31-px border)
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (loc[q] == 0xffffffffu) continue;
-            int S = 0, T = 0;
+            uint32_t X = 0;                                      // S (<= 16 x 255) | T (<= 120 x 255) << 16: one 24-bit multiply-add per pixel
 #pragma unroll
-            for (int it = 0; it < 16; it++) { const int v = (msk >> it) & 1u ? I[q][it] : 0; S += v; T += it * v; }
+            for (int it = 0; it < 16; it++) X = __umul24((uint32_t)I[q][it], kc[it]) + X;
+            const int S = (int)(X & 0xffffu), T = (int)(X >> 16);
             const int m10 = wave_sum_dpp(u * S), m01 = wave_sum_dpp(2 * T + vb * S);
             if (lane == 0) { s_m10[wv * DS_KPW + i0 + q] = m10; s_m01[wv * DS_KPW + i0 + q] = m01; }
         }
@@ -1422,8 +1428,9 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             for (int t = 0; t < 4; t++) {
                 const float x0 = qx0[t] * a - qy0[t] * b, y0 = qx0[t] * b + qy0[t] * a;
                 const float x1 = qx1[t] * a - qy1[t] * b, y1 = qx1[t] * b + qy1[t] * a;
-                const int t0 = center[__float2int_rn(y0) * (4 * DS_PW) + __float2int_rn(x0)];
-                const int t1 = center[__float2int_rn(y1) * (4 * DS_PW) + __float2int_rn(x1)];
+                // round-half-even of each coordinate as the reference's cvRound; row * 40 + column is exact in f32 (|.| < 800), one conversion
+                const int t0 = center[(int)__fmaf_rn(rintf(y0), (float)(4 * DS_PW), rintf(x0))];
+                const int t1 = center[(int)__fmaf_rn(rintf(y1), (float)(4 * DS_PW), rintf(x1))];
                 bits[t] = __ballot(t0 < t1);
             }
             if (lane < 4) {
