@@ -263,9 +263,13 @@ def run_global(ctx, n_kf=5000, n_pts=500000, iters=5, window=20, dist=None, devi
     if sms > 0:
         E, P = len(pr["ecam"]), len(pr["pts"])
         alg = E * 144 + P * 96 + n6 * (bw + 1) * 8
-        out["schur_roofline"] = {"bound": "hbm", "kernel": "k_ba_dinv + k_ba_schur_S<64> + k_ba_schur_b", "algorithmic_bytes": int(alg), "ms": sms,
+        # the global form: one workgroup per row of S with the row camera's blocks staged in LDS (k_ba_schur_row: S and b~ in one launch);
+        # BH_BA_SCHUR_ROW=0 keeps the wave-per-pair kernels of round 3
+        row = os.environ.get("BH_BA_SCHUR_ROW") != "0"
+        names = [("k_ba_dinv", 1), ("k_ba_schur_row", 1)] if row else [("k_ba_dinv", 1), ("k_ba_schur_S<64>", 1), ("k_ba_schur_b", 1)]
+        out["schur_roofline"] = {"bound": "hbm", "kernel": " + ".join(n for n, _ in names), "algorithmic_bytes": int(alg), "ms": sms,
                                  "achieved": round(alg / (sms * 1e-3) / 1e9, 1), "unit": "GB/s", "peak": 8000, "frac": round(alg / (sms * 1e-3) / 8e12, 5)}
-        cb = _counter_block(pm, [("k_ba_dinv", 1), ("k_ba_schur_S<64>", 1), ("k_ba_schur_b", 1)], sms) if pm else None
+        cb = _counter_block(pm, names, sms) if pm and all(n in pm for n, _ in names) else None
         if cb:
             out["schur_roofline"]["counters"] = cb
             out["schur_roofline"]["traffic_over_algorithmic"] = round(cb["hbm_bytes"] / alg, 2)

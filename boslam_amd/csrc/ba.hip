@@ -451,6 +451,10 @@ struct bh_ba {
     bh_buf Hpl, Hll, bl, Hpp, bp, pdiag, cdiag;
     bh_buf Dinv, db, S, bs, dxp, dxl, state, pairs, part, xch;
     bh_buf join, j_start;              // per camera pair: the (edge, edge) pairs that share a landmark (Schur complement's work list)
+    bh_buf row_start, join_slot;       // row form (k_ba_schur_row): first pair of every row; LDS slot of every join entry's first edge
+    int schur_row = 0;
+    bh_buf pair_rec, join_pt;          // wave-per-pair form only: (s1, s2, first, end) per pair in one 16-B record; landmark slot per join entry
+    long long join_len = 0;
     int chol_split = 0;                // two-way window solve: first block column of the separator (0 = one workgroup)
     int npairs = 0;
     int bw = 0;                        // scalar half-bandwidth of the reduced camera system (6*max|s1-s2| + 5)
@@ -677,13 +681,25 @@ __global__ __launch_bounds__(256) void k_ba_dinv(const double* __restrict__ Hll,
     for (long long i = (long long)((int)blockIdx.x - pblocks) * 256 + threadIdx.x; i < nS; i += step) Sm[i] = 0.0;
 }
 
+// The wave-per-pair form walks pairs -> j_start -> join -> e_pt -> Dinv: five dependent global loads before the first block arrives, for
+// ~84 join entries per pair (1.3 rounds of a wave) - the chain, not the bytes, set its 1.2 ms at config 5.  Built once per problem:
+// pair_rec[p] = (s1, s2, first, end) in one 16-B load, join_pt[t] = landmark slot of join entry t (read next to the entry, coalesced).
+__global__ void k_ba_schur_aux(const int2* __restrict__ pairs, const int* __restrict__ j_start, int npairs, const int2* __restrict__ join,
+                               const int* __restrict__ e_pt, long long M, int4* __restrict__ pair_rec, int* __restrict__ join_pt)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < npairs) pair_rec[i] = make_int4(pairs[i].x, pairs[i].y, j_start[i], j_start[i + 1]);
+    if (i < M) join_pt[i] = e_pt[join[i].x];
+}
+
 // ---- k_ba_schur_S: workgroup per camera pair (s1 <= s2): S[s1][s2] = [s1==s2](Hpp + lambda I) - sum_j Hpl_1j Dinv_j Hpl_2j'
 template <int NT>
 __device__ __forceinline__ void ba_schur_S_body(const int bid, const int ngrid, const int2* __restrict__ pairs, const int* __restrict__ j_start,
                                                     const int2* __restrict__ join, const int* __restrict__ e_pt,
                                                     const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                                                     const double* __restrict__ Hpp, const ba_state* __restrict__ St,
-                                                    int bw, int add_diag, double* __restrict__ Sm, int npairs)
+                                                    int bw, int add_diag, double* __restrict__ Sm, int npairs,
+                                                    const int4* __restrict__ pair_rec = nullptr, const int* __restrict__ join_pt = nullptr)
 {
     // NT = 256 for a few long lists (local BA), one wave per pair for many short ones (global BA).  join[j_start[p] .. j_start[p+1])
     // lists the (edge of s1, edge of s2) pairs that observe the same landmark, in landmark order: built once per problem
@@ -696,14 +712,15 @@ __device__ __forceinline__ void ba_schur_S_body(const int bid, const int ngrid, 
     const int chunk = (ngrid + 7) >> 3;
     const int pid = (bid & 7) * chunk + (bid >> 3);
     if (pid >= npairs) return;
-    const int s1 = pairs[pid].x, s2 = pairs[pid].y;
-    const int t0 = j_start[pid], t1 = j_start[pid + 1];
+    int s1, s2, t0, t1;
+    if (NT == 64 && pair_rec) { const int4 pr = pair_rec[pid]; s1 = pr.x; s2 = pr.y; t0 = pr.z; t1 = pr.w; }
+    else { s1 = pairs[pid].x; s2 = pairs[pid].y; t0 = j_start[pid]; t1 = j_start[pid + 1]; }
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0;
     for (int t = t0 + tid; t < t1; t += NT) {
         const int2 ee = join[t];
-        const int e1 = ee.x, e2 = ee.y, j = e_pt[e1];
+        const int e1 = ee.x, e2 = ee.y, j = (NT == 64 && join_pt) ? join_pt[t] : e_pt[e1];
         // the 144-B blocks are 16-B aligned (hipMalloc base, 18 doubles each): nine 16-B loads per block instead of eighteen 8-B ones -
         // every lane reads a different block, so the load count is what the texture path is billed for
         double B1[18], B2[18];
@@ -776,6 +793,161 @@ __device__ __forceinline__ void ba_schur_b_body(const int s, const int* __restri
     if (tid < 6) bs[6 * s + tid] = (use_bp ? bp[6 * s + tid] : 0.0) - acc[tid];
 }
 
+// ---- k_ba_schur_row: the global-BA form of S and b~, one workgroup per free camera s1 (row of the block-banded S).
+// What bounds the wave-per-pair kernel at config 5 (1.1 ms) is cache lines, not bytes or flops: every join entry gathers three
+// scattered blocks - Hpl[e1], Hpl[e2] (144 B: one or two 128-B lines each) and Dinv[j] - 4.2 lines per entry, 17.3 M entries, and the
+// e2 blocks are met again only ~40 rows (15 MB of gathers) later, i.e. from HBM (tools/vmem_rate.hip: a line costs a CU 3.4 cycles from
+// L2, 13-16 from HBM).  Here the ~784 edges of camera s1 are staged ONCE per row as BD_e = Hpl_e Dinv_pt(e) in LDS (144 B x SR_CAP slots),
+// so an entry of the row's 40 off-diagonal pairs gathers only Hpl[e2] (1.6 lines) and reads BD from LDS by its slot (join_slot, built
+// once per problem); b~ of the row needs the same blocks and rides along (k_ba_schur_b re-read all of Hpl: 0.33 ms).
+//   staging       thread per edge of s1: BD -> LDS, b~ += Hpl_e db_pt(e)
+//   diagonal pair all 512 threads stride its join list (duplicate observations of a landmark by one camera give e1 != e2 entries)
+//   other pairs   a wave per pair, lanes stride the pair's join list, reduce-scatter on v_permlane*_swap + DPP, lanes 0/16/32/48 store
+// All sums in fixed order (results do not depend on timing); the order differs from k_ba_schur_S's, the values agree to rounding.
+#define SR_T 512
+#define SR_CAP 1024
+__device__ __forceinline__ void sr_load18(const double* __restrict__ p, double* B)
+{
+    const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { const double2 u = q[i]; B[2 * i] = u.x; B[2 * i + 1] = u.y; }
+}
+__device__ __forceinline__ void sr_bd(const double* B1, const double* Di, double* BD)
+{
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int bb = 0; bb < 3; bb++) BD[3 * a + bb] = B1[3 * a] * Di[bb] + B1[3 * a + 1] * Di[3 + bb] + B1[3 * a + 2] * Di[6 + bb];
+}
+__global__ __launch_bounds__(SR_T) void k_ba_schur_row(const int* __restrict__ row_start, const int4* __restrict__ pair_rec, const int2* __restrict__ join,
+                                                       const int* __restrict__ join_slot, const int* __restrict__ c_start, const int* __restrict__ c_edges,
+                                                       const int* __restrict__ e_pt, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
+                                                       const double* __restrict__ db, const double* __restrict__ Hpp, const double* __restrict__ bp,
+                                                       const ba_state* __restrict__ St, int bw, int add_diag, int Cf, double* __restrict__ Sm, double* __restrict__ bs)
+{
+    extern __shared__ double s_bd[];                             // [SR_CAP][18]
+    __shared__ double s_red[42 * (SR_T / 64)];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // contiguous eighths of the rows per XCD (workgroups b and b + 8 share one): the e2 blocks of neighbouring rows overlap
+    const int chunk = ((int)gridDim.x + 7) >> 3;
+    const int s1 = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+    if (s1 >= Cf) return;
+    const int u0 = c_start[s1], n1 = c_start[s1 + 1] - u0;
+    const int first = row_start[s1], last = row_start[s1 + 1];
+    double acc[42];
+#pragma unroll
+    for (int i = 0; i < 42; i++) acc[i] = 0;
+    for (int u = tid; u < n1; u += SR_T) {
+        const int e = c_edges[u0 + u], j = e_pt[e];
+        double B1[18], BD[18];
+        sr_load18(Hpl + 18 * (size_t)e, B1);
+        const double* Di = Dinv + 9 * (size_t)j; const double* d = db + 3 * (size_t)j;
+        sr_bd(B1, Di, BD);
+        if (u < SR_CAP) {
+            double2* o = reinterpret_cast<double2*>(s_bd + 18 * (size_t)u);
+#pragma unroll
+            for (int i = 0; i < 9; i++) o[i] = make_double2(BD[2 * i], BD[2 * i + 1]);
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[36 + a] += B1[3 * a] * d[0] + B1[3 * a + 1] * d[1] + B1[3 * a + 2] * d[2];
+    }
+    __syncthreads();
+    // one join entry: acc += BD(e1) Hpl(e2)'
+    auto entry = [&](int slot, int2 ee, double* a36) {
+        double BD[18], B2[18];
+        if (slot < SR_CAP) {
+            const double2* q = reinterpret_cast<const double2*>(s_bd + 18 * (size_t)slot);
+#pragma unroll
+            for (int i = 0; i < 9; i++) { const double2 u = q[i]; BD[2 * i] = u.x; BD[2 * i + 1] = u.y; }
+        } else {                                                 // a camera with more than SR_CAP observations: the tail comes from global memory
+            double B1[18];
+            sr_load18(Hpl + 18 * (size_t)ee.x, B1);
+            sr_bd(B1, Dinv + 9 * (size_t)e_pt[ee.x], BD);
+        }
+        sr_load18(Hpl + 18 * (size_t)ee.y, B2);
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int bb = 0; bb < 6; bb++) a36[6 * a + bb] += BD[3 * a] * B2[3 * bb] + BD[3 * a + 1] * B2[3 * bb + 1] + BD[3 * a + 2] * B2[3 * bb + 2];
+    };
+    // the diagonal pair (the first of the row: pairs are sorted and every camera has its diagonal block)
+    int p0 = first;
+    if (first < last) {
+        const int4 pr = pair_rec[first];
+        if (pr.y == s1) { p0 = first + 1; for (int t = pr.z + tid; t < pr.w; t += SR_T) entry(join_slot[t], join[t], acc); }
+    }
+    d_wave_sum_rs<42>(acc);
+    d_wave_sum_rs_store<42>(acc, s_red + wv * 42);
+    __syncthreads();
+    if (tid < 42) {
+        double v = 0;
+#pragma unroll
+        for (int w = 0; w < SR_T / 64; w++) v += s_red[w * 42 + tid];
+        v = -v;
+        if (tid < 36) {
+            const int a = tid / 6, bb = tid - a * 6;
+            if (add_diag) { v += Hpp[36 * (size_t)s1 + tid]; if (a == bb) v += St->lambda; }
+            const int row = 6 * s1 + bb, col = 6 * s1 + a;       // lower band storage: element (row, col), row >= col, at Sm[row * LD + (col - row + bw)]
+            if (col <= row) Sm[(size_t)row * (bw + 1) + (col - row + bw)] = v;
+        } else bs[6 * s1 + (tid - 36)] = (add_diag ? bp[6 * s1 + (tid - 36)] : 0.0) + v;
+    }
+    // the other pairs of the row: a wave each.  The indices of a round (pair record, LDS slot, second edge) are fetched one round ahead:
+    // what a round then waits for is the gather of Hpl[e2] alone.
+    int p = p0 + wv;
+    int4 pr = p < last ? pair_rec[p] : make_int4(0, 0, 0, 0);
+    int t = pr.z + lane;
+    int slot = 0; int2 ee = make_int2(0, 0);
+    if (p < last && t < pr.w) { slot = join_slot[t]; ee = join[t]; }
+    while (p < last) {
+        double a36[36];
+#pragma unroll
+        for (int i = 0; i < 36; i++) a36[i] = 0;
+        const int4 cur = pr;
+        const int pn = p + SR_T / 64;
+        int4 nx = make_int4(0, 0, 0, 0);
+        if (pn < last) nx = pair_rec[pn];
+        for (;;) {
+            const bool live = t < cur.w;
+            const int cslot = slot; const int2 cee = ee;
+            const int tn = t + 64;
+            const bool more = __any(tn < cur.w);                 // wave-uniform: another round of this pair
+            if (more) { if (tn < cur.w) { slot = join_slot[tn]; ee = join[tn]; } }
+            else if (pn < last) { const int t2 = nx.z + lane; if (t2 < nx.w) { slot = join_slot[t2]; ee = join[t2]; } }
+            if (live) entry(cslot, cee, a36);
+            if (!more) break;
+            t = tn;
+        }
+        d_wave_sum_rs<36>(a36);
+        if ((lane & 15) == 0) {                                  // (the layout d_wave_sum_rs leaves: see d_wave_sum_rs_store)
+            const int q = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int idx = i + 9 * (q & 1) + 18 * (q >> 1);
+                const int a = idx / 6, bb = idx - a * 6;
+                const int row = 6 * cur.y + bb, col = 6 * cur.x + a;
+                if (col <= row) Sm[(size_t)row * (bw + 1) + (col - row + bw)] = -a36[i];
+            }
+        }
+        p = pn; pr = nx; t = nx.z + lane;
+    }
+}
+
+// join_slot[t] = position of join entry t's first edge inside its camera's c_edges list (the LDS slot k_ba_schur_row stages it in);
+// row_start[s] = first pair of row s in the (s1, s2)-sorted pair list.  Once per problem.
+__global__ void k_ba_schur_rank(const int* __restrict__ c_start, const int* __restrict__ c_edges, int Cf, int* __restrict__ e_rank)
+{
+    const int s = blockIdx.x;
+    for (int u = c_start[s] + threadIdx.x; u < c_start[s + 1]; u += 256) e_rank[c_edges[u]] = u - c_start[s];
+}
+__global__ void k_ba_schur_rows(const int2* __restrict__ pairs, int npairs, int Cf, const int2* __restrict__ join, const int* __restrict__ e_rank, long long M,
+                                int* __restrict__ row_start, int* __restrict__ join_slot)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < npairs) { const int s = pairs[i].x; if (i == 0 || pairs[i - 1].x != s) row_start[s] = (int)i; }
+    if (i == 0) row_start[Cf] = npairs;
+    if (i < M) join_slot[i] = e_rank[join[i].x];
+}
+
 // The kernels: S alone (one wave per pair: the global-BA form), b~ alone, and both in one launch for the 256-thread form (a local
 // window: 48 workgroups of b~ next to 1 176 of S instead of after them).
 template <int NT>
@@ -783,9 +955,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 8))) void
                                                     const int2* __restrict__ join, const int* __restrict__ e_pt,
                                                     const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                                                     const double* __restrict__ Hpp, const ba_state* __restrict__ St,
-                                                    int bw, int add_diag, double* __restrict__ Sm, int npairs)
+                                                    int bw, int add_diag, double* __restrict__ Sm, int npairs,
+                                                    const int4* __restrict__ pair_rec, const int* __restrict__ join_pt)
 {
-    ba_schur_S_body<NT>(blockIdx.x, gridDim.x, pairs, j_start, join, e_pt, Hpl, Dinv, Hpp, St, bw, add_diag, Sm, npairs);
+    ba_schur_S_body<NT>(blockIdx.x, gridDim.x, pairs, j_start, join, e_pt, Hpl, Dinv, Hpp, St, bw, add_diag, Sm, npairs, pair_rec, join_pt);
 }
 __global__ __launch_bounds__(256) void k_ba_schur_b(const int* __restrict__ c_start, const int* __restrict__ c_edges,
                                                     const int* __restrict__ e_pt, const double* __restrict__ Hpl,
@@ -2604,7 +2777,7 @@ extern "C" void bh_ba_destroy(bh_ba* ba)
     bh_buf* all[] = { &ba->cams[0], &ba->cams[1], &ba->pts[0], &ba->pts[1], &ba->e_cam, &ba->e_pt, &ba->e_meas, &ba->cslot,
                       &ba->p_start, &ba->p_edges, &ba->c_start, &ba->c_edges, &ba->err[0], &ba->err[1], &ba->chi_e[0],
                       &ba->chi_e[1], &ba->Hpl, &ba->Hll, &ba->bl, &ba->Hpp, &ba->bp, &ba->pdiag, &ba->cdiag, &ba->Dinv,
-                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch, &ba->join, &ba->j_start };
+                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch, &ba->join, &ba->j_start, &ba->pair_rec, &ba->join_pt, &ba->row_start, &ba->join_slot };
     for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     if (ba->h_state) (void)hipHostFree(ba->h_state);
     delete ba->bcr;
@@ -3855,6 +4028,27 @@ static int ba_set_problem_rest(bh_ba* ba, int C, const double* R, const double* 
         if (const char* ev = getenv("BH_BA_SCHUR_WAVE_AVG")) avg_max = atoi(ev);
         if (Cf > 0 && ba->npairs > 0 && !ba->ar && bo.M / ba->npairs <= avg_max && avg_max > 0) ba->schur_wave = 1;
     }
+    ba->join_len = bo.M;
+    if (ba->schur_wave && ba->npairs > 0) {
+        BH_TRY(bh_reserve(ctx, &ba->pair_rec, sizeof(int4) * (size_t)ba->npairs)); BH_TRY(bh_reserve(ctx, &ba->join_pt, sizeof(int) * (size_t)(bo.M + 1)));
+        const long long n = std::max<long long>(ba->npairs, bo.M);
+        hipLaunchKernelGGL(k_ba_schur_aux, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, ba->npairs,
+                           (const int2*)ba->join.p, (const int*)ba->e_pt.p, (long long)bo.M, (int4*)ba->pair_rec.p, (int*)ba->join_pt.p);
+        BH_HIP(ctx, hipGetLastError());
+        // the row form: every free camera has its diagonal pair, so every row exists; BH_BA_SCHUR_ROW=0 keeps the wave-per-pair kernels
+        const char* ev = getenv("BH_BA_SCHUR_ROW");
+        ba->schur_row = (ev && atoi(ev) == 0) ? 0 : 1;
+        if (ba->schur_row) {
+            BH_TRY(bh_reserve(ctx, &ba->row_start, sizeof(int) * ((size_t)Cf + 2))); BH_TRY(bh_reserve(ctx, &ba->join_slot, sizeof(int) * (size_t)(bo.M + 1)));
+            BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(int) * (size_t)(E > 0 ? E : 1)));
+            int* e_rank = (int*)ctx->st_a.p;
+            hipLaunchKernelGGL(k_ba_schur_rank, dim3(Cf), dim3(256), 0, ctx->stream, (const int*)ba->c_start.p, (const int*)ba->c_edges.p, Cf, e_rank);
+            hipLaunchKernelGGL(k_ba_schur_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const int2*)ba->pairs.p, ba->npairs, Cf, (const int2*)ba->join.p,
+                               (const int*)e_rank, (long long)bo.M, (int*)ba->row_start.p, (int*)ba->join_slot.p);
+            BH_HIP(ctx, hipGetLastError());
+            (void)hipFuncSetAttribute((const void*)k_ba_schur_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 18 * SR_CAP));
+        }
+    } else ba->schur_row = 0;
     BH_TRY(bh_reserve(ctx, &ba->state, sizeof(ba_state)));
     if (ba->ar) {                                          // the band must be the same everywhere: max over ranks
         double v = (double)bwb;
@@ -4050,16 +4244,25 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                 const bool dsolve = dist && ba->dsol && ba->dsol->active;
                 const size_t s_rows = dsolve ? 256 * (size_t)ba->dsol->seg * ba->world : (size_t)n6;       // sharded solve: equal row chunks per rank
                 if (!zero_in_dinv) BH_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double) * s_rows * (ba->bw + 1), st));     // blocks without a common point stay zero
-                if (ba->schur_wave)
+                if (ba->schur_wave && ba->schur_row)
+                {
+                    bh_time_begin(ctx, BH_K_BA_SCHUR);
+                    hipLaunchKernelGGL(k_ba_schur_row, dim3((Cf + 7) / 8 * 8), dim3(SR_T), sizeof(double) * 18 * SR_CAP, st, (const int*)ba->row_start.p, (const int4*)ba->pair_rec.p,
+                                       (const int2*)ba->join.p, (const int*)ba->join_slot.p, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)Dinv, (const double*)db,
+                                       (const double*)Hpp, (const double*)bp, (const ba_state*)state, ba->bw, dist ? lead : 1, Cf, S, bs);
+                    bh_time_end(ctx);
+                }
+                else if (ba->schur_wave)
                     BH_LAUNCH(ctx, BH_K_BA_SCHUR, (k_ba_schur_S<64>), dim3((ba->npairs + 7) / 8 * 8), dim3(64), st, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
-                              (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S, ba->npairs);
+                              (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S, ba->npairs,
+                              (const int4*)ba->pair_rec.p, (const int*)ba->join_pt.p);
                 else {
                     const int ngS = (ba->npairs + 7) / 8 * 8;
                     BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_Sb, dim3(ngS + Cf), dim3(256), st, ngS, (const int2*)ba->pairs.p, (const int*)ba->j_start.p, (const int2*)ba->join.p, e_pt,
                               (const double*)Hpl, (const double*)Dinv, (const double*)Hpp, (const ba_state*)state, ba->bw, dist ? lead : 1, S, ba->npairs,
                               c_start, c_edges, (const double*)db, (const double*)bp, dist ? lead : 1, bs);
                 }
-                if (ba->schur_wave)
+                if (ba->schur_wave && !ba->schur_row)
                     BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_ba_schur_b, dim3(Cf), dim3(256), st, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)db,
                               (const double*)bp, dist ? lead : 1, bs);
                 if (dsolve) { BH_TRY(ba_allreduce(ba, S, (long long)s_rows * (ba->bw + 1), 2)); BH_TRY(ba_allreduce(ba, bs, n6, 0)); }      // every rank keeps the sum of ITS rows

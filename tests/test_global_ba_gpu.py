@@ -131,3 +131,41 @@ def test_segment_wise_solve_matches_single_gpu(ctx, tmp_path, world, window):
         assert float(old[0]["det_allreduce_bytes"]) >= old_model["total"] * trials                   # S + b~ per trial (+ Hpp, bp, scalars per iteration)
         # (bytes: at this size - S is 2.6 MB, an end-block share 2.1 MB - the old scheme moves less; at configs[4], S = 59 MB on 8 ranks, it
         #  is 59 MB against 7.4 + 14.7 + 0.2 MB per rank and trial: DESIGN.md section 7)
+
+
+def _with_env(name, value, fn):
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return fn()
+    finally:
+        if old is None: del os.environ[name]
+        else: os.environ[name] = old
+
+
+def test_row_form_of_the_schur_complement_equals_the_wave_per_pair_form(ctx):
+    """The global-BA form of S and b~ (k_ba_schur_row: camera s1's blocks staged once per row in LDS) against the wave-per-pair kernels
+    (BH_BA_SCHUR_ROW=0, read at set_problem): same LM decisions, costs and damping to 1e-9, poses and landmarks to 1e-9.  The problem is large enough
+    for the one-wave-per-pair switch (>= 4096 camera pairs), and one keyframe sees 1 300 extra landmarks: more than the 1 024 blocks a
+    row keeps in LDS, so the tail of that row takes the global-memory path."""
+    pr = synth.ba_problem_sequence(n_kf=700, n_pts=20000, window=6, seed=5)
+    rng = np.random.default_rng(1)
+    hub = 350
+    extra = 1300
+    P0 = len(pr["pts"])
+    local = np.stack([rng.uniform(-1, 1, extra), rng.uniform(-0.7, 0.7, extra), rng.uniform(2.5, 5.0, extra)], axis=1)
+    Xc = pr["tgt"][hub] + local @ pr["Rgt"][hub].T
+    ecam, ept, meas = [pr["ecam"]], [pr["ept"]], [pr["meas"]]
+    fx, fy, cx, cy = pr["K"][:4]
+    for c in (hub - 1, hub, hub + 1):
+        pc = (Xc - pr["tgt"][c]) @ pr["Rgt"][c]                                   # R'(X - t)
+        uv = np.stack([fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy], axis=1)
+        ecam.append(np.full(extra, c, np.int32)); ept.append(np.arange(P0, P0 + extra, dtype=np.int32)); meas.append(uv + rng.normal(0, 1.0, uv.shape))
+    pr = dict(pr, pts=np.concatenate([pr["pts"], Xc + rng.normal(0, 0.02, Xc.shape)]), ecam=np.concatenate(ecam), ept=np.concatenate(ept), meas=np.concatenate(meas))
+    assert np.bincount(pr["ecam"])[hub] > 1024
+    (Rr, tr), pr_pts, lgr = _with_env("BH_BA_SCHUR_ROW", "1", lambda: _single(ctx, pr, 4))
+    (Rw, tw), pw_pts, lgw = _with_env("BH_BA_SCHUR_ROW", "0", lambda: _single(ctx, pr, 4))
+    assert len(lgr) == len(lgw) == 4
+    assert np.array_equal(lgr[:, 2:], lgw[:, 2:]) and np.allclose(lgr[:, :2], lgw[:, :2], rtol=1e-9, atol=0)
+    assert lgr[-1, 0] < 0.8 * lgr[0, 0]                                           # and it optimises
+    assert np.abs(Rr - Rw).max() < 1e-9 and np.abs(tr - tw).max() < 1e-9 and np.abs(pr_pts - pw_pts).max() < 1e-9
