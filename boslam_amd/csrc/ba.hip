@@ -451,6 +451,7 @@ struct bh_ba {
     bh_buf Hpl, Hll, bl, Hpp, bp, pdiag, cdiag;
     bh_buf Dinv, db, S, bs, dxp, dxl, state, pairs, part, xch;
     bh_buf join, j_start;              // per camera pair: the (edge, edge) pairs that share a landmark (Schur complement's work list)
+    bh_buf c_pt;                       // row form: landmark slot of every entry of c_edges
     bh_buf row_start, join_slot;       // row form (k_ba_schur_row): first pair of every row; LDS slot of every join entry's first edge
     int schur_row = 0;
     bh_buf pair_rec, join_pt;          // wave-per-pair form only: (s1, s2, first, end) per pair in one 16-B record; landmark slot per join entry
@@ -821,7 +822,7 @@ __device__ __forceinline__ void sr_bd(const double* B1, const double* Di, double
 }
 __global__ __launch_bounds__(SR_T) void k_ba_schur_row(const int* __restrict__ row_start, const int4* __restrict__ pair_rec, const int2* __restrict__ join,
                                                        const int* __restrict__ join_slot, const int* __restrict__ c_start, const int* __restrict__ c_edges,
-                                                       const int* __restrict__ e_pt, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
+                                                       const int* __restrict__ c_pt, const int* __restrict__ e_pt, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                                                        const double* __restrict__ db, const double* __restrict__ Hpp, const double* __restrict__ bp,
                                                        const ba_state* __restrict__ St, int bw, int add_diag, int Cf, double* __restrict__ Sm, double* __restrict__ bs)
 {
@@ -834,11 +835,17 @@ __global__ __launch_bounds__(SR_T) void k_ba_schur_row(const int* __restrict__ r
     if (s1 >= Cf) return;
     const int u0 = c_start[s1], n1 = c_start[s1 + 1] - u0;
     const int first = row_start[s1], last = row_start[s1 + 1];
+    // no camera observes a landmark twice (row_start[Cf + 1], found once per problem): the diagonal pair's join list is (e, e) for every edge
+    // of s1, and its block is summed while the blocks are staged - one phase of dependent gathers less per row
+    const bool simple_diag = row_start[Cf + 1] == 0;
+    // (the records of this wave's pairs are needed two barriers from here: asked for now)
+    const int p_first = first + 1 + wv;
+    int4 pr_first = p_first < last ? pair_rec[p_first] : make_int4(0, 0, 0, 0);
     double acc[42];
 #pragma unroll
     for (int i = 0; i < 42; i++) acc[i] = 0;
     for (int u = tid; u < n1; u += SR_T) {
-        const int e = c_edges[u0 + u], j = e_pt[e];
+        const int e = c_edges[u0 + u], j = c_pt[u0 + u];
         double B1[18], BD[18];
         sr_load18(Hpl + 18 * (size_t)e, B1);
         const double* Di = Dinv + 9 * (size_t)j; const double* d = db + 3 * (size_t)j;
@@ -850,6 +857,12 @@ __global__ __launch_bounds__(SR_T) void k_ba_schur_row(const int* __restrict__ r
         }
 #pragma unroll
         for (int a = 0; a < 6; a++) acc[36 + a] += B1[3 * a] * d[0] + B1[3 * a + 1] * d[1] + B1[3 * a + 2] * d[2];
+        if (simple_diag) {
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int bb = 0; bb < 6; bb++) acc[6 * a + bb] += BD[3 * a] * B1[3 * bb] + BD[3 * a + 1] * B1[3 * bb + 1] + BD[3 * a + 2] * B1[3 * bb + 2];
+        }
     }
     __syncthreads();
     // one join entry: acc += BD(e1) Hpl(e2)'
@@ -874,7 +887,7 @@ __global__ __launch_bounds__(SR_T) void k_ba_schur_row(const int* __restrict__ r
     int p0 = first;
     if (first < last) {
         const int4 pr = pair_rec[first];
-        if (pr.y == s1) { p0 = first + 1; for (int t = pr.z + tid; t < pr.w; t += SR_T) entry(join_slot[t], join[t], acc); }
+        if (pr.y == s1) { p0 = first + 1; if (!simple_diag) for (int t = pr.z + tid; t < pr.w; t += SR_T) entry(join_slot[t], join[t], acc); }
     }
     d_wave_sum_rs<42>(acc);
     d_wave_sum_rs_store<42>(acc, s_red + wv * 42);
@@ -894,7 +907,7 @@ __global__ __launch_bounds__(SR_T) void k_ba_schur_row(const int* __restrict__ r
     // the other pairs of the row: a wave each.  The indices of a round (pair record, LDS slot, second edge) are fetched one round ahead:
     // what a round then waits for is the gather of Hpl[e2] alone.
     int p = p0 + wv;
-    int4 pr = p < last ? pair_rec[p] : make_int4(0, 0, 0, 0);
+    int4 pr = p == p_first ? pr_first : (p < last ? pair_rec[p] : make_int4(0, 0, 0, 0));
     int t = pr.z + lane;
     int slot = 0; int2 ee = make_int2(0, 0);
     if (p < last && t < pr.w) { slot = join_slot[t]; ee = join[t]; }
@@ -934,18 +947,23 @@ __global__ __launch_bounds__(SR_T) void k_ba_schur_row(const int* __restrict__ r
 
 // join_slot[t] = position of join entry t's first edge inside its camera's c_edges list (the LDS slot k_ba_schur_row stages it in);
 // row_start[s] = first pair of row s in the (s1, s2)-sorted pair list.  Once per problem.
-__global__ void k_ba_schur_rank(const int* __restrict__ c_start, const int* __restrict__ c_edges, int Cf, int* __restrict__ e_rank)
+__global__ void k_ba_schur_rank(const int* __restrict__ c_start, const int* __restrict__ c_edges, const int* __restrict__ e_pt, int Cf, int* __restrict__ e_rank,
+                                int* __restrict__ c_pt)
 {
     const int s = blockIdx.x;
-    for (int u = c_start[s] + threadIdx.x; u < c_start[s + 1]; u += 256) e_rank[c_edges[u]] = u - c_start[s];
+    for (int u = c_start[s] + threadIdx.x; u < c_start[s + 1]; u += 256) { const int e = c_edges[u]; e_rank[e] = u - c_start[s]; c_pt[u] = e_pt[e]; }
 }
 __global__ void k_ba_schur_rows(const int2* __restrict__ pairs, int npairs, int Cf, const int2* __restrict__ join, const int* __restrict__ e_rank, long long M,
-                                int* __restrict__ row_start, int* __restrict__ join_slot)
+                                const int* __restrict__ e_cam, int* __restrict__ row_start, int* __restrict__ join_slot)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < npairs) { const int s = pairs[i].x; if (i == 0 || pairs[i - 1].x != s) row_start[s] = (int)i; }
     if (i == 0) row_start[Cf] = npairs;
-    if (i < M) join_slot[i] = e_rank[join[i].x];
+    if (i < M) {
+        const int2 ee = join[i];
+        join_slot[i] = e_rank[ee.x];
+        if (ee.x != ee.y && e_cam[ee.x] == e_cam[ee.y]) row_start[Cf + 1] = 1;      // one camera, one landmark, two observations (every writer stores 1)
+    }
 }
 
 // The kernels: S alone (one wave per pair: the global-BA form), b~ alone, and both in one launch for the 256-thread form (a local
@@ -2777,7 +2795,7 @@ extern "C" void bh_ba_destroy(bh_ba* ba)
     bh_buf* all[] = { &ba->cams[0], &ba->cams[1], &ba->pts[0], &ba->pts[1], &ba->e_cam, &ba->e_pt, &ba->e_meas, &ba->cslot,
                       &ba->p_start, &ba->p_edges, &ba->c_start, &ba->c_edges, &ba->err[0], &ba->err[1], &ba->chi_e[0],
                       &ba->chi_e[1], &ba->Hpl, &ba->Hll, &ba->bl, &ba->Hpp, &ba->bp, &ba->pdiag, &ba->cdiag, &ba->Dinv,
-                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch, &ba->join, &ba->j_start, &ba->pair_rec, &ba->join_pt, &ba->row_start, &ba->join_slot };
+                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch, &ba->join, &ba->j_start, &ba->pair_rec, &ba->join_pt, &ba->row_start, &ba->join_slot, &ba->c_pt };
     for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     if (ba->h_state) (void)hipHostFree(ba->h_state);
     delete ba->bcr;
@@ -4040,11 +4058,14 @@ static int ba_set_problem_rest(bh_ba* ba, int C, const double* R, const double* 
         ba->schur_row = (ev && atoi(ev) == 0) ? 0 : 1;
         if (ba->schur_row) {
             BH_TRY(bh_reserve(ctx, &ba->row_start, sizeof(int) * ((size_t)Cf + 2))); BH_TRY(bh_reserve(ctx, &ba->join_slot, sizeof(int) * (size_t)(bo.M + 1)));
+            BH_TRY(bh_reserve(ctx, &ba->c_pt, sizeof(int) * (size_t)(E > 0 ? E : 1)));
             BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(int) * (size_t)(E > 0 ? E : 1)));
             int* e_rank = (int*)ctx->st_a.p;
-            hipLaunchKernelGGL(k_ba_schur_rank, dim3(Cf), dim3(256), 0, ctx->stream, (const int*)ba->c_start.p, (const int*)ba->c_edges.p, Cf, e_rank);
+            BH_HIP(ctx, hipMemsetAsync((int*)ba->row_start.p + Cf + 1, 0, sizeof(int), ctx->stream));
+            hipLaunchKernelGGL(k_ba_schur_rank, dim3(Cf), dim3(256), 0, ctx->stream, (const int*)ba->c_start.p, (const int*)ba->c_edges.p, (const int*)ba->e_pt.p, Cf, e_rank,
+                               (int*)ba->c_pt.p);
             hipLaunchKernelGGL(k_ba_schur_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const int2*)ba->pairs.p, ba->npairs, Cf, (const int2*)ba->join.p,
-                               (const int*)e_rank, (long long)bo.M, (int*)ba->row_start.p, (int*)ba->join_slot.p);
+                               (const int*)e_rank, (long long)bo.M, (const int*)ba->e_cam.p, (int*)ba->row_start.p, (int*)ba->join_slot.p);
             BH_HIP(ctx, hipGetLastError());
             (void)hipFuncSetAttribute((const void*)k_ba_schur_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 18 * SR_CAP));
         }
@@ -4248,7 +4269,7 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                 {
                     bh_time_begin(ctx, BH_K_BA_SCHUR);
                     hipLaunchKernelGGL(k_ba_schur_row, dim3((Cf + 7) / 8 * 8), dim3(SR_T), sizeof(double) * 18 * SR_CAP, st, (const int*)ba->row_start.p, (const int4*)ba->pair_rec.p,
-                                       (const int2*)ba->join.p, (const int*)ba->join_slot.p, c_start, c_edges, e_pt, (const double*)Hpl, (const double*)Dinv, (const double*)db,
+                                       (const int2*)ba->join.p, (const int*)ba->join_slot.p, c_start, c_edges, (const int*)ba->c_pt.p, e_pt, (const double*)Hpl, (const double*)Dinv, (const double*)db,
                                        (const double*)Hpp, (const double*)bp, (const ba_state*)state, ba->bw, dist ? lead : 1, Cf, S, bs);
                     bh_time_end(ctx);
                 }

@@ -143,11 +143,13 @@ def _with_env(name, value, fn):
         else: os.environ[name] = old
 
 
-def test_row_form_of_the_schur_complement_equals_the_wave_per_pair_form(ctx):
+@pytest.mark.parametrize("duplicates", [False, True])
+def test_row_form_of_the_schur_complement_equals_the_wave_per_pair_form(ctx, duplicates):
     """The global-BA form of S and b~ (k_ba_schur_row: camera s1's blocks staged once per row in LDS) against the wave-per-pair kernels
     (BH_BA_SCHUR_ROW=0, read at set_problem): same LM decisions, costs and damping to 1e-9, poses and landmarks to 1e-9.  The problem is large enough
     for the one-wave-per-pair switch (>= 4096 camera pairs), and one keyframe sees 1 300 extra landmarks: more than the 1 024 blocks a
-    row keeps in LDS, so the tail of that row takes the global-memory path."""
+    row keeps in LDS, so the tail of that row takes the global-memory path.  duplicates: 200 landmarks are observed TWICE by one of their keyframes
+    (the diagonal block then has cross terms between the two observations, which the row kernel may not fold into its staging pass)."""
     pr = synth.ba_problem_sequence(n_kf=700, n_pts=20000, window=6, seed=5)
     rng = np.random.default_rng(1)
     hub = 350
@@ -163,6 +165,10 @@ def test_row_form_of_the_schur_complement_equals_the_wave_per_pair_form(ctx):
         ecam.append(np.full(extra, c, np.int32)); ept.append(np.arange(P0, P0 + extra, dtype=np.int32)); meas.append(uv + rng.normal(0, 1.0, uv.shape))
     pr = dict(pr, pts=np.concatenate([pr["pts"], Xc + rng.normal(0, 0.02, Xc.shape)]), ecam=np.concatenate(ecam), ept=np.concatenate(ept), meas=np.concatenate(meas))
     assert np.bincount(pr["ecam"])[hub] > 1024
+    if duplicates:
+        pick = rng.choice(len(pr["ecam"]), 200, replace=False)
+        pr = dict(pr, ecam=np.concatenate([pr["ecam"], pr["ecam"][pick]]), ept=np.concatenate([pr["ept"], pr["ept"][pick]]),
+                  meas=np.concatenate([pr["meas"], pr["meas"][pick] + rng.normal(0, 0.5, (200, 2))]))
     (Rr, tr), pr_pts, lgr = _with_env("BH_BA_SCHUR_ROW", "1", lambda: _single(ctx, pr, 4))
     (Rw, tw), pw_pts, lgw = _with_env("BH_BA_SCHUR_ROW", "0", lambda: _single(ctx, pr, 4))
     assert len(lgr) == len(lgw) == 4
