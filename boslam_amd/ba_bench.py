@@ -194,8 +194,10 @@ def run_global(ctx, n_kf=5000, n_pts=500000, iters=5, window=20, dist=None, devi
     ctx.synchronize()
     t_setup = time.perf_counter() - t0
     s.optimize(1)                                                                      # warm-up
+    t0 = time.perf_counter()
     s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
     ctx.synchronize()
+    t_setup2 = time.perf_counter() - t0                                                # buffers exist: uploads (host arrays in) + the structure build
     t0 = time.perf_counter()
     done = s.optimize(iters)
     ctx.synchronize()
@@ -210,7 +212,7 @@ def run_global(ctx, n_kf=5000, n_pts=500000, iters=5, window=20, dist=None, devi
     _, t = s.poses(); pts = s.points_all() if dist is not None else s.points()
     out = {"metric": "global_ba_lm_iters_per_sec", "n_gpus": world, "scaling": "strong",
            "allreduce_ms_per_iter": round(comm_ms / max(done, 1), 3), "allreduce_mb_per_iter": round(comm_bytes / max(done, 1) / 1e6, 2), "value": round(done / dt, 2), "unit": "iters/s", "iters": int(done),
-           "ms_per_iter": round(dt / done * 1e3, 2), "dtype": "f64", "set_problem_s": round(t_setup, 2),
+           "ms_per_iter": round(dt / done * 1e3, 2), "dtype": "f64", "set_problem_s": round(t_setup, 2), "set_problem_ms_warm": round(t_setup2 * 1e3, 2),
            "workload": f"configs[4]: {n_kf} keyframes x {n_pts} landmarks x {len(pr['ecam'])} observations, band +-{2 * window} keyframes",
            "robust_chi2": [float(v) for v in lg[:, 0]], "accepted": [int(v) for v in lg[:, 3]], "trials": int(lg[:, 2].sum()),
            "kernel_ms_per_iter": {k: round(v[0] / done, 3) for k, v in sorted(kt.items()) if k.startswith("k_ba")},

@@ -26,7 +26,7 @@
 #include <chrono>
 #include <cstddef>
 #include <utility>
-#include <hipcub/hipcub.hpp>
+#include "bh_scan.h"
 
 struct ba_cam {
     double q[4];            // x y z w
@@ -2922,11 +2922,16 @@ extern "C" int bh_ba_get_comm_detail(bh_ba* ba, double* out)
 // ------------------------------------------------------------------------------------------------ problem construction on the device
 // The structure g2o builds in initializeOptimization - which vertices take part, the edges by point and by free camera, the camera
 // pairs that share a landmark (the blocks of the reduced camera system) - used to be computed by host loops (1.3 ms at config 3,
-// 0.11 s at config 5, untimed).  It is now a handful of kernels + two stable radix sorts (hipcub) on the context's stream, with the
-// same outputs bit for bit:
+// 0.11 s at config 5, untimed).  It is now a handful of kernels on the context's stream with the same outputs bit for bit - counting,
+// exclusive scans (bh_scan.h) and RANKING, no sort (rounds 2 - 3 used three library radix sorts here; round 4 builds every list the way
+// the one-workgroup builder does, for any size):
 //   slots      cam_slot = rank among the used, non-fixed cameras; pt_slot = rank among the points that have an edge (exclusive scans)
-//   p_edges    edges sorted by (point slot, camera, input position): one stable 64-bit radix sort; p_start by counting + scan
-//   c_edges    the p_edges sequence stably sorted by free-camera slot (edges of fixed cameras dropped); c_start by counting + scan
+//   p_edges    per-point lists: p_start by counting + scan, filled in arbitrary order (integer atomics), then ranked inside the point by
+//              (camera, input position) - the keys are unique, the order is total, nothing depends on the fill order
+//   c_edges    the p_edges sequence filtered by free camera: positions filled per camera in arbitrary order, then ranked by position
+//              (a workgroup per camera, keys through LDS); c_pt = landmark slot of every entry
+//   join       per camera pair (counted per landmark with the pair's index = rank of its bit in the bitmap): camera s1's list looks its
+//              landmarks up in s2's (both sorted by landmark) and writes the hits in order - the kernel of the small builder
 //   pairs      camera pairs sharing a landmark: one thread per point marks its pairs in a Cf x Cf bitmap (integer atomicOr), the
 //              diagonal is always set; compacted in lexicographic order by a scan over the bitmap's popcounts
 __global__ void k_bld_mark(const int* __restrict__ ep, const int* __restrict__ pp, int E, int C, int P, int* __restrict__ cam_used,
@@ -2964,22 +2969,13 @@ __global__ void k_bld_edges(const int* __restrict__ ep, const int* __restrict__ 
     if (e < E) {
         const int c = ep[e], j = pt_slot[pp[e]];
         e_pt[e] = j;
-        key[e] = ((unsigned long long)(unsigned)j << 32) | (unsigned)c;
-        idx[e] = e;
+        if (key) { key[e] = ((unsigned long long)(unsigned)j << 32) | (unsigned)c; idx[e] = e; }
         atomicAdd(&p_cnt[j], 1);
         const int sl = cam_slot[c];
         if (sl >= 0) { if (priv) atomicAdd(&s_cc[sl], 1); else atomicAdd(&c_cnt[sl], 1); }
     }
     __syncthreads();
     if (priv) for (int i = threadIdx.x; i < Cf; i += 256) { const int v = s_cc[i]; if (v) atomicAdd(&c_cnt[i], v); }
-}
-__global__ void k_bld_camkey(const int* __restrict__ order, const int* __restrict__ ep, const int* __restrict__ cam_slot, int E, int Cf,
-                             unsigned* __restrict__ key2)
-{
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= E) return;
-    const int sl = cam_slot[ep[order[k]]];
-    key2[k] = sl >= 0 ? (unsigned)sl : (unsigned)Cf;                             // edges of fixed cameras sort behind every free one
 }
 __global__ void k_bld_pairs_mark(const int* __restrict__ p_start, const int* __restrict__ p_edges, const int* __restrict__ ep,
                                  const int* __restrict__ cam_slot, int Pa, int Cf, unsigned* __restrict__ bits, int* __restrict__ info)
@@ -3033,50 +3029,166 @@ __global__ void k_bld_gather_pts(const double* __restrict__ points, const int* _
     if (s >= 0) { pts[3 * (size_t)s] = points[3 * (size_t)j]; pts[3 * (size_t)s + 1] = points[3 * (size_t)j + 1]; pts[3 * (size_t)s + 2] = points[3 * (size_t)j + 2]; }
 }
 
-// join list of the Schur complement: for every landmark every pair (u <= v) of its free-camera edges, keyed by the camera pair
-__global__ void k_bld_join_count(const int* __restrict__ p_start, const int* __restrict__ p_edges, const int* __restrict__ ep,
-                                 const int* __restrict__ cam_slot, int Pa, int* __restrict__ cnt)
+// ---- the general builder's own kernels
+__global__ void k_g_pfill(const int* __restrict__ e_pt, int E, const int* __restrict__ p_start, int* __restrict__ pfill, int* __restrict__ tmp)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= Pa) return;
-    int f = 0;
-    for (int u = p_start[j]; u < p_start[j + 1]; u++) f += cam_slot[ep[p_edges[u]]] >= 0;
-    cnt[j] = f * (f + 1) / 2;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int j = e_pt[e];
+    tmp[p_start[j] + atomicAdd(&pfill[j], 1)] = e;
 }
-__global__ void k_bld_join_emit(const int* __restrict__ p_start, const int* __restrict__ p_edges, const int* __restrict__ ep,
-                                const int* __restrict__ cam_slot, int Pa, int Cf, const long long* __restrict__ off,
-                                unsigned long long* __restrict__ key, unsigned long long* __restrict__ val)
+// rank inside the point by (camera, input position).  Lane per point for the usual short lists; a point with more than 32 edges is
+// ranked by its whole wave afterwards (lane-strided entries, every lane walks the list).
+__global__ __launch_bounds__(256) void k_g_prank(const int* __restrict__ p_start, const int* __restrict__ tmp, const int* __restrict__ ep, int Pa,
+                                                 int* __restrict__ p_edges)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= Pa) return;
-    long long o = off[j];
-    const int a0 = p_start[j], a1 = p_start[j + 1];
-    for (int u = a0; u < a1; u++) {
-        const int e1 = p_edges[u], s1 = cam_slot[ep[e1]]; if (s1 < 0) continue;
-        for (int v = u; v < a1; v++) {
-            const int e2 = p_edges[v], s2 = cam_slot[ep[e2]]; if (s2 < 0) continue;      // edges of a point are sorted by camera: s1 <= s2
-            key[o] = (unsigned long long)s1 * Cf + s2;
-            val[o] = ((unsigned long long)(unsigned)e1 << 32) | (unsigned)e2;
-            o++;
+    const int j = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    int a0 = 0, k = 0;
+    if (j < Pa) { a0 = p_start[j]; k = p_start[j + 1] - a0; }
+    if (k <= 32)
+        for (int i = 0; i < k; i++) {
+            const int ei = tmp[a0 + i], ci = ep[ei];
+            int r = 0;
+            for (int i2 = 0; i2 < k; i2++) { const int ex = tmp[a0 + i2], c2 = ep[ex]; r += (c2 < ci || (c2 == ci && ex < ei)) ? 1 : 0; }
+            p_edges[a0 + r] = ei;
+        }
+    unsigned long long heavy = __ballot(k > 32);
+    while (heavy) {
+        const int src = __ffsll((long long)heavy) - 1; heavy &= heavy - 1;
+        const int b0 = __shfl(a0, src, 64), kk = __shfl(k, src, 64);
+        for (int i = lane; i < kk; i += 64) {
+            const int ei = tmp[b0 + i], ci = ep[ei];
+            int r = 0;
+            for (int i2 = 0; i2 < kk; i2++) { const int ex = tmp[b0 + i2], c2 = ep[ex]; r += (c2 < ci || (c2 == ci && ex < ei)) ? 1 : 0; }
+            p_edges[b0 + r] = ei;
         }
     }
 }
-__global__ void k_bld_join_start(const int2* __restrict__ pairs, int npairs, int Cf, const unsigned long long* __restrict__ key, long long M,
-                                 int* __restrict__ j_start)
+__global__ void k_g_cfill(const int* __restrict__ p_edges, const int* __restrict__ ep, const int* __restrict__ cam_slot, int E, const int* __restrict__ c_start,
+                          int* __restrict__ cfill, int* __restrict__ ctmp)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p > npairs) return;
-    if (p == npairs) { j_start[p] = (int)M; return; }
-    const unsigned long long k = (unsigned long long)pairs[p].x * Cf + pairs[p].y;
-    long long lo = 0, hi = M;
-    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (key[mid] < k) lo = mid + 1; else hi = mid; }
-    j_start[p] = (int)lo;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= E) return;
+    const int sl = cam_slot[ep[p_edges[k]]];
+    if (sl >= 0) ctmp[c_start[sl] + atomicAdd(&cfill[sl], 1)] = k;
 }
-__global__ void k_bld_join_unpack(const unsigned long long* __restrict__ val, long long M, int2* __restrict__ join)
+// a workgroup per free camera: its positions in the p_edges sequence (unique keys) are ranked against all of them, 2 048 keys at a time through
+// LDS (four keys per broadcast read).  NQ = keys a thread ranks per pass: 2 / 4 / 8 for lists up to 512 / 1 024 / any length.
+#define G_CT 2048
+template <int NQ>
+__device__ __forceinline__ void g_crank_body(int* s_k, const int a0, const int n, const int* __restrict__ ctmp, const int* __restrict__ p_edges,
+                                             const int* __restrict__ e_pt, int* __restrict__ c_edges, int* __restrict__ c_pt)
 {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t < M) join[t] = make_int2((int)(val[t] >> 32), (int)(val[t] & 0xffffffffu));
+    const int tid = threadIdx.x;
+    for (int base = 0; base < n; base += 256 * NQ) {
+        int kk[NQ], r[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { const int i = base + tid + 256 * q; kk[q] = i < n ? ctmp[a0 + i] : 0x7fffffff; r[q] = 0; }
+        for (int tb = 0; tb < n; tb += G_CT) {
+            const int m = min(G_CT, n - tb), m4 = (m + 3) & ~3;
+            __syncthreads();
+            for (int i = tid; i < m4; i += 256) s_k[i] = i < m ? ctmp[a0 + tb + i] : 0x7fffffff;      // (padding keys rank nobody)
+            __syncthreads();
+            for (int t = 0; t < m4; t += 4) {
+                const int4 v = *reinterpret_cast<const int4*>(s_k + t);
+#pragma unroll
+                for (int q = 0; q < NQ; q++) r[q] += (v.x < kk[q] ? 1 : 0) + (v.y < kk[q] ? 1 : 0) + (v.z < kk[q] ? 1 : 0) + (v.w < kk[q] ? 1 : 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int i = base + tid + 256 * q;
+            if (i < n) { const int e = p_edges[kk[q]]; c_edges[a0 + r[q]] = e; c_pt[a0 + r[q]] = e_pt[e]; }
+        }
+    }
 }
+__global__ __launch_bounds__(256) void k_g_crank(const int* __restrict__ c_start, const int* __restrict__ ctmp, const int* __restrict__ p_edges,
+                                                 const int* __restrict__ e_pt, int* __restrict__ c_edges, int* __restrict__ c_pt)
+{
+    __shared__ __attribute__((aligned(16))) int s_k[G_CT];
+    const int s = blockIdx.x, a0 = c_start[s], n = c_start[s + 1] - a0;
+    if (n <= 512) g_crank_body<2>(s_k, a0, n, ctmp, p_edges, e_pt, c_edges, c_pt);
+    else if (n <= 1024) g_crank_body<4>(s_k, a0, n, ctmp, p_edges, e_pt, c_edges, c_pt);
+    else g_crank_body<8>(s_k, a0, n, ctmp, p_edges, e_pt, c_edges, c_pt);
+}
+// ---- camera pairs and their join counts in ONE pass over the landmarks when the band is narrow: counters cnt[lo][hi - lo] (Cf x (band + 1) ints,
+// the band = largest slot distance inside a landmark, found first) instead of a Cf x Cf bitmap, its ranks and a second pass for the counts
+__global__ void k_g_band(const int* __restrict__ p_start, const int* __restrict__ p_edges, const int* __restrict__ ep, const int* __restrict__ cam_slot, int Pa,
+                         int* __restrict__ info)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    int bw = 0;
+    if (j < Pa) {
+        int lo = 0x7fffffff, hi = -1;                            // edges of a point are sorted by camera, slots grow with the camera index
+        for (int u = p_start[j]; u < p_start[j + 1]; u++) { const int sl = cam_slot[ep[p_edges[u]]]; if (sl >= 0) { lo = min(lo, sl); hi = max(hi, sl); } }
+        if (hi >= 0) bw = hi - lo;
+    }
+    for (int mm = 32; mm > 0; mm >>= 1) bw = max(bw, __shfl_xor(bw, mm, 64));
+    if (bw && (threadIdx.x & 63) == 0) atomicMax(&info[1], bw);
+}
+__global__ void k_g_bandcount(const int* __restrict__ p_start, const int* __restrict__ p_edges, const int* __restrict__ ep, const int* __restrict__ cam_slot,
+                              int Pa, int W, int* __restrict__ cnt, unsigned long long* __restrict__ total)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long mine = 0;
+    if (j < Pa) {
+        const int a0 = p_start[j], a1 = p_start[j + 1];
+        for (int u = a0; u < a1; u++) {
+            const int s1 = cam_slot[ep[p_edges[u]]]; if (s1 < 0) continue;
+            for (int v = u; v < a1; v++) {
+                const int s2 = cam_slot[ep[p_edges[v]]]; if (s2 < 0) continue;
+                const int lo = s1 < s2 ? s1 : s2, hi = s1 < s2 ? s2 : s1;
+                atomicAdd(&cnt[(size_t)lo * W + (hi - lo)], 1);
+                mine++;
+            }
+        }
+    }
+    for (int mm = 32; mm > 0; mm >>= 1) mine += __shfl_xor(mine, mm, 64);
+    if (mine && (threadIdx.x & 63) == 0) atomicAdd(total, mine);
+}
+__global__ void k_g_bandflag(const int* __restrict__ cnt, long long n, int W, int Cf, int* __restrict__ flag)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { flag[i] = 0; return; }
+    const int lo = (int)(i / W), d = (int)(i - (long long)lo * W);
+    flag[i] = (lo + d < Cf && (cnt[i] > 0 || d == 0)) ? 1 : 0;  // the diagonal blocks exist whatever the edges say
+}
+__global__ void k_g_bandemit(const int* __restrict__ cnt, const int* __restrict__ flag, const int* __restrict__ pos, long long n, int W, int2* __restrict__ pairs,
+                             int* __restrict__ j_cnt)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const int lo = (int)(i / W), d = (int)(i - (long long)lo * W);
+    pairs[pos[i]] = make_int2(lo, lo + d); j_cnt[pos[i]] = cnt[i];
+}
+// join entries per camera pair: one thread per landmark adds its (u <= v) pairs to the pair's counter; the pair's index is the rank of
+// its bit in the bitmap (pairs are emitted in bit order)
+__global__ void k_g_jcount(const int* __restrict__ p_start, const int* __restrict__ p_edges, const int* __restrict__ ep, const int* __restrict__ cam_slot,
+                           int Pa, int Cf, const unsigned* __restrict__ bits, const int* __restrict__ woff, int* __restrict__ j_cnt,
+                           unsigned long long* __restrict__ total)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long mine = 0;
+    if (j < Pa) {
+        const int a0 = p_start[j], a1 = p_start[j + 1];
+        for (int u = a0; u < a1; u++) {
+            const int s1 = cam_slot[ep[p_edges[u]]]; if (s1 < 0) continue;
+            for (int v = u; v < a1; v++) {
+                const int s2 = cam_slot[ep[p_edges[v]]]; if (s2 < 0) continue;
+                const int lo = s1 < s2 ? s1 : s2, hi = s1 < s2 ? s2 : s1;
+                const unsigned long long bit = (unsigned long long)lo * Cf + hi;
+                const unsigned w = bits[bit >> 5];
+                atomicAdd(&j_cnt[woff[bit >> 5] + __popc(w & ((1u << (bit & 31)) - 1u))], 1);
+                mine++;
+            }
+        }
+    }
+    for (int mm = 32; mm > 0; mm >>= 1) mine += __shfl_xor(mine, mm, 64);
+    if (mine && (threadIdx.x & 63) == 0) atomicAdd(total, mine);
+}
+__global__ __launch_bounds__(256) void k_g_join_merge(const int2* __restrict__ pairs, int npairs, const int* __restrict__ c_start, const int* __restrict__ c_edges,
+                                                      const int* __restrict__ c_pt, const int* __restrict__ j_start, int2* __restrict__ join);
 
 struct ba_build_out { int Cf, Pa, c_total, npairs, bwb; long long M; };
 
@@ -3087,49 +3199,41 @@ static int ba_build_device(bh_ba* ba, int C, const uint8_t* fixed, int P, const 
     bh_ctx* ctx = ba->ctx;
     hipStream_t st = ctx->stream;
     const int Ee = E > 0 ? E : 1, Ce = C > 0 ? C : 1, Pe = P > 0 ? P : 1;
-    // scratch layout (ints unless noted): ep[E] pp[E] idx[E] idx2[E] key2[E] key2b[E] | cam_used[C] camflag[C] camscan[C] | pt_used[P] ptscan[P] | info[8] | fixed u8[C]
-    BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(int) * (6 * (size_t)Ee + 3 * (size_t)Ce + 2 * (size_t)Pe + 8) + Ce + 64));
-    int* ep = (int*)ctx->st_a.p; int* pp = ep + Ee; int* idx = pp + Ee; int* idx2 = idx + Ee; unsigned* key2 = (unsigned*)(idx2 + Ee); unsigned* key2b = key2 + Ee;
-    int* cam_used = (int*)(key2b + Ee); int* camflag = cam_used + Ce; int* camscan = camflag + Ce;
+    // scratch layout (ints unless noted): ep[E] pp[E] tmp[E] ctmp[E] | cam_used[C] camflag[C] camscan[C] | pt_used[P] ptscan[P] | info[8] | fixed u8[C]
+    BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(int) * (4 * (size_t)Ee + 3 * (size_t)Ce + 2 * (size_t)Pe + 8) + Ce + 64));
+    int* ep = (int*)ctx->st_a.p; int* pp = ep + Ee; int* tmp = pp + Ee; int* ctmp = tmp + Ee;
+    int* cam_used = ctmp + Ee; int* camflag = cam_used + Ce; int* camscan = camflag + Ce;
     int* pt_used = camscan + Ce; int* ptscan = pt_used + Pe; int* info = ptscan + Pe; uint8_t* d_fixed = (uint8_t*)(info + 8);
-    BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(unsigned long long) * 2 * (size_t)Ee));
-    unsigned long long* key = (unsigned long long*)ctx->st_b.p; unsigned long long* keyb = key + Ee;
     BH_TRY(bh_reserve(ctx, &ctx->st_c, sizeof(double) * 3 * (size_t)Pe));        // user points
     BH_TRY(bh_reserve(ctx, &ba->cslot, sizeof(int) * (size_t)Ce));
     BH_TRY(bh_reserve(ctx, &ba->e_cam, sizeof(int) * (size_t)Ee)); BH_TRY(bh_reserve(ctx, &ba->e_pt, sizeof(int) * (size_t)Ee));
     BH_TRY(bh_reserve(ctx, &ba->p_edges, sizeof(int) * (size_t)Ee)); BH_TRY(bh_reserve(ctx, &ba->c_edges, sizeof(int) * (size_t)Ee));
+    BH_TRY(bh_reserve(ctx, &ba->c_pt, sizeof(int) * (size_t)Ee));
     BH_TRY(bh_reserve(ctx, &ba->p_start, sizeof(int) * ((size_t)Pe + 2))); BH_TRY(bh_reserve(ctx, &ba->c_start, sizeof(int) * ((size_t)Ce + 2)));
-    int* pt_slot = (int*)ctx->st_c.p;                                             // reuse below would clobber the points: separate buffer
-    BH_TRY(bh_reserve(ctx, &ctx->st_d, sizeof(int) * ((size_t)Pe + (size_t)Pe + (size_t)Ce + 8)));
-    pt_slot = (int*)ctx->st_d.p; int* p_cnt = pt_slot + Pe; int* c_cnt = p_cnt + Pe;
+    // pt_slot[P] p_cnt[P + 1] c_cnt[C + 1] pfill[P] cfill[C]
+    BH_TRY(bh_reserve(ctx, &ctx->st_d, sizeof(int) * (3 * (size_t)Pe + 2 * (size_t)Ce + 8)));
+    int* pt_slot = (int*)ctx->st_d.p; int* p_cnt = pt_slot + Pe; int* c_cnt = p_cnt + Pe + 1; int* pfill = c_cnt + Ce + 1; int* cfill = pfill + Pe;
     int* cam_slot = (int*)ba->cslot.p;
+    const long long nbits0 = (long long)Ce * Ce, nw0 = (nbits0 + 31) / 32;
+    BH_TRY(bh_reserve(ctx, &ctx->st_e, bh_exscan_scratch<int>(std::max<long long>(std::max<long long>(Pe, Ce), nw0) + 2) + 256));
+    void* scan_tmp = ctx->st_e.p;
     const int hinfo[8] = { 0x7fffffff, 0, 0, 0, 0, 0, 0, 0 };
     BH_HIP(ctx, hipMemcpyAsync(info, hinfo, sizeof(hinfo), hipMemcpyHostToDevice, st));
     BH_HIP(ctx, hipMemsetAsync(cam_used, 0, sizeof(int) * (size_t)Ce, st)); BH_HIP(ctx, hipMemsetAsync(pt_used, 0, sizeof(int) * (size_t)Pe, st));
-    BH_HIP(ctx, hipMemsetAsync(p_cnt, 0, sizeof(int) * ((size_t)Pe + (size_t)Ce), st));
+    BH_HIP(ctx, hipMemsetAsync(p_cnt, 0, sizeof(int) * (2 * (size_t)Pe + 2 * (size_t)Ce + 2), st));      // p_cnt, c_cnt, pfill, cfill
     if (E) { BH_HIP(ctx, hipMemcpyAsync(ep, edge_pose, sizeof(int) * (size_t)E, hipMemcpyHostToDevice, st)); BH_HIP(ctx, hipMemcpyAsync(pp, edge_point, sizeof(int) * (size_t)E, hipMemcpyHostToDevice, st)); }
     if (C) BH_HIP(ctx, hipMemcpyAsync(d_fixed, fixed, (size_t)C, hipMemcpyHostToDevice, st));
     if (P) BH_HIP(ctx, hipMemcpyAsync(ctx->st_c.p, points, sizeof(double) * 3 * (size_t)P, hipMemcpyHostToDevice, st));
     const dim3 T(256);
     auto G = [](long long n) { return dim3((unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1)); };
     if (E) hipLaunchKernelGGL(k_bld_mark, G(E), T, 0, st, (const int*)ep, (const int*)pp, E, C, P, cam_used, pt_used, info);
-    // exclusive scans (hipcub): camera flags and point flags
-    size_t tmp_bytes = 0, need = 0;
-    BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, need, camflag, camscan, Ce, st)); tmp_bytes = need;
-    BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, need, pt_used, ptscan, Pe, st)); tmp_bytes = std::max(tmp_bytes, need);
-    hipcub::DoubleBuffer<unsigned long long> kb(key, keyb); hipcub::DoubleBuffer<int> vb(idx, idx2);
-    BH_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, need, kb, vb, Ee, 0, 64, st)); tmp_bytes = std::max(tmp_bytes, need);
-    hipcub::DoubleBuffer<unsigned> kb2(key2, key2b); hipcub::DoubleBuffer<int> vb2(idx, idx2);
-    BH_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, need, kb2, vb2, Ee, 0, 32, st)); tmp_bytes = std::max(tmp_bytes, need);
-    BH_TRY(bh_reserve(ctx, &ctx->st_e, tmp_bytes + 256));
-    void* tmp = ctx->st_e.p;
     if (C) {
         hipLaunchKernelGGL(k_bld_camflag, G(C), T, 0, st, (const int*)cam_used, (const uint8_t*)d_fixed, C, ba->ar ? 1 : 0, camflag);
-        need = tmp_bytes; BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, need, camflag, camscan, C, st));
+        BH_TRY((bh_exscan<int, int>(ctx, st, camflag, camscan, C, scan_tmp)));
         hipLaunchKernelGGL(k_bld_slot, G(C), T, 0, st, (const int*)camflag, (const int*)camscan, C, cam_slot, info + 2);      // info[2] = Cf
     }
     if (P) {
-        need = tmp_bytes; BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, need, pt_used, ptscan, P, st));
+        BH_TRY((bh_exscan<int, int>(ctx, st, pt_used, ptscan, P, scan_tmp)));
         hipLaunchKernelGGL(k_bld_slot, G(P), T, 0, st, (const int*)pt_used, (const int*)ptscan, P, pt_slot, info + 3);        // info[3] = Pa
     }
     int h[8];
@@ -3141,87 +3245,90 @@ static int ba_build_device(bh_ba* ba, int C, const uint8_t* fixed, int P, const 
     int* e_pt = (int*)ba->e_pt.p;
     if (E) {
         BH_HIP(ctx, hipMemcpyAsync(ba->e_cam.p, ep, sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_bld_edges, G(E), T, 0, st, (const int*)ep, (const int*)pp, E, (const int*)pt_slot, (const int*)cam_slot, e_pt, key, idx, p_cnt, c_cnt, Cf);
-        // p_edges: stable sort by (point slot, camera); ties keep the input position
-        int bits_c = 1; while ((1ll << bits_c) < C) bits_c++;
-        int bits_p = 1; while ((1ll << bits_p) < std::max(Pa, 1)) bits_p++;
-        kb = hipcub::DoubleBuffer<unsigned long long>(key, keyb); vb = hipcub::DoubleBuffer<int>(idx, idx2);
-        need = tmp_bytes; BH_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, need, kb, vb, E, 0, 32 + bits_p, st));
-        int* order = vb.Current(); int* other = vb.Alternate();
-        BH_HIP(ctx, hipMemcpyAsync(ba->p_edges.p, order, sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, st));
-        // c_edges: the same sequence stably sorted by free-camera slot
-        hipLaunchKernelGGL(k_bld_camkey, G(E), T, 0, st, (const int*)order, (const int*)ep, (const int*)cam_slot, E, Cf, key2);
-        int bits_f = 1; while ((1ll << bits_f) < (long long)Cf + 1) bits_f++;
-        kb2 = hipcub::DoubleBuffer<unsigned>(key2, key2b); vb2 = hipcub::DoubleBuffer<int>(order, other);
-        need = tmp_bytes; BH_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, need, kb2, vb2, E, 0, bits_f, st));
-        BH_HIP(ctx, hipMemcpyAsync(ba->c_edges.p, vb2.Current(), sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, st));
-        (void)bits_c;
+        hipLaunchKernelGGL(k_bld_edges, G(E), T, 0, st, (const int*)ep, (const int*)pp, E, (const int*)pt_slot, (const int*)cam_slot, e_pt,
+                           (unsigned long long*)nullptr, (int*)nullptr, p_cnt, c_cnt, Cf);
     }
-    // p_start / c_start: exclusive scans of the counts (one extra element gives the total)
-    {
-        need = tmp_bytes; BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, need, p_cnt, (int*)ba->p_start.p, Pa + 1, st));      // p_cnt[Pa] = 0 (memset)
-        need = tmp_bytes; BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, need, c_cnt, (int*)ba->c_start.p, Cf + 1, st));
+    // p_start / c_start: exclusive scans of the counts (one extra element gives the total; p_cnt[Pa] = c_cnt[Cf] = 0 from the memset)
+    BH_TRY((bh_exscan<int, int>(ctx, st, p_cnt, (int*)ba->p_start.p, Pa + 1, scan_tmp)));
+    BH_TRY((bh_exscan<int, int>(ctx, st, c_cnt, (int*)ba->c_start.p, Cf + 1, scan_tmp)));
+    if (E) {
+        hipLaunchKernelGGL(k_g_pfill, G(E), T, 0, st, (const int*)e_pt, E, (const int*)ba->p_start.p, pfill, tmp);
+        if (Pa) hipLaunchKernelGGL(k_g_prank, G(Pa), T, 0, st, (const int*)ba->p_start.p, (const int*)tmp, (const int*)ep, Pa, (int*)ba->p_edges.p);
+        hipLaunchKernelGGL(k_g_cfill, G(E), T, 0, st, (const int*)ba->p_edges.p, (const int*)ep, (const int*)cam_slot, E, (const int*)ba->c_start.p, cfill, ctmp);
+        if (Cf) hipLaunchKernelGGL(k_g_crank, dim3(Cf), T, 0, st, (const int*)ba->c_start.p, (const int*)ctmp, (const int*)ba->p_edges.p, (const int*)e_pt,
+                                   (int*)ba->c_edges.p, (int*)ba->c_pt.p);
     }
     // camera pairs
     const long long nbits = (long long)Cf * Cf, nw = (nbits + 31) / 32;
     if (nw >= (1ll << 28)) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: %d free keyframes: the camera-pair bitmap would need %lld MB", Cf, nw >> 18);
     int npairs = 0, bwb = 0, c_total = 0;
+    long long M_total = 0;
     if (Cf) {
-        BH_TRY(bh_reserve(ctx, &ctx->st_f, sizeof(unsigned) * (size_t)nw + sizeof(int) * 2 * ((size_t)nw + 1)));
-        unsigned* bits = (unsigned*)ctx->st_f.p; int* wcnt = (int*)(bits + nw); int* woff = wcnt + nw + 1;
-        BH_HIP(ctx, hipMemsetAsync(bits, 0, sizeof(unsigned) * (size_t)nw, st));
-        BH_HIP(ctx, hipMemsetAsync(wcnt + nw, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_bld_pairs_mark, G((long long)Pa + Cf), T, 0, st, (const int*)ba->p_start.p, (const int*)ba->p_edges.p, (const int*)ep,
-                           (const int*)cam_slot, Pa, Cf, bits, info);
-        hipLaunchKernelGGL(k_bld_popc, G(nw), T, 0, st, (const unsigned*)bits, nw, wcnt);
-        size_t need2 = 0; BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, need2, wcnt, woff, (int)(nw + 1), st));
-        BH_TRY(bh_reserve(ctx, &ctx->st_g, need2 + 256));
-        BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->st_g.p, need2, wcnt, woff, (int)(nw + 1), st));
-        int hv[8];                                             // the three counts come back in ONE host read (each pageable read is a ~20 us stall)
-        BH_HIP(ctx, hipMemcpyAsync(info + 4, woff + nw, sizeof(int), hipMemcpyDeviceToDevice, st));
+        // the band (largest slot distance inside a landmark) and the number of free-camera edges come back in one read
+        if (Pa) hipLaunchKernelGGL(k_g_band, G(Pa), T, 0, st, (const int*)ba->p_start.p, (const int*)ba->p_edges.p, (const int*)ep, (const int*)cam_slot, Pa, info);
+        int hv[8];
         BH_HIP(ctx, hipMemcpyAsync(info + 5, (int*)ba->c_start.p + Cf, sizeof(int), hipMemcpyDeviceToDevice, st));
         BH_HIP(ctx, hipMemcpyAsync(hv, info, sizeof(hv), hipMemcpyDeviceToHost, st));
         BH_HIP(ctx, hipStreamSynchronize(st));
-        npairs = hv[4]; bwb = hv[1]; c_total = hv[5];
-        BH_TRY(bh_reserve(ctx, &ba->pairs, sizeof(int2) * ((size_t)npairs + 1)));
-        hipLaunchKernelGGL(k_bld_pairs_emit, G(nw), T, 0, st, (const unsigned*)bits, (const int*)woff, nw, Cf, (int2*)ba->pairs.p);
-    }
-    // the Schur complement's work list: (edge, edge) pairs per camera pair, landmarks ascending inside a pair (stable sort of the
-    // per-landmark enumeration by camera-pair key)
-    long long M_total = 0;
-    {
-        BH_TRY(bh_reserve(ctx, &ba->j_start, sizeof(int) * ((size_t)npairs + 2)));
-        long long M = 0;
-        if (Pa && Cf) {
-            int* jc = p_cnt;                                                   // reuse: per-point incidence counts (p_cnt is dead: p_start is built)
-            hipLaunchKernelGGL(k_bld_join_count, G(Pa), T, 0, st, (const int*)ba->p_start.p, (const int*)ba->p_edges.p, (const int*)ep, (const int*)cam_slot, Pa, jc);
-            BH_TRY(bh_reserve(ctx, &ctx->st_g, sizeof(long long) * ((size_t)Pa + 2) + 1024));
-            long long* joff = (long long*)ctx->st_g.p;
-            BH_HIP(ctx, hipMemsetAsync(jc + Pa, 0, sizeof(int), st));
-            size_t need3 = 0;
-            BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, need3, jc, joff, Pa + 1, st));
-            BH_TRY(bh_reserve(ctx, &ctx->st_e, need3 + 256));
-            BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->st_e.p, need3, jc, joff, Pa + 1, st));
-            BH_HIP(ctx, hipMemcpyAsync(&M, joff + Pa, sizeof(long long), hipMemcpyDeviceToHost, st));
+        bwb = hv[1]; c_total = hv[5];
+        const long long W = (long long)bwb + 1, nb = (long long)Cf * W;
+        unsigned long long M = 0;
+        int* j_cnt = nullptr;
+        const char* pm = getenv("BH_BA_PAIRS");                  // A/B + test switch: "bitmap" forces the wide-band path
+        if (nb <= (1ll << 26) && !(pm && !strcmp(pm, "bitmap"))) {
+            // narrow band: counters cnt[lo][hi - lo] mark the pairs AND count their join entries in one pass over the landmarks
+            BH_TRY(bh_reserve(ctx, &ctx->st_f, sizeof(int) * (3 * (size_t)nb + 4) + 64));
+            int* cnt = (int*)ctx->st_f.p; int* flag = cnt + nb; int* pos = flag + nb + 1;
+            unsigned long long* tot = (unsigned long long*)(((uintptr_t)(pos + nb + 1) + 15) & ~(uintptr_t)15);
+            BH_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)nb, st)); BH_HIP(ctx, hipMemsetAsync(tot, 0, sizeof(*tot), st));
+            if (Pa) hipLaunchKernelGGL(k_g_bandcount, G(Pa), T, 0, st, (const int*)ba->p_start.p, (const int*)ba->p_edges.p, (const int*)ep, (const int*)cam_slot, Pa, (int)W, cnt, tot);
+            hipLaunchKernelGGL(k_g_bandflag, G(nb + 1), T, 0, st, (const int*)cnt, nb, (int)W, Cf, flag);
+            BH_TRY(bh_reserve(ctx, &ctx->st_e, bh_exscan_scratch<int>(nb + 2) + 256));
+            BH_TRY((bh_exscan<int, int>(ctx, st, flag, pos, nb + 1, ctx->st_e.p)));
+            BH_HIP(ctx, hipMemcpyAsync(&npairs, pos + nb, sizeof(int), hipMemcpyDeviceToHost, st));
+            BH_HIP(ctx, hipMemcpyAsync(&M, tot, sizeof(M), hipMemcpyDeviceToHost, st));
             BH_HIP(ctx, hipStreamSynchronize(st));
-            if (M >= (1ll << 31)) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: %lld landmark / camera-pair incidences (limit 2^31)", M);
-            M_total = M;
-            BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(unsigned long long) * 4 * (size_t)(M + 1)));
-            unsigned long long* jk = (unsigned long long*)ctx->st_b.p; unsigned long long* jk2 = jk + M + 1; unsigned long long* jv = jk2 + M + 1; unsigned long long* jv2 = jv + M + 1;
-            hipLaunchKernelGGL(k_bld_join_emit, G(Pa), T, 0, st, (const int*)ba->p_start.p, (const int*)ba->p_edges.p, (const int*)ep, (const int*)cam_slot, Pa, Cf, (const long long*)joff, jk, jv);
-            int bits_k = 1; while ((1ll << bits_k) < (long long)Cf * Cf) bits_k++;
-            hipcub::DoubleBuffer<unsigned long long> kj(jk, jk2), vj(jv, jv2);
-            size_t need4 = 0;
-            BH_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, need4, kj, vj, (int)M, 0, bits_k, st));
-            BH_TRY(bh_reserve(ctx, &ctx->st_e, need4 + 256));
-            BH_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->st_e.p, need4, kj, vj, (int)M, 0, bits_k, st));
-            BH_TRY(bh_reserve(ctx, &ba->join, sizeof(int2) * (size_t)(M + 1)));
-            hipLaunchKernelGGL(k_bld_join_unpack, G(M), T, 0, st, (const unsigned long long*)vj.Current(), M, (int2*)ba->join.p);
-            hipLaunchKernelGGL(k_bld_join_start, G((long long)npairs + 1), T, 0, st, (const int2*)ba->pairs.p, npairs, Cf, (const unsigned long long*)kj.Current(), M, (int*)ba->j_start.p);
+            BH_TRY(bh_reserve(ctx, &ba->pairs, sizeof(int2) * ((size_t)npairs + 1)));
+            BH_TRY(bh_reserve(ctx, &ctx->st_g, sizeof(int) * ((size_t)npairs + 2) + 64));
+            j_cnt = (int*)ctx->st_g.p;
+            BH_HIP(ctx, hipMemsetAsync(j_cnt + npairs, 0, sizeof(int) * 2, st));
+            hipLaunchKernelGGL(k_g_bandemit, G(nb), T, 0, st, (const int*)cnt, (const int*)flag, (const int*)pos, nb, (int)W, (int2*)ba->pairs.p, j_cnt);
         } else {
-            BH_TRY(bh_reserve(ctx, &ba->join, sizeof(int2)));
-            BH_HIP(ctx, hipMemsetAsync(ba->j_start.p, 0, sizeof(int) * ((size_t)npairs + 2), st));
+            // wide band (a dense window with many free cameras): Cf x Cf bitmap, pairs in bit order, a second pass counts by the rank of the pair's bit
+            BH_TRY(bh_reserve(ctx, &ctx->st_f, sizeof(unsigned) * (size_t)nw + sizeof(int) * 2 * ((size_t)nw + 1)));
+            unsigned* bits = (unsigned*)ctx->st_f.p; int* wcnt = (int*)(bits + nw); int* woff = wcnt + nw + 1;
+            BH_HIP(ctx, hipMemsetAsync(bits, 0, sizeof(unsigned) * (size_t)nw, st));
+            BH_HIP(ctx, hipMemsetAsync(wcnt + nw, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_bld_pairs_mark, G((long long)Pa + Cf), T, 0, st, (const int*)ba->p_start.p, (const int*)ba->p_edges.p, (const int*)ep,
+                               (const int*)cam_slot, Pa, Cf, bits, info);
+            hipLaunchKernelGGL(k_bld_popc, G(nw), T, 0, st, (const unsigned*)bits, nw, wcnt);
+            BH_TRY((bh_exscan<int, int>(ctx, st, wcnt, woff, nw + 1, scan_tmp)));
+            BH_HIP(ctx, hipMemcpyAsync(&npairs, woff + nw, sizeof(int), hipMemcpyDeviceToHost, st));
+            BH_HIP(ctx, hipStreamSynchronize(st));
+            BH_TRY(bh_reserve(ctx, &ba->pairs, sizeof(int2) * ((size_t)npairs + 1)));
+            hipLaunchKernelGGL(k_bld_pairs_emit, G(nw), T, 0, st, (const unsigned*)bits, (const int*)woff, nw, Cf, (int2*)ba->pairs.p);
+            BH_TRY(bh_reserve(ctx, &ctx->st_g, sizeof(int) * ((size_t)npairs + 2) + 64));
+            j_cnt = (int*)ctx->st_g.p; unsigned long long* tot = (unsigned long long*)(j_cnt + (((size_t)npairs + 2 + 1) & ~(size_t)1));
+            BH_HIP(ctx, hipMemsetAsync(j_cnt, 0, sizeof(int) * ((size_t)npairs + 2) + 64, st));
+            if (Pa) {
+                hipLaunchKernelGGL(k_g_jcount, G(Pa), T, 0, st, (const int*)ba->p_start.p, (const int*)ba->p_edges.p, (const int*)ep, (const int*)cam_slot, Pa, Cf,
+                                   (const unsigned*)bits, (const int*)woff, j_cnt, tot);
+                BH_HIP(ctx, hipMemcpyAsync(&M, tot, sizeof(M), hipMemcpyDeviceToHost, st));
+                BH_HIP(ctx, hipStreamSynchronize(st));
+            }
         }
+        // the Schur complement's work list: (edge, edge) pairs per camera pair, landmarks ascending inside a pair
+        if (M >= (1ull << 31)) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_set_problem: %llu landmark / camera-pair incidences (limit 2^31)", M);
+        M_total = (long long)M;
+        BH_TRY(bh_reserve(ctx, &ba->j_start, sizeof(int) * ((size_t)npairs + 2)));
+        BH_TRY(bh_reserve(ctx, &ctx->st_e, bh_exscan_scratch<int>((long long)npairs + 2) + 256));
+        BH_TRY((bh_exscan<int, int>(ctx, st, j_cnt, (int*)ba->j_start.p, (long long)npairs + 1, ctx->st_e.p)));
+        BH_TRY(bh_reserve(ctx, &ba->join, sizeof(int2) * (size_t)(M_total + 1)));
+        if (npairs && M_total) hipLaunchKernelGGL(k_g_join_merge, dim3(npairs), T, 0, st, (const int2*)ba->pairs.p, npairs, (const int*)ba->c_start.p, (const int*)ba->c_edges.p,
+                                                  (const int*)ba->c_pt.p, (const int*)ba->j_start.p, (int2*)ba->join.p);
+    } else {
+        BH_TRY(bh_reserve(ctx, &ba->j_start, sizeof(int) * 2)); BH_TRY(bh_reserve(ctx, &ba->join, sizeof(int2)));
+        BH_HIP(ctx, hipMemsetAsync(ba->j_start.p, 0, sizeof(int) * 2, st));
     }
     out->npairs = npairs; out->bwb = bwb; out->c_total = c_total; out->M = M_total;
     // active points in slot order; host mirrors of the slots (get_points / get_poses map back through them)
@@ -3236,7 +3343,7 @@ static int ba_build_device(bh_ba* ba, int C, const uint8_t* fixed, int P, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// One-workgroup builder for local windows (round 3).  ba_build_device above is ~60 launches (three merge sorts of ~20 kernels each)
+// One-workgroup builder for local windows (round 3).  ba_build_device above is ~30 launches (~60 while it used library sorts)
 // and four host reads - 0.4 ms for a live window whose seven LM iterations take 0.6 ms, and the part of local mapping that the
 // batched optimiser does not cover.  A window with at most BLD_SF free keyframes is built by ONE 1024-thread workgroup
 // (k_bld_small: slots, edges by point, edges by camera, camera pairs, join offsets) plus one launch of a wave per camera pair
@@ -3677,49 +3784,28 @@ __global__ __launch_bounds__(256) void k_b2_cplace(const bld_view* __restrict__ 
     }
 }
 
-// One workgroup per camera pair: the (edge of s1, edge of s2) pairs on a common landmark, landmarks ascending - both cameras' lists are
-// sorted by landmark, so s1's entries look themselves up in s2's (staged in LDS) and a block scan puts the hits in order.  The
-// workgroups behind the pairs copy the measurements and gather the active landmarks (independent of everything else in the build).
-__global__ __launch_bounds__(256) void k_bld_join_merge(const bld_view* __restrict__ views, int pair_blocks)
+// One camera pair of the join: the (edge of s1, edge of s2) pairs on a common landmark, landmarks ascending (256 threads).
+__device__ __forceinline__ void bld_join_pair(const int p, const int npairs, const int2* __restrict__ pairs, const int* __restrict__ c_start,
+                                              const int* __restrict__ c_edges, const int* __restrict__ c_pt, const int* __restrict__ j_start, int2* __restrict__ join)
 {
-    const bld_view V = views[blockIdx.y];
-    if (V.C == 0 || V.info[0] != 0x7fffffff || V.info[7]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if ((int)blockIdx.x >= pair_blocks) {
-        const int nx = (int)gridDim.x - pair_blocks, i0 = ((int)blockIdx.x - pair_blocks) * 256 + tid, step = nx * 256;
-        for (int i = i0; i < V.E; i += step) { V.e_meas[2 * i] = V.meas[2 * i]; V.e_meas[2 * i + 1] = V.meas[2 * i + 1]; V.err0[2 * i] = 0; V.err0[2 * i + 1] = 0; }
-        for (int i = i0; i < V.P; i += step) {
-            const int sl = V.pslot[i];
-            if (sl >= 0) { V.pts[3 * (size_t)sl] = V.points[3 * (size_t)i]; V.pts[3 * (size_t)sl + 1] = V.points[3 * (size_t)i + 1]; V.pts[3 * (size_t)sl + 2] = V.points[3 * (size_t)i + 2]; }
-        }
-        for (int i = i0; i < V.C; i += step) { V.cams_dst[i] = V.cams_src[i]; d_cam_refresh(&V.cams_dst[i], V.K); }      // (in place, as k_ba_cam_init: the same code, the same bits)
-        // cleared: the LM control block, the residual slot past the last edge, the reduced camera system and the step (as bh_ba_set_problem's memsets)
-        const int n6 = 6 * V.info[2], bw = n6 > 0 ? min(n6 - 1, 6 * V.info[1] + 5) : 0;
-        const long long nS = (long long)n6 * (bw + 1) + 1;
-        for (long long i = i0; i < nS; i += step) V.S[i] = 0;
-        for (int i = i0; i < n6 + 6; i += step) V.dxp[i] = 0;
-        if (i0 < 2) V.err0[2 * (size_t)V.E + i0] = 0;
-        for (int i = i0; i < (int)(sizeof(ba_state) / 4); i += step) reinterpret_cast<int*>(V.state)[i] = 0;
-        return;
-    }
-    const int p = blockIdx.x;
-    if (p >= V.info[4]) return;
+    if (p >= npairs) return;
     __shared__ int s_l2[BLD_MJ];
     __shared__ int s_w[4];
-    const int2 pr = V.pairs[p];
-    const int a0 = V.c_start[pr.x], n1 = V.c_start[pr.x + 1] - a0, b0 = V.c_start[pr.y], n2 = V.c_start[pr.y + 1] - b0;
-    const int* q2 = V.c_pt + b0;                                 // landmarks of s2's list
+    const int2 pr = pairs[p];
+    const int a0 = c_start[pr.x], n1 = c_start[pr.x + 1] - a0, b0 = c_start[pr.y], n2 = c_start[pr.y + 1] - b0;
+    const int* q2 = c_pt + b0;                                 // landmarks of s2's list
     const bool staged = n2 <= BLD_MJ;
     if (staged) for (int i = tid; i < n2; i += 256) s_l2[i] = q2[i];
     __syncthreads();
-    const int* l2 = V.c_edges + b0;
-    int out = V.j_start[p];
+    const int* l2 = c_edges + b0;
+    int out = j_start[p];
     for (int i0 = 0; i0 < n1; i0 += 256) {
         const int i = i0 + tid;
         int e1 = 0, first = 0, cnt = 0;
         if (i < n1) {
-            e1 = V.c_edges[a0 + i];
-            const int j = V.c_pt[a0 + i];
+            e1 = c_edges[a0 + i];
+            const int j = c_pt[a0 + i];
             int lo = 0, hi = n2;
             if (staged) {
                 while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_l2[mid] < j) lo = mid + 1; else hi = mid; }
@@ -3744,9 +3830,42 @@ __global__ __launch_bounds__(256) void k_bld_join_merge(const bld_view* __restri
 #pragma unroll
         for (int w = 0; w < 4; w++) { const int t = s_w[w]; if (w < wv) base += t; tot += t; }
         const int wr = out + base + inc - cnt;
-        for (int k = 0; k < cnt; k++) V.join[wr + k] = make_int2(e1, l2[first + k]);
+        for (int k = 0; k < cnt; k++) join[wr + k] = make_int2(e1, l2[first + k]);
         out += tot;
     }
+}
+
+// One workgroup per camera pair: the (edge of s1, edge of s2) pairs on a common landmark, landmarks ascending - both cameras' lists are
+// sorted by landmark, so s1's entries look themselves up in s2's (staged in LDS) and a block scan puts the hits in order.  The
+// workgroups behind the pairs copy the measurements and gather the active landmarks (independent of everything else in the build).
+__global__ __launch_bounds__(256) void k_bld_join_merge(const bld_view* __restrict__ views, int pair_blocks)
+{
+    const bld_view V = views[blockIdx.y];
+    if (V.C == 0 || V.info[0] != 0x7fffffff || V.info[7]) return;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= pair_blocks) {
+        const int nx = (int)gridDim.x - pair_blocks, i0 = ((int)blockIdx.x - pair_blocks) * 256 + tid, step = nx * 256;
+        for (int i = i0; i < V.E; i += step) { V.e_meas[2 * i] = V.meas[2 * i]; V.e_meas[2 * i + 1] = V.meas[2 * i + 1]; V.err0[2 * i] = 0; V.err0[2 * i + 1] = 0; }
+        for (int i = i0; i < V.P; i += step) {
+            const int sl = V.pslot[i];
+            if (sl >= 0) { V.pts[3 * (size_t)sl] = V.points[3 * (size_t)i]; V.pts[3 * (size_t)sl + 1] = V.points[3 * (size_t)i + 1]; V.pts[3 * (size_t)sl + 2] = V.points[3 * (size_t)i + 2]; }
+        }
+        for (int i = i0; i < V.C; i += step) { V.cams_dst[i] = V.cams_src[i]; d_cam_refresh(&V.cams_dst[i], V.K); }      // (in place, as k_ba_cam_init: the same code, the same bits)
+        // cleared: the LM control block, the residual slot past the last edge, the reduced camera system and the step (as bh_ba_set_problem's memsets)
+        const int n6 = 6 * V.info[2], bw = n6 > 0 ? min(n6 - 1, 6 * V.info[1] + 5) : 0;
+        const long long nS = (long long)n6 * (bw + 1) + 1;
+        for (long long i = i0; i < nS; i += step) V.S[i] = 0;
+        for (int i = i0; i < n6 + 6; i += step) V.dxp[i] = 0;
+        if (i0 < 2) V.err0[2 * (size_t)V.E + i0] = 0;
+        for (int i = i0; i < (int)(sizeof(ba_state) / 4); i += step) reinterpret_cast<int*>(V.state)[i] = 0;
+        return;
+    }
+    bld_join_pair(blockIdx.x, V.info[4], V.pairs, V.c_start, V.c_edges, V.c_pt, V.j_start, V.join);
+}
+__global__ __launch_bounds__(256) void k_g_join_merge(const int2* __restrict__ pairs, int npairs, const int* __restrict__ c_start, const int* __restrict__ c_edges,
+                                                      const int* __restrict__ c_pt, const int* __restrict__ j_start, int2* __restrict__ join)
+{
+    bld_join_pair(blockIdx.x, npairs, pairs, c_start, c_edges, c_pt, j_start, join);
 }
 
 static void ba_builder_attr() { (void)hipFuncSetAttribute((const void*)k_bld_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bld_lds_bytes(BLD_LE, BLD_LP)); }

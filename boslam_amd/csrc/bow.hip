@@ -14,7 +14,7 @@
 #include "bh_internal.h"
 #include <math.h>
 #include <vector>
-#include <hipcub/hipcub.hpp>
+#include "bh_scan.h"
 
 // ================================================================================================ visibility gate
 __global__ __launch_bounds__(1024) void k_gate(const double* __restrict__ pts, const double* __restrict__ nrm,
@@ -757,8 +757,7 @@ static int inv_build(bh_bow* bow)
     const long long nel = bow->n_elems, ne = bow->n_entries;
     BH_TRY(bh_reserve(ctx, &bow->inv_start, sizeof(long long) * (INV_WORDS + 2)));
     BH_TRY(bh_reserve(ctx, &bow->inv_entry, sizeof(uint32_t) * (size_t)(nel + 4))); BH_TRY(bh_reserve(ctx, &bow->inv_val, sizeof(double) * (size_t)(nel + 4)));
-    size_t scan_bytes = 0;
-    BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const long long*)nullptr, (long long*)nullptr, INV_WORDS + 1, st));
+    const size_t scan_bytes = bh_exscan_scratch<long long>(INV_WORDS + 1);
     const size_t off_cnt = 0, off_wide = off_cnt + sizeof(uint32_t) * (INV_WORDS + 64), off_scan = off_wide + sizeof(long long) * (INV_WORDS + 2);
     BH_TRY(bh_reserve(ctx, &bow->inv_tmp, off_scan + scan_bytes + 256));
     uint32_t* cnt = (uint32_t*)((char*)bow->inv_tmp.p + off_cnt); long long* wide = (long long*)((char*)bow->inv_tmp.p + off_wide);
@@ -767,7 +766,7 @@ static int inv_build(bh_bow* bow)
     const int g = (int)std::min<long long>(4096, (nel + 255) / 256 + 1);
     hipLaunchKernelGGL(k_inv_count, dim3(g), dim3(256), 0, st, (const uint32_t*)bow->words.p, nel, cnt, bad);
     hipLaunchKernelGGL(k_inv_widen, dim3((INV_WORDS + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)cnt, wide, INV_WORDS + 1);
-    BH_HIP(ctx, hipcub::DeviceScan::ExclusiveSum((char*)bow->inv_tmp.p + off_scan, scan_bytes, (const long long*)wide, (long long*)bow->inv_start.p, INV_WORDS + 1, st));
+    BH_TRY((bh_exscan<long long, long long>(ctx, st, (const long long*)wide, (long long*)bow->inv_start.p, INV_WORDS + 1, (char*)bow->inv_tmp.p + off_scan)));
     int hbad = 0;
     BH_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
     BH_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * INV_WORDS, st));                      // now the per-row fill cursors

@@ -239,9 +239,10 @@ def test_global_ba_config5_full_size(ctx, monkeypatch):
 
 def test_device_built_problem_equals_host_built(ctx, monkeypatch):
     """bh_ba_set_problem builds the graph structure (slots, edges by point / by camera, camera pairs, join lists, band) on the device:
-    local windows (<= 64 free keyframes) by ONE workgroup without any sort, everything else by chip-wide kernels + radix sorts
-    (BH_BA_BUILD=general); the former host loops stay selectable (BH_BA_BUILD=host).  Same problem through all three: every
-    structural array identical, and poses, landmarks, per-edge chi2 and the LM log equal bit for bit."""
+    local windows (<= 64 free keyframes) by ONE workgroup, everything else by chip-wide kernels (BH_BA_BUILD=general: counting, scans and
+    ranking, no sort; its camera pairs either from band counters or - BH_BA_PAIRS=bitmap, the wide-band path - from a Cf x Cf bitmap);
+    the former host loops stay selectable (BH_BA_BUILD=host).  Same problem through all four: every structural array identical, and
+    poses, landmarks, per-edge chi2 and the LM log equal bit for bit."""
     probs = [synth.ba_problem(n_kf=12, n_pts=500, seed=4), synth.ba_problem(n_kf=50, n_pts=10000, seed=7),
              synth.ba_problem_sequence(n_kf=300, n_pts=9000, window=6, seed=3), synth.ba_problem(n_kf=3, n_pts=40, seed=11),
              synth.ba_problem(n_kf=20, n_pts=1500, seed=9)]
@@ -260,9 +261,12 @@ def test_device_built_problem_equals_host_built(ctx, monkeypatch):
     probs.append(dict(pr, fixed=fx))
     for pi, pr in enumerate(probs):
         res, st = [], []
-        for mode in ("device", "general", "host"):
+        for mode in ("device", "general", "host", "bitmap"):
+            monkeypatch.delenv("BH_BA_PAIRS", raising=False)
             if mode == "device":
                 monkeypatch.delenv("BH_BA_BUILD", raising=False)
+            elif mode == "bitmap":
+                monkeypatch.setenv("BH_BA_BUILD", "general"); monkeypatch.setenv("BH_BA_PAIRS", "bitmap")
             else:
                 monkeypatch.setenv("BH_BA_BUILD", mode)
             s = ba.LocalBA(ctx, pr["K"])
@@ -271,8 +275,8 @@ def test_device_built_problem_equals_host_built(ctx, monkeypatch):
             done = s.optimize(4)
             res.append((s.poses(), s.points(), s.chi2(), s.log()[:done]))
             s.close()
-        monkeypatch.delenv("BH_BA_BUILD", raising=False)
-        for other in (1, 2):
+        monkeypatch.delenv("BH_BA_BUILD", raising=False); monkeypatch.delenv("BH_BA_PAIRS", raising=False)
+        for other in (1, 2, 3):
             for name in st[0]:
                 assert np.array_equal(st[0][name], st[other][name]), (pi, name, other)
             (Rd, td), pd, cd, ld = res[0]; (Rh, th), ph, ch, lh = res[other]
