@@ -1706,7 +1706,10 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
     // Device-resident batches run as two independent chunk pipelines on two streams (each with its own workspace), so
     // the latency-bound kernels of one chunk (k_select, k_describe) overlap the VALU-bound ones of the next.
     const int nchunks = (B + chunk - 1) / chunk;
-    int pipe_cfg = BH_MAX_PIPES;
+    // two pipelines by default: measured at 1 000 frames x 640 x 480 (tools/chunk_sweep.sh, round 4) 1 / 2 / 3 / 4 pipelines of 128-frame chunks
+    // give 267 / 291 / 289 / 285 k frames/s - a second stream fills the launch gaps and the tails of the latency-bound kernels, more of them
+    // only compete for the L2 (250-frame chunks: 274 / 286 / 281)
+    int pipe_cfg = 2;
     if (const char* e = getenv("BH_ORB_PIPELINES")) { const int v = atoi(e); if (v >= 1 && v <= BH_MAX_PIPES) pipe_cfg = v; }
     const int npipe = mem == BH_MEM_DEVICE ? (nchunks < pipe_cfg ? nchunks : pipe_cfg) : 1;
     const size_t ws = (size_t)g.pyr_stride * chunk;
