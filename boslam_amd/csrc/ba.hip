@@ -451,7 +451,8 @@ struct bh_ba {
     bh_buf Hpl, Hll, bl, Hpp, bp, pdiag, cdiag;
     bh_buf Dinv, db, S, bs, dxp, dxl, state, pairs, part, xch;
     bh_buf join, j_start;              // per camera pair: the (edge, edge) pairs that share a landmark (Schur complement's work list)
-    bh_buf c_pt;                       // row form: landmark slot of every entry of c_edges
+    bh_buf c_pt, c_meas;               // row form: landmark slot / measurement of every entry of c_edges (camera-major copies)
+    int cam_major = 0;                 // c_pt / c_meas are valid for the current problem
     bh_buf row_start, join_slot;       // row form (k_ba_schur_row): first pair of every row; LDS slot of every join entry's first edge
     int schur_row = 0;
     bh_buf pair_rec, join_pt;          // wave-per-pair form only: (s1, s2, first, end) per pair in one 16-B record; landmark slot per join entry
@@ -529,7 +530,8 @@ __device__ __forceinline__ void ba_cam_body(int s, const ba_cam* __restrict__ ca
                                                 const int* __restrict__ e_cam, const int* __restrict__ e_pt,
                                                 const double* __restrict__ e_meas, const int* __restrict__ c_start,
                                                 const int* __restrict__ c_edges, ba_K K, double delta,
-                                                double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ cdiag)
+                                                double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ cdiag,
+                                                const int* __restrict__ c_pt = nullptr, const double* __restrict__ c_meas = nullptr)
 {
     __shared__ double s_red[27 * 4];
     const int tid = threadIdx.x;
@@ -537,12 +539,16 @@ __device__ __forceinline__ void ba_cam_body(int s, const ba_cam* __restrict__ ca
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0;
     const int u0 = c_start[s], u1 = c_start[s + 1];
+    // c_pt / c_meas (global-BA form): landmark slot and measurement of every c_edges entry in camera-major order, copied once per problem -
+    // the loop then gathers the landmark only (the edge's camera, landmark slot and measurement were three more scattered lines per edge);
+    // every edge of the list has this camera
+    const ba_cam* c0 = (c_meas && u0 < u1) ? cams + e_cam[c_edges[u0]] : nullptr;
     for (int u = u0 + tid; u < u1; u += 256) {
-        const int e = c_edges[u];
-        const ba_cam* c = cams + e_cam[e];
-        const double* X = pts + 3 * (size_t)e_pt[e];
+        const int e = c_meas ? 0 : c_edges[u];
+        const ba_cam* c = c_meas ? c0 : cams + e_cam[e];
+        const double* X = pts + 3 * (size_t)(c_meas ? c_pt[u] : e_pt[e]);
         double er[2], Jc[12], Jp[6], r0, r1;
-        d_edge_error(c->w2i, X, e_meas + 2 * e, er);
+        d_edge_error(c->w2i, X, c_meas ? c_meas + 2 * (size_t)u : e_meas + 2 * e, er);
         d_edge_jac(c->w2n, c->dR, c->t, X, K, Jc, Jp);
         d_huber(er[0] * er[0] + er[1] * er[1], delta, &r0, &r1);
         int k = 0;
@@ -574,10 +580,11 @@ __global__ __launch_bounds__(256) void k_ba_linearize(int nbp, const ba_cam* __r
                                                       const int* __restrict__ c_start, const int* __restrict__ c_edges, int Pa, ba_K K, double delta,
                                                       double* __restrict__ Hpl, double* __restrict__ Hll, double* __restrict__ bl,
                                                       double* __restrict__ err, double* __restrict__ chi_e, double* __restrict__ pdiag,
-                                                      double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ cdiag)
+                                                      double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ cdiag,
+                                                      const int* __restrict__ c_pt, const double* __restrict__ c_meas)
 {
     if ((int)blockIdx.x < nbp) ba_point_body(blockIdx.x, cams, pts, e_cam, e_meas, cslot, p_start, p_edges, Pa, K, delta, Hpl, Hll, bl, err, chi_e, pdiag);
-    else ba_cam_body(blockIdx.x - nbp, cams, pts, e_cam, e_pt, e_meas, c_start, c_edges, K, delta, Hpp, bp, cdiag);
+    else ba_cam_body(blockIdx.x - nbp, cams, pts, e_cam, e_pt, e_meas, c_start, c_edges, K, delta, Hpp, bp, cdiag, c_pt, c_meas);
 }
 
 #define BA_NPART 256
@@ -947,11 +954,15 @@ __global__ __launch_bounds__(SR_T) void k_ba_schur_row(const int* __restrict__ r
 
 // join_slot[t] = position of join entry t's first edge inside its camera's c_edges list (the LDS slot k_ba_schur_row stages it in);
 // row_start[s] = first pair of row s in the (s1, s2)-sorted pair list.  Once per problem.
-__global__ void k_ba_schur_rank(const int* __restrict__ c_start, const int* __restrict__ c_edges, const int* __restrict__ e_pt, int Cf, int* __restrict__ e_rank,
-                                int* __restrict__ c_pt)
+__global__ void k_ba_schur_rank(const int* __restrict__ c_start, const int* __restrict__ c_edges, const int* __restrict__ e_pt, const double* __restrict__ e_meas,
+                                int Cf, int* __restrict__ e_rank, int* __restrict__ c_pt, double* __restrict__ c_meas)
 {
     const int s = blockIdx.x;
-    for (int u = c_start[s] + threadIdx.x; u < c_start[s + 1]; u += 256) { const int e = c_edges[u]; e_rank[e] = u - c_start[s]; c_pt[u] = e_pt[e]; }
+    for (int u = c_start[s] + threadIdx.x; u < c_start[s + 1]; u += 256) {
+        const int e = c_edges[u];
+        e_rank[e] = u - c_start[s]; c_pt[u] = e_pt[e];
+        c_meas[2 * (size_t)u] = e_meas[2 * (size_t)e]; c_meas[2 * (size_t)u + 1] = e_meas[2 * (size_t)e + 1];
+    }
 }
 __global__ void k_ba_schur_rows(const int2* __restrict__ pairs, int npairs, int Cf, const int2* __restrict__ join, const int* __restrict__ e_rank, long long M,
                                 const int* __restrict__ e_cam, int* __restrict__ row_start, int* __restrict__ join_slot)
@@ -2795,7 +2806,7 @@ extern "C" void bh_ba_destroy(bh_ba* ba)
     bh_buf* all[] = { &ba->cams[0], &ba->cams[1], &ba->pts[0], &ba->pts[1], &ba->e_cam, &ba->e_pt, &ba->e_meas, &ba->cslot,
                       &ba->p_start, &ba->p_edges, &ba->c_start, &ba->c_edges, &ba->err[0], &ba->err[1], &ba->chi_e[0],
                       &ba->chi_e[1], &ba->Hpl, &ba->Hll, &ba->bl, &ba->Hpp, &ba->bp, &ba->pdiag, &ba->cdiag, &ba->Dinv,
-                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch, &ba->join, &ba->j_start, &ba->pair_rec, &ba->join_pt, &ba->row_start, &ba->join_slot, &ba->c_pt };
+                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch, &ba->join, &ba->j_start, &ba->pair_rec, &ba->join_pt, &ba->row_start, &ba->join_slot, &ba->c_pt, &ba->c_meas };
     for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     if (ba->h_state) (void)hipHostFree(ba->h_state);
     delete ba->bcr;
@@ -4181,14 +4192,17 @@ static int ba_set_problem_rest(bh_ba* ba, int C, const double* R, const double* 
             BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(int) * (size_t)(E > 0 ? E : 1)));
             int* e_rank = (int*)ctx->st_a.p;
             BH_HIP(ctx, hipMemsetAsync((int*)ba->row_start.p + Cf + 1, 0, sizeof(int), ctx->stream));
-            hipLaunchKernelGGL(k_ba_schur_rank, dim3(Cf), dim3(256), 0, ctx->stream, (const int*)ba->c_start.p, (const int*)ba->c_edges.p, (const int*)ba->e_pt.p, Cf, e_rank,
-                               (int*)ba->c_pt.p);
+            BH_TRY(bh_reserve(ctx, &ba->c_meas, sizeof(double) * 2 * (size_t)(E > 0 ? E : 1)));
+            hipLaunchKernelGGL(k_ba_schur_rank, dim3(Cf), dim3(256), 0, ctx->stream, (const int*)ba->c_start.p, (const int*)ba->c_edges.p, (const int*)ba->e_pt.p,
+                               (const double*)ba->e_meas.p, Cf, e_rank, (int*)ba->c_pt.p, (double*)ba->c_meas.p);
+            ba->cam_major = 1;
             hipLaunchKernelGGL(k_ba_schur_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const int2*)ba->pairs.p, ba->npairs, Cf, (const int2*)ba->join.p,
                                (const int*)e_rank, (long long)bo.M, (const int*)ba->e_cam.p, (int*)ba->row_start.p, (int*)ba->join_slot.p);
             BH_HIP(ctx, hipGetLastError());
             (void)hipFuncSetAttribute((const void*)k_ba_schur_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 18 * SR_CAP));
         }
     } else ba->schur_row = 0;
+    if (!ba->schur_row) ba->cam_major = 0;
     BH_TRY(bh_reserve(ctx, &ba->state, sizeof(ba_state)));
     if (ba->ar) {                                          // the band must be the same everywhere: max over ranks
         double v = (double)bwb;
@@ -4351,7 +4365,8 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
         {
             const int nbp = (Pa * BP_G + 255) / 256;
             BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_ba_linearize, dim3(nbp + Cf), dim3(256), st, nbp, cams, pts, e_cam, e_pt, e_meas, cslot, p_start, p_edges,
-                      c_start, c_edges, Pa, ba->K, huber_delta, Hpl, Hll, bl, (double*)ba->err[0].p, (double*)ba->chi_e[0].p, pdiag, Hpp, bp, cdiag);
+                      c_start, c_edges, Pa, ba->K, huber_delta, Hpl, Hll, bl, (double*)ba->err[0].p, (double*)ba->chi_e[0].p, pdiag, Hpp, bp, cdiag,
+                      ba->cam_major ? (const int*)ba->c_pt.p : (const int*)nullptr, ba->cam_major ? (const double*)ba->c_meas.p : (const double*)nullptr);
         }
         if (dist && Cf) {                                  // Hpp, bp: partial over this rank's edges -> full on every rank
             BH_TRY(ba_allreduce(ba, Hpp, 36LL * Cf, 0)); BH_TRY(ba_allreduce(ba, bp, n6, 0));
