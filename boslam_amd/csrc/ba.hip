@@ -169,6 +169,12 @@ template <int M> __device__ __forceinline__ int i_xor_dpp(int x)
     else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4e, 0xf, 0xf, false);                    // quad_perm [2,3,0,1]
     else return __builtin_amdgcn_update_dpp(0, x, 0xb1, 0xf, 0xf, false);                                          // quad_perm [1,0,3,2]
 }
+// value of lane M of the lane's quad (DPP quad_perm [M, M, M, M])
+template <int M> __device__ __forceinline__ double d_quad_bcast(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), M * 0x55, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), M * 0x55, 0xf, 0xf, false));
+}
 template <int M> __device__ __forceinline__ double d_xor_dpp(double v)
 {
     return __hiloint2double(i_xor_dpp<M>(__double2hiint(v)), i_xor_dpp<M>(__double2loint(v)));
@@ -1224,10 +1230,11 @@ __device__ __forceinline__ void ba_chol_dense_body(const double* __restrict__ A_
     const int NT = (n + 15) >> 4, T = NT * (NT - 1) / 2, LD = bw + 1;
 #ifdef CD_CLOCKS                                     // phase clocks of the panel wave (tools/chol_clocks.py; build ba.hip with -DCD_CLOCKS)
     const long long tk0 = wall_clock64();
-    long long tkA = 0, tkB = 0, tkW = 0, tkF = 0;
+    long long tkA = 0, tkB = 0, tkW = 0, tkF = 0, tkF1 = 0, tkF2 = 0;
 #endif
     if (tid == 0) { s_fail = St->chol_ok ? 0 : 1; s_flag = 0; }
     for (int i = tid; i < NT * 16; i += 1024) sy[i] = i < n ? bs[i] : 0.0;
+    for (int i = tid; i < NT * CD_TILE; i += 1024) Li[i] = 0.0;      // the blocked inverse writes the lower blocks only
     for (int e = tid; e < NT * 256; e += 1024) {      // diagonal tiles: lower part, identity padding
         const int j = e >> 8, rr = (e >> 4) & 15, cc = e & 15, r = 16 * j + rr, c = 16 * j + cc;
         double v = 0.0;
@@ -1275,19 +1282,53 @@ __device__ __forceinline__ void ba_chol_dense_body(const double* __restrict__ A_
                     row[c2] = rl >= c2 ? __builtin_fma(-lc, l2, row[c2]) : row[c2];
                 }
             }
-            // inverse of the lower-triangular factor, column rl per lane: X[i] = (delta_i,rl - sum_{k<i} L[i][k] X[k]) / L[i][i]
-            double X[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                double s2 = i == rl ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < i; k++) s2 = __builtin_fma(-d_readlane(row[k], i), X[k], s2);
-                X[i] = i >= rl ? s2 * d_readlane(myinv, i) : 0.0;
-            }
+#ifdef CD_CLOCKS
+            const long long f1 = wall_clock64(); tkF1 += f1 - f0;
+#endif
+            // Inverse of the lower-triangular factor, on all 64 lanes in 4 x 4 blocks (round 4; column rl per lane by forward substitution was
+            // 120 dependent fused multiply-adds fed by 240 v_readlane on 16 lanes: half of the panel wave's time per tile).  X[p][c] =
+            // -(1 / L[p][p]) sum_{q < p} L[p][q] X[q][c], X[c][c] = 1 / L[c][c].  L and the reciprocal diagonal go to LDS (the diagonal tile's own
+            // slot: the tile waves read Linv only).  Step d = 0..3 makes the blocks (g + d, g), g = lane >> 4: lane = (column c of the block,
+            // row r of the block) with the four rows of a column in one quad - the part of the sum over rows ABOVE the block comes from LDS
+            // (results of the earlier steps), the part inside the block runs down the quad through DPP quad broadcasts.
+            double* Lt = Dg + J * CD_TILE; double* Xt = Li + J * CD_TILE;
             if (lane < 16) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) Li[J * CD_TILE + i * CD_P + rl] = X[i];
+                for (int k = 0; k < 16; k++) Lt[rl * CD_P + k] = row[k];
+                sz[rl] = myinv;
             }
+            CD_WAVE_SYNC();
+            {
+                const int g4 = lane >> 4, cq = (lane >> 2) & 3, rq = lane & 3;
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const int bi = g4 + d, bj = g4;
+                    const bool act = bi < 4;
+                    const int pp = act ? 4 * bi + rq : 0, colx = 4 * bj + cq;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4 * d; q++) acc = __builtin_fma(Lt[pp * CD_P + 4 * bj + q], Xt[(4 * bj + q) * CD_P + colx], acc);
+                    const double ip = sz[pp];
+                    double Lm[3];
+#pragma unroll
+                    for (int m = 0; m < 3; m++) Lm[m] = Lt[pp * CD_P + 4 * (act ? bi : 0) + m];
+                    double xv = 0.0;
+#define CD_INV_STEP(m)                                                                                                     \
+                    {                                                                                                          \
+                        const double cand = d == 0 ? (rq == cq ? ip : (rq > cq ? -ip * acc : 0.0)) : -ip * acc;                \
+                        const double xm = d_quad_bcast<m>(cand);                                                               \
+                        xv = rq == m ? cand : xv;                                                                              \
+                        if (m < 3) acc = rq > m ? __builtin_fma(Lm[m < 3 ? m : 0], xm, acc) : acc;                             \
+                    }
+                    CD_INV_STEP(0) CD_INV_STEP(1) CD_INV_STEP(2) CD_INV_STEP(3)
+#undef CD_INV_STEP
+                    if (act) Xt[pp * CD_P + colx] = xv;
+                    CD_WAVE_SYNC();
+                }
+            }
+#ifdef CD_CLOCKS
+            tkF2 += wall_clock64() - f1;
+#endif
             if (bad && lane == 0) s_fail = 1;
             CD_WAVE_SYNC();
             // y_J = Linv y_J (row rl of Linv through LDS)
@@ -1453,7 +1494,7 @@ __device__ __forceinline__ void ba_chol_dense_body(const double* __restrict__ A_
     if (s_fail) { if (tid == 0) St->chol_ok = 0; for (int i = tid; i < n; i += 1024) x[i] = 0; return; }
     for (int i = tid; i < n; i += 1024) x[i] = sx[i];
 #ifdef CD_CLOCKS
-    if (tid == 0) { St->dbg[0] = tkA - tk0; St->dbg[1] = tkB - tkA; St->dbg[2] = wall_clock64() - tkB; St->dbg[3] = tkW; St->dbg[4] = tkF; }
+    if (tid == 0) { St->dbg[0] = tkA - tk0; St->dbg[1] = tkB - tkA; St->dbg[2] = wall_clock64() - tkB; St->dbg[3] = tkW; St->dbg[4] = tkF; St->dbg[5] = tkF1; St->dbg[6] = tkF2; }
 #endif
 #undef CD_A
 }
