@@ -726,19 +726,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // Every lane loads from an address clamped into its row (level base + 32-bit offset: scalar base + vector offset form, no 64-bit
     // multiply per load, no predicate): a word further than 8 px beyond the border is never read with a non-zero weight, the words that
     // straddle the border are overwritten by the fix lanes below.
+    // Buffer loads (round 4): the lane's row x pitch + column is ONE 24-bit multiply-add, the step of seven rows per load rides in the scalar
+    // offset - as flat loads the compiler formed every address with a 64-bit multiply-add, a move and a 64-bit add (18 of them, the 64-bit
+    // multiply at a quarter of the rate, in a kernel that is bound by vector issue).
     const uint32_t xwc = (uint32_t)min(max(x0 - 4 + 4 * lc, 0), L.pitch - 4);
+    const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, 0x7fffffff, 0x00020000);
     if (yin) {
-        const uint8_t* org = img + (uint32_t)((y0 - 4) * L.pitch);
+        const int vo = (int)(__umul24((uint32_t)(y0 - 4 + lr0), (uint32_t)L.pitch) + xwc);
 #pragma unroll
         for (int j = 0; j < NLD; j++) {
-            const int r = min(lr0 + 7 * j, FPX_H - 1);
-            pw[j] = *reinterpret_cast<const uint32_t*>(org + ((uint32_t)(r * L.pitch) + xwc));
+            if (7 * (NLD - 1) + 6 < FPX_H || j < NLD - 1) pw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_img, vo, 7 * j * L.pitch, 0);
+            else pw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_img, (int)(__umul24((uint32_t)(y0 - 4 + min(lr0 + 7 * j, FPX_H - 1)), (uint32_t)L.pitch) + xwc), 0, 0);
         }
     } else
 #pragma unroll
     for (int j = 0; j < NLD; j++) {
         const int ry = reflect101(y0 - 4 + lr0 + 7 * j, L.h);
-        pw[j] = *reinterpret_cast<const uint32_t*>(img + ((uint32_t)(ry * L.pitch) + xwc));
+        pw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_img, (int)(__umul24((uint32_t)ry, (uint32_t)L.pitch) + xwc), 0, 0);
     }
     // The words that straddle or lie just beyond the left / right border (one on the left, at most three on the right, per row) are
     // gathered byte by byte with reflection - by 160 dedicated lanes, once: as a branch of the loop above, every wave of a border tile
@@ -982,12 +986,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         {   // whole 128-byte row segments; tile base in scalar registers, one 32-bit offset per lane
             const int wd = tid & 31, r0 = tid >> 5;
             uint8_t* bt = blur + fbase + (uint32_t)(y0 * L.pitch + x0);
+            const __amdgpu_buffer_rsrc_t rs_bt = __builtin_amdgcn_make_buffer_rsrc(bt, 0, 0x7fffffff, 0x00020000);
             const bool xin = x0 + 4 * wd < L.w;
-            const uint32_t o0 = (uint32_t)(r0 * L.pitch + 4 * wd);
+            const int o0 = (int)(__umul24((uint32_t)r0, (uint32_t)L.pitch) + 4u * (uint32_t)wd);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int row = r0 + 8 * k;
-                if (xin && y0 + row < L.h) *reinterpret_cast<uint32_t*>(bt + (o0 + (uint32_t)(8 * k * L.pitch))) = s_o[row * 33 + wd];
+                if (xin && y0 + row < L.h) __builtin_amdgcn_raw_buffer_store_b32(s_o[row * 33 + wd], rs_bt, o0, 8 * k * L.pitch, 0);
             }
         }
     }
