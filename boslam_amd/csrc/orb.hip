@@ -1120,8 +1120,10 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     __shared__ int s_thr, s_m, s_kept;
 
     const int tid = threadIdx.x;
-    const int level = blockIdx.x;
-    const size_t f = blockIdx.y;
+    // frames along x (the fast launch index): with levels along x and eight levels, workgroup b lands on XCD b mod 8 = its LEVEL - one XCD had every
+    // level-0 list (a third of all candidates, the largest images) and another only the smallest
+    const int level = blockIdx.y;
+    const size_t f = blockIdx.x;
     const size_t fb = f * g.pyr_stride;
     const bh_level_geom L = g.lv[level];
     const int n2 = 2 * L.nfeat;
@@ -1801,7 +1803,7 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         BH_LAUNCH(ctx, BH_K_FAST, k_fast, dim3(g.ntiles, nb), dim3(256), st, pyr, mpyr, clist, ccnt, blur, g,
                   (const uint32_t*)ctx->tab.p + g.tab_len + 4, (uint32_t*)ctx->status.p, (const uint32_t*)mbits,
                   (const uint32_t*)ctx->tab.p + align_up(g.tab_len + 4 + g.ntiles + 64, 4));
-        BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(g.nlevels, nb), dim3(SEL_T), st, pyr, clist, ccnt, g, sel_cap, (uint32_t*)Wk.sel_xy.p,
+        BH_LAUNCH(ctx, BH_K_SELECT, k_select, dim3(nb, g.nlevels), dim3(SEL_T), st, pyr, clist, ccnt, g, sel_cap, (uint32_t*)Wk.sel_xy.p,
                   (float*)Wk.sel_resp.p, (int*)Wk.sel_cnt.p, (uint32_t*)ctx->status.p);
         BH_LAUNCH(ctx, BH_K_BRIEF, k_describe, dim3(8 * ((max_kp + 3) / 4) * ((nb + 8 * DS_KPW - 1) / (8 * DS_KPW))), dim3(256), st, pyr, blur, g,
                   (const uint32_t*)ctx->tab.p + g.tab_len + 4 + g.ntiles, (float)params->patchSize, sel_cap, max_kp, nb, (const uint32_t*)Wk.sel_xy.p, (const float*)Wk.sel_resp.p,
