@@ -704,11 +704,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
 
     const int tid = threadIdx.x;
-    const uint32_t tt = tile_tab[blockIdx.x];                   // level | tile column << 4 | tile row << 16 (host-built: no per-wave level search / division)
+    // Which (tile, frame): workgroups b and b + 8 of the launch order share an XCD (observed placement; speed only).  The tiles of ONE frame go to
+    // workgroups of equal b mod 8, in consecutive launch positions: x-adjacent tiles read the two halves of the same 128-B lines (a tile row is 134
+    // bytes at any alignment) and y-adjacent ones share six halo rows - dealt tile by tile over the XCDs every such line was fetched into two or three L2s.
+    int ti = blockIdx.x, frame = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, grp = lin / (8 * (int)gridDim.x), r = lin - grp * 8 * (int)gridDim.x;
+        frame = grp * 8 + (r & 7); ti = r >> 3;
+    }
+    const uint32_t tt = tile_tab[ti];                           // level | tile column << 4 | tile row << 16 (host-built: no per-wave level search / division)
     const int level = tt & 15;
     const bh_level_geom L = g.lv[level];
     const int x0 = (int)((tt >> 4) & 0xfffu) * TILE_W, y0 = (int)(tt >> 16) * TILE_H;
-    const int frame = blockIdx.y;
     const size_t fbase = (size_t)frame * g.pyr_stride + L.off;
     const uint8_t* img = pyr + fbase;
 
