@@ -350,7 +350,7 @@ def run_rank(args):
                                "frames_per_gpu": B, "mean_kp_per_frame": float(n_kp.mean()),
                                "mean_matches_per_pair": float(n_match[1:].mean()) if B > 1 else 0.0,
                                "pairs_matched_per_step": pairs_total,
-                               "pipelines_per_gpu": args.pipelines or int(os.environ.get("BH_ORB_PIPELINES", "4")),
+                               "pipelines_per_gpu": args.pipelines or int(os.environ.get("BH_ORB_PIPELINES", "2")),      # the library's default (orb.hip: pipe_cfg)
                                "parallelism": f"frames sharded x{world}, one-descriptor-row halo to the next rank, no collective"},
                     "roofline": roofline})
         if args.cpu_sample > 0 and world == 1:                # cpu_baseline: rank 0 at N=1 only
