@@ -160,3 +160,28 @@ def test_config2_full_size_batch(ctx):
     for i in (1, 500, 999):                                               # and the matcher against the oracle on a few pairs
         oq, ot, od = oracle.match_crosscheck(desc[i, :n[i]], desc[i - 1, :n[i - 1]])
         assert np.array_equal(qi[i, :nm[i]], oq) and np.array_equal(ti[i, :nm[i]], ot) and np.array_equal(dd[i, :nm[i]], od)
+
+
+@pytest.mark.parametrize("B", [9, 21, 141])
+def test_ragged_batches_do_not_depend_on_the_launch_mapping(ctx, B):
+    """Batch sizes that are not multiples of eight (the kernels tie frames to XCDs by launch index when they are, and fall back when not;
+    k_describe's frame-per-step layout leaves part of its last wave empty): every frame's keypoints and descriptors equal those of the
+    same image run alone, through the host path and through the HBM-resident path (141 = one full 128-frame chunk + a ragged one)."""
+    import torch
+    nd = 5
+    bgr, depth = synth.render_batch(nd)
+    params = frontend.make_params(nfeatures=600)
+    ref = []
+    for f in range(nd):
+        k1, d1, n1 = frontend.orb_detect_describe(ctx, bgr[f:f + 1], depth=depth[f:f + 1], params=params)
+        ref.append((k1[0, :n1[0]].tobytes(), d1[0, :n1[0]].copy(), int(n1[0])))             # (rows beyond n_kp are not written)
+    pick = (np.arange(B) * 3 + 1) % nd
+    big_bgr = np.ascontiguousarray(bgr[pick]); big_depth = np.ascontiguousarray(depth[pick])
+    kps, desc, n = frontend.orb_detect_describe(ctx, big_bgr, depth=big_depth, params=params)
+    for i, f in enumerate(pick):
+        assert n[i] == ref[f][2] and np.array_equal(desc[i, :n[i]], ref[f][1]) and kps[i, :n[i]].tobytes() == ref[f][0], (i, f)
+    fe = frontend.DeviceFrontEnd(ctx, B, 480, 640, params)
+    fe.run(torch.from_numpy(big_bgr).cuda(), torch.from_numpy(big_depth.view(np.int16)).cuda())
+    torch.cuda.synchronize(); ctx.synchronize(); ctx.status()
+    dn = fe.n_kp.cpu().numpy(); dd = fe.desc.cpu().numpy()
+    assert np.array_equal(dn, n) and all(np.array_equal(dd[i, :n[i]], desc[i, :n[i]]) for i in range(B))
