@@ -415,8 +415,9 @@ def run_rank(args):
             lo = trk.lm["out"]; st2 = lo["status"][1:].cpu().numpy()
             r["local_map_chain"] = {"frames_per_s": round(B * 5 / el2, 1), "ms_per_step": round(el2 / 5 * 1e3, 3), "frames": B, "candidates_per_frame": 2 * m_,
                                     "stages": "the chain above -> visibility gate over the local map -> gather of the survivors' descriptors / points -> match `<= 30` -> "
-                                              "CamOnlyBA -> >= 15 inliers (Tracker.update's two tracking stages, no host hop)",
-                                    "tracked_frames": int((st2 == 0).sum()), "mean_gated": float(lo["n_gate"][1:].float().mean().item()),
+                                              "CamOnlyBA -> >= 15 inliers (Tracker.update's two tracking stages, no host hop; a frame the first stage lost is skipped, "
+                                              "slam/tracking.py:205-212)",
+                                    "tracked_frames": int((st2 == 0).sum()), "skipped_after_stage1": int((st2 == 5).sum()), "mean_gated": float(lo["n_gate"][1:].float().mean().item()),
                                     "mean_matches": float(lo["n_match"][1:].float().mean().item()), "mean_inliers": float(lo["n_inlier"][1:].float().mean().item())}
             del trk
             if rank == 0:

@@ -50,7 +50,7 @@ _SIGS = {
     "bh_pose_graph_optimize": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, C.POINTER(_i), C.POINTER(_i)]),
     "bh_loop_fuse_pairs": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _i, _i]),
     "bh_kf_add_map_points": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _i]),
-    "bh_track_local_map": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _i, _i, _i, _vp, _i, _d, _d,
+    "bh_track_local_map": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _i, _i, _i, _vp, _i, _d, _d,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     "bh_align_se3_ransac": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _i]),
     "bh_ba_create": (_i, [_vp, _vp, C.POINTER(_vp)]),

@@ -339,7 +339,9 @@ __global__ __launch_bounds__(KFA_T) void k_kf_add(int kf_id, double t0, double t
             nrm = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
             valid = nrm > 0.0;
             id = des2mp[i];
-            create = valid && (id < 0 || id >= cap || !alive[id]);
+            // id >= next_id cannot be a map point of the caller's map (ids come from the counter): "not in self.mps", whatever rows earlier
+            // chunks of THIS call have just made alive - the verdict must not depend on the chunk size
+            create = valid && (id < 0 || id >= next_id || id >= cap || !alive[id]);
         }
         const unsigned long long bm = __ballot(create);
         const int before = __popcll(bm & ((1ull << lane) - 1ull));

@@ -150,14 +150,22 @@ extern "C" int bh_track_refkf(bh_ctx* ctx, const uint8_t* q_desc, const int* nq,
 // candidates -> ordered gather of the survivors' medoid descriptors and points into the matcher's train layout -> the chain of
 // bh_track_refkf with the `<=` distance test of :121 -> the candidate index of every match (what ids_matching_mps[inds] needs).
 
-// see_vector of a frame whose pose has just been set (camera.py:26-29 on a fresh Frame: R (0, 0, 1) normalised)
-__global__ void k_tlm_see(const double* __restrict__ R, double* __restrict__ see, int B)
+// see_vector of a frame whose pose has just been set (camera.py:26-29 on a fresh Frame: R (0, 0, 1) normalised), and the candidate count
+// the gate works on: Tracker.update runs _track_local_map only `if is_ok` (slam/tracking.py:205-212) - a frame whose first stage did not
+// return BH_TRACK_OK gets zero candidates (nothing is gated, matched or optimised for it) and the verdict BH_TRACK_SKIPPED
+__global__ void k_tlm_prep(const double* __restrict__ R, double* __restrict__ see, const int* __restrict__ stage1, const int* __restrict__ M,
+                           int* __restrict__ M_eff, int B)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const double x = R[9 * b + 2], y = R[9 * b + 5], z = R[9 * b + 8];
-    const double n = sqrt(x * x + y * y + z * z);
-    see[3 * b] = x / n; see[3 * b + 1] = y / n; see[3 * b + 2] = z / n;
+    const bool run = !stage1 || stage1[b] == BH_TRACK_OK;
+    M_eff[b] = run ? M[b] : 0;
+    if (see) {
+        const double x = R[9 * b + 2], y = R[9 * b + 5], z = R[9 * b + 8];
+        const double n = sqrt(x * x + y * y + z * z);
+        const bool ok = run && n > 0.0;                            // a skipped frame's R may still be all zero
+        see[3 * b] = ok ? x / n : 0.0; see[3 * b + 1] = ok ? y / n : 0.0; see[3 * b + 2] = ok ? z / n : 1.0;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_tlm_gather(const int* __restrict__ gate_idx, const int* __restrict__ n_gate, int m_stride,
@@ -176,16 +184,19 @@ __global__ __launch_bounds__(256) void k_tlm_gather(const int* __restrict__ gate
 
 __global__ __launch_bounds__(256) void k_tlm_finish(const int* __restrict__ gate_idx, const int* __restrict__ n_gate, int m_stride,
                                                     const int* __restrict__ tidx, const int* __restrict__ n_match, int out_stride,
-                                                    int* __restrict__ cand, int* __restrict__ status)
+                                                    const int* __restrict__ stage1, int* __restrict__ cand, int* __restrict__ status)
 {
     const size_t b = blockIdx.x;
     const int n = min(n_match[b], out_stride);
     for (int i = threadIdx.x; i < n; i += 256) cand[b * out_stride + i] = gate_idx[b * m_stride + tidx[b * out_stride + i]];
-    if (threadIdx.x == 0 && n_gate[b] == 0) status[b] = BH_TRACK_NO_CANDIDATES;       // `if len(feats) == 0: return False` (:116-117)
+    if (threadIdx.x == 0) {
+        if (stage1 && stage1[b] != BH_TRACK_OK) status[b] = BH_TRACK_SKIPPED;         // `if is_ok:` around the call (:205-212)
+        else if (n_gate[b] == 0) status[b] = BH_TRACK_NO_CANDIDATES;                  // `if len(feats) == 0: return False` (:116-117)
+    }
 }
 
 extern "C" int bh_track_local_map(bh_ctx* ctx, const uint8_t* q_desc, const int* nq, const int64_t* q_xy, int q_stride,
-                                  const double* R_in, const double* t_in, const double* see,
+                                  const double* R_in, const double* t_in, const double* see, const int* stage1_status,
                                   const double* mp_pts, const double* mp_normals, const uint8_t* mp_feat, const int* M, int m_stride, int B,
                                   int width, int height, double cos_thr, int d_max, int min_matches, int min_inliers,
                                   const double K[5], int iters, double huber_delta, double chi2_thr,
@@ -203,18 +214,20 @@ extern "C" int bh_track_local_map(bh_ctx* ctx, const uint8_t* q_desc, const int*
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t nm = (size_t)B * m_stride, no = (size_t)B * out_stride, nqs = (size_t)B * q_stride;
     // workspace: gathered train descriptors / points, the see vectors when the caller leaves them to the pose
-    BH_TRY(bh_reserve(ctx, &ctx->tl_w, al(nm * 32) + al(sizeof(double) * 3 * nm) + al(sizeof(double) * 3 * B)));
+    BH_TRY(bh_reserve(ctx, &ctx->tl_w, al(nm * 32) + al(sizeof(double) * 3 * nm) + al(sizeof(double) * 3 * B) + al(sizeof(int) * B)));
     char* wp = (char*)ctx->tl_w.p;
     uint8_t* g_desc = (uint8_t*)wp; wp += al(nm * 32);
     double* g_pts = (double*)wp; wp += al(sizeof(double) * 3 * nm);
-    double* d_see_w = (double*)wp;
+    double* d_see_w = (double*)wp; wp += al(sizeof(double) * 3 * B);
+    int* d_Meff = (int*)wp;
+    const int* d_s1 = stage1_status;
     const uint8_t* d_q = q_desc; const int* d_nq = nq; const long long* d_xy = (const long long*)q_xy; const double* d_Ri = R_in; const double* d_ti = t_in;
     const double* d_see = see; const double* d_mp = mp_pts; const double* d_mn = mp_normals; const uint8_t* d_mf = mp_feat; const int* d_M = M;
     int *d_gi = gate_idx, *d_ng = n_gate, *d_qi = qidx, *d_ti2 = tidx, *d_ca = cand, *d_di = dist, *d_nm = n_match, *d_ni = n_inlier, *d_st = status;
     double *d_R = R, *d_t = t; uint8_t* d_in = inlier;
     if (mem == BH_MEM_HOST) {
         for (int b = 0; b < B; b++) if (nq[b] < 0 || nq[b] > q_stride || M[b] < 0 || M[b] > m_stride) return bh_set_err(ctx, BH_ERR_INVALID, "bh_track_local_map: count outside [0, stride]");
-        const size_t in_b = al(nqs * 32) + al(sizeof(long long) * 2 * nqs) + al(sizeof(int) * 2 * B) + al(sizeof(double) * 15 * B) + 2 * al(sizeof(double) * 3 * nm) + al(nm * 32);
+        const size_t in_b = al(nqs * 32) + al(sizeof(long long) * 2 * nqs) + al(sizeof(int) * 3 * B) + al(sizeof(double) * 15 * B) + 2 * al(sizeof(double) * 3 * nm) + al(nm * 32);
         const size_t out_b = al(sizeof(int) * nm) + 4 * al(sizeof(int) * no) + 4 * al(sizeof(int) * B) + al(sizeof(double) * 12 * B) + al(no);
         BH_TRY(bh_reserve(ctx, &ctx->tl_in, in_b + out_b));
         char* ip = (char*)ctx->tl_in.p;
@@ -222,10 +235,11 @@ extern "C" int bh_track_local_map(bh_ctx* ctx, const uint8_t* q_desc, const int*
         char* p;
         if (!(p = up(q_desc, nqs * 32))) return bh_set_err(ctx, BH_ERR_HIP, "bh_track_local_map: upload failed"); d_q = (const uint8_t*)p;
         if (!(p = up(q_xy, sizeof(long long) * 2 * nqs))) return bh_set_err(ctx, BH_ERR_HIP, "bh_track_local_map: upload failed"); d_xy = (const long long*)p;
-        {   // nq and M side by side
-            char* d = ip; ip += al(sizeof(int) * 2 * B);
+        {   // nq, M and the first stage's verdicts side by side
+            char* d = ip; ip += al(sizeof(int) * 3 * B);
             BH_HIP(ctx, hipMemcpyAsync(d, nq, sizeof(int) * B, hipMemcpyHostToDevice, st)); BH_HIP(ctx, hipMemcpyAsync(d + sizeof(int) * B, M, sizeof(int) * B, hipMemcpyHostToDevice, st));
             d_nq = (const int*)d; d_M = d_nq + B;
+            if (stage1_status) { BH_HIP(ctx, hipMemcpyAsync(d + 2 * sizeof(int) * B, stage1_status, sizeof(int) * B, hipMemcpyHostToDevice, st)); d_s1 = d_M + B; }
         }
         {   // R, t, see
             double* d = (double*)ip; ip += al(sizeof(double) * 15 * B);
@@ -242,15 +256,16 @@ extern "C" int bh_track_local_map(bh_ctx* ctx, const uint8_t* q_desc, const int*
         d_R = (double*)ip; d_t = d_R + 9 * (size_t)B; ip += al(sizeof(double) * 12 * B);
         d_in = (uint8_t*)ip;
     }
-    if (!d_see) {                                                  // the frame's see_vector follows from the pose the first half has just set
-        hipLaunchKernelGGL(k_tlm_see, dim3((B + 63) / 64), dim3(64), 0, st, d_Ri, d_see_w, B);
-        d_see = d_see_w;
+    if (!d_see || d_s1) {                                          // the frame's see_vector follows from the pose the first half has just set
+        hipLaunchKernelGGL(k_tlm_prep, dim3((B + 63) / 64), dim3(64), 0, st, d_Ri, d_see ? (double*)nullptr : d_see_w, d_s1, d_M, d_Meff, B);
+        if (!d_see) d_see = d_see_w;
+        d_M = d_Meff;
     }
     BH_TRY(bh_visibility_gate(ctx, d_mp, d_mn, d_M, B, m_stride, d_Ri, d_ti, d_see, K[0], K[2], K[3], width, height, cos_thr, d_gi, d_ng, BH_MEM_DEVICE));
     BH_LAUNCH(ctx, BH_K_GATE, k_tlm_gather, dim3((m_stride + 255) / 256, B), dim3(256), st, (const int*)d_gi, (const int*)d_ng, m_stride, d_mf, d_mp, g_desc, g_pts);
     BH_TRY(bh_track_refkf(ctx, d_q, d_nq, (const int64_t*)d_xy, q_stride, g_desc, d_ng, g_pts, m_stride, B, d_max, 1, min_matches, min_inliers, K, iters, huber_delta, chi2_thr,
                           d_qi, d_ti2, d_di, d_nm, d_R, d_t, d_in, d_ni, d_st, out_stride, BH_MEM_DEVICE));
-    BH_LAUNCH(ctx, BH_K_GATE, k_tlm_finish, dim3(B), dim3(256), st, (const int*)d_gi, (const int*)d_ng, m_stride, (const int*)d_ti2, (const int*)d_nm, out_stride, d_ca, d_st);
+    BH_LAUNCH(ctx, BH_K_GATE, k_tlm_finish, dim3(B), dim3(256), st, (const int*)d_gi, (const int*)d_ng, m_stride, (const int*)d_ti2, (const int*)d_nm, out_stride, d_s1, d_ca, d_st);
     BH_HIP(ctx, hipGetLastError());
     if (mem == BH_MEM_HOST) {
         BH_HIP(ctx, hipMemcpyAsync(gate_idx, d_gi, sizeof(int) * nm, hipMemcpyDeviceToHost, st));

@@ -208,7 +208,9 @@ class DeviceTracker:
     def set_local_map(self, mp_pts, mp_normals, mp_feat, M):
         """Device tensors of the local map's candidates per frame, in the loop order of slam/tracking.py:97-99: mp_pts / mp_normals f64[B][Sm][3],
         mp_feat u8[B][Sm][32], M int32[B].  From then on run() chains Tracker._track_local_map (bh_track_local_map) behind the reference-keyframe
-        step of every frame i >= 1, on the pose that step produced - the whole of Tracker.update's two tracking stages without a host hop."""
+        step of every frame i >= 1, on the pose that step produced - the whole of Tracker.update's two tracking stages without a host hop.  As in
+        Tracker.update (`if is_ok:`, slam/tracking.py:205-212) a frame the first stage lost is not run: its local-map status is TRACK_SKIPPED, so
+        "tracked" = (lm status == TRACK_OK) needs no AND with the first stage's status."""
         torch, B, m, dev = self.torch, self.B, self.max_kp, mp_pts.device
         Sm = mp_pts.shape[1]
         o = dict(gate_idx=torch.zeros((B, Sm), dtype=torch.int32, device=dev), n_gate=torch.zeros((B,), dtype=torch.int32, device=dev))
@@ -219,6 +221,8 @@ class DeviceTracker:
         o["R"] = torch.zeros((B, 9), dtype=torch.float64, device=dev); o["t"] = torch.zeros((B, 3), dtype=torch.float64, device=dev)
         o["inlier"] = torch.zeros((B, m), dtype=torch.uint8, device=dev)
         self.lm = dict(pts=mp_pts.contiguous(), nrm=mp_normals.contiguous(), feat=mp_feat.contiguous(), M=M.contiguous(), Sm=Sm, out=o)
+        # the tensors above were produced on torch's stream; run() reads them on the library's own (non-blocking) stream: order the two once, here
+        torch.cuda.current_stream(dev).synchronize()
 
     def run(self, bgr, depth):
         """Enqueues ORB, the back-projection and the B - 1 tracking problems; does not synchronise.  Pair i (frame i vs i-1) at row i."""
@@ -240,7 +244,8 @@ class DeviceTracker:
                 o = {k: v.data_ptr() + v.element_size() * (v.numel() // self.B) for k, v in lm["out"].items()}      # row 1 onwards
                 tracking.track_local_map_device(c, self.desc.data_ptr() + 32 * m, self.n_kp.data_ptr() + 4, self.kp_xy.data_ptr() + 16 * m, m,
                                                 self.R.data_ptr() + 72, self.t.data_ptr() + 24, None, lm["pts"].data_ptr() + 24 * Sm, lm["nrm"].data_ptr() + 24 * Sm,
-                                                lm["feat"].data_ptr() + 32 * Sm, lm["M"].data_ptr() + 4, Sm, self.B - 1, self.K, o, m, width=self.W, height=self.H)
+                                                lm["feat"].data_ptr() + 32 * Sm, lm["M"].data_ptr() + 4, Sm, self.B - 1, self.K, o, m,
+                                                stage1_status=self.status.data_ptr() + 4, width=self.W, height=self.H)
 
 
 def mp_add_observations(ctx, obs_desc, obs_cnt, n_obs, normal, feat, new_desc, new_n):

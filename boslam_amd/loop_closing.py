@@ -29,7 +29,8 @@ def similarity_transformation(ctx, kf, cand, d_hamming_max=30, iterations=200, i
     the loop with the end".  kf, cand: objects with .des (u8[N][32]) and .cloud_kp (f64[N][3], the back-projected keypoints of
     camera.py:90-118) - the current keyframe and the loop candidate loop_candidate_detection returned.  Their descriptors are matched as
     the tracker matches them (cross-check, `distance < d_hamming_max`, slam/tracking.py:56-57), the matched 3-D points are aligned by
-    bh_align_se3_ransac: cloud_kf ~ R cloud_cand + t.  Returns (R, t, n_inliers) or (None, None, 0) - too few matches / no consistent
+    bh_align_se3_ransac: cloud_kf ~ R cloud_cand + t (with the reference's map-frame cloud_kp this is the drift of the map between the two
+    keyframes, see GlobalMapManager; with camera-frame clouds it is the relative camera pose T_kf^-1 T_cand).  Returns (R, t, n_inliers) or (None, None, 0) - too few matches / no consistent
     alignment (a false BoW candidate)."""
     import numpy as np
     from . import frontend, align
@@ -100,11 +101,27 @@ class GlobalMapManager:
       local_ids   kf -> frame ids of kf's local window (CovisibilityGraph.get_local_map), excluded from the candidates
       map_points  kf -> (ids, feat u8[N][32], pt3d f64[N][3], n_obs int[N]) of the map points seen around kf (both ends of the loop)
       pose_graph  () -> (frame ids, R f64[K][3][3], t f64[K][3], fixed bool[K], ei, ej, Zr, Zt, w): the essential graph as it stands
-    update returns None when no loop is accepted, else dict(candidate, R, t, n_inliers, fused = [(survivor id, loser id)], poses = (ids, R, t))."""
+    update returns None when no loop is accepted, else dict(candidate, R, t, n_inliers, fused = [(survivor id, loser id)], poses = (ids, R, t)).
+
+    ONE convention for (R, t), the reference's data model: `cloud_kp` of a keyframe and `pt3d` of a map point are MAP-frame coordinates
+    (camera.py:32-35 `transform2global` rewrites cloud_kp with the frame's pose; slam/covisibility_graph.py:125-131 builds MapPoint.pt3d from
+    kf.cloud_kp), and a pose of pose_graph() is camera-in-map, p_map = R p_cam + t (the T of `Z ~ T_i^-1 T_j`).  The alignment of the two ends'
+    clouds is then the DRIFT of the map between them, cloud_kf ~ W cloud_cand with W = (R, t) near the identity: _loop_fusion compares map points
+    in that frame (|pt_a - (R pt_b + t)|), and the loop edge between the two CAMERAS is Z = T_kf^-1 W T_cand (a point the candidate's camera sees
+    at p lies at T_cand p in the candidate's part of the map, at W T_cand p in the current keyframe's part, at T_kf^-1 W T_cand p in its camera)."""
 
     def __init__(self, ctx, dbow, get_kf, local_ids, map_points, pose_graph, min_score=0.05, loop_weight=25.0):
         self.ctx, self.dbow, self.get_kf, self.local_ids, self.map_points, self.pose_graph = ctx, dbow, get_kf, local_ids, map_points, pose_graph
         self.min_score, self.loop_weight = min_score, loop_weight
+
+    @staticmethod
+    def loop_edge(R_kf, t_kf, R_cand, t_cand, R, t):
+        """Z = T_kf^-1 W T_cand as (Zr, Zt): the relative camera pose the drift W = (R, t) of the map between the loop's ends implies."""
+        import numpy as np
+        R_kf = np.asarray(R_kf, dtype=np.float64).reshape(3, 3); R_cand = np.asarray(R_cand, dtype=np.float64).reshape(3, 3)
+        t_kf = np.asarray(t_kf, dtype=np.float64).reshape(3); t_cand = np.asarray(t_cand, dtype=np.float64).reshape(3)
+        R = np.asarray(R, dtype=np.float64).reshape(3, 3); t = np.asarray(t, dtype=np.float64).reshape(3)
+        return R_kf.T @ R @ R_cand, R_kf.T @ (R @ t_cand + t - t_kf)
 
     def update(self, kf):
         import numpy as np
@@ -121,11 +138,13 @@ class GlobalMapManager:
         fused = [((ids_a[a], ids_b[b]) if k else (ids_b[b], ids_a[a])) for a, b, k in zip(pa, pb, ka)]
         ids, Rk, tk, fixed, ei, ej, Zr, Zt, w = self.pose_graph()
         ids = list(ids)
-        # the loop edge: candidate -> current keyframe.  cloud_kf ~ R cloud_cand + t relates the two CAMERA frames, i.e. T_kf^-1 T_cand = (R, t)
-        ei = list(ei) + [ids.index(kf.id)]; ej = list(ej) + [ids.index(fid)]
-        Zr = np.concatenate([np.asarray(Zr, dtype=np.float64).reshape(-1, 3, 3), np.asarray(R)[None]], 0)
-        Zt = np.concatenate([np.asarray(Zt, dtype=np.float64).reshape(-1, 3), np.asarray(t)[None]], 0)
+        Rk = np.asarray(Rk, dtype=np.float64).reshape(-1, 3, 3); tk = np.asarray(tk, dtype=np.float64).reshape(-1, 3)
+        i_kf, i_cand = ids.index(kf.id), ids.index(fid)
+        # the loop edge current keyframe -> candidate: the clouds are map-frame, so (R, t) is the map's drift W and Z = T_kf^-1 W T_cand
+        zr, zt = self.loop_edge(Rk[i_kf], tk[i_kf], Rk[i_cand], tk[i_cand], R, t)
+        ei = list(ei) + [i_kf]; ej = list(ej) + [i_cand]
+        Zr = np.concatenate([np.asarray(Zr, dtype=np.float64).reshape(-1, 3, 3), zr[None]], 0)
+        Zt = np.concatenate([np.asarray(Zt, dtype=np.float64).reshape(-1, 3), zt[None]], 0)
         w = list(w) + [self.loop_weight]
         Ro, to, log, kept, cg = essential_graph_optimization(self.ctx, Rk, tk, fixed, ei, ej, Zr, Zt, w)
-        return dict(candidate=fid, score=score, R=R, t=t, n_inliers=n_inl, fused=fused, poses=(ids, Ro, to), cost_log=log)
-
+        return dict(candidate=fid, score=score, R=R, t=t, n_inliers=n_inl, fused=fused, poses=(ids, Ro, to), cost_log=log, loop_edge=(zr, zt))

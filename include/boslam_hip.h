@@ -141,6 +141,8 @@ int bh_mp_add_observation(bh_ctx* ctx, int M, uint8_t* obs_desc, int* obs_cnt, i
  * obs_cnt / n_obs / first_kf int[cap].  action int[N]: 0 = skipped (|n| == 0), 1 = created, 2 = observed - what add_edge_to_cg (:136)
  * and KeyFrame.make_mp2kp (nodes.py:36-39: {des2mp[i]: kp_arr[i]}) need, both of which stay with the host's graph.
  * *n_created: the new map points (the caller's next MapPoint.cnt = next_id + *n_created).  BH_ERR_CAPACITY when the table is full.
+ * Precondition (both memory modes; device arrays are not validated): des2mp[i] is -1 or an id the map has handed out, i.e. < next_id.  An entry
+ * >= next_id counts as "not in self.mps" and creates a map point, independent of the rows this call itself creates.
  * BH_MEM_HOST copies the whole table up and back (tests, small maps); the live use keeps the table in HBM (BH_MEM_DEVICE). */
 int bh_kf_add_map_points(bh_ctx* ctx, int kf_id, const double frame_t[3], int N, const uint8_t* des, const double* cloud_kp, int* des2mp,
                          int cap, int next_id, uint8_t* alive, double* pt3d, double* normal, uint8_t* feat, uint8_t* obs_desc, int* obs_kf,
@@ -173,6 +175,7 @@ int bh_pose_only_ba(bh_ctx* ctx, const double* pix, const double* pts, const int
 #define BH_TRACK_BA_FAILED    2
 #define BH_TRACK_FEW_INLIERS  3
 #define BH_TRACK_NO_CANDIDATES 4   /* bh_track_local_map: no map point passed the gate (`if len(feats) == 0: return False`, tracking.py:116-117) */
+#define BH_TRACK_SKIPPED       5   /* bh_track_local_map: the frame's first stage did not return BH_TRACK_OK (`if is_ok:`, tracking.py:205-212) */
 int bh_track_refkf(bh_ctx* ctx, const uint8_t* q_desc, const int* nq, const int64_t* q_xy, int q_stride,
                    const uint8_t* t_desc, const int* nt, const double* t_pts, int t_stride, int B,
                    int d_max, int inclusive, int min_matches, int min_inliers,
@@ -187,16 +190,19 @@ int bh_track_refkf(bh_ctx* ctx, const uint8_t* q_desc, const int* nq, const int6
  * >= min_inliers (:136).
  * Inputs: q_desc u8[B][q_stride][32], nq[B], q_xy i64[B][q_stride][2] (frame.des, frame.kp_arr); R_in f64[B][9], t_in f64[B][3] (frame.R,
  *   frame.t: the pose the first half set); see f64[B][3] (frame.see_vector) or NULL = R (0,0,1) normalised, what Frame.setPose leaves
- *   on a fresh frame (camera.py:26-29); the candidates in the loop order of :97-99 - every (local keyframe, its map point) pair, so a map
+ *   on a fresh frame (camera.py:26-29); stage1_status int[B] or NULL: the verdicts of bh_track_refkf for the same frames - Tracker.update calls
+ *   _track_local_map only `if is_ok` (tracking.py:205-212), so a frame whose first stage is not BH_TRACK_OK is not gated, matched or
+ *   optimised (n_gate = n_match = n_inlier = 0, R / t untouched) and reports BH_TRACK_SKIPPED; NULL runs every frame (a caller that has
+ *   already filtered); the candidates in the loop order of :97-99 - every (local keyframe, its map point) pair, so a map
  *   point seen from several keyframes appears several times, as in the reference: mp_pts / mp_normals f64[B][m_stride][3] (mp.pt3d,
  *   mp.nf()), mp_feat u8[B][m_stride][32] (mp.featf()), M[B]; K = {fx, fy, cx, cy, baseline} (the gate uses fx, cx, cy like cam_map).
  * Outputs: gate_idx int[B][m_stride], n_gate[B]: the candidates that pass the gate, in order (ids_matching_kfs / ids_matching_mps are the
  *   caller's id arrays at these indices; num_frames_visible_increment applies to them); qidx / tidx / dist / n_match as bh_track_refkf
  *   (tidx indexes the GATED list, like `inds`); cand int[B][out_stride] = gate_idx[tidx]: the candidate index of each match, so
  *   ids_matching_mps[inds[inliers]] = mp_ids[cand[inlier]]; R, t, inlier, n_inlier as bh_track_refkf;
- *   status[b] = BH_TRACK_OK | BH_TRACK_NO_CANDIDATES | BH_TRACK_FEW_MATCHES | BH_TRACK_BA_FAILED | BH_TRACK_FEW_INLIERS. */
+ *   status[b] = BH_TRACK_OK | BH_TRACK_SKIPPED | BH_TRACK_NO_CANDIDATES | BH_TRACK_FEW_MATCHES | BH_TRACK_BA_FAILED | BH_TRACK_FEW_INLIERS. */
 int bh_track_local_map(bh_ctx* ctx, const uint8_t* q_desc, const int* nq, const int64_t* q_xy, int q_stride,
-                       const double* R_in, const double* t_in, const double* see,
+                       const double* R_in, const double* t_in, const double* see, const int* stage1_status,
                        const double* mp_pts, const double* mp_normals, const uint8_t* mp_feat, const int* M, int m_stride, int B,
                        int width, int height, double cos_thr, int d_max, int min_matches, int min_inliers,
                        const double K[5], int iters, double huber_delta, double chi2_thr,

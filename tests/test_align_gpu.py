@@ -157,3 +157,79 @@ def test_pose_graph_optimisation_closes_a_drifting_loop(ctx):
     assert l1[0] < 1e-20 and np.abs(R1 - Rgt).max() < 1e-9 and np.abs(t1 - tgt).max() < 1e-9
     with pytest.raises(Exception):
         loop_closing.essential_graph_optimization(ctx, Rgt, tgt, np.zeros(K, bool), ei, ej, np.stack([z[0] for z in Zc]), np.stack([z[1] for z in Zc]), w)
+
+
+def test_global_map_manager_update_closes_a_loop_with_map_frame_clouds(ctx):
+    """GlobalMapManager.update end to end in the reference's data model: cloud_kp and MapPoint.pt3d are MAP-frame coordinates
+    (camera.py:32-35, slam/covisibility_graph.py:125-131), so the alignment of the loop's two ends is the drift W of the map and the loop edge
+    is T_kf^-1 W T_cand.  A ring of keyframes with drifting odometry: the BoW stage must find the keyframe at the start of the ring, the fused
+    pairs must be the same physical points, the loop edge must equal the true relative camera pose, and the pose errors must shrink."""
+    import oracle
+    from boslam_amd import bow, loop_closing
+    rng = np.random.default_rng(31)
+    K, M, per_kf = 40, 4000, 300
+    ang = np.linspace(0, 2 * np.pi, K, endpoint=False)
+    Rgt = np.stack([oracle._so3_exp(np.array([0.0, a, 0.0])) @ oracle._so3_exp(rng.normal(0, 0.02, 3)) for a in ang])
+    tgt = np.stack([4 * np.sin(ang), 0.05 * rng.normal(size=K), 4 * np.cos(ang)], 1)
+    pa_ = rng.uniform(0, 2 * np.pi, M)
+    pts = np.stack([6 * np.sin(pa_), rng.uniform(-1, 1, M), 6 * np.cos(pa_)], 1) + rng.normal(0, 0.3, (M, 3))
+    feats = rng.integers(0, 256, (M, 32), dtype=np.uint8)
+    rel = lambda i, j: (Rgt[i].T @ Rgt[j], Rgt[i].T @ (tgt[j] - tgt[i]))
+    ei, ej, Zr, Zt, w = [], [], [], [], []
+    for i in range(K - 1):
+        Rz, tz = rel(i, i + 1)
+        ei.append(i); ej.append(i + 1); Zr.append(Rz @ oracle._so3_exp(rng.normal(0, 0.006, 3))); Zt.append(tz + rng.normal(0, 0.015, 3)); w.append(1.0)
+    R0 = [Rgt[0]]; t0 = [tgt[0]]
+    for i in range(K - 1):                                        # dead reckoning: the drift the loop has to absorb
+        R0.append(R0[-1] @ Zr[i]); t0.append(t0[-1] + R0[-2] @ Zt[i])
+    R0 = np.stack(R0); t0 = np.stack(t0)
+    drift = np.abs(t0 - tgt).max()
+    assert drift > 0.1
+
+    class KF:
+        pass
+    kfs = []
+    for i in range(K):
+        seen = np.argsort(np.linalg.norm(pts - tgt[i] * 1.5, axis=1))[:per_kf]          # the points next to this stretch of the ring
+        f = KF(); f.id = 700 + i; f.seen = seen
+        d = feats[seen].copy()
+        flip = rng.random(d.shape) < 0.01
+        d ^= (flip * (1 << rng.integers(0, 8, d.shape))).astype(np.uint8)
+        f.des = d
+        p_cam = (pts[seen] - tgt[i]) @ Rgt[i] + rng.normal(0, 0.003, (per_kf, 3))          # what the camera measures
+        f.cloud_kp = p_cam @ R0[i].T + t0[i]                                                # map frame, through the ESTIMATED pose
+        kfs.append(f)
+    shared = np.intersect1d(kfs[K - 1].seen, kfs[0].seen)
+    assert len(shared) > 150
+    db = bow.Dbow(synth.vocabulary(k=10, L=4, seed=6), ctx=ctx)
+    for f in kfs:
+        db.add(f)
+    by_id = {f.id: f for f in kfs}
+    ids_all = [f.id for f in kfs]
+
+    def map_points(kf):                                             # map points created around kf: its own estimate of the points it sees
+        side = 0 if kf.id < 700 + K // 2 else 100000
+        return side + kf.seen, feats[kf.seen], kf.cloud_kp, np.full(per_kf, 3 if side else 5, np.int32)
+
+    fixed = np.zeros(K, bool); fixed[0] = True
+    gm = loop_closing.GlobalMapManager(ctx, db, by_id.__getitem__, lambda kf: [kf.id - 1, kf.id - 2, kf.id - 3], map_points,
+                                       lambda: (ids_all, R0, t0, fixed, ei, ej, np.stack(Zr), np.stack(Zt), w))
+    out = gm.update(kfs[K - 1])
+    assert out is not None and out["candidate"] == 700 and out["n_inliers"] >= 100
+    # the alignment is the map's drift between the two ends, not a camera-to-camera pose
+    Wr, Wt = out["R"], out["t"]
+    ia = {p: k for k, p in enumerate(kfs[K - 1].seen)}; ib = {p: k for k, p in enumerate(kfs[0].seen)}
+    A = np.stack([kfs[K - 1].cloud_kp[ia[p]] for p in shared]); B = np.stack([kfs[0].cloud_kp[ib[p]] for p in shared])
+    assert np.abs(A - (B @ Wr.T + Wt)).max() < 0.03
+    # fused pairs: the same physical point on both sides, the better observed side (B, 5 observations) survives
+    assert len(out["fused"]) >= 0.8 * len(shared)
+    assert all(s + 100000 == l for s, l in out["fused"])
+    assert {s for s, _ in out["fused"]} <= set(shared.tolist())
+    # the loop edge is the true relative camera pose, to the noise of the alignment
+    zr, zt = out["loop_edge"]
+    Rz, tz = rel(K - 1, 0)
+    assert np.abs(zr - Rz).max() < 0.01 and np.abs(zt - tz).max() < 0.03
+    assert np.abs(Wr - Rz).max() > 0.1                               # W itself is nowhere near it (what the edge was before the fix)
+    ids, Ro, to = out["poses"]
+    assert ids == ids_all and np.array_equal(Ro[0], R0[0])
+    assert np.abs(to - tgt).max() < 0.4 * drift and out["cost_log"][-1] < 0.1 * out["cost_log"][0]

@@ -161,3 +161,16 @@ def test_track_local_map_matches_oracle_composition(ctx):
     see = np.tile(np.array([0.05, -0.02, 1.0]) / np.linalg.norm([0.05, -0.02, 1.0]), (7, 1))
     got2 = tracking.track_local_map(ctx, p["q_desc"], p["nq"], p["q_xy"], p["R"], p["t"], p["mp_pts"], p["mp_normals"], p["mp_feat"], p["M"], p["K"], see=see)
     _check_local_map(p, got2, see=see)
+    # Tracker.update calls _track_local_map only `if is_ok` (slam/tracking.py:205-212): with the first stage's verdicts passed in, the frames it
+    # lost are not run at all (also when their pose is still all zero, FEW_MATCHES leaves R / t untouched) and say so; the others are unchanged
+    s1 = np.array([0, 0, 0, 0, 0, tracking.TRACK_FEW_MATCHES, tracking.TRACK_FEW_INLIERS], np.int32)
+    R0 = p["R"].copy(); R0[5] = 0.0
+    for see_k in (None, see):
+        got3 = tracking.track_local_map(ctx, p["q_desc"], p["nq"], p["q_xy"], R0, p["t"], p["mp_pts"], p["mp_normals"], p["mp_feat"], p["M"], p["K"],
+                                        see=see_k, stage1_status=s1)
+        ref3 = got if see_k is None else got2
+        assert np.array_equal(got3["status"][:5], ref3["status"][:5]) and (got3["status"][5:] == tracking.TRACK_SKIPPED).all()
+        assert (got3["n_gate"][5:] == 0).all() and (got3["n_match"][5:] == 0).all() and (got3["n_inlier"][5:] == 0).all()
+        for k in ("gate_idx", "qidx", "tidx", "cand", "dist", "inlier", "n_gate", "n_match", "n_inlier"):
+            assert np.array_equal(got3[k][:5], ref3[k][:5]), k
+        assert np.array_equal(got3["R"][:5], ref3["R"][:5]) and np.array_equal(got3["t"][:5], ref3["t"][:5])
