@@ -14,6 +14,7 @@
 // Every integer stage is exact; the float formulas (Harris response, fastAtan2, cos/sin of the angle) are written
 // one IEEE operation at a time and the file is compiled with -ffp-contract=off.
 #include "bh_internal.h"
+#include <type_traits>
 #include <math.h>
 #include <float.h>
 #include <vector>
@@ -752,18 +753,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         pw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_img, (int)(__umul24((uint32_t)ry, (uint32_t)L.pitch) + xwc), 0, 0);
     }
     // The words that straddle or lie just beyond the left / right border (one on the left, at most three on the right, per row) are
-    // gathered byte by byte with reflection - by 160 dedicated lanes, once: as a branch of the loop above, every wave of a border tile
-    // ran the 4-byte gather for each of its six loads because some lane always needed it (~300 of the tile's ~1 000 instructions per wave).
+    // filled with reflection by 160 dedicated lanes, once: as a branch of the loop above, every wave of a border tile ran a 4-byte gather
+    // for each of its six loads because some lane always needed it (~300 of the tile's ~1 000 instructions per wave).
+    // Round 5: the reflected pixels of a row are pixels of the SAME row, up to 8 columns inside the border - bytes the loop above has just
+    // put into the LDS row.  The fix lanes pick them up there after the barrier (four byte reads at tile positions p or A - p) instead of
+    // reflecting four addresses and gathering four bytes from global memory: ~25 instead of ~80 instructions in three of the four waves
+    // of 63 % of the tiles.  Only a tile whose last columns are narrower than the reflection reaches (fewer than 12 image columns in it, or a level
+    // under 16 pixels wide) still gathers from global memory.
     const bool xedge = !interior && (x0 == 0 || x0 + TILE_W + 4 > L.w);
+    const bool fix_lds = xedge && L.w >= 16 && (x0 + TILE_W + 4 <= L.w || L.w - x0 >= 12);
     uint32_t fixv = 0; int fixi = -1;
     if (xedge && tid < 4 * FPX_H) {
         const int r = tid >> 2, q = tid & 3, y = y0 - 4 + r;
         const int c = q == 0 ? 0 : ((L.w - x0 + 4) >> 2) + q - 1, x = x0 - 4 + 4 * c;
         if (c < FRW && y < L.h + 8 && x < L.w + 8 && (x < 0 || x + 3 >= L.w)) {
-            const uint8_t* row = img + (size_t)reflect101(y, L.h) * L.pitch;
-#pragma unroll
-            for (int k = 0; k < 4; k++) fixv |= (uint32_t)row[reflect101(x + k, L.w)] << (8 * k);
             fixi = r * FPW + 1 + c;
+            if (!fix_lds) {
+                const uint8_t* row = img + (size_t)reflect101(y, L.h) * L.pitch;
+#pragma unroll
+                for (int k = 0; k < 4; k++) fixv |= (uint32_t)row[reflect101(x + k, L.w)] << (8 * k);
+            }
         }
     }
     uint32_t mw = 0;
@@ -795,7 +804,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (ldl && r < FPX_H) s_px[r * FPW + 1 + lc] = pw[j];
     }
     __syncthreads();
-    if (xedge) { if (fixi >= 0) s_px[fixi] = fixv; __syncthreads(); }
+    if (xedge) {
+        if (fixi >= 0) {
+            if (fix_lds) {
+                // tile position p = 4 c + k of the lane's word (0 = column x0 - 4): left of the image (only c = 0 of a tile with x0 = 0) the
+                // reflection of p is 8 - p; right of it, with e = w - x0 + 4 the first position outside, 2 (e - 1) - p; positions inside stay.
+                // The source bytes are pixels the aligned loads above wrote (a concurrent fix of a straddling word rewrites its inside bytes
+                // with the same values).
+                const int c = fixi - (fixi / FPW) * FPW - 1, e = L.w - x0 + 4;
+                const int A = c == 0 && x0 == 0 ? 8 : 2 * (e - 1), th = c == 0 && x0 == 0 ? 0 : e;
+                const uint8_t* rowb = reinterpret_cast<const uint8_t*>(s_px) + (fixi - 1 - c) * 4 + 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int p = 4 * c + k; fixv |= (uint32_t)rowb[p < th ? p : A - p] << (8 * k); }
+            }
+            s_px[fixi] = fixv;
+        }
+        __syncthreads();
+    }
 
     const uint8_t* px = reinterpret_cast<const uint8_t*>(s_px);
     uint8_t* s_sc = reinterpret_cast<uint8_t*>(s_scw);
@@ -808,38 +833,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // loaded once, no division per item.  A lane collects the verdicts of its <= 20 pixels in one register (bit 8 k + it = pixel k of
     // round it) and reserves its list entries with ONE LDS atomic; the entries are written by a loop over the set bits (about one per
     // lane: ~5 % of the pixels pass) instead of four predicated blocks per item.
+    // Round 5 (the kernel is bound by vector issue, so what a round issues besides its 30 packed operations counts): the round's rows are
+    // a compile-time offset from ONE lane address (the row clamp is needed in the last round only); the loop exists twice, for tiles whose
+    // score rows are all valid (every tile but those of a level's first and last tile row: no row test, two compares and two selects per
+    // round less) and for the others - as one loop the compiler turned the uniform test into selects; the byte selectors of the v_perm
+    // unpacking live in scalar registers (as literals they were re-materialised into vector registers in every round).
     {
-        const fs2 T = fs2{ (short)thr, (short)thr };
-        const int sy0 = tid / FPW, w = tid - sy0 * FPW;
+        const int sy0 = min(tid / FPW, 6), w = tid - (tid / FPW) * FPW;      // (lanes 252 .. 255 hold no item: their column mask is 0)
         const uint32_t vmw = tid < 7 * FPW ? s_vm[w] : 0u;
         // rows: the tile's score rows y0-1 .. y0+32 all inside [ylo, yhi] (every tile but those of the level's first and last tile rows):
         // no row test per round; a band of 7 rows with no row inside (edgeThreshold = 31 leaves the first 29 rows of a level unscored)
         // is skipped by the whole workgroup.
         const bool allrows = y0 - 1 >= ylo && y0 + TILE_H <= yhi;
         const bool anycol = xlo <= xhi;
-        uint32_t M = 0;
+        uint32_t SEL01, SEL23, SEL12, SEL34, SELSG;
+        asm volatile("s_mov_b32 %0, 0x0c010c00\n\ts_mov_b32 %1, 0x0c030c02\n\ts_mov_b32 %2, 0x0c020c01\n\ts_mov_b32 %3, 0x0c040c03\n\ts_mov_b32 %4, 0x07050301"
+                     : "=s"(SEL01), "=s"(SEL23), "=s"(SEL12), "=s"(SEL34), "=s"(SELSG));
+        const uint32_t* const cw0 = s_px + (sy0 + 3) * FPW + w;
+        const uint32_t* const cw4 = s_px + (min(sy0 + 28, FSC_H - 1) + 3) * FPW + w;
+        const fs2 T = fs2{ (short)thr, (short)thr };
+        auto pretest = [&](auto ar) -> uint32_t {
+            constexpr bool AR = decltype(ar)::value;
+            uint32_t M = 0;
 #pragma unroll
-        for (int it = 0; it < (FSC_H + 6) / 7; it++) {
-            const int yb0 = y0 - 1 + 7 * it, yb1 = y0 - 1 + min(7 * it + 6, FSC_H - 1);      // the band's rows (uniform)
-            if (!(anycol && yb1 >= ylo && yb0 <= yhi)) continue;
-            const int sy = sy0 + 7 * it;
-            uint32_t vm = (7 * it + 6 < FSC_H || sy < FSC_H) ? vmw : 0u;
-            if (!allrows) { const int y = y0 - 1 + sy; vm = (y >= ylo && y <= yhi) ? vm : 0u; }
-            const uint32_t* cw = s_px + min(sy, FSC_H - 1) * FPW + w + 3 * FPW;
-            const uint32_t W0 = cw[0], Wm = cw[-1], Wp = cw[1], U = cw[-3 * FPW], D = cw[3 * FPW];
-            // packed 16-bit operand pairs: pixels (0,1) and (2,3) of the word; left = pixel - 3, right = pixel + 3
-            const fs2 C0 = fpk(0, W0, 0x0c010c00u), C1 = fpk(0, W0, 0x0c030c02u);
-            const fs2 U0 = fpk(0, U, 0x0c010c00u), U1 = fpk(0, U, 0x0c030c02u);
-            const fs2 D0 = fpk(0, D, 0x0c010c00u), D1 = fpk(0, D, 0x0c030c02u);
-            const fs2 L0 = fpk(0, Wm, 0x0c020c01u), L1 = fpk(W0, Wm, 0x0c040c03u);
-            const fs2 R0 = fpk(Wp, W0, 0x0c040c03u), R1 = fpk(0, Wp, 0x0c020c01u);
-            const fs2 dk0 = fmx(fmn(D0, U0), fmn(R0, L0)), br0 = fmn(fmx(D0, U0), fmx(R0, L0));
-            const fs2 dk1 = fmx(fmn(D1, U1), fmn(R1, L1)), br1 = fmn(fmx(D1, U1), fmx(R1, L1));
-            const fs2 m0 = T - fmx(C0 - dk0, br0 - C0);             // negative <=> darker pair below v - thr, or brighter pair above v + thr
-            const fs2 m1 = T - fmx(C1 - dk1, br1 - C1);
-            const uint32_t P = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, m1), __builtin_bit_cast(uint32_t, m0), 0x07050301u) & vm;
-            M |= P >> (7 - it);                                      // vm leaves only the sign bits 7, 15, 23, 31
-        }
+            for (int it = 0; it < (FSC_H + 6) / 7; it++) {
+                const int yb0 = y0 - 1 + 7 * it, yb1 = y0 - 1 + min(7 * it + 6, FSC_H - 1);      // the band's rows (uniform)
+                if (!AR && !(yb1 >= ylo && yb0 <= yhi)) continue;
+                const int sy = sy0 + 7 * it;
+                uint32_t vm = (7 * it + 6 < FSC_H || sy < FSC_H) ? vmw : 0u;
+                if (!AR) { const int y = y0 - 1 + sy; vm = (y >= ylo && y <= yhi) ? vm : 0u; }
+                const uint32_t* cw = 7 * it + 6 < FSC_H ? cw0 + 7 * it * FPW : cw4;
+                const uint32_t W0 = cw[0], Wm = cw[-1], Wp = cw[1], U = cw[-3 * FPW], D = cw[3 * FPW];
+                // packed 16-bit operand pairs: pixels (0,1) and (2,3) of the word; left = pixel - 3, right = pixel + 3
+                const fs2 C0 = fpk(0, W0, SEL01), C1 = fpk(0, W0, SEL23);
+                const fs2 U0 = fpk(0, U, SEL01), U1 = fpk(0, U, SEL23);
+                const fs2 D0 = fpk(0, D, SEL01), D1 = fpk(0, D, SEL23);
+                const fs2 L0 = fpk(0, Wm, SEL12), L1 = fpk(W0, Wm, SEL34);
+                const fs2 R0 = fpk(Wp, W0, SEL34), R1 = fpk(0, Wp, SEL12);
+                const fs2 dk0 = fmx(fmn(D0, U0), fmn(R0, L0)), br0 = fmn(fmx(D0, U0), fmx(R0, L0));
+                const fs2 dk1 = fmx(fmn(D1, U1), fmn(R1, L1)), br1 = fmn(fmx(D1, U1), fmx(R1, L1));
+                const fs2 m0 = T - fmx(C0 - dk0, br0 - C0);             // negative <=> darker pair below v - thr, or brighter pair above v + thr
+                const fs2 m1 = T - fmx(C1 - dk1, br1 - C1);
+                const uint32_t P = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, m1), __builtin_bit_cast(uint32_t, m0), SELSG) & vm;
+                M |= P >> (7 - it);                                      // vm leaves only the sign bits 7, 15, 23, 31
+            }
+            return M;
+        };
+        uint32_t M = 0;
+        if (anycol) M = allrows ? pretest(std::true_type{}) : pretest(std::false_type{});
         if (M) {
             const int cnt = __popc(M);
             int pos = lds_add_rtn(&s_n, cnt);
