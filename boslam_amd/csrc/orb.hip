@@ -694,10 +694,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ uint32_t s_mask[TILE_H * (TILE_W / 32)];         // the tile of the bit-packed mask (no HBM round trip in phase 3)
     __shared__ __attribute__((aligned(16))) uint32_t s_scw[FITEMS];
     __shared__ __attribute__((aligned(16))) uint32_t s_k1[4];   // 16 constant bytes: the blur's "+128" rides through spare k slots of its second product
-    __shared__ uint16_t s_list[FLIST_CAP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[FLIST_CAP];      // (its space stages the kept corners once phase 2 is through)
     __shared__ uint32_t s_vm[FPW];
     __shared__ uint16_t s_cl[FCL_CAP];                          // the candidates phase 2 found to be corners: phase 3 walks these, not the whole candidate list
-    uint32_t* const s_out = s_px;                               // kept corners (phase 3): strict 3x3 maxima, at most one per 2x2 block = 1024 <= FPX_H * FPW
     __shared__ int s_n, s_k, s_base, s_c;
 #ifdef FAST_LDS_PAD                                              // diagnostic builds: fewer workgroups per CU (does a co-running kernel of another stream fill the gap?)
     __shared__ uint32_t s_pad[FAST_LDS_PAD];
@@ -983,7 +982,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     {
         typedef int fv4 __attribute__((ext_vector_type(4)));
         typedef int fv16 __attribute__((ext_vector_type(16)));
-        const int lane = tid & 63, wv = tid >> 6, n = lane & 31, h = lane >> 5;
+        const int lane = tid & 63, wv = tid >> 6, rn = lane & 31, h = lane >> 5;
         const fv4* gt = reinterpret_cast<const fv4*>(gtab) + lane;
         const uint8_t* pxb = reinterpret_cast<const uint8_t*>(s_px);
         fv4 alo[2], ahi[2];
@@ -991,7 +990,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const fv4 P1B0 = gt[0], P1B1 = gt[64];
 #pragma unroll
             for (int rb = 0; rb < 2; rb++) {
-                const uint8_t* rp = pxb + min(32 * rb + n, FPX_H - 1) * FROW + 32 * wv + 16 * h;
+                const uint8_t* rp = pxb + min(32 * rb + rn, FPX_H - 1) * FROW + 32 * wv + 16 * h;
                 // k slots 48 .. 63 of the second product (lane half 1) only meet zero taps: they carry the constant bytes (1, 1, 0, ..)
                 // against taps (64, 64, 0, ..) instead - the "+ 128" without sixteen accumulator moves
                 fv4 a0 = *reinterpret_cast<const fv4*>(rp), a1 = *reinterpret_cast<const fv4*>(h ? reinterpret_cast<const uint8_t*>(s_k1) : rp + 32);
@@ -1019,22 +1018,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         for (int i = 0; i < 16; i++) accL[i] = (accH[i] << 8) + CI;
         accL = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo[0], P2B0, accL, 0, 0, 0);
         accL = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo[1], P2B1, accL, 0, 0, 0);
-        // lane = output row n; registers 4 g .. 4 g + 3 = columns 32 w + 8 g + 4 h + (0..3): bits 16 .. 24 of the sums, clamped to 255
+        // lane = output row rn; registers 4 g .. 4 g + 3 = columns 32 w + 8 g + 4 h + (0..3): bits 16 .. 24 of the sums, clamped to 255
         uint32_t* s_o = s_px;                                      // 32 rows x 33 words
-        __syncthreads();                                           // every wave has read its pixels
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        const us2 lim = us2{ 255, 255 };
+        uint32_t ob[4];
 #pragma unroll
         for (int g2 = 0; g2 < 4; g2++) {
-            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-            const us2 lim = us2{ 255, 255 };
             const us2 p01 = __builtin_elementwise_min(__builtin_bit_cast(us2, __builtin_amdgcn_perm((uint32_t)accL[4 * g2 + 1], (uint32_t)accL[4 * g2], 0x07060302u)), lim);
             const us2 p23 = __builtin_elementwise_min(__builtin_bit_cast(us2, __builtin_amdgcn_perm((uint32_t)accL[4 * g2 + 3], (uint32_t)accL[4 * g2 + 2], 0x07060302u)), lim);
-            s_o[n * 33 + 8 * wv + 2 * g2 + h] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
+            ob[g2] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
         }
-        __syncthreads();
-        {   // whole 128-byte row segments; tile base in scalar registers, one 32-bit offset per lane
+        // ---- phase 3: kept corners are staged in LDS as (score << 24) | (score-tile byte index), then the tile reserves its
+        // range of the level's corner list with ONE global atomic (a returning atomic per wave was measured 35 % slower: every wave
+        // then waits out an L2 round trip on a counter all tiles of the level contend for).
+        // Round 5: in the common case (the corners fit s_cl) phase 3 needs neither the pixel tile nor the candidate list, so it runs HERE, on
+        // the heels of the blur's products, staging into the dead candidate list - and the tail of the kernel is two barriers (every wave is
+        // through with the pixels -> the blurred rows are transposed through the pixel tile's space while lane 0 reserves the list range ->
+        // row stores and list entries go out together) where the blur and phase 3 one after the other took five.
+        const int nc = s_c;
+        const bool cl = nc <= FCL_CAP;                              // corners listed: ~60 % of the candidates; otherwise walk the candidates as before
+        const int n3 = cl ? nc : n;
+        uint32_t* const s_out = cl ? reinterpret_cast<uint32_t*>(s_list) : s_px;      // kept corners: strict 3x3 maxima, at most one per 2x2 block = 1024 entries
+        const size_t lv = (size_t)frame * g.nlevels + level;
+        uint8_t* bt = blur + fbase + (uint32_t)(y0 * L.pitch + x0);
+        const __amdgpu_buffer_rsrc_t rs_bt = __builtin_amdgcn_make_buffer_rsrc(bt, 0, 0x7fffffff, 0x00020000);
+        auto blur_rows_out = [&]() {   // whole 128-byte row segments; tile base in scalar registers, one 32-bit offset per lane
             const int wd = tid & 31, r0 = tid >> 5;
-            uint8_t* bt = blur + fbase + (uint32_t)(y0 * L.pitch + x0);
-            const __amdgpu_buffer_rsrc_t rs_bt = __builtin_amdgcn_make_buffer_rsrc(bt, 0, 0x7fffffff, 0x00020000);
             const bool xin = x0 + 4 * wd < L.w;
             const int o0 = (int)(__umul24((uint32_t)r0, (uint32_t)L.pitch) + 4u * (uint32_t)wd);
 #pragma unroll
@@ -1042,53 +1052,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 const int row = r0 + 8 * k;
                 if (xin && y0 + row < L.h) __builtin_amdgcn_raw_buffer_store_b32(s_o[row * 33 + wd], rs_bt, o0, 8 * k * L.pitch, 0);
             }
-        }
-    }
-    __syncthreads();                                            // the pixel tile is dead from here on: s_out takes its place
-#if defined(FAST_STOP) && FAST_STOP == 4
-    return;
-#endif
-    // ---- phase 3: kept corners are staged in LDS as (score << 24) | (score-tile byte index), then the tile reserves its
-    // range of the level's corner list with ONE global atomic (a returning atomic per wave was measured 35 % slower: every wave
-    // then waits out an L2 round trip on a counter all tiles of the level contend for)
-    const int nc = s_c;
-    const bool cl = nc <= FCL_CAP;                              // corners listed: ~60 % of the candidates; otherwise walk the candidates as before
-    const int n3 = cl ? nc : n;
-    for (int j = tid; j < n3; j += 256) {
-        const int b = cl ? s_cl[j] : (ovf ? j : s_list[j]);
-        const int sc = s_sc[b];
-        if (sc == 0) continue;
-        const int sy = b / FROW, xb = b - sy * FROW;
-        if (sy < 1 || sy > TILE_H || xb < 8 || xb >= 8 + TILE_W) continue;            // halo positions belong to the neighbour tiles
-        const int x = x0 - 8 + xb, y = y0 - 1 + sy;
-        if (!(x >= et && x < L.w - et && y >= et && y < L.h - et)) continue;
-        const uint8_t* q = s_sc + b;
-        const bool keep = sc > q[-1] && sc > q[1] && sc > q[-FROW - 1] && sc > q[-FROW] && sc > q[-FROW + 1] &&
-                          sc > q[FROW - 1] && sc > q[FROW] && sc > q[FROW + 1];
-        if (!keep) continue;
-        if (mbits) { if (!((s_mask[(sy - 1) * (TILE_W / 32) + ((xb - 8) >> 5)] >> ((xb - 8) & 31)) & 1u)) continue; }
-        else if (mpyr && mpyr[fbase + (size_t)y * L.pitch + x] == 0) continue;
-        const int k = atomicAdd(&s_k, 1);
-        s_out[k] = ((uint32_t)sc << 24) | (uint32_t)b;
-    }
-    __syncthreads();
-    const int kk = s_k;
-    const size_t lv = (size_t)frame * g.nlevels + level;
+        };
+        auto nms = [&]() {
+            for (int j = tid; j < n3; j += 256) {
+                const int b = cl ? s_cl[j] : (ovf ? j : s_list[j]);
+                const int sc = s_sc[b];
+                if (sc == 0) continue;
+                const int sy = b / FROW, xb = b - sy * FROW;
+                if (sy < 1 || sy > TILE_H || xb < 8 || xb >= 8 + TILE_W) continue;            // halo positions belong to the neighbour tiles
+                const int x = x0 - 8 + xb, y = y0 - 1 + sy;
+                if (!(x >= et && x < L.w - et && y >= et && y < L.h - et)) continue;
+                const uint8_t* q = s_sc + b;
+                const bool keep = sc > q[-1] && sc > q[1] && sc > q[-FROW - 1] && sc > q[-FROW] && sc > q[-FROW + 1] &&
+                                  sc > q[FROW - 1] && sc > q[FROW] && sc > q[FROW + 1];
+                if (!keep) continue;
+                if (mbits) { if (!((s_mask[(sy - 1) * (TILE_W / 32) + ((xb - 8) >> 5)] >> ((xb - 8) & 31)) & 1u)) continue; }
+                else if (mpyr && mpyr[fbase + (size_t)y * L.pitch + x] == 0) continue;
+                const int k = atomicAdd(&s_k, 1);
+                s_out[k] = ((uint32_t)sc << 24) | (uint32_t)b;
+            }
+        };
+        auto reserve = [&]() {
 #if defined(FAST_STOP) && FAST_STOP == 5      // diagnostic: no returning global atomic at the tile's end (wrong lists)
-    if (tid == 0 && kk) s_base = 0;
+            if (tid == 0 && s_k) s_base = 0;
 #else
-    if (tid == 0 && kk) s_base = atomicAdd(&ccnt[lv], kk);
+            if (tid == 0 && s_k) s_base = atomicAdd(&ccnt[lv], s_k);
 #endif
-    __syncthreads();
-    if (kk) {
-        const int base = s_base;
-        uint2* dst = clist + (size_t)frame * g.list_stride + L.list_off;
-        for (int i = tid; i < kk; i += 256) {
-            const uint32_t e = s_out[i];
-            const int b = e & 0xffffffu, sy = b / FROW, xb = b - sy * FROW;
-            const uint32_t x = (uint32_t)(x0 - 8 + xb), y = (uint32_t)(y0 - 1 + sy);
-            if (base + i < L.list_cap) dst[base + i] = make_uint2((y << 16) | x, e >> 24);
-            else atomicOr(status, BH_ST_CAND_OVERFLOW);
+        };
+        auto list_out = [&]() {
+            const int kk = s_k;
+            if (kk) {
+                const int base = s_base;
+                uint2* dst = clist + (size_t)frame * g.list_stride + L.list_off;
+                for (int i = tid; i < kk; i += 256) {
+                    const uint32_t e = s_out[i];
+                    const int b = e & 0xffffffu, sy = b / FROW, xb = b - sy * FROW;
+                    const uint32_t x = (uint32_t)(x0 - 8 + xb), y = (uint32_t)(y0 - 1 + sy);
+                    if (base + i < L.list_cap) dst[base + i] = make_uint2((y << 16) | x, e >> 24);
+                    else atomicOr(status, BH_ST_CAND_OVERFLOW);
+                }
+            }
+        };
+#if defined(FAST_STOP) && FAST_STOP == 4
+        __syncthreads();
+#pragma unroll
+        for (int g2 = 0; g2 < 4; g2++) s_o[rn * 33 + 8 * wv + 2 * g2 + h] = ob[g2];
+        __syncthreads();
+        blur_rows_out();
+        return;
+#endif
+        if (cl) {
+            nms();
+            __syncthreads();                                       // every wave has read its pixels; the kept corners are staged
+#pragma unroll
+            for (int g2 = 0; g2 < 4; g2++) s_o[rn * 33 + 8 * wv + 2 * g2 + h] = ob[g2];
+            reserve();
+            __syncthreads();
+            blur_rows_out();
+            list_out();
+        } else {                                                   // more corners than s_cl holds: phase 3 walks the candidate list (or the tile) and stages in the pixel tile's space
+            __syncthreads();                                       // every wave has read its pixels
+#pragma unroll
+            for (int g2 = 0; g2 < 4; g2++) s_o[rn * 33 + 8 * wv + 2 * g2 + h] = ob[g2];
+            __syncthreads();
+            blur_rows_out();
+            __syncthreads();                                       // the pixel tile is dead from here on: s_out takes its place
+            nms();
+            __syncthreads();
+            reserve();
+            __syncthreads();
+            list_out();
         }
     }
 }
