@@ -253,6 +253,72 @@ __device__ void d_block_sum(double* v, double* s_red)
     for (int i = 0; i < NV; i++) { double s = 0; for (int w = 0; w < NW; w++) s += s_red[w * NV + i]; v[i] = s; }
 }
 
+// ---- fan-in of per-workgroup partial sums (round 5).  The Levenberg control needs three big sums per trial - chi over the edges at the
+// linearisation point and at the trial state, dx'(lambda dx + b) over the landmark steps - and a maximum over the diagonal once.  They used
+// to be separate launches behind the kernels that produce their terms (k_ba_partial x 2, k_ba_prep, k_ba_decide: four of a local window's ten
+// launches per iteration, ~7 us each with the gap in front).  Now every workgroup of the producing kernel leaves the sum of ITS terms (fixed
+// order) in a slot of its own, and the workgroup that arrives LAST - an agent-scope counter - adds the slots up in slot order and runs the
+// control step.  No workgroup waits for another; the result does not depend on which one is last.
+// Visibility across the XCDs' private L2s: a slot is written by ONE write-through (agent-scope atomic) store, drained before that lane's counter
+// add; the last arriver acquires at agent scope and reads the slots with agent-scope loads (never through the scalar cache).
+__device__ __forceinline__ void fan_store(double* p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double fan_load(const double* p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// one wave (all 64 lanes): the n slots summed in a fixed order - lane l takes slots l, l + 64, .. one after the other, then the xor tree;
+// the same bits whichever workgroup (of whatever size) runs it, which is what keeps a batched window bitwise equal to the same window alone
+__device__ __forceinline__ double fan_sum(const double* part, int n)
+{
+    const int lane = threadIdx.x & 63;
+    double t = 0;
+    for (int i0 = lane; i0 < n; i0 += 64 * 8) {                  // eight loads in flight per lane (one after the other they cost a memory round trip each)
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = i0 + 64 * k < n ? fan_load(part + i0 + 64 * k) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) t += v[k];                   // (+ 0.0 beyond the end: the sums are sums of squares and of dx'(lambda dx + b) terms, never -0.0)
+    }
+    for (int m = 32; m > 0; m >>= 1) t += d_shfl_xor(t, m);
+    return t;
+}
+__device__ __forceinline__ double fan_max(const double* part, int n, double t)
+{
+    const int lane = threadIdx.x & 63;
+    for (int i0 = lane; i0 < n; i0 += 64 * 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = i0 + 64 * k < n ? fan_load(part + i0 + 64 * k) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) t = fmax(t, v[k]);
+    }
+    for (int m = 32; m > 0; m >>= 1) t = fmax(t, d_shfl_xor(t, m));
+    return t;
+}
+// every thread of the workgroup calls it (lane 0 has stored the workgroup's slots): true, in every thread, in the workgroup that arrives last of `total`
+__device__ __forceinline__ bool fan_arrive(int* counter, int total)
+{
+    __shared__ int s_tk;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the slot stores of this lane have left the CU (write-through)
+        s_tk = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const bool last = s_tk == total - 1;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return last;
+}
+// sum of one value per thread over a 256-thread workgroup, fixed order (valid in every thread); s4: 4 doubles of LDS
+__device__ __forceinline__ double fan_block_sum256(double v, double* s4)
+{
+    double a[1] = { v };
+    d_block_sum<1, 256>(a, s4);
+    return a[0];
+}
+
 // in-register 6x6 Cholesky solve; returns false if not positive definite
 __device__ bool d_chol6(double* A /*36*/, double* b /*6*/)
 {
@@ -434,6 +500,7 @@ struct ba_state {                 // device-resident LM control block
     long long dbg[8];             // k_ba_chol_sw phase clocks (bh_ba_debug_band_solve)
     // batched local BA (bh_ba_batch_optimize): the Levenberg control flow of a window, kept on the device
     int b_it, b_iters, b_need_lin, b_done, b_cur, b_last_err, b_verbose, b_fail;
+    int tick[2];                  // fan-in arrival counters: [0] linearisation -> prep, [1] trial errors -> decide (zero between launches)
 };
 
 struct bh_ba {
@@ -455,7 +522,7 @@ struct bh_ba {
     bh_buf p_start, p_edges, c_start, c_edges;
     bh_buf err[2], chi_e[2];           // [0] at the current state (iteration start), [1] at the trial state
     bh_buf Hpl, Hll, bl, Hpp, bp, pdiag, cdiag;
-    bh_buf Dinv, db, S, bs, dxp, dxl, state, pairs, part, xch;
+    bh_buf Dinv, db, S, bs, dxp, dxl, state, pairs, part, xch, fan;
     bh_buf join, j_start;              // per camera pair: the (edge, edge) pairs that share a landmark (Schur complement's work list)
     bh_buf c_pt, c_meas;               // row form: landmark slot / measurement of every entry of c_edges (camera-major copies)
     int cam_major = 0;                 // c_pt / c_meas are valid for the current problem
@@ -471,6 +538,7 @@ struct bh_ba {
     int chol_dense = 0;                // whole factor on chip (k_ba_chol_dense): 6 Cf <= 288, the local-BA window
     int chol_bcr = 0;                  // block cyclic reduction over the whole chip (long narrow systems: global BA)
     ba_state* h_state = nullptr;       // pinned, device-writable: k_ba_decide's verdict (polled by bh_ba_optimize)
+    struct bh_ba_batch* self = nullptr; // a local window alone is a batch of one (bh_ba_optimize: device-side control flow, the host one round ahead)
     int seq = 0;
     struct bcr_dev* bcr = nullptr;
     struct dbcr_dev* dsol = nullptr;   // distributed reduced-camera solve (sharded mode, long banded systems)
@@ -484,6 +552,9 @@ struct bh_ba {
     double comm_ms = 0; long long comm_bytes = 0;
 };
 
+// fan-in slots of a window (ba->fan): [l_chi nbp][l_max nbp][c_max Cf][u_sum nbp][e_chi ceil(E / 256)]
+static size_t ba_fan_doubles(size_t Pa, size_t Cf, size_t E) { const size_t nbp = (Pa * 8 + 255) / 256; return 3 * nbp + Cf + (E + 255) / 256 + 8; }
+
 // ---- k_ba_point: 8 lanes per active point; residual + Huber + Jacobians; Hll, bl, per-edge Hpl, per-edge error/chi
 #define BP_G 8
 __device__ __forceinline__ void ba_point_body(int bid, const ba_cam* __restrict__ cams, const double* __restrict__ pts,
@@ -491,8 +562,10 @@ __device__ __forceinline__ void ba_point_body(int bid, const ba_cam* __restrict_
                                                   const int* __restrict__ cslot, const int* __restrict__ p_start,
                                                   const int* __restrict__ p_edges, int Pa, ba_K K, double delta,
                                                   double* __restrict__ Hpl, double* __restrict__ Hll, double* __restrict__ bl,
-                                                  double* __restrict__ err, double* __restrict__ chi_e, double* __restrict__ pdiag)
+                                                  double* __restrict__ err, double* __restrict__ chi_e, double* __restrict__ pdiag,
+                                                  double* __restrict__ mine = nullptr /* [2]: this thread's sum of chi, its landmark's max |diag| */)
 {
+    double chi_sum = 0, md_mine = 0;
     const int gid = (bid * 256 + threadIdx.x) / BP_G, sub = threadIdx.x & (BP_G - 1);
     const bool live = gid < Pa;
     const int j = live ? gid : 0;
@@ -509,6 +582,7 @@ __device__ __forceinline__ void ba_point_body(int bid, const ba_cam* __restrict_
             d_edge_jac(c->w2n, c->dR, c->t, X, K, Jc, Jp);
             d_huber(er[0] * er[0] + er[1] * er[1], delta, &r0, &r1);
             err[2 * e] = er[0]; err[2 * e + 1] = er[1]; chi_e[e] = r0;
+            chi_sum += r0;
             acc[0] += r1 * (Jp[0] * Jp[0] + Jp[3] * Jp[3]); acc[1] += r1 * (Jp[0] * Jp[1] + Jp[3] * Jp[4]); acc[2] += r1 * (Jp[0] * Jp[2] + Jp[3] * Jp[5]);
             acc[3] += r1 * (Jp[1] * Jp[1] + Jp[4] * Jp[4]); acc[4] += r1 * (Jp[1] * Jp[2] + Jp[4] * Jp[5]); acc[5] += r1 * (Jp[2] * Jp[2] + Jp[5] * Jp[5]);
             acc[6] -= r1 * (Jp[0] * er[0] + Jp[3] * er[1]); acc[7] -= r1 * (Jp[1] * er[0] + Jp[4] * er[1]); acc[8] -= r1 * (Jp[2] * er[0] + Jp[5] * er[1]);
@@ -527,8 +601,10 @@ __device__ __forceinline__ void ba_point_body(int bid, const ba_cam* __restrict_
         double* H = Hll + 9 * (size_t)j;
         H[0] = acc[0]; H[1] = acc[1]; H[2] = acc[2]; H[3] = acc[1]; H[4] = acc[3]; H[5] = acc[4]; H[6] = acc[2]; H[7] = acc[4]; H[8] = acc[5];
         bl[3 * j] = acc[6]; bl[3 * j + 1] = acc[7]; bl[3 * j + 2] = acc[8];
-        pdiag[j] = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+        md_mine = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+        pdiag[j] = md_mine;
     }
+    if (mine) { mine[0] = chi_sum; mine[1] = md_mine; }
 }
 
 // ---- k_ba_cam: workgroup per free camera: Hpp (6x6) and bp (6) over the camera's edges
@@ -537,7 +613,8 @@ __device__ __forceinline__ void ba_cam_body(int s, const ba_cam* __restrict__ ca
                                                 const double* __restrict__ e_meas, const int* __restrict__ c_start,
                                                 const int* __restrict__ c_edges, ba_K K, double delta,
                                                 double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ cdiag,
-                                                const int* __restrict__ c_pt = nullptr, const double* __restrict__ c_meas = nullptr)
+                                                const int* __restrict__ c_pt = nullptr, const double* __restrict__ c_meas = nullptr,
+                                                double* __restrict__ md_out = nullptr /* thread 0: the camera's max |diag| */)
 {
     __shared__ double s_red[27 * 4];
     const int tid = threadIdx.x;
@@ -572,6 +649,7 @@ __device__ __forceinline__ void ba_cam_body(int s, const ba_cam* __restrict__ ca
         for (int a = 0; a < 6; a++) for (int bb = a; bb < 6; bb++) { H[a * 6 + bb] = acc[k]; H[bb * 6 + a] = acc[k]; k++; }
         for (int a = 0; a < 6; a++) { bp[6 * s + a] = acc[21 + a]; md = fmax(md, fabs(H[a * 6 + a])); }
         cdiag[s] = md;
+        if (md_out) *md_out = md;
     }
 }
 
@@ -580,6 +658,46 @@ __device__ __forceinline__ void ba_cam_body(int s, const ba_cam* __restrict__ ca
 // ---- k_ba_linearize: the per-landmark and the per-camera halves of buildSystem in ONE launch (workgroups [0, nbp) take landmarks,
 // the rest one free camera each): they are independent, and as two launches of 18 us each the second - 48 workgroups on a local
 // window - left most of the chip idle.
+// What a workgroup of the linearisation leaves for the fan-in: slot bx of chi / max (landmark workgroups), slot s of cmax (camera workgroups)
+struct ba_fan {
+    double *l_chi, *l_max, *c_max;      // linearisation: [nbp], [nbp], [Cf]
+    double *u_sum, *e_chi;              // trial: [landmark workgroups of the update], [workgroups of the error kernel]
+};
+static ba_fan ba_fan_of(const bh_ba* ba)
+{
+    const size_t nbp = ((size_t)ba->Pa * BP_G + 255) / 256;
+    double* f = (double*)ba->fan.p;
+    ba_fan F; F.l_chi = f; F.l_max = f + nbp; F.c_max = f + 2 * nbp; F.u_sum = f + 2 * nbp + ba->Cf; F.e_chi = f + 3 * nbp + ba->Cf;
+    return F;
+}
+__device__ __forceinline__ void ba_lin_fan_store(bool point_block, int slot, const double* mine, double md_cam, const ba_fan& F, double* s8)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (point_block) {
+        const double cs = fan_block_sum256(mine[0], s8);
+        double m = mine[1];
+        for (int k = 32; k > 0; k >>= 1) m = fmax(m, d_shfl_xor(m, k));
+        if (lane == 0) s8[4 + wv] = m;
+        __syncthreads();
+        if (tid == 0) { fan_store(F.l_chi + slot, cs); fan_store(F.l_max + slot, fmax(fmax(s8[4], s8[5]), fmax(s8[6], s8[7]))); }
+    } else if (tid == 0) fan_store(F.c_max + slot, md_cam);
+}
+// k_ba_prep's work from the slots: one wave
+// (phase 1, multi-GPU: this rank's chi and the maximum over ITS landmarks go to S->red for the all-reduce hook; k_ba_prep's phase 2 folds in the
+// cameras' maxima - replicated, known only after the all-reduce of Hpp - and takes the decision)
+__device__ __forceinline__ void ba_prep_fan(const ba_fan& F, int nbp, int Cf, int first, int phase, ba_state* __restrict__ S)
+{
+    if (threadIdx.x >= 64) return;
+    const double chi = fan_sum(F.l_chi, nbp);
+    double md = 0;
+    if (first) { md = fan_max(F.l_max, nbp, 0.0); if (phase == 0) md = fan_max(F.c_max, Cf, md); }
+    if (threadIdx.x == 0) {
+        if (phase == 1) { S->red[0] = chi; S->red[1] = md; return; }
+        S->chi_cur = chi;
+        if (first) { S->max_diag = md; S->lambda = 1e-5 * md; S->ni = 2; }
+        S->qmax = 0; S->accepted = 0; S->again = 0; S->terminate = 0; S->rho = 0; S->chol_ok = 1;
+    }
+}
 __global__ __launch_bounds__(256) void k_ba_linearize(int nbp, const ba_cam* __restrict__ cams, const double* __restrict__ pts,
                                                       const int* __restrict__ e_cam, const int* __restrict__ e_pt, const double* __restrict__ e_meas,
                                                       const int* __restrict__ cslot, const int* __restrict__ p_start, const int* __restrict__ p_edges,
@@ -587,10 +705,20 @@ __global__ __launch_bounds__(256) void k_ba_linearize(int nbp, const ba_cam* __r
                                                       double* __restrict__ Hpl, double* __restrict__ Hll, double* __restrict__ bl,
                                                       double* __restrict__ err, double* __restrict__ chi_e, double* __restrict__ pdiag,
                                                       double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ cdiag,
-                                                      const int* __restrict__ c_pt, const double* __restrict__ c_meas)
+                                                      const int* __restrict__ c_pt, const double* __restrict__ c_meas,
+                                                      ba_fan F, ba_state* __restrict__ S, int first, int phase)
 {
-    if ((int)blockIdx.x < nbp) ba_point_body(blockIdx.x, cams, pts, e_cam, e_meas, cslot, p_start, p_edges, Pa, K, delta, Hpl, Hll, bl, err, chi_e, pdiag);
-    else ba_cam_body(blockIdx.x - nbp, cams, pts, e_cam, e_pt, e_meas, c_start, c_edges, K, delta, Hpp, bp, cdiag, c_pt, c_meas);
+    __shared__ double s_f[8];
+    double mine[2] = { 0, 0 }, md_cam = 0;
+    const bool pb = (int)blockIdx.x < nbp;
+    if (pb) ba_point_body(blockIdx.x, cams, pts, e_cam, e_meas, cslot, p_start, p_edges, Pa, K, delta, Hpl, Hll, bl, err, chi_e, pdiag, mine);
+    else ba_cam_body(blockIdx.x - nbp, cams, pts, e_cam, e_pt, e_meas, c_start, c_edges, K, delta, Hpp, bp, cdiag, c_pt, c_meas, &md_cam);
+    if (!F.l_chi) return;                                        // (BH_BA_FAN=0: the sums as separate launches, the A/B reference)
+    ba_lin_fan_store(pb, pb ? (int)blockIdx.x : (int)blockIdx.x - nbp, mine, md_cam, F, s_f);
+    if (fan_arrive(&S->tick[0], (int)gridDim.x)) {
+        ba_prep_fan(F, nbp, (int)gridDim.x - nbp, first, phase, S);
+        if (threadIdx.x == 0) __hip_atomic_store(&S->tick[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 #define BA_NPART 256
@@ -628,14 +756,14 @@ __device__ __forceinline__ void ba_prep_body(const double* __restrict__ chi_e, i
     __shared__ double s_max[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double v[1] = { 0 };
-    if (phase != 2) {
+    if (phase < 2) {
         if (part) { if (tid < BA_NPART) v[0] = part[2 * tid]; }
         else for (int e = tid; e < Ea; e += 1024) v[0] += chi_e[e];
     }
     d_block_sum<1, 1024>(v, s_red);
     double md = 0;
     if (first && phase != 2) {
-        for (int j = tid; j < Pa; j += 1024) md = fmax(md, pdiag[j]);
+        if (phase != 3) for (int j = tid; j < Pa; j += 1024) md = fmax(md, pdiag[j]);
         for (int c = tid; c < Cf; c += 1024) md = fmax(md, cdiag[c]);
         for (int m = 32; m > 0; m >>= 1) md = fmax(md, d_shfl_xor(md, m));
         if (lane == 0) s_max[wv] = md;
@@ -645,6 +773,7 @@ __device__ __forceinline__ void ba_prep_body(const double* __restrict__ chi_e, i
     if (tid == 0) {
         if (phase == 1) { S->red[0] = v[0]; S->red[1] = md; return; }
         if (phase == 2) { v[0] = S->red[0]; md = S->red[1]; }
+        if (phase == 3) { v[0] = S->red[0]; md = fmax(S->red[1], md); }      // fan-in form: red[1] holds the landmarks' maximum, md the cameras'
         S->chi_cur = v[0];
         if (first) { S->max_diag = md; S->lambda = 1e-5 * md; S->ni = 2; }
         S->qmax = 0; S->accepted = 0; S->again = 0; S->terminate = 0; S->rho = 0; S->chol_ok = 1;
@@ -2484,8 +2613,10 @@ __device__ __forceinline__ void ba_update_body(int bid, const ba_cam* __restrict
                                                    const int* __restrict__ p_start, const int* __restrict__ p_edges,
                                                    const int* __restrict__ e_cam, const double* __restrict__ Hpl,
                                                    const double* __restrict__ Dinv, const double* __restrict__ bl,
-                                                   const double* __restrict__ dxp, double* __restrict__ dxl, ba_K K)
+                                                   const double* __restrict__ dxp, double* __restrict__ dxl, ba_K K,
+                                                   double lambda = 0.0, double* __restrict__ mine = nullptr /* this thread's dx'(lambda dx + b) */)
 {
+    if (mine) *mine = 0.0;
     if (bid < pblocks) {
         // BP_G lanes per landmark (as the linearisation): a lane takes every BP_G-th edge - one thread per landmark walked its ~8 edges one
         // dependent load chain after the other (k_ba_update: 25 us at configs[2], 13 us for a live window) - and the partial sums of
@@ -2509,12 +2640,15 @@ __device__ __forceinline__ void ba_update_body(int bid, const ba_cam* __restrict
         if (!live || sub) return;
         const double c[3] = { bl[3 * j] - acc[0], bl[3 * j + 1] - acc[1], bl[3 * j + 2] - acc[2] };
         const double* Di = Dinv + 9 * (size_t)j;
+        double q = 0;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             const double dl = Di[3 * a] * c[0] + Di[3 * a + 1] * c[1] + Di[3 * a + 2] * c[2];
             dxl[3 * j + a] = dl;
             pts_t[3 * j + a] = pts[3 * j + a] + dl;
+            q += dl * (lambda * dl + bl[3 * j + a]);
         }
+        if (mine) *mine = q;
     } else {
         const int i = (bid - pblocks) * 256 + threadIdx.x;
         if (i >= C) return;
@@ -2530,33 +2664,80 @@ __global__ __launch_bounds__(256) void k_ba_update(const ba_cam* __restrict__ ca
                                                    const int* __restrict__ p_start, const int* __restrict__ p_edges,
                                                    const int* __restrict__ e_cam, const double* __restrict__ Hpl,
                                                    const double* __restrict__ Dinv, const double* __restrict__ bl,
-                                                   const double* __restrict__ dxp, double* __restrict__ dxl, ba_K K)
+                                                   const double* __restrict__ dxp, double* __restrict__ dxl, ba_K K,
+                                                   ba_fan F, const ba_state* __restrict__ S)
 {
-    ba_update_body(blockIdx.x, cams, cams_t, pts, pts_t, cslot, C, Pa, pblocks, p_start, p_edges, e_cam, Hpl, Dinv, bl, dxp, dxl, K);
+    __shared__ double s_f[4];
+    double mine = 0;
+    ba_update_body(blockIdx.x, cams, cams_t, pts, pts_t, cslot, C, Pa, pblocks, p_start, p_edges, e_cam, Hpl, Dinv, bl, dxp, dxl, K, F.u_sum ? S->lambda : 0.0, &mine);
+    if (!F.u_sum || (int)blockIdx.x >= pblocks) return;
+    const double t = fan_block_sum256(mine, s_f);
+    if (threadIdx.x == 0) fan_store(F.u_sum + blockIdx.x, t);    // read by the last workgroup of the NEXT launch (k_ba_err)
 }
 
 // ---- k_ba_err: per-edge error and robust chi at the trial state
 __device__ __forceinline__ void ba_err_body(int bid, const ba_cam* __restrict__ cams, const double* __restrict__ pts,
                                                 const int* __restrict__ e_cam, const int* __restrict__ e_pt,
                                                 const double* __restrict__ e_meas, int Ea, double delta,
-                                                double* __restrict__ err, double* __restrict__ chi_e)
+                                                double* __restrict__ err, double* __restrict__ chi_e, double* __restrict__ mine = nullptr)
 {
     const int e = bid * 256 + threadIdx.x;
+    if (mine) *mine = 0.0;
     if (e >= Ea) return;
     double er[2], r0, r1;
     d_edge_error(cams[e_cam[e]].w2i, pts + 3 * (size_t)e_pt[e], e_meas + 2 * e, er);
     d_huber(er[0] * er[0] + er[1] * er[1], delta, &r0, &r1);
     err[2 * e] = er[0]; err[2 * e + 1] = er[1]; chi_e[e] = r0;
+    if (mine) *mine = r0;
 }
+__device__ __forceinline__ void ba_decide_fan(const ba_fan& F, int n_e, int n_u, const double* __restrict__ dxp, const double* __restrict__ bp, int n6,
+                                              int phase, int cam_part, ba_state* __restrict__ S, ba_state* host_out, int seq);
 __global__ __launch_bounds__(256) void k_ba_err(const ba_cam* __restrict__ cams, const double* __restrict__ pts,
                                                 const int* __restrict__ e_cam, const int* __restrict__ e_pt,
                                                 const double* __restrict__ e_meas, int Ea, double delta,
-                                                double* __restrict__ err, double* __restrict__ chi_e)
+                                                double* __restrict__ err, double* __restrict__ chi_e,
+                                                ba_fan F, int n_u, const double* __restrict__ dxp, const double* __restrict__ bp, int n6,
+                                                int phase, int cam_part, ba_state* __restrict__ S, ba_state* host_out, int seq)
 {
-    ba_err_body(blockIdx.x, cams, pts, e_cam, e_pt, e_meas, Ea, delta, err, chi_e);
+    __shared__ double s_f[4];
+    double mine = 0;
+    ba_err_body(blockIdx.x, cams, pts, e_cam, e_pt, e_meas, Ea, delta, err, chi_e, &mine);
+    if (!F.e_chi) return;
+    const double t = fan_block_sum256(mine, s_f);
+    if (threadIdx.x == 0) fan_store(F.e_chi + blockIdx.x, t);
+    if (fan_arrive(&S->tick[1], (int)gridDim.x)) {
+        ba_decide_fan(F, (int)gridDim.x, n_u, dxp, bp, n6, phase, cam_part, S, host_out, seq);
+        if (threadIdx.x == 0) __hip_atomic_store(&S->tick[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- k_ba_decide: Levenberg gain ratio and lambda schedule (OptimizationAlgorithmLevenberg::solve)
+__device__ __forceinline__ void ba_verdict(double chi_trial, double denom, double lambda, ba_state* __restrict__ S, ba_state* host_out, int seq)
+{
+    double tempChi = chi_trial;
+    if (!S->chol_ok) tempChi = DBL_MAX;
+    double rho = S->chi_cur - tempChi;
+    const double scale = denom + 1e-3;
+    rho /= scale;
+    S->chi_trial = tempChi; S->scale = scale; S->rho = rho;
+    if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - d_cube(2 * rho - 1);             // g2o: 1. - pow((2*rho-1), 3)
+        alpha = fmin(alpha, 2. / 3.);
+        S->lambda = lambda * fmax(1. / 3., alpha); S->ni = 2; S->chi_cur = tempChi; S->accepted = 1;
+    } else {
+        S->lambda = lambda * S->ni; S->ni *= 2; S->accepted = 0;
+    }
+    S->qmax += 1;
+    S->again = (rho < 0 && S->qmax < 10) ? 1 : 0;
+    S->terminate = (!S->again && (S->qmax == 10 || rho == 0)) ? 1 : 0;
+    S->chol_ok = 1;                                  // re-arm for the next trial
+    if (host_out) {                                  // the host polls pinned memory for the verdict instead of waiting on a copy + stream sync
+        ba_state t = *S; t.pad = 0;
+        *host_out = t;
+        __threadfence_system();
+        __atomic_store_n(&host_out->pad, seq, __ATOMIC_RELEASE);
+    }
+}
 __device__ __forceinline__ void ba_decide_body(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxp,
                                                     const double* __restrict__ bp, int n6, const double* __restrict__ dxl,
                                                     const double* __restrict__ bl, int n3, int phase, int cam_part,
@@ -2579,29 +2760,30 @@ __device__ __forceinline__ void ba_decide_body(const double* __restrict__ chi_e,
     if (tid == 0) {
         if (phase == 1) { S->red[0] = v[0]; S->red[1] = v[1]; S->red[2] = S->chol_ok ? 0.0 : 1.0; return; }
         if (phase == 2) { v[0] = S->red[0]; v[1] = S->red[1]; if (S->red[2] > 0) S->chol_ok = 0; }
-        double tempChi = v[0];
-        if (!S->chol_ok) tempChi = DBL_MAX;
-        double rho = S->chi_cur - tempChi;
-        const double scale = v[1] + 1e-3;
-        rho /= scale;
-        S->chi_trial = tempChi; S->scale = scale; S->rho = rho;
-        if (rho > 0 && isfinite(tempChi)) {
-            double alpha = 1. - d_cube(2 * rho - 1);             // g2o: 1. - pow((2*rho-1), 3)
-            alpha = fmin(alpha, 2. / 3.);
-            S->lambda = lambda * fmax(1. / 3., alpha); S->ni = 2; S->chi_cur = tempChi; S->accepted = 1;
-        } else {
-            S->lambda = lambda * S->ni; S->ni *= 2; S->accepted = 0;
-        }
-        S->qmax += 1;
-        S->again = (rho < 0 && S->qmax < 10) ? 1 : 0;
-        S->terminate = (!S->again && (S->qmax == 10 || rho == 0)) ? 1 : 0;
-        S->chol_ok = 1;                                  // re-arm for the next trial
-        if (host_out) {                                  // the host polls pinned memory for the verdict instead of waiting on a copy + stream sync
-            ba_state t = *S; t.pad = 0;
-            *host_out = t;
-            __threadfence_system();
-            __atomic_store_n(&host_out->pad, seq, __ATOMIC_RELEASE);
-        }
+        ba_verdict(v[0], v[1], lambda, S, host_out, seq);
+    }
+}
+// the fan-in form (single GPU): chi of the trial from the error kernel's slots, the landmark half of the denominator from the update's, the
+// camera half summed here; one wave
+// (phase 1, multi-GPU: this rank's sums go to S->red for the all-reduce hook, k_ba_decide's phase 2 takes the decision; cam_part: this rank
+// contributes the replicated camera half of the denominator)
+__device__ __forceinline__ void ba_decide_fan(const ba_fan& F, int n_e, int n_u, const double* __restrict__ dxp, const double* __restrict__ bp, int n6,
+                                              int phase, int cam_part, ba_state* __restrict__ S, ba_state* host_out, int seq)
+{
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    const double lambda = S->lambda;
+    const double chi = fan_sum(F.e_chi, n_e);
+    double q = fan_sum(F.u_sum, n_u);
+    if (cam_part) {
+        double c = 0;
+        for (int i = lane; i < n6; i += 64) c += dxp[i] * (lambda * dxp[i] + bp[i]);
+        for (int m = 32; m > 0; m >>= 1) c += d_shfl_xor(c, m);
+        q += c;
+    }
+    if (lane == 0) {
+        if (phase == 1) { S->red[0] = chi; S->red[1] = q; S->red[2] = S->chol_ok ? 0.0 : 1.0; return; }
+        ba_verdict(chi, q, lambda, S, host_out, seq);
     }
 }
 __global__ __launch_bounds__(1024) void k_ba_decide(const double* __restrict__ chi_e, int Ea, const double* __restrict__ dxp,
@@ -2623,11 +2805,12 @@ struct ba_view {
     const int *e_cam, *e_pt; const double* e_meas; const int* cslot;
     const int *p_start, *p_edges, *c_start, *c_edges;
     double *err[2], *chi_e[2];
-    double *Hpl, *Hll, *bl, *Hpp, *bp, *pdiag, *cdiag, *Dinv, *db, *S, *bs, *dxp, *dxl, *part;
+    double *Hpl, *Hll, *bl, *Hpp, *bp, *pdiag, *cdiag, *Dinv, *db, *S, *bs, *dxp, *dxl;
     const int2* pairs; const int* j_start; const int2* join;
     ba_state* state; ba_state* hstate;
     int C, Cf, Pa, Ea, npairs, bw, n6, pad;
     ba_K K;
+    ba_fan fan;                   // the window's fan-in slots (the same sums, in the same order, as bh_ba_optimize)
 };
 
 // Which (window, block) a workgroup of a (blocks, windows-rounded-up-to-8) grid works on.  Consecutive workgroup ids go round the 8 XCDs,
@@ -2636,6 +2819,7 @@ struct ba_view {
 // thrashed every L2 and the Schur launch ran at HBM speed (87 us; the same windows one at a time: 12.5 us each).
 __device__ __forceinline__ bool bb_where(int W, int& w, int& bid)
 {
+    if (gridDim.y == 1) { w = 0; bid = blockIdx.x; return true; }      // a batch of ONE window (bh_ba_optimize): its workgroups go round all XCDs
     const int nb = gridDim.x, lin = blockIdx.y * nb + blockIdx.x, v = lin >> 3, g = v / nb;
     w = 8 * g + (lin & 7); bid = v - g * nb;
     return w < W;
@@ -2646,6 +2830,7 @@ __global__ void k_bb_init(const ba_view* __restrict__ views, int W, int iters, i
     const int w = blockIdx.x * 64 + threadIdx.x;
     if (w >= W) return;
     ba_state* S = views[w].state;
+    S->tick[0] = 0; S->tick[1] = 0;
     S->b_it = 0; S->b_iters = iters; S->b_need_lin = 1; S->b_done = (views[w].Ea == 0 || iters <= 0) ? 1 : 0; S->b_last_err = 0; S->b_verbose = verbose; S->b_fail = 0;
 }
 __global__ void k_bb_setcur(const ba_view* __restrict__ views, const int* __restrict__ cur, int W)
@@ -2656,22 +2841,19 @@ __global__ void k_bb_setcur(const ba_view* __restrict__ views, const int* __rest
 
 __global__ __launch_bounds__(256) void k_bb_linearize(const ba_view* __restrict__ views, int W, double delta)
 {
+    __shared__ double s_f[8];
     int w, bx;
     if (!bb_where(W, w, bx)) return;
     const ba_view& V = views[w];
     const ba_state* S = V.state;
     if (S->b_done || !S->b_need_lin) return;
     const int nbp = (V.Pa * BP_G + 255) / 256, cur = S->b_cur;
+    double mine[2] = { 0, 0 }, md_cam = 0;
     if (bx < nbp) ba_point_body(bx, V.cams[cur], V.pts[cur], V.e_cam, V.e_meas, V.cslot, V.p_start, V.p_edges, V.Pa, V.K, delta, V.Hpl, V.Hll, V.bl,
-                                             V.err[0], V.chi_e[0], V.pdiag);
-    else if (bx < nbp + V.Cf) ba_cam_body(bx - nbp, V.cams[cur], V.pts[cur], V.e_cam, V.e_pt, V.e_meas, V.c_start, V.c_edges, V.K, delta, V.Hpp, V.bp, V.cdiag);
-}
-__global__ __launch_bounds__(1024) void k_bb_partial(const ba_view* __restrict__ views, int trial)
-{
-    const ba_view& V = views[blockIdx.y];
-    const ba_state* S = V.state;
-    if (S->b_done || !V.part || (!trial && !S->b_need_lin)) return;
-    ba_partial_body(V.chi_e[trial], V.Ea, trial ? V.dxl : nullptr, V.bl, 3 * V.Pa, S, V.part);
+                                             V.err[0], V.chi_e[0], V.pdiag, mine);
+    else if (bx < nbp + V.Cf) ba_cam_body(bx - nbp, V.cams[cur], V.pts[cur], V.e_cam, V.e_pt, V.e_meas, V.c_start, V.c_edges, V.K, delta, V.Hpp, V.bp, V.cdiag, nullptr, nullptr, &md_cam);
+    else return;
+    ba_lin_fan_store(bx < nbp, bx < nbp ? bx : bx - nbp, mine, md_cam, V.fan, s_f);      // (read by k_bb_prep, the next launch)
 }
 __global__ __launch_bounds__(1024) void k_bb_prep(const ba_view* __restrict__ views)
 {
@@ -2679,7 +2861,7 @@ __global__ __launch_bounds__(1024) void k_bb_prep(const ba_view* __restrict__ vi
     ba_state* S = V.state;
     if (S->b_done || !S->b_need_lin) return;
     const int first = S->b_it == 0 ? 1 : 0;
-    ba_prep_body(V.chi_e[0], V.Ea, V.pdiag, V.Pa, V.cdiag, V.Cf, first, 0, V.part, S);
+    ba_prep_fan(V.fan, (V.Pa * BP_G + 255) / 256, V.Cf, first, 0, S);
     if (threadIdx.x == 0) {
         S->b_last_err = 0;
         if (first && !isfinite(S->max_diag)) { S->b_done = 1; S->b_fail = 1; }          // non-finite Hessian at the initial estimate
@@ -2734,7 +2916,13 @@ __global__ __launch_bounds__(256) void k_bb_update(const ba_view* __restrict__ v
     const int pblocks = (V.Pa * BP_G + 255) / 256, cblocks = (V.C + 255) / 256;
     if (S->b_done || bx >= pblocks + cblocks) return;
     const int cur = S->b_cur;
-    ba_update_body(bx, V.cams[cur], V.cams[cur ^ 1], V.pts[cur], V.pts[cur ^ 1], V.cslot, V.C, V.Pa, pblocks, V.p_start, V.p_edges, V.e_cam, V.Hpl, V.Dinv, V.bl, V.dxp, V.dxl, V.K);
+    __shared__ double s_f[4];
+    double mine = 0;
+    ba_update_body(bx, V.cams[cur], V.cams[cur ^ 1], V.pts[cur], V.pts[cur ^ 1], V.cslot, V.C, V.Pa, pblocks, V.p_start, V.p_edges, V.e_cam, V.Hpl, V.Dinv, V.bl, V.dxp, V.dxl, V.K,
+                   S->lambda, &mine);
+    if (bx >= pblocks) return;
+    const double t = fan_block_sum256(mine, s_f);
+    if (threadIdx.x == 0) fan_store(V.fan.u_sum + bx, t);
 }
 __global__ __launch_bounds__(256) void k_bb_err(const ba_view* __restrict__ views, int W, double delta)
 {
@@ -2744,23 +2932,28 @@ __global__ __launch_bounds__(256) void k_bb_err(const ba_view* __restrict__ view
     const ba_state* S = V.state;
     if (S->b_done || bx * 256 >= V.Ea) return;
     const int cur = S->b_cur;
-    ba_err_body(bx, V.cams[cur ^ 1], V.pts[cur ^ 1], V.e_cam, V.e_pt, V.e_meas, V.Ea, delta, V.err[1], V.chi_e[1]);
+    __shared__ double s_f[4];
+    double mine = 0;
+    ba_err_body(bx, V.cams[cur ^ 1], V.pts[cur ^ 1], V.e_cam, V.e_pt, V.e_meas, V.Ea, delta, V.err[1], V.chi_e[1], &mine);
+    const double t = fan_block_sum256(mine, s_f);
+    if (threadIdx.x == 0) fan_store(V.fan.e_chi + bx, t);
 }
 __global__ __launch_bounds__(1024) void k_bb_decide(const ba_view* __restrict__ views, int seq)
 {
     const ba_view& V = views[blockIdx.y];
     ba_state* S = V.state;
+    ba_state* const hout = V.hstate + (seq & 1);             // the verdict slot of this round's parity (the host is at most one round behind)
     if (S->b_done) {
         if (threadIdx.x == 0 && S->b_fail == 1) {                // a window that failed in k_bb_prep: tell the host once
             S->b_fail = 2;
             ba_state t = *S; t.pad = 0;
-            *V.hstate = t;
+            *hout = t;
             __threadfence_system();
-            __atomic_store_n(&V.hstate->pad, seq, __ATOMIC_RELEASE);
+            __atomic_store_n(&hout->pad, seq, __ATOMIC_RELEASE);
         }
         return;
     }
-    ba_decide_body(V.chi_e[1], V.Ea, V.dxp, V.bp, V.n6, V.dxl, V.bl, 3 * V.Pa, 0, 1, V.part, S, nullptr, 0);
+    ba_decide_fan(V.fan, (V.Ea + 255) / 256, (V.Pa * BP_G + 255) / 256, V.dxp, V.bp, V.n6, 0, 1, S, nullptr, 0);
     if (threadIdx.x == 0) {                                      // the control flow of bh_ba_optimize's host loop
         if (S->accepted) S->b_cur ^= 1;
         S->b_last_err = 1;                                       // the trial's errors are the last computeActiveErrors
@@ -2770,9 +2963,9 @@ __global__ __launch_bounds__(1024) void k_bb_decide(const ba_view* __restrict__ 
             if (S->terminate || S->b_it >= S->b_iters) S->b_done = 1;
         } else S->b_need_lin = 0;
         ba_state t = *S; t.pad = 0;
-        *V.hstate = t;
+        *hout = t;
         __threadfence_system();
-        __atomic_store_n(&V.hstate->pad, seq, __ATOMIC_RELEASE);
+        __atomic_store_n(&hout->pad, seq, __ATOMIC_RELEASE);
     }
 }
 
@@ -2850,9 +3043,10 @@ extern "C" void bh_ba_destroy(bh_ba* ba)
     bh_buf* all[] = { &ba->cams[0], &ba->cams[1], &ba->pts[0], &ba->pts[1], &ba->e_cam, &ba->e_pt, &ba->e_meas, &ba->cslot,
                       &ba->p_start, &ba->p_edges, &ba->c_start, &ba->c_edges, &ba->err[0], &ba->err[1], &ba->chi_e[0],
                       &ba->chi_e[1], &ba->Hpl, &ba->Hll, &ba->bl, &ba->Hpp, &ba->bp, &ba->pdiag, &ba->cdiag, &ba->Dinv,
-                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch, &ba->join, &ba->j_start, &ba->pair_rec, &ba->join_pt, &ba->row_start, &ba->join_slot, &ba->c_pt, &ba->c_meas };
+                      &ba->db, &ba->S, &ba->bs, &ba->dxp, &ba->dxl, &ba->state, &ba->pairs, &ba->part, &ba->xch, &ba->fan, &ba->join, &ba->j_start, &ba->pair_rec, &ba->join_pt, &ba->row_start, &ba->join_slot, &ba->c_pt, &ba->c_meas };
     for (bh_buf* b : all) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     if (ba->h_state) (void)hipHostFree(ba->h_state);
+    if (ba->self) bh_ba_batch_destroy(ba->self);
     delete ba->bcr;
     delete ba;
 }
@@ -4307,6 +4501,7 @@ static int ba_set_problem_rest(bh_ba* ba, int C, const double* R, const double* 
     BH_TRY(bh_reserve(ctx, &ba->S, sizeof(double) * ((size_t)rows_pad * (size_t)(ba->bw + 1) + 1))); BH_TRY(bh_reserve(ctx, &ba->bs, sizeof(double) * (n6 + 6)));
     BH_TRY(bh_reserve(ctx, &ba->dxp, sizeof(double) * ((size_t)rows_pad + 6))); BH_TRY(bh_reserve(ctx, &ba->dxl, sizeof(double) * 3 * ((size_t)Pa + 1)));
     BH_TRY(bh_reserve(ctx, &ba->part, sizeof(double) * 2 * BA_NPART));
+    BH_TRY(bh_reserve(ctx, &ba->fan, sizeof(double) * ba_fan_doubles(Pa, Cf, E)));
     if (!small) {
         BH_HIP(ctx, hipMemsetAsync(ba->state.p, 0, sizeof(ba_state), ctx->stream));
         BH_HIP(ctx, hipMemsetAsync(ba->err[0].p, 0, sizeof(double) * 2 * (E + 1), ctx->stream));
@@ -4388,6 +4583,19 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
     if (iters_done) *iters_done = 0;
     const int C = ba->C, Cf = ba->Cf, Pa = ba->Pa, Ea = ba->Ea, n6 = 6 * Cf;
     if (Ea == 0 || iters <= 0) return BH_OK;
+    // A local window (dense on-chip solve) runs as a batch of ONE: the same kernel bodies - bitwise the same result (asserted for batches) -
+    // with the Levenberg control flow on the device, so the host enqueues trial t + 1 before it has seen the verdict of trial t and the
+    // device never idles through the host's poll -> launch turnaround (~25 us of a 260 us iteration at configs[2], of a 60 us one at the live
+    // size).  The host-driven loop below stays for everything else (banded / cyclic-reduction solves, the multi-GPU form) and as the A/B
+    // reference (BH_BA_SELF_BATCH=0).
+    const bool self_off = getenv("BH_BA_SELF_BATCH") && atoi(getenv("BH_BA_SELF_BATCH")) == 0;
+    if (!ba->ar && ba->chol_dense && Cf > 0 && !self_off) {
+        if (!ba->self) { bh_ba* one = ba; BH_TRY(bh_ba_batch_create(ctx, 1, &one, &ba->self)); }
+        int itd = 0;
+        const int brc = bh_ba_batch_optimize(ba->self, iters, huber_delta, verbose_errors, &itd);
+        if (iters_done) *iters_done = itd;
+        return brc;
+    }
     const int* e_cam = (const int*)ba->e_cam.p; const int* e_pt = (const int*)ba->e_pt.p; const double* e_meas = (const double*)ba->e_meas.p;
     const int* cslot = (const int*)ba->cslot.p;
     const int* p_start = (const int*)ba->p_start.p; const int* p_edges = (const int*)ba->p_edges.p;
@@ -4398,7 +4606,13 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
     ba_state* state = (ba_state*)ba->state.p;
     double* red = (double*)((char*)ba->state.p + offsetof(ba_state, red));
     const bool dist = ba->ar != nullptr;
-    double* part = Ea > 16384 ? (double*)ba->part.p : nullptr;       // two-stage sums above this size (one workgroup streams ~50 GB/s: 80 k residuals took 22 + 31 us in k_ba_prep / k_ba_decide)
+    double* part = Ea > 16384 ? (double*)ba->part.p : nullptr;       // (multi-GPU form) two-stage sums above this size (one workgroup streams ~50 GB/s: 80 k residuals took 22 + 31 us in k_ba_prep / k_ba_decide)
+    // the sums of the Levenberg control ride in the kernels that produce their terms (fan-in, see fan_store); in the multi-GPU form the last
+    // workgroup leaves this rank's sums in state->red for the all-reduce hook and phase 2 of k_ba_prep / k_ba_decide takes the decision
+    const bool fan_off = getenv("BH_BA_FAN") && atoi(getenv("BH_BA_FAN")) == 0;       // A/B switch
+    const bool use_fan = !fan_off;
+    ba_fan F = {}; if (use_fan) F = ba_fan_of(ba);
+    if (use_fan) BH_HIP(ctx, hipMemsetAsync(&state->tick[0], 0, sizeof(int) * 2, st));
     const int lead = ba->rank == 0 ? 1 : 0;              // the rank that contributes the replicated camera terms
     ba->comm_ms = 0; ba->comm_bytes = 0; ba->ar_bytes = 0;
     if (ba->dsol) { ba->dsol->bytes_rs = ba->dsol->bytes_ag = 0; ba->dsol->ms_replicated = 0; ba->dsol->n_replicated = 0; }
@@ -4410,21 +4624,24 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
             const int nbp = (Pa * BP_G + 255) / 256;
             BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_ba_linearize, dim3(nbp + Cf), dim3(256), st, nbp, cams, pts, e_cam, e_pt, e_meas, cslot, p_start, p_edges,
                       c_start, c_edges, Pa, ba->K, huber_delta, Hpl, Hll, bl, (double*)ba->err[0].p, (double*)ba->chi_e[0].p, pdiag, Hpp, bp, cdiag,
-                      ba->cam_major ? (const int*)ba->c_pt.p : (const int*)nullptr, ba->cam_major ? (const double*)ba->c_meas.p : (const double*)nullptr);
+                      ba->cam_major ? (const int*)ba->c_pt.p : (const int*)nullptr, ba->cam_major ? (const double*)ba->c_meas.p : (const double*)nullptr,
+                      F, state, it == 0 ? 1 : 0, dist ? 1 : 0);
         }
         if (dist && Cf) {                                  // Hpp, bp: partial over this rank's edges -> full on every rank
             BH_TRY(ba_allreduce(ba, Hpp, 36LL * Cf, 0)); BH_TRY(ba_allreduce(ba, bp, n6, 0));
             hipLaunchKernelGGL(k_ba_cdiag, dim3((Cf + 63) / 64), dim3(64), 0, st, (const double*)Hpp, Cf, cdiag);
         }
-        if (part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_partial, dim3(BA_NPART), dim3(1024), st, (const double*)ba->chi_e[0].p, Ea, (const double*)nullptr,
-                            (const double*)nullptr, 0, (const ba_state*)state, part);
-        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_prep, dim3(1), dim3(1024), st, (const double*)ba->chi_e[0].p, Ea, (const double*)pdiag, Pa,
-                  (const double*)cdiag, Cf, it == 0 ? 1 : 0, dist ? 1 : 0, (const double*)part, state);
+        if (!use_fan) {
+            if (part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_partial, dim3(BA_NPART), dim3(1024), st, (const double*)ba->chi_e[0].p, Ea, (const double*)nullptr,
+                                (const double*)nullptr, 0, (const ba_state*)state, part);
+            BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_prep, dim3(1), dim3(1024), st, (const double*)ba->chi_e[0].p, Ea, (const double*)pdiag, Pa,
+                      (const double*)cdiag, Cf, it == 0 ? 1 : 0, dist ? 1 : 0, (const double*)part, state);
+        }
         if (dist) {
             BH_TRY(ba_allreduce(ba, red, 1, 0));
             if (it == 0) BH_TRY(ba_allreduce(ba, red + 1, 1, 1));
             BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_prep, dim3(1), dim3(1024), st, (const double*)ba->chi_e[0].p, Ea, (const double*)pdiag, Pa,
-                      (const double*)cdiag, Cf, it == 0 ? 1 : 0, 2, (const double*)part, state);
+                      (const double*)cdiag, Cf, it == 0 ? 1 : 0, use_fan ? 3 : 2, (const double*)part, state);
         }
         ba_state hs;
         if (it == 0) {
@@ -4484,16 +4701,19 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
                 }
             }
             const int upblocks = (Pa * BP_G + 255) / 256;       // the update's landmark workgroups: BP_G lanes per landmark
-            BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_update, dim3(upblocks + cblocks), dim3(256), st, cams, cams_t, pts, pts_t, cslot, C, Pa, upblocks,
-                      p_start, p_edges, e_cam, (const double*)Hpl, (const double*)Dinv, (const double*)bl, (const double*)dxp, dxl, ba->K);
-            BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_err, dim3((Ea + 255) / 256), dim3(256), st, (const ba_cam*)cams_t, (const double*)pts_t, e_cam, e_pt,
-                      e_meas, Ea, huber_delta, (double*)ba->err[1].p, (double*)ba->chi_e[1].p);
-            if (part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_partial, dim3(BA_NPART), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxl,
-                                (const double*)bl, 3 * Pa, (const ba_state*)state, part);
             const int seq = ++ba->seq;
             ba_state* hpin = ba->h_state;                // may be null (allocation failed): then the copy + sync path below
-            BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_decide, dim3(1), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxp, (const double*)bp,
-                      n6, (const double*)dxl, (const double*)bl, 3 * Pa, dist ? 1 : 0, dist ? lead : 1, (const double*)part, state, dist ? (ba_state*)nullptr : hpin, seq);
+            BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_update, dim3(upblocks + cblocks), dim3(256), st, cams, cams_t, pts, pts_t, cslot, C, Pa, upblocks,
+                      p_start, p_edges, e_cam, (const double*)Hpl, (const double*)Dinv, (const double*)bl, (const double*)dxp, dxl, ba->K, F, (const ba_state*)state);
+            BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_err, dim3((Ea + 255) / 256), dim3(256), st, (const ba_cam*)cams_t, (const double*)pts_t, e_cam, e_pt,
+                      e_meas, Ea, huber_delta, (double*)ba->err[1].p, (double*)ba->chi_e[1].p, F, upblocks, (const double*)dxp, (const double*)bp, n6,
+                      dist ? 1 : 0, dist ? lead : 1, state, dist ? (ba_state*)nullptr : hpin, seq);
+            if (!use_fan) {
+                if (part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_partial, dim3(BA_NPART), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxl,
+                                    (const double*)bl, 3 * Pa, (const ba_state*)state, part);
+                BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_decide, dim3(1), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxp, (const double*)bp,
+                          n6, (const double*)dxl, (const double*)bl, 3 * Pa, dist ? 1 : 0, dist ? lead : 1, (const double*)part, state, dist ? (ba_state*)nullptr : hpin, seq);
+            }
             if (dist) {
                 BH_TRY(ba_allreduce(ba, red, 3, 0));
                 BH_LAUNCH(ctx, BH_K_BA_OTHER, k_ba_decide, dim3(1), dim3(1024), st, (const double*)ba->chi_e[1].p, Ea, (const double*)dxp, (const double*)bp,
@@ -4533,7 +4753,7 @@ struct bh_ba_batch {
     bh_ctx* ctx = nullptr;
     std::vector<bh_ba*> win;
     bh_buf views, curs;
-    ba_state* hstates = nullptr;      // pinned, one per window: k_bb_decide's verdicts
+    ba_state* hstates = nullptr;      // pinned, TWO per window (round parity): k_bb_decide's verdicts - the host runs one round ahead of them
     int seq = 0;
 };
 
@@ -4546,11 +4766,11 @@ extern "C" int bh_ba_batch_create(bh_ctx* ctx, int W, bh_ba* const* windows, bh_
     (void)hipFuncSetAttribute((const void*)k_bb_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
     bh_ba_batch* b = new bh_ba_batch();
     b->ctx = ctx; b->win.assign(windows, windows + W);
-    if (hipHostMalloc((void**)&b->hstates, sizeof(ba_state) * W, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+    if (hipHostMalloc((void**)&b->hstates, sizeof(ba_state) * 2 * W, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
         (void)hipGetLastError(); delete b;
         return bh_set_err(ctx, BH_ERR_HIP, "bh_ba_batch_create: pinned allocation failed");
     }
-    memset(b->hstates, 0, sizeof(ba_state) * W);
+    memset(b->hstates, 0, sizeof(ba_state) * 2 * W);
     *out = b;
     return BH_OK;
 }
@@ -4569,12 +4789,12 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
 {
     if (!b) return BH_ERR_INVALID;
     bh_ctx* ctx = b->ctx;
-    const int W = (int)b->win.size(), W8 = (W + 7) & ~7;          // grids are (blocks, windows rounded up to 8): see bb_where
+    const int W = (int)b->win.size(), W8 = W == 1 ? 1 : (W + 7) & ~7;      // grids are (blocks, windows rounded up to 8): see bb_where
     BH_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     std::vector<ba_view> hv(W);
     std::vector<int> hcur(W);
-    int g_lin = 1, g_pb = 1, g_schur = 1, g_upd = 1, g_eb = 1, g_s64 = 0, any_part = 0;
+    int g_lin = 1, g_pb = 1, g_schur = 1, g_upd = 1, g_eb = 1, g_s64 = 0;
     for (int w = 0; w < W; w++) {
         bh_ba* ba = b->win[w];
         if (!ba->have_problem) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_optimize: window %d has no problem set", w);
@@ -4589,9 +4809,9 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
         V.Hpl = (double*)ba->Hpl.p; V.Hll = (double*)ba->Hll.p; V.bl = (double*)ba->bl.p; V.Hpp = (double*)ba->Hpp.p; V.bp = (double*)ba->bp.p;
         V.pdiag = (double*)ba->pdiag.p; V.cdiag = (double*)ba->cdiag.p; V.Dinv = (double*)ba->Dinv.p; V.db = (double*)ba->db.p;
         V.S = (double*)ba->S.p; V.bs = (double*)ba->bs.p; V.dxp = (double*)ba->dxp.p; V.dxl = (double*)ba->dxl.p;
-        V.part = ba->Ea > 16384 ? (double*)ba->part.p : nullptr;              // the same two-stage sums as bh_ba_optimize
+        V.fan = ba_fan_of(ba);
         V.pairs = (const int2*)ba->pairs.p; V.j_start = (const int*)ba->j_start.p; V.join = (const int2*)ba->join.p;
-        V.state = (ba_state*)ba->state.p; V.hstate = b->hstates + w;
+        V.state = (ba_state*)ba->state.p; V.hstate = b->hstates + 2 * w;
         V.C = ba->C; V.Cf = ba->Cf; V.Pa = ba->Pa; V.Ea = ba->Ea; V.npairs = ba->npairs; V.bw = ba->bw; V.n6 = 6 * ba->Cf; V.K = ba->K; V.pad = ba->schur_wave;
         if (ba->schur_wave) g_s64 = std::max(g_s64, (ba->npairs + 7) / 8 * 8);
         hcur[w] = ba->cur;
@@ -4601,7 +4821,6 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
         g_schur = std::max(g_schur, (ba->npairs + 7) / 8 * 8 + ba->Cf);
         g_upd = std::max(g_upd, (ba->Pa * BP_G + 255) / 256 + (ba->C + 255) / 256);
         g_eb = std::max(g_eb, (ba->Ea + 255) / 256);
-        any_part |= V.part != nullptr;
         if (iters_done) iters_done[w] = 0;
     }
     BH_TRY(bh_reserve(ctx, &b->views, sizeof(ba_view) * W)); BH_TRY(bh_reserve(ctx, &b->curs, sizeof(int) * W));
@@ -4614,14 +4833,15 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
     std::vector<char> done(W, 0);
     int active = 0;
     for (int w = 0; w < W; w++) { done[w] = (b->win[w]->Ea == 0 || iters <= 0) ? 1 : 0; active += !done[w]; b->win[w]->last_err_sel = 0; }
-    bool need_lin = true;
     int rc = BH_OK;
-    for (int round = 0; active > 0 && round < iters * 10 + 2; round++) {
-        if (need_lin) {
-            BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_bb_linearize, dim3(g_lin, W8), dim3(256), st, views, W, huber_delta);
-            if (any_part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_partial, dim3(BA_NPART, W), dim3(1024), st, views, 0);
-            BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_prep, dim3(1, W), dim3(1024), st, views);
-        }
+    // One round = one Levenberg trial of every live window.  Which kernels a window runs in a round is decided ON THE DEVICE (b_need_lin, b_done,
+    // b_cur in its control block), so the host does not have to know a round's verdicts before it enqueues the next one: it stays ONE round
+    // ahead (round r + 1 is in the queue while the verdicts of round r are polled; two pinned verdict slots per window, by round parity).  The
+    // device never waits for the host's poll -> launch turnaround, which was ~25 us of an iteration (a tenth of a configs[2] window's, half of a
+    // live window's); the one surplus round at the end finds every window done and returns at once.
+    auto enqueue_round = [&](int seq) {
+        BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_bb_linearize, dim3(g_lin, W8), dim3(256), st, views, W, huber_delta);      // (windows that retry with a larger lambda skip these two)
+        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_prep, dim3(1, W), dim3(1024), st, views);
         BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_dinv, dim3(g_pb + 8, W8), dim3(256), st, views, W);
         BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_schur, dim3(g_schur, W8), dim3(256), st, views, W);
         if (g_s64) BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_schur64, dim3(g_s64, W8), dim3(64), st, views, W);
@@ -4630,14 +4850,19 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
         bh_time_end(ctx);
         BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_bb_update, dim3(g_upd, W8), dim3(256), st, views, W);
         BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_bb_err, dim3(g_eb, W8), dim3(256), st, views, W, huber_delta);
-        if (any_part) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_partial, dim3(BA_NPART, W), dim3(1024), st, views, 1);
-        const int seq = ++b->seq;
         BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_decide, dim3(1, W), dim3(1024), st, views, seq);
+    };
+    const bool look_off = getenv("BH_BA_LOOKAHEAD") && atoi(getenv("BH_BA_LOOKAHEAD")) == 0;      // A/B switch: enqueue a round only after the last one's verdicts
+    int seq_cur = 0;
+    if (active > 0) { seq_cur = ++b->seq; enqueue_round(seq_cur); }
+    for (int round = 0; active > 0 && round < iters * 10 + 2; round++) {
+        int seq_next = 0;
+        if (!look_off) { seq_next = ++b->seq; enqueue_round(seq_next); }
         BH_HIP(ctx, hipGetLastError());
-        need_lin = false;
+        const int seq = seq_cur;
         for (int w = 0; w < W; w++) {
             if (done[w]) continue;
-            ba_state* hp = b->hstates + w;
+            ba_state* hp = b->hstates + 2 * w + (seq & 1);
             // Poll the pinned verdict for a bounded TIME (a spin count would turn a round that is merely slow - many or large windows, a
             // profiler attached, a busy host core - into an error); after that the stream itself decides: a successful synchronise means
             // the round has finished, so the verdict must be there; only a failing synchronise, or a verdict that is still missing after
@@ -4666,10 +4891,11 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
                 ba->log.push_back((double)hs.qmax); ba->log.push_back((double)hs.accepted);
                 ba->iters_done = hs.b_it;
                 if (iters_done) iters_done[w] = hs.b_it;
-                need_lin = true;
             }
             if (hs.b_done) { done[w] = 1; active--; }
         }
+        if (look_off) { if (active > 0) { seq_cur = ++b->seq; enqueue_round(seq_cur); } }
+        else seq_cur = seq_next;
     }
     for (int w = 0; w < W; w++) b->win[w]->verbose_last = verbose_errors;
     return rc;

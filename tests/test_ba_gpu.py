@@ -284,10 +284,14 @@ def test_device_built_problem_equals_host_built(ctx, monkeypatch):
             assert np.array_equal(pd, ph, equal_nan=True) and np.array_equal(cd, ch)
 
 
-def test_batched_windows_equal_single_window_runs_bitwise(ctx):
+def test_batched_windows_equal_single_window_runs_bitwise(ctx, monkeypatch):
     """bh_ba_batch_optimize: W windows of different sizes advance in lockstep (one launch per kernel and trial for all of them).  Every
     window must come out bit for bit as bh_ba_optimize leaves it: poses, landmarks, per-edge chi2, the Levenberg log - including a
-    window that needs retries (a gross outlier start), one with no free landmark edges removed, and non-verbose error semantics."""
+    window that needs retries (a gross outlier start), one with no free landmark edges removed, and non-verbose error semantics.
+    The single-window reference is the HOST-driven loop of bh_ba_optimize (BH_BA_SELF_BATCH=0: one trial enqueued at a time, the host
+    deciding between linearisation and retry from the verdict it reads); by default a local window runs as a batch of one with the control
+    flow on the device and the host one round ahead - that default is compared with the host loop too."""
+    monkeypatch.setenv("BH_BA_SELF_BATCH", "0")
     probs = [synth.ba_problem(n_kf=6, n_pts=150, seed=1), synth.ba_problem(n_kf=12, n_pts=500, seed=4), synth.ba_problem(n_kf=50, n_pts=10000, seed=7),
              synth.ba_problem(n_kf=20, n_pts=1500, seed=9), synth.ba_problem(n_kf=9, n_pts=200, seed=2), synth.ba_problem(n_kf=30, n_pts=4000, seed=12)]
     for seed in (9, 14):                                                    # small windows that reach the numerical floor: rejected trials, lambda grows
@@ -303,6 +307,16 @@ def test_batched_windows_equal_single_window_runs_bitwise(ctx):
             done = s.optimize(NIT, verbose_errors=verbose)
             single.append((done, s.poses(), s.points().copy(), s.chi2().copy(), s.log()[:done].copy()))
             s.close()
+        monkeypatch.delenv("BH_BA_SELF_BATCH")
+        for pr, ref in list(zip(probs, single))[::3]:                        # the default path of bh_ba_optimize: a batch of one, host one round ahead
+            s = ba.LocalBA(ctx, pr["K"])
+            s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+            done = s.optimize(NIT, verbose_errors=verbose)
+            R, t = s.poses()
+            assert done == ref[0] and np.array_equal(R, ref[1][0]) and np.array_equal(t, ref[1][1]) and np.array_equal(s.points(), ref[2], equal_nan=True)
+            assert np.array_equal(s.chi2(), ref[3]) and np.array_equal(s.log()[:done], ref[4])
+            s.close()
+        monkeypatch.setenv("BH_BA_SELF_BATCH", "0")
         wins = [ba.LocalBA(ctx, pr["K"]) for pr in probs]
         # all windows set up by ONE call: the local ones are built together (a workgroup each), the 50-keyframe one goes the general way
         ba.set_problems(ctx, wins, [(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"]) for pr in probs])
@@ -373,3 +387,29 @@ def test_set_problems_mixed_windows_and_errors(ctx):
         wins[0].optimize(1)
     for s in wins:
         s.close()
+
+
+def test_control_sums_and_lookahead_switches_agree(ctx, monkeypatch):
+    """Round 5: the sums of the Levenberg control ride in the producing kernels (fan-in: per-workgroup slots, the last arriver adds them up) and
+    the host enqueues a round before it has seen the last one's verdicts.  Both have an A/B switch: BH_BA_LOOKAHEAD=0 must not change a bit;
+    BH_BA_FAN=0 (the sums as separate launches, another fixed summation order) must give the same Levenberg decisions and the same states to
+    rounding - on a local window (host loop), and on the banded solver path."""
+    for pr, env in ((synth.ba_problem(n_kf=12, n_pts=500, seed=4), {}), (synth.ba_problem(n_kf=50, n_pts=10000, seed=7), {}),
+                    (synth.ba_problem(n_kf=12, n_pts=500, seed=4), {"BH_BA_SELF_BATCH": "0"})):
+        res = {}
+        for name, sw in (("default", {}), ("nolook", {"BH_BA_LOOKAHEAD": "0"}), ("nofan", {"BH_BA_FAN": "0", "BH_BA_SELF_BATCH": "0"})):
+            for k, v in {**env, **sw}.items():
+                monkeypatch.setenv(k, v)
+            s = ba.LocalBA(ctx, pr["K"])
+            s.set_problem(pr["R"], pr["t"], pr["fixed"], pr["pts"], pr["ecam"], pr["ept"], pr["meas"])
+            done = s.optimize(10)
+            res[name] = (done, s.poses(), s.points().copy(), s.log()[:done].copy())
+            s.close()
+            for k in {**env, **sw}:
+                monkeypatch.delenv(k)
+        d0, (R0, t0), p0, l0 = res["default"]
+        d1, (R1, t1), p1, l1 = res["nolook"]
+        assert d1 == d0 and np.array_equal(R1, R0) and np.array_equal(t1, t0) and np.array_equal(p1, p0) and np.array_equal(l1, l0)
+        d2, (R2, t2), p2, l2 = res["nofan"]
+        assert d2 == d0 and np.array_equal(l2[:, 2:], l0[:, 2:])                       # trials per iteration, accept flags
+        assert np.allclose(l2[:, :2], l0[:, :2], rtol=1e-9) and np.abs(R2 - R0).max() < 1e-9 and np.abs(t2 - t0).max() < 1e-9 and np.abs(p2 - p0).max() < 1e-9
