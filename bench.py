@@ -303,16 +303,18 @@ def run_rank(args):
         alg_bytes = ALG_BYTES_PER_FRAME * frames_per_launch / per_level          # 1 592 000 B per frame
         achieved = alg_bytes / avg_s / 1e9
         k_bytes = per_frame_bytes.get(dom, ALG_BYTES_PER_FRAME) * frames_per_launch / per_level
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                per_frame = json.load(open(pmc)).get(dom)          # HBM bytes per frame from the PMC passes (tools/pmc_traffic.py)
-                traffic = int(per_frame * frames_per_launch / per_level) if per_frame else None
-            except Exception:                                       # noqa: BLE001
-                traffic = None
+        # HBM bytes per frame from the PMC passes (tools/pmc_traffic.py): a property of the kernel as committed - a summary collected on another
+        # build of the kernel source is not combined with this run's times (boslam_amd/_profiles.py): traffic stays null and the reason is given
+        from boslam_amd import _profiles
+        traffic, traffic_note = None, None
+        tr, why = _profiles.load("profiles/r05_pmc_traffic.json", ["orb.hip", "match.hip"])
+        if tr is not None and why is None:
+            per_frame = tr.get({"k_gray_mask": "k_gray_bits", "k_pyr_down": "k_pyr_down_bits"}.get(dom, dom)) or tr.get(dom)
+            traffic = int(per_frame * frames_per_launch / per_level) if per_frame else None
+        else:
+            traffic_note = why
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, **({"traffic_note": traffic_note} if traffic_note else {}),
                     "avg_launch_ms": round(dom_ms / dom_n, 4), "alg_bytes_per_launch": int(alg_bytes),
                     "byte_model": "SURVEY 8(d): 1 592 000 B/frame (BGR + depth in, descriptors + keypoints out) x frames per launch",
                     "kernel_achieved": round(k_bytes / avg_s / 1e9, 2), "kernel_frac": round(k_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 5),
@@ -326,10 +328,13 @@ def run_rank(args):
         # The front end is bound by vector-instruction ISSUE, not by HBM: price the dominant kernel on that too.
         # peak = what tools/valu_rate.hip measured on this chip for the instruction class the kernel is made of (packed 16-bit, v_perm,
         # three-operand integer ops: 4 cycles per wave64 instruction; only a handful of plain 32-bit ops issue in 2); achieved = the
-        # kernel's SQ_INSTS_VALU per launch (profiles/r04_pmc_summary.json, launches of 128 frames) over the live launch time.
+        # kernel's SQ_INSTS_VALU per launch (profiles/r05_pmc_summary.json, launches of 128 frames) over the live launch time.
         try:
-            vr = json.load(open(os.path.join(ROOT, "profiles", "r04_valu_rate.json")))["results"]
-            ps = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_summary.json")))
+            vr = json.load(open(os.path.join(ROOT, "profiles", "r04_valu_rate.json")))["results"]      # (a measurement of the chip, not of a kernel)
+            ps, why = _profiles.load("profiles/r05_pmc_summary.json", ["orb.hip", "match.hip"])
+            if ps is None or why:
+                roofline["valu"] = _profiles.stale_block("profiles/r05_pmc_summary.json", why or "absent")
+                raise LookupError
             cls = ["PERM", "PKADD", "PKSUB", "PKMIN", "PKMAX", "PKMIN3", "PKMAX3", "LSHLOR", "LSHLADD", "MAD24", "ALIGNBIT", "DOT4", "DOT2", "BFE", "MINU", "MAXI"]
             peak4 = float(np.median([vr[k]["w8"]["chip_winstr_per_s"] for k in cls if k in vr]))
             peak2 = float(np.median([vr[k]["w8"]["chip_winstr_per_s"] for k in ("XOR", "SUB", "OR", "AND", "LSHR", "ASHR", "MOV", "FMA") if k in vr]))

@@ -6,23 +6,28 @@ import numpy as np
 from . import ba, synth
 
 
-_PMC_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_ba_pmc.json")
+_PMC_REL = "profiles/r05_ba_pmc.json"
 
 
 def _pmc(workload):
-    """Per-launch hardware counters of the BA kernels (rocprofv3 --pmc, tools/prof_r04.sh -> tools/ba_pmc.py; the committed summary).
+    """Per-launch hardware counters of the BA kernels (rocprofv3 --pmc, tools/prof_r05.sh -> tools/ba_pmc.py; the committed summary).
     bench.py cannot run the profiler inside its timed run: the counters per launch are a property of the kernel and the workload, the
-    durations next to them are measured live."""
-    try:
-        import json
-        with open(_PMC_FILE) as f:
-            return json.load(f).get(workload, {})
-    except (OSError, ValueError):
+    durations next to them are measured live.  A summary collected on another build of ba.hip is not used (see _profiles): the blocks
+    derived from it say `stale` instead."""
+    from . import _profiles
+    d, why = _profiles.load(_PMC_REL, ["ba.hip"])
+    if d is None:
         return {}
+    if why:
+        return {"_stale": why}
+    return d.get(workload, {})
 
 
 def _counter_block(pm, names, live_ms):
     """Counter flops / bytes of the named kernels (per launch, summed over `names` = (kernel, launches per iteration)) against the live time."""
+    if "_stale" in pm:
+        from . import _profiles
+        return _profiles.stale_block(_PMC_REL, pm["_stale"])
     fl = rd = rdu = wr = busy = 0.0
     have = False
     for k, n in names:
@@ -36,7 +41,7 @@ def _counter_block(pm, names, live_ms):
     if not have or live_ms <= 0:
         return None
     t = live_ms * 1e-3
-    return {"source": "profiles/r04_ba_pmc.json (rocprofv3 --pmc, counters per launch) over the live kernel time",
+    return {"source": _PMC_REL + " (rocprofv3 --pmc, counters per launch) over the live kernel time",
             "mfma_f64_flops": int(fl), "mfma_tflops": round(fl / t / 1e12, 5), "mfma_frac_of_peak": round(fl / t / 78.6e12, 6),
             "mfma_busy_simds": round(busy / (t * 2.4e9), 3),
             "hbm_bytes": int(rd + wr), "hbm_bytes_fetch_uncorrected": int(rdu + wr), "hbm_gbps": round((rd + wr) / t / 1e9, 1),
@@ -104,7 +109,8 @@ def run(ctx, dev=None, repeats=5):
                                  "frac_of_cus_used": round(flops / (ms * 1e-3) / (78.6e12 / 256), 4), "mfma_flops_per_solve": int(flops),
                                  "note": note}
         pm = _pmc("local")
-        cb = _counter_block(pm, [(kname, 1)], ms)
+        # (a local window runs as a batch of one: the profiler sees the batched kernels' names)
+        cb = _counter_block(pm, [("k_bb_chol" if "k_bb_chol" in pm else kname, 1)], ms)
         if cb:
             out["solve_roofline"]["counters"] = cb
     # the Schur complement (S = Hpp - sum Hpl Hll^-1 Hpl', b~): the iteration's HBM-side stage.  Algorithmic bytes: per edge the 6 x 3 Hpl
@@ -115,10 +121,12 @@ def run(ctx, dev=None, repeats=5):
         alg = E * 144 + P * 96 + n6 * n6 * 8
         out["schur_roofline"] = {"bound": "hbm", "kernel": "k_ba_dinv + k_ba_schur_Sb", "algorithmic_bytes": int(alg), "ms": sms,
                                  "achieved": round(alg / (sms * 1e-3) / 1e9, 1), "unit": "GB/s", "peak": 8000, "frac": round(alg / (sms * 1e-3) / 8e12, 5)}
-        cb = _counter_block(_pmc("local"), [("k_ba_dinv", 1), ("k_ba_schur_Sb", 1)], sms)
+        pml = _pmc("local")
+        cb = _counter_block(pml, [("k_bb_dinv", 1), ("k_bb_schur", 1)] if "k_bb_schur" in pml else [("k_ba_dinv", 1), ("k_ba_schur_Sb", 1)], sms)
         if cb:
             out["schur_roofline"]["counters"] = cb
-            out["schur_roofline"]["traffic_over_algorithmic"] = round(cb["hbm_bytes"] / alg, 2)
+            if not cb.get("stale"):
+                out["schur_roofline"]["traffic_over_algorithmic"] = round(cb["hbm_bytes"] / alg, 2)
     s.close()
     return out
 
@@ -168,9 +176,12 @@ def run_batch(ctx, W=64, n_kf=50, n_pts=10000, iters=10, repeats=3, n_distinct=8
            "speedup_incl_set_problem": round((tot / (opt + st)) / (iters / (one + float(np.median(t_set1)))), 1),
            "iters_done_min_max": [int(done.min()), int(done.max())], "final_robust_chi2_first_windows": chi}
     pmb = _pmc("batch") if (W == 64 and n_kf == 50) else {}
-    if "k_bb_schur" in pmb:                              # the round's largest kernel: how much of its gathered Hpl traffic reaches the fabric (profile run, 64 windows)
+    if "_stale" in pmb:
+        from . import _profiles
+        out["schur_counters"] = _profiles.stale_block(_PMC_REL, pmb["_stale"])
+    elif "k_bb_schur" in pmb:                              # the round's largest kernel: how much of its gathered Hpl traffic reaches the fabric (profile run, 64 windows)
         e = pmb["k_bb_schur"]; d = e["derived"]
-        out["schur_counters"] = {"source": "profiles/r04_ba_pmc.json", "kernel": "k_bb_schur", "us_per_round": e["mean_us"],
+        out["schur_counters"] = {"source": _PMC_REL, "kernel": "k_bb_schur", "us_per_round": e["mean_us"],
                                  "hbm_bytes_per_round": int(d["hbm_read_bytes"] + d["hbm_write_bytes"]),
                                  "hbm_bytes_per_round_fetch_uncorrected": int(d["hbm_read_bytes_uncorrected"] + d["hbm_write_bytes"]),
                                  "hbm_gbps": d["hbm_gbps"], "hbm_frac_of_peak": round(d["hbm_gbps"] / 8000.0, 4),
@@ -254,10 +265,11 @@ def run_global(ctx, n_kf=5000, n_pts=500000, iters=5, window=20, dist=None, devi
                                      "mfma_flops_per_solve": int(flops),
                                      "note": "two dependency chains of ~%d block columns, one CU each; the dense f64 MFMA peak of 78.6 TFLOP/s is for 256 CUs" % (nblk // cus)}
     pm = _pmc("global") if dist is None else {}
+    stale = "_stale" in pm
     if pm and "solve_roofline" in out and "k_bcr" in out["solve_roofline"]["kernel"]:
-        # launches per solve from the profile itself: dispatches of each kernel over the dispatches of k_ba_prep (one per trial)
-        trials_prof = max(pm.get("k_ba_prep", {}).get("dispatches", 0), 1)
-        names = [(k, pm[k]["dispatches"] / trials_prof) for k in ("k_ba_chol_dense<true>", "k_bcr_trsm", "k_bcr_update", "k_bcr_back", "k_bcr_extract") if k in pm]
+        # launches per solve from the profile itself: dispatches of each kernel over the dispatches of k_ba_err (one per trial)
+        trials_prof = 1 if stale else max(pm.get("k_ba_err", {}).get("dispatches", 0), 1)
+        names = [] if stale else [(k, pm[k]["dispatches"] / trials_prof) for k in ("k_ba_chol_dense<true>", "k_bcr_trsm", "k_bcr_update", "k_bcr_back", "k_bcr_extract") if k in pm]
         cb = _counter_block(pm, names, ms)
         if cb:
             out["solve_roofline"]["counters"] = cb
@@ -271,10 +283,11 @@ def run_global(ctx, n_kf=5000, n_pts=500000, iters=5, window=20, dist=None, devi
         names = [("k_ba_dinv", 1), ("k_ba_schur_row", 1)] if row else [("k_ba_dinv", 1), ("k_ba_schur_S<64>", 1), ("k_ba_schur_b", 1)]
         out["schur_roofline"] = {"bound": "hbm", "kernel": " + ".join(n for n, _ in names), "algorithmic_bytes": int(alg), "ms": sms,
                                  "achieved": round(alg / (sms * 1e-3) / 1e9, 1), "unit": "GB/s", "peak": 8000, "frac": round(alg / (sms * 1e-3) / 8e12, 5)}
-        cb = _counter_block(pm, names, sms) if pm and all(n in pm for n, _ in names) else None
+        cb = _counter_block(pm, names, sms) if pm and (stale or all(n in pm for n, _ in names)) else None
         if cb:
             out["schur_roofline"]["counters"] = cb
-            out["schur_roofline"]["traffic_over_algorithmic"] = round(cb["hbm_bytes"] / alg, 2)
+            if not cb.get("stale"):
+                out["schur_roofline"]["traffic_over_algorithmic"] = round(cb["hbm_bytes"] / alg, 2)
     lms = out["kernel_ms_per_iter"].get("k_ba_linearize", 0.0)
     if lms > 0 and pm:
         cb = _counter_block(pm, [("k_ba_linearize", 1)], lms)

@@ -86,10 +86,20 @@ __global__ __launch_bounds__(MT) void k_match(const uint8_t* __restrict__ q, con
             const int q0 = c * MM_QC, qn = min(MM_QC, nq - q0), nrows = (qn + 31) & ~31;
             if (nchunks > 1 || r == 0) {
                 __syncthreads();
-                for (int it = tid; it < nrows * 16; it += MT) {             // (row, 16-bit slice) -> one fragment
-                    const int i = it >> 4, cs = it & 15;
-                    const uint32_t bits = i < qn ? *reinterpret_cast<const uint16_t*>(qbase + (size_t)(q0 + i) * 32 + 2 * cs) : 0u;
-                    s_a[((i >> 5) * 8 + (cs >> 1)) * 64 + (i & 31) + 32 * (cs & 1)] = mm_unpack16(bits);
+                // (row, half of the descriptor) -> eight fragments.  Consecutive lanes take consecutive ROWS, so the 16-byte stores of one
+                // instruction are contiguous (round 4 had a lane per (row, 16-bit slice) with the slice on the fast index: the sixteen lanes
+                // of a row stored 512 B apart - one set of four banks - and SQ_LDS_BANK_CONFLICT was three times the LDS-active cycles)
+                for (int it = tid; it < nrows * 2; it += MT) {
+                    const int hf = it >= nrows ? 1 : 0, i = it - hf * nrows;
+                    uint4 u = make_uint4(0, 0, 0, 0);
+                    if (i < qn) u = qb[2 * (q0 + i) + hf];
+                    const uint32_t w4[4] = { u.x, u.y, u.z, u.w };
+                    mm_v4* dst = s_a + ((i >> 5) * 8 + 4 * hf) * 64 + (i & 31);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        dst[j * 64] = mm_unpack16(w4[j] & 0xffffu);
+                        dst[j * 64 + 32] = mm_unpack16(w4[j] >> 16);
+                    }
                 }
                 for (int i = tid; i < nrows; i += MT) {
                     int kv = 0x3fffffff;                                    // padding rows never win

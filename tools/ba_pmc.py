@@ -75,4 +75,7 @@ for wl in ("local", "global", "batch"):
             d["hbm_gbps_uncorrected"] = round((rb * 1024.0 + wb * 1024.0) / ns, 3)      # above 8 000 corrected: the x2 rule does not hold for that kernel
         res[k] = {"dispatches": e["dispatches"], "mean_us": round(ns * 1e-3, 3), "counters": {a: round(b, 1) for a, b in sorted(c.items())}, "derived": d}
     out[wl] = res
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from boslam_amd import _profiles
+out["_meta"] = _profiles.meta(["ba.hip"])
 print(json.dumps(out, indent=1))

@@ -35,4 +35,7 @@ for k, cs in sorted(acc.items()):
     dv["lds_conflict_frac"] = ratio("SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS")
     dv["wait_frac"] = ratio("SQ_WAIT_ANY", "SQ_WAVE_CYCLES")
     out[k]["derived"] = {a: b for a, b in dv.items() if b is not None}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from boslam_amd import _profiles
+out["_meta"] = _profiles.meta(["orb.hip", "match.hip"])
 print(json.dumps(out, indent=1))

@@ -15,7 +15,10 @@ out = {"_note": "HBM bytes per FRAME = (FETCH_SIZE x factor + WRITE_SIZE) KiB pe
                 "summed over their launches per frame batch; k_bow_* entries are bytes per launch (one query of configs[3] on one GPU).  factor 2 = kernels with >= 8 B/lane loads (gfx950 FETCH_SIZE correction, "
                 "calibrated on k_gray_mask), 1 otherwise." % fpl, "_factors": WIDE}
 agg = {}
+out["_meta"] = d.get("_meta")
 for k, v in d.items():
+    if k.startswith("_"):
+        continue
     base = k.split("<")[0]
     if base.startswith("k_ba") or "FETCH_SIZE" not in v:
         continue
