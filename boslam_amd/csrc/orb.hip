@@ -1361,8 +1361,10 @@ __constant__ __attribute__((aligned(4))) signed char c_pattern[1024] = {
 #endif
 #define DS_PR 37               // BRIEF window: the pattern's largest radius is 18.385, so a rotated, rounded coordinate is within +-18
 #define DS_PH 18
-#define DS_NL ((DS_PR * 10 + 63) / 64)   // staging loads per lane (6)
-#define DS_PW 10               // words per window row (37 bytes + up to 3 of alignment = 40 B)
+#ifndef DS_PW
+#define DS_PW 12               // words per staged window row: 37 bytes + up to 3 of alignment = 40 B are needed; 48 B (a multiple of 16) keep every lane QUAD
+#endif                         // inside one row - with 10 words a quad straddled two rows in half of the cases, which costs the address path 4 x (tools/vmem_rate.hip)
+#define DS_NL ((DS_PR * DS_PW + 63) / 64)   // staging loads per lane (7)
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                   bh_orb_geom g, const uint32_t* __restrict__ ic_mask, float patch_size, int sel_cap, int max_kp, int nframes,
                                                   const uint32_t* __restrict__ sel_xy, const float* __restrict__ sel_resp,
