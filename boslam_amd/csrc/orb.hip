@@ -264,7 +264,10 @@ __device__ __forceinline__ void pyr_xsetup(pyr_xs& X, const bh_level_geom& D, co
 {
     X.x = x;
     X.over = min(max(x + 4 - D.w, 0), 4);                      // outputs of this lane beyond the row
-    const uint4 tx4 = *reinterpret_cast<const uint4*>(tab + D.tabx_off + (X.over == 4 ? 0 : x));
+    const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(tab), 0, 0x7fffffff, 0x00020000);
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    const u4v t4 = __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rs_tab, (X.over == 4 ? 0 : x) << 2, D.tabx_off << 2, 0));
+    const uint4 tx4 = make_uint4(t4.x, t4.y, t4.z, t4.w);
     const uint32_t txs[4] = { tx4.x, tx4.y, tx4.z, tx4.w };
     const uint32_t base = tx4.x >> 16;
     X.mmin = 256u;
@@ -285,14 +288,19 @@ __device__ __forceinline__ void pyr_xsetup(pyr_xs& X, const bh_level_geom& D, co
     X.mcol = base >> 5; X.mbit = base & 31u;
 }
 
-__device__ __forceinline__ void pyr_load(pyr_ld& L, const uint8_t* __restrict__ src, const uint32_t* __restrict__ ms, const bh_level_geom& S,
+// Buffer loads (round 5): a row's offset is ONE 24-bit multiply-add per load (rows and pitches are far below 2^24) - as pointer arithmetic every
+// load cost a full 32-bit multiply (quarter rate: ten of them were a sixth of the kernel's vector cycles) and a 64-bit add.
+typedef uint32_t pyr_u3 __attribute__((ext_vector_type(3)));
+typedef uint32_t pyr_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pyr_load(pyr_ld& L, __amdgpu_buffer_rsrc_t rs_src, __amdgpu_buffer_rsrc_t rs_ms, const bh_level_geom& S,
                                          const pyr_xs& X, int r0, int r1)
 {
-    const uint32_t* qa = reinterpret_cast<const uint32_t*>(src + (uint32_t)(r0 * S.pitch) + X.boff);
-    const uint32_t* qb = reinterpret_cast<const uint32_t*>(src + (uint32_t)(r1 * S.pitch) + X.boff);
-    L.a0 = qa[0]; L.a1 = qa[1]; L.a2 = qa[2]; L.b0 = qb[0]; L.b1 = qb[1]; L.b2 = qb[2];
-    const uint32_t* pa = ms + (uint32_t)(r0 * S.mpitch) + X.mcol; const uint32_t* pb = ms + (uint32_t)(r1 * S.mpitch) + X.mcol;
-    L.ma0 = pa[0]; L.ma1 = pa[1]; L.mb0 = pb[0]; L.mb1 = pb[1];
+    const pyr_u3 a = __builtin_bit_cast(pyr_u3, __builtin_amdgcn_raw_buffer_load_b96(rs_src, (int)(__umul24((uint32_t)r0, (uint32_t)S.pitch) + X.boff), 0, 0));
+    const pyr_u3 b = __builtin_bit_cast(pyr_u3, __builtin_amdgcn_raw_buffer_load_b96(rs_src, (int)(__umul24((uint32_t)r1, (uint32_t)S.pitch) + X.boff), 0, 0));
+    L.a0 = a.x; L.a1 = a.y; L.a2 = a.z; L.b0 = b.x; L.b1 = b.y; L.b2 = b.z;
+    const pyr_u2 ma = __builtin_bit_cast(pyr_u2, __builtin_amdgcn_raw_buffer_load_b64(rs_ms, (int)((__umul24((uint32_t)r0, (uint32_t)S.mpitch) + X.mcol) << 2), 0, 0));
+    const pyr_u2 mb = __builtin_bit_cast(pyr_u2, __builtin_amdgcn_raw_buffer_load_b64(rs_ms, (int)((__umul24((uint32_t)r1, (uint32_t)S.mpitch) + X.mcol) << 2), 0, 0));
+    L.ma0 = ma.x; L.ma1 = ma.y; L.mb0 = mb.x; L.mb1 = mb.y;
 }
 
 __device__ __forceinline__ void pyr_row(const pyr_ld& L, const pyr_xs& X, uint32_t yc, int lane, uint32_t* o4, uint32_t* nbw)
@@ -340,7 +348,7 @@ __device__ __forceinline__ int pyr_div_groups(int idx, int groups)
 {
     const int q = idx >> 4, d = groups >> 4;
     int yb = (int)((float)q * __builtin_amdgcn_rcpf((float)d));
-    const int r = q - yb * d;
+    const int r = q - __mul24(yb, d);
     yb += r >= d ? 1 : (r < 0 ? -1 : 0);
     return yb;
 }
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_bits(uint8_t* __restrict__ pyr
     const int groups = D.pitch >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int yb = pyr_div_groups(idx, groups);
-    const int x = (idx - yb * groups) << 2, y0 = yb * PD_R;
+    const int x = (idx - __mul24(yb, groups)) << 2, y0 = yb * PD_R;
     if (y0 >= D.h) return;                                     // whole rows (pitch / 4 is a multiple of 16 lanes: DPP rows leave together)
     // wave-uniform 64-bit bases, 32-bit lane offsets: the loads and stores take the scalar-base + vector-offset form
     const uint8_t* __restrict__ src = pyr + (size_t)blockIdx.y * g.pyr_stride + S.off;
@@ -364,23 +372,29 @@ __global__ __launch_bounds__(256) void k_pyr_down_bits(uint8_t* __restrict__ pyr
     uint32_t* __restrict__ md = mbits + (size_t)blockIdx.y * g.mstride + D.moff;
     pyr_xs X;
     pyr_xsetup(X, D, tab, x);
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ms = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ms), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(md, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(tab), 0, 0x7fffffff, 0x00020000);
     pyr_ld L[PD_R]; uint32_t yc[PD_R];
 #pragma unroll
     for (int k = 0; k < PD_R; k++) {                            // all loads of the PD_R rows before the first store (same pointer: they would serialise)
-        const uint32_t ty = tab[D.taby_off + min(y0 + k, D.h - 1)];      // rows beyond the level repeat the last one and are not stored
+        const uint32_t ty = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_tab, min(y0 + k, D.h - 1) << 2, D.taby_off << 2, 0);      // rows beyond the level repeat the last one and are not stored
         const int r0 = (int)(ty >> 16), r1 = min(r0 + 1, S.h - 1);
         yc[k] = ty & 0xffffu;
-        pyr_load(L[k], src, ms, S, X, r0, r1);
+        pyr_load(L[k], rs_src, rs_ms, S, X, r0, r1);
     }
     uint32_t o4[PD_R], nbw[PD_R];
 #pragma unroll
     for (int k = 0; k < PD_R; k++) pyr_row(L[k], X, yc[k], threadIdx.x, &o4[k], &nbw[k]);
+    const int od = (int)(__umul24((uint32_t)y0, (uint32_t)D.pitch) + (uint32_t)x), om = (int)((__umul24((uint32_t)y0, (uint32_t)D.mpitch) + (uint32_t)(x >> 5)) << 2);
 #pragma unroll
     for (int k = 0; k < PD_R; k++) {
         const int y = y0 + k;
         if (y < D.h) {
-            *reinterpret_cast<uint32_t*>(dst + (uint32_t)(y * D.pitch + x)) = o4[k];
-            if ((threadIdx.x & 7) == 7) md[(uint32_t)(y * D.mpitch + (x >> 5))] = nbw[k];
+            __builtin_amdgcn_raw_buffer_store_b32(o4[k], rs_dst, od, k * D.pitch, 0);
+            if ((threadIdx.x & 7) == 7) __builtin_amdgcn_raw_buffer_store_b32(nbw[k], rs_md, om, k * D.mpitch * 4, 0);
         }
     }
 }
@@ -1425,7 +1439,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             if (loc[q] == 0xffffffffu) continue;                 // wave-uniform
             const bh_level_geom L = g.lv[loc[q] >> 28];
             const uint8_t* __restrict__ lvl = pyr + (size_t)(fbase + 8 * (i0 + q)) * g.pyr_stride + L.off;           // wave-uniform base, 32-bit lane offsets
-            const uint32_t o = (uint32_t)(((int)((loc[q] >> 14) & 0x3fffu) + vb) * L.pitch + (int)(loc[q] & 0x3fffu) + u);
+            const uint32_t o = __umul24((uint32_t)((int)((loc[q] >> 14) & 0x3fffu) + vb), (uint32_t)L.pitch) + (uint32_t)((int)(loc[q] & 0x3fffu) + u);      // (24-bit multiply: a full 32-bit one runs at a quarter of the rate)
             // buffer loads: the lane offset stays one VGPR, the row step rides in the scalar offset (16 address adds per keypoint saved)
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(lvl), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
@@ -1489,7 +1503,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int j = wv * DS_KPW + i0 + q;
-            const uint32_t loc = s_loc[j], bxy = s_bxy[j];
+            const uint32_t loc = s_loc[j], bxy = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_bxy[j]);
             have[q] = loc != 0xffffffffu;                       // wave-uniform
             if (!have[q]) continue;
             const int level = __builtin_amdgcn_readfirstlane((int)(loc >> 28));
@@ -1497,9 +1511,13 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             pa[q] = s_a[j]; pb[q] = s_b[j];
             const int bx = (int)(bxy & 0xffffu) - DS_PH, by = (int)(bxy >> 16) - DS_PH;
             sh[q] = bx & 3;
+            // buffer loads from a wave-uniform window origin: the lane's (row x pitch + byte offset) is ONE 24-bit multiply-add per load - as pointer
+            // arithmetic each of the 7 x 16 loads cost a 64-bit multiply-add at a quarter of the rate (a fifth of this kernel's vector cycles)
             const uint8_t* org = blur + (size_t)(fbase + 8 * (i0 + q)) * g.pyr_stride + L.off + (size_t)by * L.pitch + (bx & ~3);
+            const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(org), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-            for (int m = 0; m < DS_NL; m++) wq[q][m] = *reinterpret_cast<const uint32_t*>(org + (uint32_t)((int)(stg[m] & 63u) * L.pitch + (int)((stg[m] >> 6) & 63u)));
+            for (int m = 0; m < DS_NL; m++)
+                wq[q][m] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsb, (int)(__umul24(stg[m] & 63u, (uint32_t)L.pitch) + ((stg[m] >> 6) & 63u)), 0, 0);
         }
 #pragma unroll
         for (int q = 0; q < 2; q++) {
