@@ -174,10 +174,10 @@ __global__ __launch_bounds__(256) void k_gray_bits(const uint8_t* __restrict__ i
     {   // idx / groups: both multiples of 16 apart from idx's low bits, the divisor at most 4096 / 4; a float quotient off by one is put right
         const int q = idx >> 4, d = groups >> 4;
         y = (int)((float)q * __builtin_amdgcn_rcpf((float)d));
-        const int r = q - y * d;
+        const int r = q - __mul24(y, d);
         y += r >= d ? 1 : (r < 0 ? -1 : 0);
     }
-    const int x = (idx - y * groups) << 2;
+    const int x = (idx - __mul24(y, groups)) << 2;      // (24-bit multiplies throughout: a full 32-bit one runs at a quarter of the rate)
     if (y >= H) return;                                        // whole rows leave together (groups is a multiple of 16: DPP rows stay whole)
     const uint8_t* __restrict__ fimg = img + (size_t)blockIdx.y * H * W * 3;
     const uint16_t* __restrict__ fd = depth + (size_t)blockIdx.y * H * W;
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void k_gray_bits(const uint8_t* __restrict__ i
     uint32_t* __restrict__ fm = mbits + (size_t)blockIdx.y * mstride;
     uint32_t g4 = 0, nib = 0;
     if (x < W) {
-        const uint32_t px = (uint32_t)(y * W + x);
-        const uint32_t* sp = reinterpret_cast<const uint32_t*>(fimg + px * 3u);
+        const uint32_t px = __umul24((uint32_t)y, (uint32_t)W) + (uint32_t)x;
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(fimg + __umul24(px, 3u));
         const uint32_t a = sp[0], b = sp[1], c = sp[2];       // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
         const uint32_t h0 = __builtin_amdgcn_udot4(a, 7u | 37u << 8 | 19u << 16, 0u, false), l0 = __builtin_amdgcn_udot4(a, 76u | 145u << 8 | 35u << 16, 8192u, false);
         const uint32_t h1 = __builtin_amdgcn_udot4(a, 7u << 24, __builtin_amdgcn_udot4(b, 37u | 19u << 8, 0u, false), false);
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void k_gray_bits(const uint8_t* __restrict__ i
         const uint32_t ny = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(gm_us2, d.y), one));
         nib = ((nx | nx >> 15) & 3u) | ((ny | ny >> 15) & 3u) << 2;
     }
-    *reinterpret_cast<uint32_t*>(fp + (uint32_t)(y * pitch + x)) = g4;
+    *reinterpret_cast<uint32_t*>(fp + (__umul24((uint32_t)y, (uint32_t)pitch) + (uint32_t)x)) = g4;
     const uint32_t wd = nib_gather8(nib, threadIdx.x);
-    if ((threadIdx.x & 7) == 7) fm[(uint32_t)(y * mpitch + (x >> 5))] = wd;
+    if ((threadIdx.x & 7) == 7) fm[__umul24((uint32_t)y, (uint32_t)mpitch) + (uint32_t)(x >> 5)] = wd;
 }
 
 // ------------------------------------------------------------------------------------------------ pyramid level l from l-1
@@ -668,6 +668,10 @@ __device__ __forceinline__ int reflect101(int i, int n)
 #define FCL_CAP 1536             // corner list entries (more: phase 3 walks the candidate list instead)
 
 typedef short fs2 __attribute__((ext_vector_type(2)));
+// byte index of the score tile -> row: b / 144 for b < 2^15 as one 24-bit multiply and a shift (14564 = ceil(2^21 / 144): the error b x 0.44 / 2^21 stays
+// below 1 / 144 there; the compiler's division by a constant is a 32-bit multiply-high, a quarter-rate instruction)
+static_assert(FROW == 144, "frow_div assumes 144-byte tile rows");
+__device__ __forceinline__ int frow_div(int b) { return (int)(__umul24((uint32_t)b, 14564u) >> 21); }
 __device__ __forceinline__ fs2 fswap(fs2 a) { return fs2{ a.y, a.x }; }
 __device__ __forceinline__ fs2 fmn(fs2 a, fs2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ fs2 fmx(fs2 a, fs2 b) { return __builtin_elementwise_max(a, b); }
@@ -775,12 +779,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // under 16 pixels wide) still gathers from global memory.
     const bool xedge = !interior && (x0 == 0 || x0 + TILE_W + 4 > L.w);
     const bool fix_lds = xedge && L.w >= 16 && (x0 + TILE_W + 4 <= L.w || L.w - x0 >= 12);
-    uint32_t fixv = 0; int fixi = -1;
+    uint32_t fixv = 0; int fixi = -1, fixc = 0;
     if (xedge && tid < 4 * FPX_H) {
         const int r = tid >> 2, q = tid & 3, y = y0 - 4 + r;
         const int c = q == 0 ? 0 : ((L.w - x0 + 4) >> 2) + q - 1, x = x0 - 4 + 4 * c;
         if (c < FRW && y < L.h + 8 && x < L.w + 8 && (x < 0 || x + 3 >= L.w)) {
-            fixi = r * FPW + 1 + c;
+            fixi = r * FPW + 1 + c; fixc = c;
             if (!fix_lds) {
                 const uint8_t* row = img + (size_t)reflect101(y, L.h) * L.pitch;
 #pragma unroll
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t mw = 0;
     if (mbits && tid < TILE_H * (TILE_W / 32)) {
         const int my = y0 + tid / (TILE_W / 32), mwi = (x0 >> 5) + (tid & (TILE_W / 32 - 1));
-        if (my < L.h && mwi < (L.pitch >> 5)) mw = mbits[(size_t)frame * g.mstride + L.moff + (size_t)my * L.mpitch + mwi];
+        if (my < L.h && mwi < (L.pitch >> 5)) mw = (mbits + (size_t)frame * g.mstride + L.moff)[__umul24((uint32_t)my, (uint32_t)L.mpitch) + (uint32_t)mwi];      // (uniform base, 24-bit row multiply)
     }
     const int thr = g.fast_thr, et = g.edge_thr;
     // Only pixels that can survive the border filter, or suppress a survivor in the 3x3 NMS, need a score:
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 // reflection of p is 8 - p; right of it, with e = w - x0 + 4 the first position outside, 2 (e - 1) - p; positions inside stay.
                 // The source bytes are pixels the aligned loads above wrote (a concurrent fix of a straddling word rewrites its inside bytes
                 // with the same values).
-                const int c = fixi - (fixi / FPW) * FPW - 1, e = L.w - x0 + 4;
+                const int c = fixc, e = L.w - x0 + 4;
                 const int A = c == 0 && x0 == 0 ? 8 : 2 * (e - 1), th = c == 0 && x0 == 0 ? 0 : e;
                 const uint8_t* rowb = reinterpret_cast<const uint8_t*>(s_px) + (fixi - 1 - c) * 4 + 4;
 #pragma unroll
@@ -924,7 +928,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         int b;
         if (ovf) {
             b = j;
-            const int sy = b / FROW, xb = b - sy * FROW, y = y0 - 1 + sy;
+            const int sy = frow_div(b), xb = b - sy * FROW, y = y0 - 1 + sy;
             if (!(y >= ylo && y <= yhi && ((s_vm[xb >> 2] >> (8 * (xb & 3))) & 0x80u))) continue;
         } else b = s_list[j];
         // The ring as 8 registers (ring[k] | ring[k + 8] << 16): one v_lshl_or per pair, then the 16 differences are 8 packed subtractions.
@@ -1072,7 +1076,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 const int b = cl ? s_cl[j] : (ovf ? j : s_list[j]);
                 const int sc = s_sc[b];
                 if (sc == 0) continue;
-                const int sy = b / FROW, xb = b - sy * FROW;
+                const int sy = frow_div(b), xb = b - sy * FROW;
                 if (sy < 1 || sy > TILE_H || xb < 8 || xb >= 8 + TILE_W) continue;            // halo positions belong to the neighbour tiles
                 const int x = x0 - 8 + xb, y = y0 - 1 + sy;
                 if (!(x >= et && x < L.w - et && y >= et && y < L.h - et)) continue;
@@ -1100,7 +1104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 uint2* dst = clist + (size_t)frame * g.list_stride + L.list_off;
                 for (int i = tid; i < kk; i += 256) {
                     const uint32_t e = s_out[i];
-                    const int b = e & 0xffffffu, sy = b / FROW, xb = b - sy * FROW;
+                    const int b = e & 0xffffffu, sy = frow_div(b), xb = b - sy * FROW;
                     const uint32_t x = (uint32_t)(x0 - 8 + xb), y = (uint32_t)(y0 - 1 + sy);
                     if (base + i < L.list_cap) dst[base + i] = make_uint2((y << 16) | x, e >> 24);
                     else atomicOr(status, BH_ST_CAND_OVERFLOW);
