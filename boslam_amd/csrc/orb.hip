@@ -1232,7 +1232,17 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     if (tid < 256) s_hs[tid] = 0;
     if (tid == 0) { s_thr = 1; s_m = 0; s_kept = 0; }
     __syncthreads();
-    for (int i = tid; i < nc; i += SEL_T) atomicAdd(&s_hs[lst[i].y & 255u], 1u);      // score histogram of the level's corners
+    // The workgroup is a chain of dependent phases and the launch lasts as long as its slowest workgroup (a level-0 list): what it waits for is
+    // memory round trips in series.  Round 5: the first SEL_LR x 512 list entries are loaded ONCE, all loads in flight together (the histogram pass
+    // and the candidate pass each walked the list 512 entries per round trip), and the nine rows of a Harris window are requested before the
+    // first is used (the compiler's schedule had five in flight and fetched the other four one behind the other).
+    constexpr int SEL_LR = 4;
+    uint2 lr[SEL_LR];
+#pragma unroll
+    for (int k = 0; k < SEL_LR; k++) { const int i = tid + k * SEL_T; lr[k] = i < nc ? lst[i] : make_uint2(0u, 0u); }
+#pragma unroll
+    for (int k = 0; k < SEL_LR; k++) if (tid + k * SEL_T < nc) atomicAdd(&s_hs[lr[k].y & 255u], 1u);      // score histogram of the level's corners
+    for (int i = tid + SEL_LR * SEL_T; i < nc; i += SEL_T) atomicAdd(&s_hs[lst[i].y & 255u], 1u);
     __syncthreads();
     if (tid >= 1 && tid < 256) {
         uint32_t suf = 0;
@@ -1243,7 +1253,10 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     __syncthreads();
     const uint32_t thr = n2 > 0 ? (uint32_t)s_thr : 256u;
     // (b) the corners at or above the threshold (ties at the cut all kept), in whatever order the list has them
-    for (int i = tid; i < nc; i += SEL_T) {
+#pragma unroll
+    for (int k = 0; k < SEL_LR; k++)
+        if (tid + k * SEL_T < nc && lr[k].y >= thr) { const int pos = atomicAdd(&s_m, 1); if (pos < CAND_CAP) s_xy[pos] = lr[k].x; }
+    for (int i = tid + SEL_LR * SEL_T; i < nc; i += SEL_T) {
         const uint2 r = lst[i];
         if (r.y >= thr) { const int pos = atomicAdd(&s_m, 1); if (pos < CAND_CAP) s_xy[pos] = r.x; }
     }
@@ -1264,7 +1277,15 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const uint8_t* p = img + (size_t)(cy - 4) * L.pitch + ((cx - 4) & ~3);
         const uint32_t sh = ((uint32_t)(cx - 4) & 3u) << 3;
         fs2 X0[5], X1[5], X2[5];
-#define SEL_ROW(X, row) { const uint32_t* q_ = reinterpret_cast<const uint32_t*>(p + (size_t)(row) * L.pitch); const uint32_t w0_ = q_[0], w1_ = q_[1], w2_ = q_[2]; \
+        uint32_t RW[9][3];                                      // all nine rows in flight together
+#pragma unroll
+        for (int row = 0; row < 9; row++) {
+            const uint32_t* q_ = reinterpret_cast<const uint32_t*>(p + (size_t)row * L.pitch);
+            RW[row][0] = q_[0]; RW[row][1] = q_[1]; RW[row][2] = q_[2];
+        }
+#pragma unroll
+        for (int row = 0; row < 9; row++) asm volatile("" : "+v"(RW[row][0]), "+v"(RW[row][1]), "+v"(RW[row][2]));      // (keeps the loads above the first use)
+#define SEL_ROW(X, row) { const uint32_t w0_ = RW[row][0], w1_ = RW[row][1], w2_ = RW[row][2]; \
             const uint32_t lo_ = __builtin_amdgcn_alignbit(w1_, w0_, sh), hi_ = __builtin_amdgcn_alignbit(w2_, w1_, sh); \
             X[0] = fpk(0, lo_, 0x0c010c00u); X[1] = fpk(0, lo_, 0x0c030c02u); X[2] = fpk(0, hi_, 0x0c010c00u); X[3] = fpk(0, hi_, 0x0c030c02u); \
             X[4] = __builtin_bit_cast(fs2, (w2_ >> sh) & 255u); }
