@@ -298,16 +298,28 @@ __device__ __forceinline__ double fan_max(const double* part, int n, double t)
     for (int m = 32; m > 0; m >>= 1) t = fmax(t, d_shfl_xor(t, m));
     return t;
 }
-// every thread of the workgroup calls it (lane 0 has stored the workgroup's slots): true, in every thread, in the workgroup that arrives last of `total`
-__device__ __forceinline__ bool fan_arrive(int* counter, int total)
+// every thread of the workgroup calls it (lane 0 has stored the workgroup's slots): true, in every thread, in the workgroup that arrives last of `total`.
+// Two levels: workgroup `bid` counts into the counter of its group of 64 (grp[bid / 64]), the last of a group into `top` - the 15 000 workgroups of a
+// configs[4] launch adding to ONE word serialise in the L2 (~25 ns each: the error kernel took 430 us instead of 80).  The last arrivers put the
+// counters back to zero for the next launch.
+__device__ __forceinline__ bool fan_arrive(int* top, int* grp, int bid, int total)
 {
     __shared__ int s_tk;
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the slot stores of this lane have left the CU (write-through)
-        s_tk = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int g = bid >> 6, ngroups = (total + 63) >> 6, gsize = min(64, total - (g << 6));
+        int last = 0;
+        if (__hip_atomic_fetch_add(grp + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+            __hip_atomic_store(grp + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(top, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) {
+                __hip_atomic_store(top, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        s_tk = last;
     }
     __syncthreads();
-    const bool last = s_tk == total - 1;
+    const bool last = s_tk != 0;
     if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return last;
 }
@@ -317,6 +329,35 @@ __device__ __forceinline__ double fan_block_sum256(double v, double* s4)
     double a[1] = { v };
     d_block_sum<1, 256>(a, s4);
     return a[0];
+}
+// The sum of n slots by a workgroup, the same bits whoever runs it: up to FAN_WAVE_MAX slots by wave 0 alone (fan_sum: what a batched window's
+// 1024-thread control kernels and a single window's 256-thread last arriver both do); beyond that - configs[4] has 15 000 slots, one wave would walk
+// them in 30 dependent round trips - thread t of a 256-thread workgroup takes slots t, t + 256, .. and the workgroup adds up in fixed order (only
+// bh_ba_optimize's own kernels see such sizes).  Valid in thread 0.  Every thread of the workgroup calls it.
+#define FAN_WAVE_MAX 2048
+__device__ __forceinline__ double fan_sum_wg(const double* part, int n, double* s4)
+{
+    if (n <= FAN_WAVE_MAX) return threadIdx.x < 64 ? fan_sum(part, n) : 0.0;
+    double t = 0;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = i0 + 256 * k < n ? fan_load(part + i0 + 256 * k) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) t += v[k];
+    }
+    return fan_block_sum256(t, s4);
+}
+__device__ __forceinline__ double fan_max_wg(const double* part, int n, double t0, double* s4)
+{
+    if (n <= FAN_WAVE_MAX) return threadIdx.x < 64 ? fan_max(part, n, t0) : t0;
+    double t = t0;
+    for (int i = threadIdx.x; i < n; i += 256) t = fmax(t, fan_load(part + i));
+    for (int m = 32; m > 0; m >>= 1) t = fmax(t, d_shfl_xor(t, m));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = t;
+    __syncthreads();
+    return fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3]));
 }
 
 // in-register 6x6 Cholesky solve; returns false if not positive definite
@@ -553,7 +594,7 @@ struct bh_ba {
 };
 
 // fan-in slots of a window (ba->fan): [l_chi nbp][l_max nbp][c_max Cf][u_sum nbp][e_chi ceil(E / 256)]
-static size_t ba_fan_doubles(size_t Pa, size_t Cf, size_t E) { const size_t nbp = (Pa * 8 + 255) / 256; return 3 * nbp + Cf + (E + 255) / 256 + 8; }
+static size_t ba_fan_doubles(size_t Pa, size_t Cf, size_t E) { const size_t nbp = (Pa * 8 + 255) / 256, ne = (E + 255) / 256; return 3 * nbp + Cf + ne + 8 + (nbp + Cf + ne) / 128 + 8; }
 
 // ---- k_ba_point: 8 lanes per active point; residual + Huber + Jacobians; Hll, bl, per-edge Hpl, per-edge error/chi
 #define BP_G 8
@@ -662,12 +703,14 @@ __device__ __forceinline__ void ba_cam_body(int s, const ba_cam* __restrict__ ca
 struct ba_fan {
     double *l_chi, *l_max, *c_max;      // linearisation: [nbp], [nbp], [Cf]
     double *u_sum, *e_chi;              // trial: [landmark workgroups of the update], [workgroups of the error kernel]
+    int* grp;                           // arrival counters per group of 64 workgroups (zero between launches)
 };
 static ba_fan ba_fan_of(const bh_ba* ba)
 {
     const size_t nbp = ((size_t)ba->Pa * BP_G + 255) / 256;
     double* f = (double*)ba->fan.p;
     ba_fan F; F.l_chi = f; F.l_max = f + nbp; F.c_max = f + 2 * nbp; F.u_sum = f + 2 * nbp + ba->Cf; F.e_chi = f + 3 * nbp + ba->Cf;
+    F.grp = (int*)(f + 3 * nbp + ba->Cf + ((size_t)ba->Ea + 255) / 256 + 1);
     return F;
 }
 __device__ __forceinline__ void ba_lin_fan_store(bool point_block, int slot, const double* mine, double md_cam, const ba_fan& F, double* s8)
@@ -687,10 +730,10 @@ __device__ __forceinline__ void ba_lin_fan_store(bool point_block, int slot, con
 // cameras' maxima - replicated, known only after the all-reduce of Hpp - and takes the decision)
 __device__ __forceinline__ void ba_prep_fan(const ba_fan& F, int nbp, int Cf, int first, int phase, ba_state* __restrict__ S)
 {
-    if (threadIdx.x >= 64) return;
-    const double chi = fan_sum(F.l_chi, nbp);
+    __shared__ double s_w[4];
+    const double chi = fan_sum_wg(F.l_chi, nbp, s_w);
     double md = 0;
-    if (first) { md = fan_max(F.l_max, nbp, 0.0); if (phase == 0) md = fan_max(F.c_max, Cf, md); }
+    if (first) { md = fan_max_wg(F.l_max, nbp, 0.0, s_w); if (phase == 0) md = fan_max_wg(F.c_max, Cf, md, s_w); }
     if (threadIdx.x == 0) {
         if (phase == 1) { S->red[0] = chi; S->red[1] = md; return; }
         S->chi_cur = chi;
@@ -715,10 +758,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(int nbp, const ba_cam* __r
     else ba_cam_body(blockIdx.x - nbp, cams, pts, e_cam, e_pt, e_meas, c_start, c_edges, K, delta, Hpp, bp, cdiag, c_pt, c_meas, &md_cam);
     if (!F.l_chi) return;                                        // (BH_BA_FAN=0: the sums as separate launches, the A/B reference)
     ba_lin_fan_store(pb, pb ? (int)blockIdx.x : (int)blockIdx.x - nbp, mine, md_cam, F, s_f);
-    if (fan_arrive(&S->tick[0], (int)gridDim.x)) {
-        ba_prep_fan(F, nbp, (int)gridDim.x - nbp, first, phase, S);
-        if (threadIdx.x == 0) __hip_atomic_store(&S->tick[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (fan_arrive(&S->tick[0], F.grp, (int)blockIdx.x, (int)gridDim.x)) ba_prep_fan(F, nbp, (int)gridDim.x - nbp, first, phase, S);
 }
 
 #define BA_NPART 256
@@ -2676,19 +2716,27 @@ __global__ __launch_bounds__(256) void k_ba_update(const ba_cam* __restrict__ ca
 }
 
 // ---- k_ba_err: per-edge error and robust chi at the trial state
+__host__ __device__ __forceinline__ int ba_err_ept(int Ea) { return Ea > (1 << 18) ? 4 : 1; }
+__host__ __device__ __forceinline__ int ba_err_blocks(int Ea) { const int per = 256 * ba_err_ept(Ea); return (Ea + per - 1) / per; }
 __device__ __forceinline__ void ba_err_body(int bid, const ba_cam* __restrict__ cams, const double* __restrict__ pts,
                                                 const int* __restrict__ e_cam, const int* __restrict__ e_pt,
                                                 const double* __restrict__ e_meas, int Ea, double delta,
                                                 double* __restrict__ err, double* __restrict__ chi_e, double* __restrict__ mine = nullptr)
 {
-    const int e = bid * 256 + threadIdx.x;
-    if (mine) *mine = 0.0;
-    if (e >= Ea) return;
-    double er[2], r0, r1;
-    d_edge_error(cams[e_cam[e]].w2i, pts + 3 * (size_t)e_pt[e], e_meas + 2 * e, er);
-    d_huber(er[0] * er[0] + er[1] * er[1], delta, &r0, &r1);
-    err[2 * e] = er[0]; err[2 * e + 1] = er[1]; chi_e[e] = r0;
-    if (mine) *mine = r0;
+    // a workgroup takes 256 x ept consecutive observations: one per thread for a local window, four beyond 2^18 observations (configs[4]: a quarter of the
+    // workgroups, whose fixed cost - the workgroup's sum, its slot, its arrival - was more than the 1 us of work a workgroup had)
+    const int ept = ba_err_ept(Ea);
+    double acc = 0.0;
+    for (int k = 0; k < ept; k++) {
+        const int e = (bid * ept + k) * 256 + threadIdx.x;
+        if (e >= Ea) break;
+        double er[2], r0, r1;
+        d_edge_error(cams[e_cam[e]].w2i, pts + 3 * (size_t)e_pt[e], e_meas + 2 * e, er);
+        d_huber(er[0] * er[0] + er[1] * er[1], delta, &r0, &r1);
+        err[2 * e] = er[0]; err[2 * e + 1] = er[1]; chi_e[e] = r0;
+        acc += r0;
+    }
+    if (mine) *mine = acc;
 }
 __device__ __forceinline__ void ba_decide_fan(const ba_fan& F, int n_e, int n_u, const double* __restrict__ dxp, const double* __restrict__ bp, int n6,
                                               int phase, int cam_part, ba_state* __restrict__ S, ba_state* host_out, int seq);
@@ -2705,10 +2753,7 @@ __global__ __launch_bounds__(256) void k_ba_err(const ba_cam* __restrict__ cams,
     if (!F.e_chi) return;
     const double t = fan_block_sum256(mine, s_f);
     if (threadIdx.x == 0) fan_store(F.e_chi + blockIdx.x, t);
-    if (fan_arrive(&S->tick[1], (int)gridDim.x)) {
-        ba_decide_fan(F, (int)gridDim.x, n_u, dxp, bp, n6, phase, cam_part, S, host_out, seq);
-        if (threadIdx.x == 0) __hip_atomic_store(&S->tick[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (fan_arrive(&S->tick[1], F.grp, (int)blockIdx.x, (int)gridDim.x)) ba_decide_fan(F, (int)gridDim.x, n_u, dxp, bp, n6, phase, cam_part, S, host_out, seq);
 }
 
 // ---- k_ba_decide: Levenberg gain ratio and lambda schedule (OptimizationAlgorithmLevenberg::solve)
@@ -2770,15 +2815,22 @@ __device__ __forceinline__ void ba_decide_body(const double* __restrict__ chi_e,
 __device__ __forceinline__ void ba_decide_fan(const ba_fan& F, int n_e, int n_u, const double* __restrict__ dxp, const double* __restrict__ bp, int n6,
                                               int phase, int cam_part, ba_state* __restrict__ S, ba_state* host_out, int seq)
 {
-    if (threadIdx.x >= 64) return;
+    __shared__ double s_w[4];
     const int lane = threadIdx.x;
     const double lambda = S->lambda;
-    const double chi = fan_sum(F.e_chi, n_e);
-    double q = fan_sum(F.u_sum, n_u);
-    if (cam_part) {
+    const double chi = fan_sum_wg(F.e_chi, n_e, s_w);
+    double q = fan_sum_wg(F.u_sum, n_u, s_w);
+    if (cam_part) {                                              // (the same rule for the camera half: one wave up to FAN_WAVE_MAX unknowns, the 256-thread workgroup beyond)
         double c = 0;
-        for (int i = lane; i < n6; i += 64) c += dxp[i] * (lambda * dxp[i] + bp[i]);
-        for (int m = 32; m > 0; m >>= 1) c += d_shfl_xor(c, m);
+        if (n6 <= FAN_WAVE_MAX) {
+            if (lane < 64) {
+                for (int i = lane; i < n6; i += 64) c += dxp[i] * (lambda * dxp[i] + bp[i]);
+                for (int m = 32; m > 0; m >>= 1) c += d_shfl_xor(c, m);
+            }
+        } else {
+            for (int i = lane; i < n6; i += 256) c += dxp[i] * (lambda * dxp[i] + bp[i]);
+            c = fan_block_sum256(c, s_w);
+        }
         q += c;
     }
     if (lane == 0) {
@@ -2930,7 +2982,7 @@ __global__ __launch_bounds__(256) void k_bb_err(const ba_view* __restrict__ view
     if (!bb_where(W, w, bx)) return;
     const ba_view& V = views[w];
     const ba_state* S = V.state;
-    if (S->b_done || bx * 256 >= V.Ea) return;
+    if (S->b_done || bx >= ba_err_blocks(V.Ea)) return;
     const int cur = S->b_cur;
     __shared__ double s_f[4];
     double mine = 0;
@@ -2953,7 +3005,7 @@ __global__ __launch_bounds__(1024) void k_bb_decide(const ba_view* __restrict__ 
         }
         return;
     }
-    ba_decide_fan(V.fan, (V.Ea + 255) / 256, (V.Pa * BP_G + 255) / 256, V.dxp, V.bp, V.n6, 0, 1, S, nullptr, 0);
+    ba_decide_fan(V.fan, ba_err_blocks(V.Ea), (V.Pa * BP_G + 255) / 256, V.dxp, V.bp, V.n6, 0, 1, S, nullptr, 0);
     if (threadIdx.x == 0) {                                      // the control flow of bh_ba_optimize's host loop
         if (S->accepted) S->b_cur ^= 1;
         S->b_last_err = 1;                                       // the trial's errors are the last computeActiveErrors
@@ -4589,7 +4641,8 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
     // size).  The host-driven loop below stays for everything else (banded / cyclic-reduction solves, the multi-GPU form) and as the A/B
     // reference (BH_BA_SELF_BATCH=0).
     const bool self_off = getenv("BH_BA_SELF_BATCH") && atoi(getenv("BH_BA_SELF_BATCH")) == 0;
-    if (!ba->ar && ba->chol_dense && Cf > 0 && !self_off) {
+    const bool fan_small = ((size_t)Ea + 255) / 256 <= FAN_WAVE_MAX && ((size_t)Pa * BP_G + 255) / 256 <= FAN_WAVE_MAX;      // (the batch's 1024-thread control kernels sum their slots with one wave)
+    if (!ba->ar && ba->chol_dense && Cf > 0 && fan_small && !self_off) {
         if (!ba->self) { bh_ba* one = ba; BH_TRY(bh_ba_batch_create(ctx, 1, &one, &ba->self)); }
         int itd = 0;
         const int brc = bh_ba_batch_optimize(ba->self, iters, huber_delta, verbose_errors, &itd);
@@ -4612,7 +4665,10 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
     const bool fan_off = getenv("BH_BA_FAN") && atoi(getenv("BH_BA_FAN")) == 0;       // A/B switch
     const bool use_fan = !fan_off;
     ba_fan F = {}; if (use_fan) F = ba_fan_of(ba);
-    if (use_fan) BH_HIP(ctx, hipMemsetAsync(&state->tick[0], 0, sizeof(int) * 2, st));
+    if (use_fan) {
+        BH_HIP(ctx, hipMemsetAsync(&state->tick[0], 0, sizeof(int) * 2, st));
+        BH_HIP(ctx, hipMemsetAsync(F.grp, 0, sizeof(int) * (((size_t)Pa * BP_G + 255) / 256 + Cf + ((size_t)Ea + 255) / 256 + 63) / 64 + 8, st));
+    }
     const int lead = ba->rank == 0 ? 1 : 0;              // the rank that contributes the replicated camera terms
     ba->comm_ms = 0; ba->comm_bytes = 0; ba->ar_bytes = 0;
     if (ba->dsol) { ba->dsol->bytes_rs = ba->dsol->bytes_ag = 0; ba->dsol->ms_replicated = 0; ba->dsol->n_replicated = 0; }
@@ -4705,7 +4761,7 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
             ba_state* hpin = ba->h_state;                // may be null (allocation failed): then the copy + sync path below
             BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_update, dim3(upblocks + cblocks), dim3(256), st, cams, cams_t, pts, pts_t, cslot, C, Pa, upblocks,
                       p_start, p_edges, e_cam, (const double*)Hpl, (const double*)Dinv, (const double*)bl, (const double*)dxp, dxl, ba->K, F, (const ba_state*)state);
-            BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_err, dim3((Ea + 255) / 256), dim3(256), st, (const ba_cam*)cams_t, (const double*)pts_t, e_cam, e_pt,
+            BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_ba_err, dim3(ba_err_blocks(Ea)), dim3(256), st, (const ba_cam*)cams_t, (const double*)pts_t, e_cam, e_pt,
                       e_meas, Ea, huber_delta, (double*)ba->err[1].p, (double*)ba->chi_e[1].p, F, upblocks, (const double*)dxp, (const double*)bp, n6,
                       dist ? 1 : 0, dist ? lead : 1, state, dist ? (ba_state*)nullptr : hpin, seq);
             if (!use_fan) {
@@ -4801,6 +4857,8 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
         if (ba->ar) return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_optimize: window %d is a sharded (multi-GPU) problem", w);
         if (ba->Cf > 0 && !ba->chol_dense)
             return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_optimize: window %d has %d free keyframes; the batch takes local windows (<= %d unknowns): use bh_ba_optimize", w, ba->Cf, 16 * CD_MAXT);
+        if (((size_t)ba->Ea + 255) / 256 > FAN_WAVE_MAX || ((size_t)ba->Pa * BP_G + 255) / 256 > FAN_WAVE_MAX)
+            return bh_set_err(ctx, BH_ERR_INVALID, "bh_ba_batch_optimize: window %d has %d observations / %d landmarks; the batch takes windows of at most %d: use bh_ba_optimize", w, ba->Ea, ba->Pa, 256 * FAN_WAVE_MAX);
         ba_view& V = hv[w];
         memset(&V, 0, sizeof(V));
         for (int k = 0; k < 2; k++) { V.cams[k] = (ba_cam*)ba->cams[k].p; V.pts[k] = (double*)ba->pts[k].p; V.err[k] = (double*)ba->err[k].p; V.chi_e[k] = (double*)ba->chi_e[k].p; }
@@ -4820,7 +4878,7 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
         g_pb = std::max(g_pb, (ba->Pa + 255) / 256);
         g_schur = std::max(g_schur, (ba->npairs + 7) / 8 * 8 + ba->Cf);
         g_upd = std::max(g_upd, (ba->Pa * BP_G + 255) / 256 + (ba->C + 255) / 256);
-        g_eb = std::max(g_eb, (ba->Ea + 255) / 256);
+        g_eb = std::max(g_eb, ba_err_blocks(ba->Ea));
         if (iters_done) iters_done[w] = 0;
     }
     BH_TRY(bh_reserve(ctx, &b->views, sizeof(ba_view) * W)); BH_TRY(bh_reserve(ctx, &b->curs, sizeof(int) * W));
