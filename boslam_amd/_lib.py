@@ -71,6 +71,7 @@ _SIGS = {
     "bh_ba_debug_band_solve": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "bh_ba_window_problem": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "bh_ba_set_allreduce": (_i, [_vp, _vp, _vp, _i, _i]),
+    "bh_ba_set_allreduce_ordered": (_i, [_vp, _i]),
     "bh_ba_get_comm": (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_longlong)]),
     "bh_ba_get_comm_detail": (_i, [_vp, _vp]),
     "bh_solve_pnp_ransac": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i]),

@@ -3,6 +3,7 @@
 Conventions follow the reference's g2o usage (slam/optimizer.py): poses are SBACam estimates, i.e. camera-in-world
 (R, t); the projection of world point X is K * R'(X - t)."""
 import ctypes as C
+import os
 import numpy as np
 from . import _lib
 from ._lib import BH_MEM_HOST
@@ -240,9 +241,12 @@ def exchange_bytes_per_trial(n_unknowns, bw, world, segments=True):
     return dict(reduce_scatter=rs, all_gather=ag, allreduce=ar, total=rs + ag + ar)
 
 
-def make_allreduce_hook(ctx, dist, device=None):
+def make_allreduce_hook(ctx, dist, device=None, stream=None):
     """bh_allreduce_fn over torch.distributed.  With a device-capable backend ("nccl" = RCCL over xGMI) the library's device
-    buffer is reduced in place; with "gloo" it is staged through host memory (CPU rehearsals)."""
+    buffer is reduced in place; with "gloo" it is staged through host memory (CPU rehearsals).
+    stream: a torch stream the context has adopted (Context.set_stream).  The collectives are then issued with it as torch's current stream -
+    RCCL's work is ordered against the current stream on both sides - so they queue behind the library's kernels and the kernels after them
+    queue behind the collectives: no host synchronisation (bh_ba_set_allreduce_ordered)."""
     import torch
     on_device = dist.get_backend() == "nccl"
     L = _lib.lib()
@@ -254,17 +258,20 @@ def make_allreduce_hook(ctx, dist, device=None):
             count = int(count)
             world, rank = dist.get_world_size(), dist.get_rank()
             if on_device:
-                t = torch.as_tensor(_DeviceF64(dev, count), device=device or "cuda")
-                if op < 2:
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
-                else:
-                    ch = count // world
-                    mine = t[rank * ch:(rank + 1) * ch]
-                    if op == 2:
-                        dist.reduce_scatter_tensor(mine, t)                 # RCCL: in place (output = the rank's chunk of the input)
+                import contextlib
+                with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                    t = torch.as_tensor(_DeviceF64(dev, count), device=device or "cuda")
+                    if op < 2:
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
                     else:
-                        dist.all_gather_into_tensor(t, mine)                # RCCL: in place
-                torch.cuda.current_stream(t.device).synchronize()
+                        ch = count // world
+                        mine = t[rank * ch:(rank + 1) * ch]
+                        if op == 2:
+                            dist.reduce_scatter_tensor(mine, t)             # RCCL: in place (output = the rank's chunk of the input)
+                        else:
+                            dist.all_gather_into_tensor(t, mine)            # RCCL: in place
+                    if stream is None:
+                        torch.cuda.current_stream(t.device).synchronize()
             else:                                                            # gloo rehearsal: staged through host memory
                 h = np.empty(count, np.float64)
                 if L.bh_ctx_copy(ctx.h, _lib.ptr(h), C.c_void_p(dev), 8 * count, 0) != 0:
@@ -292,8 +299,22 @@ class GlobalBA(LocalBA):
         super().__init__(ctx, K)
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self._hook = make_allreduce_hook(ctx, dist, device)          # keep the CFUNCTYPE object alive
+        # RCCL: ONE stream orders the library's kernels and the collectives (the context adopts a torch stream, as frontend.DeviceFrontEnd does for
+        # its halo transfers): the hook enqueues, nobody synchronises.  BH_BA_HOOK_SYNC=1 keeps the synchronising hook (A/B); gloo always stages.
+        self._stream = None
+        if dist.get_backend() == "nccl" and os.environ.get("BH_BA_HOOK_SYNC") != "1":
+            import torch
+            self._stream = torch.cuda.Stream(device=device or "cuda")
+            ctx.set_stream(self._stream.cuda_stream)
+        self._hook = make_allreduce_hook(ctx, dist, device, stream=self._stream)          # keep the CFUNCTYPE object alive
         ctx.check(_lib.lib().bh_ba_set_allreduce(self.h, C.cast(self._hook, C.c_void_p), None, self.rank, self.world))
+        if self._stream is not None:
+            ctx.check(_lib.lib().bh_ba_set_allreduce_ordered(self.h, 1))
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self, "_stream", None) is not None:
+            self.ctx.synchronize(); self.ctx.set_stream(None); self._stream = None
+        super().close()
 
     def set_problem(self, R, t, fixed, points, edge_pose, edge_point, meas):
         """Takes the WHOLE problem on every rank and keeps this rank's landmark shard."""

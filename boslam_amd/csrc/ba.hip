@@ -589,6 +589,7 @@ struct bh_ba {
     // landmark-sharded multi-GPU mode (bh_ba_set_allreduce)
     bh_allreduce_fn ar = nullptr;
     void* ar_user = nullptr;
+    int ar_ordered = 0;                // the hook enqueues on the context's stream: no host synchronisation around it
     int rank = 0, world = 1;
     double comm_ms = 0; long long comm_bytes = 0;
 };
@@ -3112,6 +3113,13 @@ extern "C" int bh_ba_set_allreduce(bh_ba* ba, bh_allreduce_fn fn, void* user, in
     return BH_OK;
 }
 
+extern "C" int bh_ba_set_allreduce_ordered(bh_ba* ba, int ordered)
+{
+    if (!ba) return BH_ERR_INVALID;
+    ba->ar_ordered = ordered ? 1 : 0;
+    return BH_OK;
+}
+
 extern "C" int bh_ba_get_comm(bh_ba* ba, double* ms, long long* bytes)
 {
     if (!ba) return BH_ERR_INVALID;
@@ -3124,7 +3132,7 @@ extern "C" int bh_ba_get_comm(bh_ba* ba, double* ms, long long* bytes)
 static int ba_allreduce(bh_ba* ba, void* dev, long long count, int op)
 {
     bh_ctx* ctx = ba->ctx;
-    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ba->ar_ordered) BH_HIP(ctx, hipStreamSynchronize(ctx->stream));      // (stream-ordered hooks enqueue behind the kernels instead: bh_ba_set_allreduce_ordered)
     const auto t0 = std::chrono::steady_clock::now();
     const int r = ba->ar(ba->ar_user, dev, count, op);
     ba->comm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

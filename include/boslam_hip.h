@@ -332,6 +332,11 @@ int  bh_ba_debug_band_solve(bh_ctx* ctx, const double* band, const double* rhs, 
  * Call before bh_ba_set_problem.  fn == NULL restores the single-GPU behaviour. */
 typedef int (*bh_allreduce_fn)(void* user, void* dev_buf, long long count, int op);
 int  bh_ba_set_allreduce(bh_ba* ba, bh_allreduce_fn fn, void* user, int rank, int world);
+/* Stream-ordered hooks (round 5).  By default the library synchronises its stream before it calls fn and expects the result to be visible
+ * when fn returns - ten host synchronisations per Levenberg trial of the segment scheme.  A hook that ENQUEUES its collective on the context's
+ * own stream (bh_ctx_set_stream: e.g. a torch stream RCCL's work is ordered against) needs neither: with ordered != 0 the library calls fn
+ * without synchronising and goes on enqueueing behind it.  bh_ba_get_comm's milliseconds are then the enqueue time only. */
+int  bh_ba_set_allreduce_ordered(bh_ba* ba, int ordered);
 /* wall time spent inside fn and bytes handed to it since the last bh_ba_optimize began */
 int  bh_ba_get_comm(bh_ba* ba, double* ms, long long* bytes);
 /* Sharded mode in detail since the last bh_ba_optimize began, out f64[8]: bytes received through plain all-reduces, through the
