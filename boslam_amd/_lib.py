@@ -78,6 +78,7 @@ _SIGS = {
     "bh_rodrigues": (_i, [_vp, _i, _vp]),
     "bh_debug_pnp_trace": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bh_debug_f64_ops": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "bh_debug_p3p": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "bh_visibility_gate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _d, _d, _d, _i, _i, _d, _vp, _vp, _i]),
     "bh_bow_create": (_i, [_vp, C.POINTER(_vp)]),
     "bh_bow_destroy": (None, [_vp]),

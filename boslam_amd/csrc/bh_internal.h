@@ -75,6 +75,7 @@ struct bh_ctx {
     int         last_pipe = 0;
     bh_buf      st_img, st_mask, st_depth, st_kps, st_desc, st_nkp;     // host-mode staging
     bh_buf      st_a, st_b, st_c, st_d, st_e, st_f, st_g, st_h;         // generic staging (match / BA)
+    bh_buf      pnp_p0;                                                  // four-point PnP problems: the P3P pose per problem (k_pnp_p3p -> k_pnp_ransac)
     bh_buf      tl_w, tl_in;                                              // bh_track_local_map: gathered train side / see vectors, host-mode staging
     bh_buf      tr_w, tr_in;                                              // bh_track_refkf: intermediates (raw matches, gathered BA inputs, chi2), host-mode inputs
     void*       pin = nullptr;                                            // pinned host staging (grow-only): small problems go up in one copy and come back in one

@@ -84,7 +84,7 @@ extern "C" void bh_ctx_destroy(bh_ctx* ctx)
     for (int p = 0; p < BH_MAX_PIPES; p++) { bh_orb_ws& W = ctx->ows[p]; bh_buf* wsb[] = { &W.pyr, &W.mpyr, &W.clist, &W.blur, &W.hist, &W.sel_xy, &W.sel_resp, &W.sel_cnt }; for (bh_buf* b : wsb) release(b); }
     bh_buf* all[] = { &ctx->tab, &ctx->rtab, &ctx->status, &ctx->tr_w, &ctx->tr_in, &ctx->tl_w, &ctx->tl_in,
                       &ctx->st_img, &ctx->st_mask, &ctx->st_depth, &ctx->st_kps, &ctx->st_desc, &ctx->st_nkp,
-                      &ctx->st_a, &ctx->st_b, &ctx->st_c, &ctx->st_d, &ctx->st_e, &ctx->st_f, &ctx->st_g, &ctx->st_h };
+                      &ctx->st_a, &ctx->st_b, &ctx->st_c, &ctx->st_d, &ctx->st_e, &ctx->st_f, &ctx->st_g, &ctx->st_h, &ctx->pnp_p0 };
     for (bh_buf* b : all) release(b);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     (void)drain_timing(ctx);

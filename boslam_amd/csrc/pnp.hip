@@ -17,6 +17,7 @@
 #include <float.h>
 #include "detmath.h"
 #include "pnp_small.h"
+#include "p3p_small.h"
 
 #define PNP_T 64            // one wave per problem: RANSAC iterations in sequence (as OpenCV runs them), each one wave-parallel
 #define PNP_TRACE_HYP 32       // test hook: hypotheses traced per problem
@@ -557,12 +558,30 @@ __device__ int p_update_iters(double p, double ep, int model_points, int max_ite
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
 }
 
+// The four-point problems of a batch (OpenCV: npoints == 4 -> SOLVEPNP_P3P on all four, one hypothesis): a lane per problem solves the
+// perspective-three-point quartic of p3p_small.h and leaves the pose for k_pnp_ransac, which scores, refines and writes it like any other
+// winner.  Its own launch: the quartic's scan and the closed-form alignment would cost the RANSAC kernel registers it does not have (434).
+__global__ void k_pnp_p3p(const double* __restrict__ obj_in, const double* __restrict__ img_in, const int* __restrict__ n_arr, int stride, int B,
+                          pnp_K K, double* __restrict__ pose0)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || n_arr[b] != 4) return;
+    double obj[12], img[8], R[9], t[3];
+    for (int i = 0; i < 12; i++) obj[i] = (double)(float)obj_in[(size_t)b * stride * 3 + i];        // CV_64F -> CV_32F, as the RANSAC path rounds its input
+    for (int i = 0; i < 8; i++) img[i] = (double)(float)img_in[(size_t)b * stride * 2 + i];
+    double* o = pose0 + (size_t)b * 13;
+    const int ok = p3_solve4(obj, img, K.fu, K.fv, K.uc, K.vc, R, t);
+    o[12] = ok ? 1.0 : 0.0;
+    if (ok) { for (int k = 0; k < 9; k++) o[k] = R[k]; for (int k = 0; k < 3; k++) o[9 + k] = t[k]; }
+}
+
 __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__ obj_in, const double* __restrict__ img_in,
                                                       const int* __restrict__ n_arr, int stride, pnp_K K, int iterations,
                                                       double reproj_error, double confidence, double* __restrict__ rvec,
                                                       double* __restrict__ tvec, int* __restrict__ inliers,
                                                       int* __restrict__ n_inliers, int* __restrict__ ok_out,
-                                                      uint8_t* __restrict__ mask_ws, int lm_max, double* trace_all)
+                                                      uint8_t* __restrict__ mask_ws, int lm_max, double* trace_all,
+                                                      const double* __restrict__ pose0)
 {
     __shared__ int s_idx[5];                                  // the current iteration's sample (drawn lazily: any iterationsCount works)
     __shared__ double s_ws[3 * 144 + 12];
@@ -579,7 +598,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
     const double* img = img_in + b * (size_t)stride * 2;
     uint8_t* mask = mask_ws + b * (size_t)stride;
     int* out_idx = inliers + b * (size_t)stride;
-    if (n < 5) { if (tid == 0) { ok_out[b] = 0; n_inliers[b] = 0; } return; }
+    if (n < 4 || (n == 4 && !(pose0 && pose0[b * 13 + 12] > 0.0))) { if (tid == 0) { ok_out[b] = 0; n_inliers[b] = 0; } return; }
     const int niter0 = n == 5 ? 1 : max(1, iterations);
     // phase 0: the sample stream of cv::RNG((uint64)-1) is drawn LAZILY, five indices at the start of each iteration, by lane 0 (an
     // accepted model shrinks the iteration budget to one or two on a tracking problem; drawing all `iterations` samples up front was
@@ -589,7 +608,9 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
     // typical tracking problem needs a handful of hypotheses, not all `iterations`); inside an iteration the wave cooperates:
     // EPnP's 12x12 eigen-decomposition in LDS, the reprojection test one point per lane
     const float thr2 = (float)(reproj_error * reproj_error);
-    {
+    if (n == 4) {                                               // the four-point model of k_pnp_p3p: the one hypothesis of this problem
+        if (tid == 0) { s_best = 0; for (int k = 0; k < 12; k++) s_pose[k] = pose0[b * 13 + k]; }
+    } else {
         int best = -1, max_good = 0, niters = niter0;
         double bR[9], bt[3];
         for (int it = 0; it < niters; it++) {
@@ -647,7 +668,7 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
     // inlier mask of the winner
     for (int i = tid; i < n; i += PNP_T) {
         uint8_t m = 1;
-        if (n > 5) {
+        if (n != 5) {
             const double X[3] = { (double)(float)obj[3 * i], (double)(float)obj[3 * i + 1], (double)(float)obj[3 * i + 2] };
             const double x = p_dot(s_pose, X) + s_pose[9], y = p_dot(s_pose + 3, X) + s_pose[10], z = p_dot(s_pose + 6, X) + s_pose[11];
             const float pu = (float)(K.fu * x / z + K.uc), pv = (float)(K.fv * y / z + K.vc);
@@ -657,6 +678,10 @@ __global__ __launch_bounds__(PNP_T) void k_pnp_ransac(const double* __restrict__
         mask[i] = m;
     }
     __syncthreads();
+    if (n == 4) {                                               // count == modelPoints: accepted only when all four points are inliers
+        const bool all4 = mask[0] && mask[1] && mask[2] && mask[3];
+        if (!all4) { if (tid == 0) { ok_out[b] = 0; n_inliers[b] = 0; } return; }
+    }
     // phase 4: Levenberg-Marquardt on the inliers.  The normal equations are summed in POINT ORDER, like the sequential CPU
     // restatement (a tree reduction would differ in the last bits, and this pose feeds the next frame's float32-rounded input):
     // per 64-point chunk every lane writes its point's two Jacobian rows and residuals to LDS, then lane k < 28 walks the chunk
@@ -808,8 +833,10 @@ extern "C" int bh_solve_pnp_ransac(bh_ctx* ctx, const double* obj, const double*
         d_r = (double*)ctx->st_d.p; d_t = d_r + 3 * (size_t)B; d_in = (int*)ctx->st_e.p;
     }
     pnp_K Kd = { K[0], K[1], K[2], K[3] };
+    BH_TRY(bh_reserve(ctx, &ctx->pnp_p0, sizeof(double) * 13 * (size_t)B));
+    hipLaunchKernelGGL(k_pnp_p3p, dim3((B + 63) / 64), dim3(64), 0, st, d_obj, d_img, d_n, stride, B, Kd, (double*)ctx->pnp_p0.p);
     BH_LAUNCH(ctx, BH_K_PNP, k_pnp_ransac, dim3(B), dim3(PNP_T), st, d_obj, d_img, d_n, stride, Kd, iterations, reproj_error,
-              confidence, d_r, d_t, d_in, d_ni, d_ok, (uint8_t*)ctx->st_h.p, 20, (double*)nullptr);
+              confidence, d_r, d_t, d_in, d_ni, d_ok, (uint8_t*)ctx->st_h.p, 20, (double*)nullptr, (const double*)ctx->pnp_p0.p);
     BH_HIP(ctx, hipGetLastError());
     if (mem == BH_MEM_HOST) {
         BH_HIP(ctx, hipMemcpyAsync(rvec, d_r, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
@@ -850,7 +877,7 @@ extern "C" int bh_debug_pnp_trace(bh_ctx* ctx, const double* obj, const double* 
     pnp_K Kd = { K[0], K[1], K[2], K[3] };
     hipLaunchKernelGGL(k_pnp_ransac, dim3(B), dim3(PNP_T), 0, st, (const double*)ctx->st_a.p, (const double*)ctx->st_b.p,
                        (const int*)ctx->st_c.p, stride, Kd, iterations, reproj_error, confidence, d_r, d_t, (int*)ctx->st_e.p,
-                       d_ni, d_ok, (uint8_t*)ctx->st_h.p, 20, (double*)ctx->st_f.p);
+                       d_ni, d_ok, (uint8_t*)ctx->st_h.p, 20, (double*)ctx->st_f.p, (const double*)nullptr);      // (the trace hook is for the RANSAC path: four-point problems report failure here)
     BH_HIP(ctx, hipGetLastError());
     BH_HIP(ctx, hipMemcpyAsync(rvec, d_r, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
     BH_HIP(ctx, hipMemcpyAsync(tvec, d_t, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
@@ -891,6 +918,29 @@ extern "C" int bh_debug_f64_ops(bh_ctx* ctx, const double* a, const double* b, i
     hipLaunchKernelGGL(k_debug_f64_ops, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)ctx->st_a.p, (const double*)ctx->st_b.p, n, (double*)ctx->st_f.p);
     BH_HIP(ctx, hipGetLastError());
     BH_HIP(ctx, hipMemcpyAsync(out, ctx->st_f.p, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+    BH_HIP(ctx, hipStreamSynchronize(st));
+    return BH_OK;
+}
+
+// bh_debug_p3p: the four-point model of k_pnp_p3p for B problems on host arrays (obj f64[B][4][3], img f64[B][4][2]): pose f64[B][13] =
+// R (9), t (3), ok - compared bit for bit with the checker's p3p_small.h in the tests
+extern "C" int bh_debug_p3p(bh_ctx* ctx, const double* obj, const double* img, int B, const double K[4], double* pose)
+{
+    if (!ctx || !obj || !img || !K || !pose || B < 1) return BH_ERR_INVALID;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    BH_TRY(bh_reserve(ctx, &ctx->st_a, sizeof(double) * 12 * (size_t)B)); BH_TRY(bh_reserve(ctx, &ctx->st_b, sizeof(double) * 8 * (size_t)B));
+    BH_TRY(bh_reserve(ctx, &ctx->st_c, sizeof(int) * (size_t)B)); BH_TRY(bh_reserve(ctx, &ctx->pnp_p0, sizeof(double) * 13 * (size_t)B));
+    std::vector<int> n4(B, 4);
+    BH_HIP(ctx, hipMemcpyAsync(ctx->st_a.p, obj, sizeof(double) * 12 * (size_t)B, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipMemcpyAsync(ctx->st_b.p, img, sizeof(double) * 8 * (size_t)B, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipMemcpyAsync(ctx->st_c.p, n4.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipMemsetAsync(ctx->pnp_p0.p, 0, sizeof(double) * 13 * (size_t)B, st));
+    pnp_K Kd = { K[0], K[1], K[2], K[3] };
+    hipLaunchKernelGGL(k_pnp_p3p, dim3((B + 63) / 64), dim3(64), 0, st, (const double*)ctx->st_a.p, (const double*)ctx->st_b.p, (const int*)ctx->st_c.p, 4, B, Kd,
+                       (double*)ctx->pnp_p0.p);
+    BH_HIP(ctx, hipGetLastError());
+    BH_HIP(ctx, hipMemcpyAsync(pose, ctx->pnp_p0.p, sizeof(double) * 13 * (size_t)B, hipMemcpyDeviceToHost, st));
     BH_HIP(ctx, hipStreamSynchronize(st));
     return BH_OK;
 }

@@ -103,9 +103,11 @@ def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None, rve
     """-> (retval, rvec (3,1), tvec (3,1), inliers (k,1) int32 | None), like cv2.  The final pose is the reprojection-error
     minimiser over the RANSAC inliers for both ITERATIVE and EPNP flags.
 
-    NOT cv2 for exactly four points: OpenCV 3.x switches its minimal solver to P3P when n == 4 (5 points and EPnP otherwise); that
-    branch is not built - n == 4 returns (False, zeros, zeros, None).  The reference never gets there: its only live call site needs
-    >= 10 matches first (experiments/pnp_two_way_tracking.py:45,57-61).  Any iterationsCount is accepted."""
+    Exactly four points (round 5): OpenCV 3.x switches its minimal solver to P3P when n == 4 - one hypothesis from all four points (the
+    first three give up to four poses, the fourth picks one), accepted only when all four are inliers - and so does this (p3p_small.h: the
+    same construction restated from the classical derivation, OpenCV's p3p.cpp not being available; parity unpinned like the rest of the
+    path).  The reference never gets there: its only live call site needs >= 10 matches first (experiments/pnp_two_way_tracking.py:45,57-61).
+    Any iterationsCount is accepted."""
     import ctypes as C
     if distCoeffs is not None and np.any(np.asarray(distCoeffs) != 0):
         raise ValueError("non-zero distortion is not supported (the reference always passes zeros, camera.py:82)")

@@ -366,7 +366,9 @@ int bh_ba_window_problem(bh_ctx* ctx, int K, const int* nbr_start, const int* nb
 /* ---- PnP + RANSAC, Rodrigues -----------------------------------------------------------------------------------------
  * Replaces cv2.solvePnPRansac(obj, img, K, distCoeffs=0, flags=cv2.SOLVEPNP_ITERATIVE) and cv2.Rodrigues(v)[0] —
  * experiments/pnp_two_way_tracking.py:57-61,68-69 (slam/tracking.py:68-71 is dead code) — for B problems.
- *   obj f64[B][stride][3], img f64[B][stride][2], n int[B] (n >= 5; n == 4, where OpenCV switches to P3P, reports ok = 0)
+ *   obj f64[B][stride][3], img f64[B][stride][2], n int[B] (n >= 4.  n == 4 takes OpenCV's four-point branch: model_points = 4 with
+ *   SOLVEPNP_P3P - ONE hypothesis from all four points, the first three correspondences solved for up to four poses and the fourth picking
+ *   the one it reprojects best, accepted only when all four are inliers; n < 4 reports ok = 0)
  *   K = {fx, fy, cx, cy}; distortion is zero in the reference (camera.py:82, config.py:34)
  *   defaults of the reference call: iterations 100, reproj_error 8.0, confidence 0.99 (any iterationsCount: the sample stream of
  *   cv::RNG((uint64)-1) is drawn hypothesis by hypothesis)
@@ -387,6 +389,8 @@ int bh_debug_pnp_trace(bh_ctx* ctx, const double* obj, const double* img, const 
                        const double K[4], int iterations, double reproj_error, double confidence,
                        double* rvec, double* tvec, int* inliers, int* n_inliers, int* ok, double* trace);
 int bh_debug_f64_ops(bh_ctx* ctx, const double* a, const double* b, int n, double* out);
+/* the four-point model (n == 4 branch of bh_solve_pnp_ransac) alone: obj f64[B][4][3], img f64[B][4][2] -> pose f64[B][13] = R, t, found */
+int bh_debug_p3p(bh_ctx* ctx, const double* obj, const double* img, int B, const double K[4], double* pose);
 
 /* ---- local-map visibility gate ------------------------------------------------------------------------------------
  * Replaces the per-map-point loop of Tracker._track_local_map — slam/tracking.py:97-111 — for B frames:

@@ -315,6 +315,29 @@ def solve_pnp_ransac(obj, img, K4, iterations=100, reproj_error=8.0, confidence=
     return bool(ok), rvec, tvec, inl[:ni.value].copy()
 
 
+def p3_roots(A):
+    """positive real roots of the quartic A[0] v^4 + .. + A[4] as p3p_small.h finds them (sign scan + bisection)"""
+    A = np.ascontiguousarray(A, dtype=np.float64); v = np.zeros(4)
+    n = lib().orc_p3_roots(_p(A), _p(v))
+    return v[:n].copy()
+
+
+def p3_solve3(X, f):
+    """up to four poses (R, t) with s_i f_i = R X_i + t for three correspondences (p3p_small.h)"""
+    X = np.ascontiguousarray(X, dtype=np.float64).reshape(3, 3); f = np.ascontiguousarray(f, dtype=np.float64).reshape(3, 3)
+    Rs = np.zeros((4, 3, 3)); ts = np.zeros((4, 3))
+    n = lib().orc_p3_solve3(_p(X), _p(f), _p(Rs), _p(ts))
+    return Rs[:n].copy(), ts[:n].copy()
+
+
+def p3_solve4(obj, img, K4):
+    """solvePnPRansac's four-point model (p3p_small.h): (ok, R, t)"""
+    obj = np.ascontiguousarray(obj, dtype=np.float64).reshape(4, 3); img = np.ascontiguousarray(img, dtype=np.float64).reshape(4, 2)
+    K4 = np.ascontiguousarray(K4, dtype=np.float64); R = np.zeros((3, 3)); t = np.zeros(3)
+    ok = lib().orc_p3_solve4(_p(obj), _p(img), _p(K4), _p(R), _p(t))
+    return bool(ok), R, t
+
+
 def mp_add_observation(obs, n_obs, normal, feat, new_desc, new_n):
     """MapPoint.add_observation, slam/nodes.py:142-156, line by line in numpy as the reference runs it (dbow.distance = Hamming distance
     of the two descriptors).  obs: list of u8[32] descriptors.  Returns (obs, n_obs, normal, feat)."""

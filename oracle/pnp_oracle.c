@@ -34,6 +34,7 @@
 #include <float.h>
 #include "detmath.h"
 #include "pnp_small.h"
+#include "p3p_small.h"
 
 /* ---------- small linear algebra ---------- */
 /* cyclic Jacobi for symmetric A (n<=12), eigenvalues descending in d, eigenvectors in ROWS of Vt */
@@ -520,7 +521,7 @@ int orc_solve_pnp_ransac(const double* obj_in, const double* img_in, int n, cons
                          double reproj_error, double confidence, double* rvec, double* tvec, int* inlier_idx, int* n_inliers)
 {
     *n_inliers = 0;
-    if (n < 5) return 0;
+    if (n < 4) return 0;
     epnp_K K = { Kin[0], Kin[1], Kin[2], Kin[3] };
     double* obj = malloc(sizeof(double) * 3 * n); double* img = malloc(sizeof(double) * 2 * n);
     for (int i = 0; i < 3 * n; i++) obj[i] = (double)(float)obj_in[i];          /* CV_64F -> CV_32F */
@@ -530,7 +531,22 @@ int orc_solve_pnp_ransac(const double* obj_in, const double* img_in, int n, cons
     int max_good = 0, niters = iterations_count > 1 ? iterations_count : 1, ok = 0;
     const float thr2 = (float)(reproj_error * reproj_error);
     uint64_t st = (uint64_t)-1;
-    if (n == 5) {
+    if (n == 4) {
+        /* OpenCV: npoints == 4 -> model_points = 4, SOLVEPNP_P3P; count == modelPoints -> ONE hypothesis from all four points, accepted only
+         * when all four are inliers (goodCount > max(maxGoodCount, modelPoints - 1)).  p3p_small.h: pose of the first three, picked by the fourth. */
+        if (p3_solve4(obj, img, K.fu, K.fv, K.uc, K.vc, bestR, bestt)) {
+            int good = 0;
+            for (int i = 0; i < 4; i++) {
+                const double* X = obj + 3 * i;
+                double x = epnp_dot(bestR, X) + bestt[0], y = epnp_dot(bestR + 3, X) + bestt[1], z = epnp_dot(bestR + 6, X) + bestt[2];
+                float pu = (float)(K.fu * x / z + K.uc), pv = (float)(K.fv * y / z + K.vc);
+                float du = (float)img[2 * i] - pu, dv = (float)img[2 * i + 1] - pv;
+                best_mask[i] = du * du + dv * dv <= thr2;
+                good += best_mask[i];
+            }
+            if (good == 4) max_good = 4;
+        }
+    } else if (n == 5) {
         epnp_solve(obj, img, 5, K, bestR, bestt);
         memset(best_mask, 1, n); max_good = 5;
     } else {
@@ -597,3 +613,8 @@ void orc_ps_qr_solve_6x4(const double* A, const double* b, double* x)
     ps_qr_solve_6x4(Ac, bc, x);
 }
 int orc_ps_chol6_solve(const double* A, const double* b, double* x) { return ps_chol6_solve(A, b, x); }
+
+/* test access to p3p_small.h: roots of a quartic; the up-to-four poses of three correspondences; the four-point model */
+int orc_p3_roots(const double* A, double* v) { return p3_roots(A, v); }
+int orc_p3_solve3(const double* X, const double* f, double* Rs, double* ts) { return p3_solve3(X, f, Rs, ts); }
+int orc_p3_solve4(const double* obj, const double* img, const double* K, double* R, double* t) { return p3_solve4(obj, img, K[0], K[1], K[2], K[3], R, t); }

@@ -61,7 +61,7 @@ def test_brief_pattern_table_digest():
     assert np.array_equal(vals, oracle.pattern())
 
 
-@pytest.mark.parametrize("name", ["detmath.h", "pnp_small.h", "se3_small.h"])
+@pytest.mark.parametrize("name", ["detmath.h", "pnp_small.h", "se3_small.h", "p3p_small.h"])
 def test_shared_fixed_order_headers_are_identical(name):
     """The product and the checker evaluate these routines with the same statements: the two copies must not drift apart."""
     mark = "/* ---- identical from here on ---- */"

@@ -483,3 +483,56 @@ def test_pose_graph_edge_jacobians_by_finite_differences():
                     rs.append(oracle.pose_graph_edge(Rn if side == 0 else Ri, tn if side == 0 else ti, Rn if side == 1 else Rj, tn if side == 1 else tj, Zr, Zt, False)[0])
                 num[:, k] = (rs[0] - rs[1]) / (2 * h)
             assert np.abs(num - J).max() < 1e-6, (trial, side, np.abs(num - J).max())
+
+
+def test_p3p_small_against_numpy_roots_and_generated_poses():
+    """p3p_small.h (the four-point branch of solvePnPRansac, shared as text with the kernel) on its own: the quartic's positive roots equal
+    numpy.roots' (also the close pairs a plain sign scan would miss), every pose of the three-point problem reproduces its three rays, the
+    generating pose is among them, and the fourth point picks it."""
+    rng = np.random.default_rng(5)
+    K4 = np.array([384.239013671875, 384.239013671875, 322.432373046875, 239.6533203125])
+
+    def rot(w):
+        th = np.linalg.norm(w); k = w / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    # roots: quartics with prescribed positive roots, incl. pairs 1e-3 apart (inside one step of the scan)
+    for roots in ([0.5, 1.0, 1.001, 2.0], [0.2, 0.9], [1.0187672, 1.0198805, 0.8086565, 1.171291], [3.0, 3.002, 40.0, 41.0]):
+        A = np.poly(roots + [-1.0 - 0.3j, -1.0 + 0.3j][:4 - len(roots)]).real if len(roots) < 4 else np.poly(roots)
+        got = oracle.p3_roots(A)
+        assert len(got) == len(roots) and np.allclose(np.sort(got), np.sort(roots), rtol=1e-9), (roots, got)
+    assert len(oracle.p3_roots(np.poly([-1.0, -2.0, -3.0, -0.5]))) == 0                   # no positive root
+    n_ok = 0
+    for trial in range(400):
+        R = rot(rng.normal(size=3) * 0.5); t = np.array([rng.normal() * 0.3, rng.normal() * 0.3, 2 + rng.random() * 3])
+        X = rng.uniform(-1, 1, (4, 3)); P = X @ R.T + t
+        if (P[:, 2] < 0.5).any():
+            continue
+        f = P[:3] / np.linalg.norm(P[:3], axis=1)[:, None]
+        Rs, ts = oracle.p3_solve3(X[:3], f)
+        assert 1 <= len(Rs) <= 4
+        errs = []
+        for Ri, ti in zip(Rs, ts):
+            assert np.abs(Ri @ Ri.T - np.eye(3)).max() < 1e-9 and abs(np.linalg.det(Ri) - 1) < 1e-9
+            Q = X[:3] @ Ri.T + ti                                                             # on the three rays, at positive depth
+            assert (Q[:, 2] > 0).all() and np.abs(Q / np.linalg.norm(Q, axis=1)[:, None] - f).max() < 1e-6
+            errs.append(max(np.abs(Ri - R).max(), np.abs(ti - t).max()))
+        if min(errs) < 1e-5:
+            n_ok += 1
+        img = np.stack([K4[0] * P[:, 0] / P[:, 2] + K4[2], K4[1] * P[:, 1] / P[:, 2] + K4[3]], 1)
+        ok, Rg, tg = oracle.p3_solve4(X, img, K4)
+        assert ok
+    assert n_ok >= 0.98 * trial * 0.9                                                         # (a near-double root costs digits, not the solution)
+    # degenerate: coincident points -> no model
+    X = np.zeros((4, 3)); X[:, 2] = 3.0
+    assert oracle.p3_solve4(X, np.tile(K4[2:], (4, 1)), K4)[0] is False
+    # the full four-point path of the checker: pose recovered after the refinement, all four inliers; an inconsistent fourth point fails
+    R = rot(np.array([0.1, -0.2, 0.05])); t = np.array([0.1, -0.05, 0.4])
+    X = np.array([[-0.5, -0.4, 2.0], [0.6, -0.3, 2.5], [0.1, 0.5, 3.0], [-0.3, 0.2, 2.2]])
+    P = X @ R.T + t
+    img = np.stack([K4[0] * P[:, 0] / P[:, 2] + K4[2], K4[1] * P[:, 1] / P[:, 2] + K4[3]], 1)
+    ok, rv, tv, inl = oracle.solve_pnp_ransac(X, img, K4)
+    assert ok and np.array_equal(inl, [0, 1, 2, 3]) and np.abs(oracle.rodrigues(rv) - R).max() < 1e-5 and np.abs(tv - t).max() < 1e-5
+    img2 = img.copy(); img2[3] += 60.0
+    assert oracle.solve_pnp_ransac(X, img2, K4)[0] is False
+    assert oracle.solve_pnp_ransac(X[:3], img[:3], K4)[0] is False
