@@ -4921,9 +4921,14 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
     const bool look_off = getenv("BH_BA_LOOKAHEAD") && atoi(getenv("BH_BA_LOOKAHEAD")) == 0;      // A/B switch: enqueue a round only after the last one's verdicts
     int seq_cur = 0;
     if (active > 0) { seq_cur = ++b->seq; enqueue_round(seq_cur); }
+    std::vector<int> it_known(W, 0);                           // iterations a window had completed at the last verdict the host has read
     for (int round = 0; active > 0 && round < iters * 10 + 2; round++) {
         int seq_next = 0;
-        if (!look_off) { seq_next = ++b->seq; enqueue_round(seq_next); }
+        // no look-ahead behind a round that ends the run if its trials are accepted (every live window is in its last iteration): the surplus
+        // round - eight launches that find everything done - would sit in front of the caller's next call; a retry there costs one host turn-around
+        bool may_end = true;
+        for (int w = 0; w < W && may_end; w++) if (!done[w] && it_known[w] + 1 < iters) may_end = false;
+        if (!look_off && !may_end) { seq_next = ++b->seq; enqueue_round(seq_next); }
         BH_HIP(ctx, hipGetLastError());
         const int seq = seq_cur;
         for (int w = 0; w < W; w++) {
@@ -4952,6 +4957,7 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
             bh_ba* ba = b->win[w];
             if (hs.b_fail) { done[w] = 1; active--; rc = bh_set_err(ctx, BH_ERR_NUMERIC, "bh_ba_batch_optimize: non-finite Hessian at the initial estimate of window %d", w); continue; }
             ba->cur = hs.b_cur; ba->last_err_sel = hs.b_last_err;
+            it_known[w] = hs.b_it;
             if (!hs.again) {
                 ba->log.push_back(hs.accepted ? hs.chi_cur : hs.chi_trial); ba->log.push_back(hs.lambda);
                 ba->log.push_back((double)hs.qmax); ba->log.push_back((double)hs.accepted);
@@ -4960,8 +4966,8 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
             }
             if (hs.b_done) { done[w] = 1; active--; }
         }
-        if (look_off) { if (active > 0) { seq_cur = ++b->seq; enqueue_round(seq_cur); } }
-        else seq_cur = seq_next;
+        if (seq_next) seq_cur = seq_next;
+        else if (active > 0) { seq_cur = ++b->seq; enqueue_round(seq_cur); }
     }
     for (int w = 0; w < W; w++) b->win[w]->verbose_last = verbose_errors;
     return rc;
