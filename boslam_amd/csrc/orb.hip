@@ -165,6 +165,28 @@ __global__ __launch_bounds__(256) void k_gray_mask(const uint8_t* __restrict__ i
 // dot products), the four depth values to a nibble by one packed min per register, frame-uniform 64-bit bases with 32-bit lane
 // offsets.  50 vector instructions per lane where the general kernel above takes 118; both are at the HBM roof on their own, but the
 // front end as a whole is bound by vector-instruction issue, and this kernel runs beside the others.
+// four pixels (x .. x + 3 of row y, x < W) of the reference call's level 0: gray bytes g4 and the mask nibble (depth != 0)
+__device__ __forceinline__ void gray_item4(const uint8_t* __restrict__ fimg, const uint16_t* __restrict__ fd, int W, int y, int x, uint32_t& g4, uint32_t& nib)
+{
+    const uint32_t px = __umul24((uint32_t)y, (uint32_t)W) + (uint32_t)x;
+    const uint32_t* sp = reinterpret_cast<const uint32_t*>(fimg + __umul24(px, 3u));
+    const uint32_t a = sp[0], b = sp[1], c = sp[2];       // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+    const uint32_t h0 = __builtin_amdgcn_udot4(a, 7u | 37u << 8 | 19u << 16, 0u, false), l0 = __builtin_amdgcn_udot4(a, 76u | 145u << 8 | 35u << 16, 8192u, false);
+    const uint32_t h1 = __builtin_amdgcn_udot4(a, 7u << 24, __builtin_amdgcn_udot4(b, 37u | 19u << 8, 0u, false), false);
+    const uint32_t l1 = __builtin_amdgcn_udot4(a, 76u << 24, __builtin_amdgcn_udot4(b, 145u | 35u << 8, 8192u, false), false);
+    const uint32_t h2 = __builtin_amdgcn_udot4(b, 7u << 16 | 37u << 24, __builtin_amdgcn_udot4(c, 19u, 0u, false), false);
+    const uint32_t l2 = __builtin_amdgcn_udot4(b, 76u << 16 | 145u << 24, __builtin_amdgcn_udot4(c, 35u, 8192u, false), false);
+    const uint32_t h3 = __builtin_amdgcn_udot4(c, 7u << 8 | 37u << 16 | 19u << 24, 0u, false), l3 = __builtin_amdgcn_udot4(c, 76u << 8 | 145u << 16 | 35u << 24, 8192u, false);
+    g4 = __builtin_amdgcn_ubfe((h0 << 8) + l0, 14u, 8u) | __builtin_amdgcn_ubfe((h1 << 8) + l1, 14u, 8u) << 8 |
+         __builtin_amdgcn_ubfe((h2 << 8) + l2, 14u, 8u) << 16 | __builtin_amdgcn_ubfe((h3 << 8) + l3, 14u, 8u) << 24;
+    typedef unsigned short gm_us2 __attribute__((ext_vector_type(2)));
+    const uint2 d = *reinterpret_cast<const uint2*>(fd + px);
+    const gm_us2 one = gm_us2{ 1, 1 };
+    const uint32_t nx = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(gm_us2, d.x), one));      // 1 / 0 in each half
+    const uint32_t ny = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(gm_us2, d.y), one));
+    nib = ((nx | nx >> 15) & 3u) | ((ny | ny >> 15) & 3u) << 2;
+}
+
 __global__ __launch_bounds__(256) void k_gray_bits(const uint8_t* __restrict__ img, const uint16_t* __restrict__ depth, uint8_t* __restrict__ pyr,
                                                    int W, int H, int pitch, int pyr_stride, uint32_t* __restrict__ mbits, int mpitch, int mstride)
 {
@@ -184,30 +206,11 @@ __global__ __launch_bounds__(256) void k_gray_bits(const uint8_t* __restrict__ i
     uint8_t* __restrict__ fp = pyr + (size_t)blockIdx.y * pyr_stride;
     uint32_t* __restrict__ fm = mbits + (size_t)blockIdx.y * mstride;
     uint32_t g4 = 0, nib = 0;
-    if (x < W) {
-        const uint32_t px = __umul24((uint32_t)y, (uint32_t)W) + (uint32_t)x;
-        const uint32_t* sp = reinterpret_cast<const uint32_t*>(fimg + __umul24(px, 3u));
-        const uint32_t a = sp[0], b = sp[1], c = sp[2];       // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-        const uint32_t h0 = __builtin_amdgcn_udot4(a, 7u | 37u << 8 | 19u << 16, 0u, false), l0 = __builtin_amdgcn_udot4(a, 76u | 145u << 8 | 35u << 16, 8192u, false);
-        const uint32_t h1 = __builtin_amdgcn_udot4(a, 7u << 24, __builtin_amdgcn_udot4(b, 37u | 19u << 8, 0u, false), false);
-        const uint32_t l1 = __builtin_amdgcn_udot4(a, 76u << 24, __builtin_amdgcn_udot4(b, 145u | 35u << 8, 8192u, false), false);
-        const uint32_t h2 = __builtin_amdgcn_udot4(b, 7u << 16 | 37u << 24, __builtin_amdgcn_udot4(c, 19u, 0u, false), false);
-        const uint32_t l2 = __builtin_amdgcn_udot4(b, 76u << 16 | 145u << 24, __builtin_amdgcn_udot4(c, 35u, 8192u, false), false);
-        const uint32_t h3 = __builtin_amdgcn_udot4(c, 7u << 8 | 37u << 16 | 19u << 24, 0u, false), l3 = __builtin_amdgcn_udot4(c, 76u << 8 | 145u << 16 | 35u << 24, 8192u, false);
-        g4 = __builtin_amdgcn_ubfe((h0 << 8) + l0, 14u, 8u) | __builtin_amdgcn_ubfe((h1 << 8) + l1, 14u, 8u) << 8 |
-             __builtin_amdgcn_ubfe((h2 << 8) + l2, 14u, 8u) << 16 | __builtin_amdgcn_ubfe((h3 << 8) + l3, 14u, 8u) << 24;
-        typedef unsigned short gm_us2 __attribute__((ext_vector_type(2)));
-        const uint2 d = *reinterpret_cast<const uint2*>(fd + px);
-        const gm_us2 one = gm_us2{ 1, 1 };
-        const uint32_t nx = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(gm_us2, d.x), one));      // 1 / 0 in each half
-        const uint32_t ny = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(gm_us2, d.y), one));
-        nib = ((nx | nx >> 15) & 3u) | ((ny | ny >> 15) & 3u) << 2;
-    }
+    if (x < W) gray_item4(fimg, fd, W, y, x, g4, nib);
     *reinterpret_cast<uint32_t*>(fp + (__umul24((uint32_t)y, (uint32_t)pitch) + (uint32_t)x)) = g4;
     const uint32_t wd = nib_gather8(nib, threadIdx.x);
     if ((threadIdx.x & 7) == 7) fm[__umul24((uint32_t)y, (uint32_t)mpitch) + (uint32_t)(x >> 5)] = wd;
 }
-
 // ------------------------------------------------------------------------------------------------ pyramid level l from l-1
 // INTER_LINEAR_EXACT arithmetic: horizontal 8.8 fixed point, vertical 16.16, round to nearest.
 // One lane produces 4 output pixels.  Its 4 coefficient entries come in one 16-B load; the <= 6 source columns they
@@ -395,6 +398,108 @@ __global__ __launch_bounds__(256) void k_pyr_down_bits(uint8_t* __restrict__ pyr
         if (y < D.h) {
             __builtin_amdgcn_raw_buffer_store_b32(o4[k], rs_dst, od, k * D.pitch, 0);
             if ((threadIdx.x & 7) == 7) __builtin_amdgcn_raw_buffer_store_b32(nbw[k], rs_md, om, k * D.mpitch * 4, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ level 0 and level 1 in one launch
+// k_gray_l1 (round 5): the reference call's gray + mask-bit level 0 AND level 1 of the pyramid by one workgroup per strip of GL_SR level-1
+// rows.  k_gray_bits streams 1.9 MB per frame at the HBM roof with 60 % of its vector-issue slots idle, and level 1 is a third of the
+// pyramid's pixels at ~30 instructions each with little memory traffic: here the workgroups of a CU sit in different phases - some
+// waiting for their BGR / depth words, some resizing - so the resize rides in the issue slots the stream leaves free.  A workgroup
+//   1. computes the level-0 rows its level-1 rows read (src(y1a) .. src(y1b - 1) + 1: at most GL_R0) with gray_item4, writes them to
+//      HBM (the rows two strips share are written twice, identically) and keeps them, with their mask words, in LDS;
+//   2. resizes from LDS with the arithmetic of k_pyr_down_bits (pyr_xsetup / pyr_row: the same statements, so the same bytes) and
+//      stores level 1.  Level 0 is not read back from HBM, and one launch per chunk is gone.
+#define GL_R0 26               // level-0 rows a workgroup stages (18.8 KB of LDS at 640 columns: eight workgroups per CU)
+__device__ __forceinline__ void pyr_load_lds(pyr_ld& L, const uint8_t* __restrict__ sg, const uint32_t* __restrict__ sm, int pitch, int mpitch,
+                                             const pyr_xs& X, int r0, int r1)
+{
+    const uint32_t* qa = reinterpret_cast<const uint32_t*>(sg + __umul24((uint32_t)r0, (uint32_t)pitch) + X.boff);
+    const uint32_t* qb = reinterpret_cast<const uint32_t*>(sg + __umul24((uint32_t)r1, (uint32_t)pitch) + X.boff);
+    L.a0 = qa[0]; L.a1 = qa[1]; L.a2 = qa[2]; L.b0 = qb[0]; L.b1 = qb[1]; L.b2 = qb[2];
+    const uint32_t* pa = sm + __umul24((uint32_t)r0, (uint32_t)mpitch) + X.mcol; const uint32_t* pb = sm + __umul24((uint32_t)r1, (uint32_t)mpitch) + X.mcol;
+    L.ma0 = pa[0]; L.ma1 = pa[1]; L.mb0 = pb[0]; L.mb1 = pb[1];
+}
+__global__ __launch_bounds__(256) void k_gray_l1(const uint8_t* __restrict__ img, const uint16_t* __restrict__ depth, uint8_t* __restrict__ pyr,
+                                                 bh_orb_geom g, int sr, const uint32_t* __restrict__ tab, uint32_t* __restrict__ mbits, uint32_t* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t gl_sm[];
+    const bh_level_geom S = g.lv[0], D = g.lv[1];
+    uint8_t* const sg = gl_sm;                                             // [GL_R0][S.pitch + 16] gray rows (+16: a 12-byte window may start at the last column group)
+    const int gp = S.pitch + 16;
+    uint32_t* const sm = reinterpret_cast<uint32_t*>(gl_sm + (size_t)GL_R0 * gp);      // [GL_R0][S.mpitch + 1] mask words
+    const int mp = S.mpitch + 1;
+    const int tid = threadIdx.x, W = g.W, H = g.H;
+    const int y1a = blockIdx.x * sr, y1b = min(D.h, y1a + sr);
+    const uint8_t* __restrict__ fimg = img + (size_t)blockIdx.y * H * W * 3;
+    const uint16_t* __restrict__ fd = depth + (size_t)blockIdx.y * H * W;
+    uint8_t* __restrict__ fp = pyr + (size_t)blockIdx.y * g.pyr_stride;
+    uint32_t* __restrict__ fm = mbits + (size_t)blockIdx.y * g.mstride;
+    const int ra = (int)(tab[D.taby_off + y1a] >> 16);
+    int rb = min((int)(tab[D.taby_off + y1b - 1] >> 16) + 1, S.h - 1);
+    if (blockIdx.x == gridDim.x - 1) rb = S.h - 1;                          // (the last strip finishes level 0 whatever the last source row is)
+    const int nr = rb - ra + 1;
+    if (nr > GL_R0) { if (tid == 0) atomicOr(status, BH_ST_CAND_OVERFLOW); return; }      // cannot happen: the host sizes sr for the scale factor
+    // ---- level 0 rows ra .. rb: gray + mask bits -> HBM and LDS
+    const int groups = S.pitch >> 2;                                       // a multiple of 16: the 16 lanes of a DPP row share an image row
+    for (int idx = tid; idx < nr * groups; idx += 256) {
+        int r;
+        {
+            const int q = idx >> 4, d = groups >> 4;
+            r = (int)((float)q * __builtin_amdgcn_rcpf((float)d));
+            const int rem = q - __mul24(r, d);
+            r += rem >= d ? 1 : (rem < 0 ? -1 : 0);
+        }
+        const int x = (idx - __mul24(r, groups)) << 2, y = ra + r;
+        uint32_t g4 = 0, nib = 0;
+        if (x < W) gray_item4(fimg, fd, W, y, x, g4, nib);
+        *reinterpret_cast<uint32_t*>(fp + (__umul24((uint32_t)y, (uint32_t)S.pitch) + (uint32_t)x)) = g4;
+        *reinterpret_cast<uint32_t*>(sg + __umul24((uint32_t)r, (uint32_t)gp) + (uint32_t)x) = g4;
+        const uint32_t wd = nib_gather8(nib, tid);
+        if ((tid & 7) == 7) { fm[__umul24((uint32_t)y, (uint32_t)S.mpitch) + (uint32_t)(x >> 5)] = wd; sm[__umul24((uint32_t)r, (uint32_t)mp) + (uint32_t)(x >> 5)] = wd; }
+    }
+    for (int i = tid; i < nr * 6; i += 256) {                              // the words behind a row's last column group / mask word: zero (only padding columns meet them)
+        const int r = i / 6, k = i - r * 6;
+        if (k < 4) *reinterpret_cast<uint32_t*>(sg + __umul24((uint32_t)r, (uint32_t)gp) + (uint32_t)S.pitch + 4u * k) = 0u;
+        else sm[__umul24((uint32_t)r, (uint32_t)mp) + (uint32_t)(S.pitch >> 5) + (uint32_t)(k - 4)] = 0u;
+    }
+    __syncthreads();
+    // ---- level 1 rows y1a .. y1b - 1 from the LDS rows (two rows x four pixels per lane item, as k_pyr_down_bits)
+    uint8_t* __restrict__ dst = fp + D.off;
+    uint32_t* __restrict__ md = fm + D.moff;
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(md, 0, 0x7fffffff, 0x00020000);
+    const int g1 = D.pitch >> 2, npair = (y1b - y1a + 1) >> 1;
+    for (int idx = tid; idx < npair * g1; idx += 256) {
+        int yb;
+        {
+            const int q = idx >> 4, d = g1 >> 4;
+            yb = (int)((float)q * __builtin_amdgcn_rcpf((float)d));
+            const int rem = q - __mul24(yb, d);
+            yb += rem >= d ? 1 : (rem < 0 ? -1 : 0);
+        }
+        const int x = (idx - __mul24(yb, g1)) << 2, y0 = y1a + 2 * yb;
+        pyr_xs X;
+        pyr_xsetup(X, D, tab, x);
+        pyr_ld L[2]; uint32_t yc[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t ty = tab[D.taby_off + min(y0 + k, D.h - 1)];
+            const int r0 = (int)(ty >> 16), r1 = min(r0 + 1, S.h - 1);
+            yc[k] = ty & 0xffffu;
+            pyr_load_lds(L[k], sg, sm, gp, mp, X, min(r0, rb) - ra, min(r1, rb) - ra);
+        }
+        uint32_t o4[2], nbw[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) pyr_row(L[k], X, yc[k], tid, &o4[k], &nbw[k]);
+        const int od = (int)(__umul24((uint32_t)y0, (uint32_t)D.pitch) + (uint32_t)x), om = (int)((__umul24((uint32_t)y0, (uint32_t)D.mpitch) + (uint32_t)(x >> 5)) << 2);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (y0 + k < y1b) {
+                __builtin_amdgcn_raw_buffer_store_b32(o4[k], rs_dst, od, k * D.pitch, 0);
+                if ((tid & 7) == 7) __builtin_amdgcn_raw_buffer_store_b32(nbw[k], rs_md, om, k * D.mpitch * 4, 0);
+            }
         }
     }
 }
@@ -1905,16 +2010,27 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         int* ccnt = (int*)(hist + (size_t)256 * g.nlevels * chunk);
 
         BH_HIP(ctx, hipMemsetAsync(ccnt, 0, sizeof(int) * g.nlevels * chunk, st));
+        bool gl_fused = false; int gl_sr = 0;
         {
             const int n = (g.lv[0].pitch >> 2) * g.lv[0].h;
-            if (mbits && channels == 3 && (W & 3) == 0 && !getenv("BH_ORB_GRAY_GENERAL"))      // the reference call's case
+            // level 0 + level 1 in one launch (k_gray_l1) when the reference call's case applies, a second level exists and the staged rows fit LDS
+            gl_sr = ((int)((GL_R0 - 2) / params->scaleFactor)) & ~1;
+            const size_t gl_lds = (size_t)GL_R0 * (g.lv[0].pitch + 16) + (size_t)GL_R0 * (g.lv[0].mpitch + 1) * 4;
+            gl_fused = mbits && channels == 3 && (W & 3) == 0 && g.nlevels >= 2 && !ctx->pm_ok && gl_sr >= 2 && gl_lds <= 64 * 1024 && !getenv("BH_ORB_GRAY_GENERAL") &&
+                       !(getenv("BH_ORB_GRAY_L1") && atoi(getenv("BH_ORB_GRAY_L1")) == 0);
+            if (gl_fused) {
+                bh_time_begin(ctx, BH_K_GRAY);
+                hipLaunchKernelGGL(k_gray_l1, dim3((g.lv[1].h + gl_sr - 1) / gl_sr, nb), dim3(256), gl_lds, st, d_img, d_depth, pyr, g, gl_sr, (const uint32_t*)ctx->tab.p, mbits,
+                                   (uint32_t*)ctx->status.p);
+                bh_time_end(ctx);
+            } else if (mbits && channels == 3 && (W & 3) == 0 && !getenv("BH_ORB_GRAY_GENERAL"))      // the reference call's case
                 BH_LAUNCH(ctx, BH_K_GRAY, k_gray_bits, dim3((n + 255) / 256, nb), dim3(256), st, d_img, d_depth, pyr, W, H, g.lv[0].pitch, g.pyr_stride, mbits,
                           g.lv[0].mpitch, g.mstride);
             else
                 BH_LAUNCH(ctx, BH_K_GRAY, k_gray_mask, dim3((n + 255) / 256, nb), dim3(256), st, d_img, channels, d_mask, d_depth,
                           pyr, mpyr, W, H, g.lv[0].pitch, g.pyr_stride, mbits, g.lv[0].mpitch, g.mstride);
         }
-        for (int l = 1; l < g.nlevels; l++) {
+        for (int l = gl_fused ? 2 : 1; l < g.nlevels; l++) {
             if (mbits && ctx->pm_ok) {
                 BH_LAUNCH(ctx, BH_K_PYR, k_pyr_mfma, dim3(ctx->pm[l].tiles_x, ctx->pm[l].tiles_y + (g.lv[l].h + PM_MH - 1) / PM_MH, nb), dim3(256), st, pyr, g, l, (const uint32_t*)ctx->tab.p,
                           (const uint32_t*)ctx->rtab.p, ctx->pm[l], mbits);
