@@ -411,7 +411,12 @@ __global__ __launch_bounds__(256) void k_pyr_down_bits(uint8_t* __restrict__ pyr
 //      HBM (the rows two strips share are written twice, identically) and keeps them, with their mask words, in LDS;
 //   2. resizes from LDS with the arithmetic of k_pyr_down_bits (pyr_xsetup / pyr_row: the same statements, so the same bytes) and
 //      stores level 1.  Level 0 is not read back from HBM, and one launch per chunk is gone.
+#ifndef GL_PR
+#define GL_PR 4                // level-1 rows per lane item in phase 2 (the column set-up is paid once per item)
+#endif
+#ifndef GL_R0
 #define GL_R0 26               // level-0 rows a workgroup stages (18.8 KB of LDS at 640 columns: eight workgroups per CU)
+#endif
 __device__ __forceinline__ void pyr_load_lds(pyr_ld& L, const uint8_t* __restrict__ sg, const uint32_t* __restrict__ sm, int pitch, int mpitch,
                                              const pyr_xs& X, int r0, int r1)
 {
@@ -470,8 +475,8 @@ __global__ __launch_bounds__(256) void k_gray_l1(const uint8_t* __restrict__ img
     uint32_t* __restrict__ md = fm + D.moff;
     const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(md, 0, 0x7fffffff, 0x00020000);
-    const int g1 = D.pitch >> 2, npair = (y1b - y1a + 1) >> 1;
-    for (int idx = tid; idx < npair * g1; idx += 256) {
+    const int g1 = D.pitch >> 2, nblk = (y1b - y1a + GL_PR - 1) / GL_PR;
+    for (int idx = tid; idx < nblk * g1; idx += 256) {
         int yb;
         {
             const int q = idx >> 4, d = g1 >> 4;
@@ -479,26 +484,21 @@ __global__ __launch_bounds__(256) void k_gray_l1(const uint8_t* __restrict__ img
             const int rem = q - __mul24(yb, d);
             yb += rem >= d ? 1 : (rem < 0 ? -1 : 0);
         }
-        const int x = (idx - __mul24(yb, g1)) << 2, y0 = y1a + 2 * yb;
+        const int x = (idx - __mul24(yb, g1)) << 2, y0 = y1a + GL_PR * yb;
         pyr_xs X;
-        pyr_xsetup(X, D, tab, x);
-        pyr_ld L[2]; uint32_t yc[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const uint32_t ty = tab[D.taby_off + min(y0 + k, D.h - 1)];
-            const int r0 = (int)(ty >> 16), r1 = min(r0 + 1, S.h - 1);
-            yc[k] = ty & 0xffffu;
-            pyr_load_lds(L[k], sg, sm, gp, mp, X, min(r0, rb) - ra, min(r1, rb) - ra);
-        }
-        uint32_t o4[2], nbw[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) pyr_row(L[k], X, yc[k], tid, &o4[k], &nbw[k]);
+        pyr_xsetup(X, D, tab, x);                                          // once per GL_PR rows (LDS rows: no load latency to spread over more lanes)
         const int od = (int)(__umul24((uint32_t)y0, (uint32_t)D.pitch) + (uint32_t)x), om = (int)((__umul24((uint32_t)y0, (uint32_t)D.mpitch) + (uint32_t)(x >> 5)) << 2);
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < GL_PR; k++) {
+            const uint32_t ty = tab[D.taby_off + min(y0 + k, D.h - 1)];
+            const int r0 = (int)(ty >> 16), r1 = min(r0 + 1, S.h - 1);
+            pyr_ld L;
+            pyr_load_lds(L, sg, sm, gp, mp, X, min(r0, rb) - ra, min(r1, rb) - ra);
+            uint32_t o4, nbw;
+            pyr_row(L, X, ty & 0xffffu, tid, &o4, &nbw);
             if (y0 + k < y1b) {
-                __builtin_amdgcn_raw_buffer_store_b32(o4[k], rs_dst, od, k * D.pitch, 0);
-                if ((tid & 7) == 7) __builtin_amdgcn_raw_buffer_store_b32(nbw[k], rs_md, om, k * D.mpitch * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(o4, rs_dst, od, k * D.pitch, 0);
+                if ((tid & 7) == 7) __builtin_amdgcn_raw_buffer_store_b32(nbw, rs_md, om, k * D.mpitch * 4, 0);
             }
         }
     }
