@@ -14,6 +14,7 @@
 #include "bh_internal.h"
 #include <math.h>
 #include <vector>
+#include <chrono>
 #include "bh_scan.h"
 
 // ================================================================================================ visibility gate
@@ -122,6 +123,7 @@ struct bh_bow {
     bh_buf inv_slots, inv_acc;     // device copy of the slot table; the slots' accumulator arrays
     bh_buf dq;                     // device-resident queries (BH_MEM_DEVICE): a slot of their own (slot 0's scratch, the caller's query arrays), its in / out block and the "answered" flag
     char   slot0_host[128] = {0};  // host copy of slot 0 (an inv_slot), the template of that slot
+    int q_seq = 0;                 // tag of the last single host query (the result block carries it: the host polls for it instead of a stream wake-up)
 };
 
 // grow a device buffer keeping its first `keep` bytes
@@ -406,12 +408,13 @@ extern "C" int bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const doubl
 //          query, term |q - d| - |q| - |d|) appended to one of the four lists of its bucket of 64 entries (four, picked by the rank's
 //          low bits: a relocalisation query hits its near-duplicate entry ~1000 times, and returning atomics on ONE counter serialise);
 //          what a list cannot hold goes to a global overflow list with the full entry id;
-//   k_inv_reduce   one wave per bucket: ranks the bucket's records by (entry, word rank) and adds them IN THAT ORDER - per entry the
-//          ascending word order of DBoW3's accumulation, so scores are bit-identical to the scan and to the oracle; buckets that
-//          overflowed are only noted;
-//   k_inv_heavy    one 1024-lane workgroup per noted bucket: its lists + its share of the overflow list, the same ranking and ordered sums;
-//   k_inv_select   one workgroup: a threshold from the 16 wave minima (k <= 16 of them are k actual values, so at least k accumulators
-//          lie at or below it), the few accumulators at or below it collected and ordered by (value, id), results to pinned host memory.
+//   k_inv_finish   every workgroup: a wave per bucket ranks the bucket's records by (entry, word rank) and adds them IN THAT ORDER - per
+//          entry the ascending word order of DBoW3's accumulation, so scores are bit-identical to the scan and to the oracle; buckets
+//          that overflowed are only noted.  The LAST workgroup to arrive (agent-scope counter) then takes the noted buckets - its 1024
+//          lanes rank a bucket's lists + its share of the overflow list through a (slot, rank) bitmap, the same ordered sums - and
+//          selects: a threshold from the 16 wave minima of the bucket minima (k <= 16 of them are k actual values, so at least k
+//          accumulators lie at or below it), the few accumulators at or below it collected and ordered by (value, id), results to
+//          pinned host memory.  (Rounds 3 - 4 ran these as three launches, k_inv_reduce / k_inv_heavy / k_inv_select.)
 // Anything that does not fit (overflow list, heavy-bucket table, a heavy bucket beyond 4096 records) raises a flag: the scan answers.
 #define INV_WORDS BOW_BITS
 #define INV_KMAX 16                                           // results the select kernel can deliver (k <= 16 wave minima)
@@ -422,7 +425,7 @@ extern "C" int bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const doubl
 #define INV_HCAP 4096                                         // records a heavy bucket's workgroup can rank
 #define INV_SELCAP 1024                                       // accumulators at or below the threshold
 
-struct inv_ctl { int ovf_cnt, heavy_cnt, flags, pad; int heavy_bk[INV_HEAVY_MAX]; int heavy_n[INV_HEAVY_MAX][INV_NSUB]; };
+struct inv_ctl { int ovf_cnt, heavy_cnt, flags, tick; int heavy_bk[INV_HEAVY_MAX]; int heavy_n[INV_HEAVY_MAX][INV_NSUB]; };      // tick: workgroups of k_inv_finish that have reduced their buckets
 // One query slot: its own scratch (bucket lists, overflow list, accumulators, control block) and its pinned in / out block
 //   [int nq][int k][pad 8] [u32 words[BOW_QMAX]] [f64 vals[BOW_QMAX]] [int n][int fallback][f64 scores[INV_KMAX]][int ids[INV_KMAX]].
 // bh_bow_query_l1 uses slot 0; bh_bow_query_l1_batch runs up to INV_QSLOTS queries per launch (blockIdx.y = slot).
@@ -463,10 +466,11 @@ __global__ void k_inv_widen(const uint32_t* __restrict__ cnt, long long* __restr
 }
 
 __global__ __launch_bounds__(256) void k_inv_gather(const inv_slot* __restrict__ slots, const long long* __restrict__ inv_start,
-                                                    const uint32_t* __restrict__ inv_entry, const double* __restrict__ inv_val, int scap)
+                                                    const uint32_t* __restrict__ inv_entry, const double* __restrict__ inv_val, int scap, int nq1)
 {
     const inv_slot S = slots[blockIdx.y];
-    const uint32_t* __restrict__ qw = S.qw; const double* __restrict__ qv = S.qv; const int nq = S.hdr[0];
+    // (nq1 >= 0: a single host query - its length rides in the launch instead of behind a read of the pinned block, one PCIe round trip less)
+    const uint32_t* __restrict__ qw = S.qw; const double* __restrict__ qv = S.qv; const int nq = nq1 >= 0 ? nq1 : S.hdr[0];
     int* __restrict__ bcnt = S.bcnt; uint32_t* __restrict__ bkey = S.bkey; double* __restrict__ bval = S.bval; inv_ctl* __restrict__ ctl = S.ctl;
     uint32_t* __restrict__ okey = S.okey; double* __restrict__ oval = S.oval;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -512,8 +516,27 @@ __device__ __forceinline__ int inv_lower_bound(const uint32_t* s_okey, int n, ui
 __device__ __forceinline__ double inv_ordered_sum(const uint32_t* s_okey, const double* s_oval, int n, int l, bool* any)
 {
     const int a = inv_lower_bound(s_okey, n, (uint32_t)l << INV_RANK_BITS), b = inv_lower_bound(s_okey, n, (uint32_t)(l + 1) << INV_RANK_BITS);
+    // the additions are one dependent chain (the order is the result), so the LDS reads must not sit in it: eight values are fetched
+    // while the previous eight are added (a read-wait-add loop was 25 of the heavy kernel's 35 us for a relocalisation query's ~1000 hits)
     double acc = 0.0;
-    for (int i = a; i < b; i++) acc += s_oval[i];
+    int i = a;
+    if (b - a >= 8) {
+        double c[8], nx[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) c[u] = s_oval[i + u];
+        for (; i + 16 <= b; i += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) nx[u] = s_oval[i + 8 + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += c[u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) c[u] = nx[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += c[u];
+        i += 8;
+    }
+    for (; i < b; i++) acc += s_oval[i];
     *any = b > a;
     return acc;
 }
@@ -525,96 +548,58 @@ __device__ __forceinline__ double inv_wave_min(double v, int lane)
 }
 
 #define INV_LCAP 256                                           // records a light bucket's wave ranks (4 lists x 64)
-__global__ __launch_bounds__(256) void k_inv_reduce(const inv_slot* __restrict__ slots, int scap, long long n_entries, const uint8_t* __restrict__ keep, long long nb)
-{
-    const inv_slot S = slots[blockIdx.y];
-    int* __restrict__ bcnt = S.bcnt; const uint32_t* __restrict__ bkey = S.bkey; const double* __restrict__ bval = S.bval;
-    double* __restrict__ acc_out = S.acc; inv_ctl* __restrict__ ctl = S.ctl; double* __restrict__ bmin = S.bmin;
-    __shared__ uint32_t s_key[4][INV_LCAP], s_okey[4][INV_LCAP];
-    __shared__ double s_val[4][INV_LCAP], s_oval[4][INV_LCAP];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long bk = (long long)blockIdx.x * 4 + wv;
-    if (bk >= nb) return;
-    int c[INV_NSUB], n = 0; bool heavy = false;
-#pragma unroll
-    for (int u = 0; u < INV_NSUB; u++) { c[u] = bcnt[bk * INV_NSUB + u]; heavy = heavy || c[u] > scap; }
-    if (lane < INV_NSUB) bcnt[bk * INV_NSUB + lane] = 0;       // ready for the next query
-    if (heavy) {                                               // some of its records sit in the overflow list: k_inv_heavy takes the bucket
-        if (lane == 0) {
-            const int hp = atomicAdd(&ctl->heavy_cnt, 1);
-            if (hp < INV_HEAVY_MAX) { ctl->heavy_bk[hp] = (int)bk; for (int u = 0; u < INV_NSUB; u++) ctl->heavy_n[hp][u] = min(c[u], scap); }
-            else ctl->flags = 1;
-        }
-        return;
-    }
-#pragma unroll
-    for (int u = 0; u < INV_NSUB; u++) {
-        for (int i = lane; i < c[u]; i += 64) { s_key[wv][n + i] = bkey[((size_t)bk * INV_NSUB + u) * scap + i]; s_val[wv][n + i] = bval[((size_t)bk * INV_NSUB + u) * scap + i]; }
-        n += c[u];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    inv_rank_sort(s_key[wv], s_val[wv], s_okey[wv], s_oval[wv], n, lane, 64);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    bool any;
-    const double acc = inv_ordered_sum(s_okey[wv], s_oval[wv], n, lane, &any);   // lane l owns entry 64 bk + l: its hits in ascending word order
-    const long long e = bk * 64 + lane;
-    const double v = (any && e < n_entries && (!keep || keep[e])) ? acc : INFINITY;
-    if (e < n_entries) acc_out[e] = v;
-    const double bm = inv_wave_min(v, lane);
-    if (lane == 0) bmin[bk] = bm;
-}
+#define INV_FIN_T 1024                                         // k_inv_finish: 16 waves = 16 buckets per workgroup
+#define INV_FIN_BK (INV_FIN_T / 64)
 
-__global__ __launch_bounds__(1024) void k_inv_heavy(const inv_slot* __restrict__ slots, int scap, long long n_entries, const uint8_t* __restrict__ keep)
+// one heavy bucket (its lists + its share of the overflow list) by the whole workgroup: O(n) sort by a (slot, rank) bitmap, ordered sums
+__device__ __forceinline__ void inv_heavy_bucket(const inv_slot& S, int hb, int scap, long long n_entries, const uint8_t* __restrict__ keep, uint32_t* hsm, int* s_n)
 {
-    const inv_slot S = slots[blockIdx.y];
-    const uint32_t* __restrict__ bkey = S.bkey; const double* __restrict__ bval = S.bval; double* __restrict__ acc_out = S.acc; inv_ctl* __restrict__ ctl = S.ctl;
-    const uint32_t* __restrict__ okey = S.okey; const double* __restrict__ oval = S.oval; double* __restrict__ bmin = S.bmin;
-    extern __shared__ uint32_t hsm[];
+    const uint32_t* __restrict__ bkey = S.bkey; const double* __restrict__ bval = S.bval; double* acc_out = S.acc; inv_ctl* ctl = S.ctl;
+    const uint32_t* __restrict__ okey = S.okey; const double* __restrict__ oval = S.oval; double* bmin = S.bmin;
     uint32_t* s_key = hsm; uint32_t* s_okey = hsm + INV_HCAP;
     double* s_val = reinterpret_cast<double*>(hsm + 2 * INV_HCAP); double* s_oval = s_val + INV_HCAP;
-    __shared__ int s_n;
-    const int hb = blockIdx.x, tid = threadIdx.x;
-    if (hb >= min(ctl->heavy_cnt, INV_HEAVY_MAX)) return;
+    const int tid = threadIdx.x;
     const long long bk = ctl->heavy_bk[hb];
     int n0 = 0;
     for (int u = 0; u < INV_NSUB; u++) {
         const int cu = ctl->heavy_n[hb][u];
-        for (int i = tid; i < cu; i += 1024) { s_key[n0 + i] = bkey[((size_t)bk * INV_NSUB + u) * scap + i]; s_val[n0 + i] = bval[((size_t)bk * INV_NSUB + u) * scap + i]; }
+        for (int i = tid; i < cu; i += INV_FIN_T) { s_key[n0 + i] = bkey[((size_t)bk * INV_NSUB + u) * scap + i]; s_val[n0 + i] = bval[((size_t)bk * INV_NSUB + u) * scap + i]; }
         n0 += cu;
     }
-    if (tid == 0) s_n = n0;
+    if (tid == 0) *s_n = n0;
     __syncthreads();
     const int novf = min(ctl->ovf_cnt, INV_OVF_CAP);
-    for (int i0 = 0; i0 < novf; i0 += 1024) {                  // (whole waves iterate: the append below is aggregated per wave - 800 returning
+    for (int i0 = 0; i0 < novf; i0 += INV_FIN_T) {             // (whole waves iterate: the append below is aggregated per wave - 800 returning
         const int i = i0 + tid;                                //  LDS atomics on one counter serialise: 38 us)
         const uint32_t k = i < novf ? okey[i] : 0xffffffffu;
+        const double ov = i < novf ? oval[i] : 0.0;            // (asked for with the key: not a second round trip behind the test)
         const bool mine = i < novf && (long long)(k >> (INV_RANK_BITS + 6)) == bk;
         const unsigned long long bm = __ballot(mine);
         if (bm) {
             const int lane = tid & 63, leader = __ffsll((long long)bm) - 1;
             int base = 0;
-            if (lane == leader) base = atomicAdd(&s_n, __popcll(bm));
+            if (lane == leader) base = atomicAdd(s_n, __popcll(bm));
             base = __shfl(base, leader, 64);
             const int pos = base + __popcll(bm & ((1ull << lane) - 1ull));
-            if (mine && pos < INV_HCAP) { s_key[pos] = k & ((64u << INV_RANK_BITS) - 1u); s_val[pos] = oval[i]; }
+            if (mine && pos < INV_HCAP) { s_key[pos] = k & ((64u << INV_RANK_BITS) - 1u); s_val[pos] = ov; }
         }
     }
     __syncthreads();
-    const int n = s_n;
-    if (n > INV_HCAP) { if (tid == 0) ctl->flags = 1; return; }
+    const int n = *s_n;
+    if (n > INV_HCAP) { if (tid == 0) ctl->flags = 1; __syncthreads(); return; }      // (uniform: the scan answers this query)
     // Sort by (slot, rank) in O(n): the (slot, rank) pairs are distinct, so a bitmap of 64 slots x 2048 ranks says where every record
     // goes: position = records of earlier slots + set bits of the slot below the rank.  (Ranking every record against every other,
     // as the light buckets do, is 740 k comparisons on one CU for a relocalisation query's near-duplicate entry: 28 us.)
     uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_oval + INV_HCAP);       // [64][64] words
     int* s_wp = reinterpret_cast<int*>(s_bm + 4096);                        // [64][64] set bits of the slot before word w
     int* s_so = s_wp + 4096;                                                // [64] records of earlier slots
-    for (int i = tid; i < 4096; i += 1024) s_bm[i] = 0;
+    for (int i = tid; i < 4096; i += INV_FIN_T) s_bm[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) { const uint32_t key = s_key[i]; atomicOr(&s_bm[key >> 5], 1u << (key & 31)); }      // key = slot << 11 | rank: word = key >> 5
+    for (int i = tid; i < n; i += INV_FIN_T) { const uint32_t key = s_key[i]; atomicOr(&s_bm[key >> 5], 1u << (key & 31)); }      // key = slot << 11 | rank: word = key >> 5
     __syncthreads();
     {
         const int lane = tid & 63, wv = tid >> 6;
-        for (int sl = wv; sl < 64; sl += 16) {                 // a wave per slot: exclusive prefix of its 64 words' popcounts
+        for (int sl = wv; sl < 64; sl += INV_FIN_BK) {         // a wave per slot: exclusive prefix of its 64 words' popcounts
             const int c = __popc(s_bm[sl * 64 + lane]);
             int incl = c;
             for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
@@ -630,7 +615,7 @@ __global__ __launch_bounds__(1024) void k_inv_heavy(const inv_slot* __restrict__
         s_so[tid] = incl - c;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
+    for (int i = tid; i < n; i += INV_FIN_T) {
         const uint32_t key = s_key[i];
         const int pos = s_so[key >> INV_RANK_BITS] + s_wp[key >> 5] + __popc(s_bm[key >> 5] & ((1u << (key & 31)) - 1u));
         s_okey[pos] = key; s_oval[pos] = s_val[i];
@@ -645,27 +630,28 @@ __global__ __launch_bounds__(1024) void k_inv_heavy(const inv_slot* __restrict__
         const double bm = inv_wave_min(v, tid);
         if (tid == 0) bmin[bk] = bm;
     }
+    __syncthreads();                                           // (the staging arrays are free for the next bucket; acc / bmin are read after a fence)
 }
 
 // results -> pinned host memory: [int n][int fallback][double scores[k]][int ids[k]].  Works from the buckets' minima: the k-th
 // smallest of the 16 wave minima T is an upper bound of the k-th best accumulator (k <= 16 distinct buckets hold a value <= T); only
 // buckets whose minimum is <= T can hold a result, and there are few of them.
-__global__ __launch_bounds__(1024) void k_inv_select(const inv_slot* __restrict__ slots, long long nb, long long n_entries)
+#define INV_PIN_SEQ (2 + 3 * INV_KMAX)                       // int index of the tag inside the result block (behind n, fallback, scores, ids)
+__device__ __forceinline__ void inv_select(const inv_slot& S, long long nb, long long n_entries, int k, uint32_t* hsm, int* s_cnt, int seq)
 {
-    const inv_slot S = slots[blockIdx.y];
-    const double* __restrict__ acc = S.acc; const double* __restrict__ bmin = S.bmin; const int k = S.hdr[1]; inv_ctl* __restrict__ ctl = S.ctl;
+    const double* __restrict__ acc = S.acc; const double* bmin = S.bmin; inv_ctl* ctl = S.ctl;
     char* __restrict__ hout = S.hout;
-    __shared__ double s_wmin[16];
-    __shared__ double s_cv[INV_SELCAP];
-    __shared__ int s_ci[INV_SELCAP];
-    __shared__ int s_bl[INV_SELCAP / 16];
-    __shared__ int s_m, s_nb;
-    __shared__ double s_T;
+    double* s_wmin = reinterpret_cast<double*>(hsm);           // [16]
+    double* s_cv = s_wmin + 16;                                // [INV_SELCAP]
+    int* s_ci = reinterpret_cast<int*>(s_cv + INV_SELCAP);     // [INV_SELCAP]
+    int* s_bl = s_ci + INV_SELCAP;                             // [INV_SELCAP / 16]
+    double* s_T = reinterpret_cast<double*>(s_bl + INV_SELCAP / 16);
+    int& s_m = s_cnt[0]; int& s_nb = s_cnt[1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double mn = INFINITY, mine[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const long long b = tid + 1024 * u; mine[u] = b < nb ? bmin[b] : INFINITY; mn = fmin(mn, mine[u]); }
-    for (long long b = tid + 4096; b < nb; b += 1024) mn = fmin(mn, bmin[b]);
+    for (int u = 0; u < 4; u++) { const long long b = tid + INV_FIN_T * u; mine[u] = b < nb ? bmin[b] : INFINITY; mn = fmin(mn, mine[u]); }
+    for (long long b = tid + 4 * INV_FIN_T; b < nb; b += INV_FIN_T) mn = fmin(mn, bmin[b]);
     mn = inv_wave_min(mn, lane);
     if (lane == 0) s_wmin[wv] = mn;
     if (tid == 0) { s_m = 0; s_nb = 0; }
@@ -674,16 +660,16 @@ __global__ __launch_bounds__(1024) void k_inv_select(const inv_slot* __restrict_
         double v[16];
         for (int i = 0; i < 16; i++) v[i] = s_wmin[i];
         for (int i = 0; i < 16; i++) for (int j = i + 1; j < 16; j++) if (v[j] < v[i]) { const double t = v[i]; v[i] = v[j]; v[j] = t; }
-        s_T = v[k - 1];
+        *s_T = v[k - 1];
     }
     __syncthreads();
-    const double T = s_T;                                      // +inf when fewer than k waves saw a hit: then every bucket with a hit is listed
+    const double T = *s_T;                                     // +inf when fewer than k waves saw a hit: then every bucket with a hit is listed
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        const long long b = tid + 1024 * u;
+        const long long b = tid + INV_FIN_T * u;
         if (mine[u] <= T && mine[u] < INFINITY) { const int p = atomicAdd(&s_nb, 1); if (p < INV_SELCAP / 16) s_bl[p] = (int)b; }
     }
-    for (long long b = tid + 4096; b < nb; b += 1024) {
+    for (long long b = tid + 4 * INV_FIN_T; b < nb; b += INV_FIN_T) {
         const double v = bmin[b];
         if (v <= T && v < INFINITY) { const int p = atomicAdd(&s_nb, 1); if (p < INV_SELCAP / 16) s_bl[p] = (int)b; }
     }
@@ -692,7 +678,7 @@ __global__ __launch_bounds__(1024) void k_inv_select(const inv_slot* __restrict_
     int* hi = reinterpret_cast<int*>(hout);
     bool bad = nbl > INV_SELCAP / 16;
     if (!bad) {
-        for (int i = wv; i < nbl; i += 16) {                   // a wave per listed bucket: one accumulator per lane
+        for (int i = wv; i < nbl; i += INV_FIN_BK) {           // a wave per listed bucket: one accumulator per lane
             const long long e = (long long)s_bl[i] * 64 + lane;
             const double v = e < n_entries ? acc[e] : INFINITY;
             if (v <= T && v < INFINITY) { const int p = atomicAdd(&s_m, 1); if (p < INV_SELCAP) { s_cv[p] = v; s_ci[p] = (int)e; } }
@@ -701,14 +687,89 @@ __global__ __launch_bounds__(1024) void k_inv_select(const inv_slot* __restrict_
     __syncthreads();
     const int m = s_m;
     bad = bad || m > INV_SELCAP;
-    if (bad) { if (tid == 0) { hi[0] = 0; hi[1] = 1; ctl->ovf_cnt = 0; ctl->heavy_cnt = 0; ctl->flags = 0; } return; }
-    if (tid < m) {                                             // order by (value, id): position = number of candidates that come first
+    if (!bad && tid < m) {                                     // order by (value, id): position = number of candidates that come first
         const double v = s_cv[tid]; const int id = s_ci[tid];
         int pos = 0;
         for (int j = 0; j < m; j++) { const double ov = s_cv[j]; pos += (ov < v || (ov == v && s_ci[j] < id)) ? 1 : 0; }
         if (pos < k) { reinterpret_cast<double*>(hout + 8)[pos] = -v / 2.0; reinterpret_cast<int*>(hout + 8 + 8 * INV_KMAX)[pos] = id; }
     }
-    if (tid == 0) { hi[0] = min(m, k); hi[1] = ctl->flags; ctl->ovf_cnt = 0; ctl->heavy_cnt = 0; ctl->flags = 0; }      // counters ready for the next query
+    if (seq) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __syncthreads(); }      // the scores / ids of the other lanes before the tag
+    if (tid == 0) {
+        hi[0] = bad ? 0 : min(m, k); hi[1] = bad ? 1 : ctl->flags;
+        ctl->ovf_cnt = 0; ctl->heavy_cnt = 0; ctl->flags = 0;      // counters ready for the next query
+        // a single host query polls for this tag (pinned, coherent memory) instead of waiting for the stream: the wake-up costs more than the kernels
+        if (seq) __hip_atomic_store(&hi[INV_PIN_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// k_inv_finish (round 5): everything behind the gather in ONE launch (was k_inv_reduce -> k_inv_heavy -> k_inv_select: three dependent
+// launches of 7 + 35 + 21 us for a relocalisation query, most of it launch, drain and first-load latency of one-workgroup kernels).
+//   every workgroup   a wave per bucket of 64 entries: rank its records by (entry, word rank), add them in that order, bucket minimum;
+//                     buckets whose lists overflowed are noted in ctl;
+//   arrival           release fence, one agent-scope add on ctl->tick per workgroup;
+//   the last arriver  (acquire fence) takes the noted heavy buckets one after the other - there is one for a relocalisation query, none
+//                     for most others - and then selects the k best and writes the slot's result block.  No workgroup waits for another.
+__global__ __launch_bounds__(INV_FIN_T) void k_inv_finish(const inv_slot* __restrict__ slots, int scap, long long n_entries, const uint8_t* __restrict__ keep,
+                                                          long long nb, int k1, int seq)
+{
+    extern __shared__ uint32_t hsm[];
+    __shared__ int s_cnt[4];
+    const inv_slot S = slots[blockIdx.y];
+    const int k = k1 >= 0 ? k1 : S.hdr[1];                      // (asked for now, used by the last arriver only)
+    inv_ctl* ctl = S.ctl;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    {
+        int* __restrict__ bcnt = S.bcnt; const uint32_t* __restrict__ bkey = S.bkey; const double* __restrict__ bval = S.bval;
+        double* acc_out = S.acc; double* bmin = S.bmin;
+        // per wave: key[256] okey[256] (u32), val[256] oval[256] (f64) = 6 KB
+        uint32_t* w_key = hsm + (size_t)wv * (6 * INV_LCAP); uint32_t* w_okey = w_key + INV_LCAP;
+        double* w_val = reinterpret_cast<double*>(w_okey + INV_LCAP); double* w_oval = w_val + INV_LCAP;
+        const long long bk = (long long)blockIdx.x * INV_FIN_BK + wv;
+        if (bk < nb) {
+            int c[INV_NSUB], n = 0; bool heavy = false;
+#pragma unroll
+            for (int u = 0; u < INV_NSUB; u++) { c[u] = bcnt[bk * INV_NSUB + u]; heavy = heavy || c[u] > scap; }
+            if (lane < INV_NSUB) bcnt[bk * INV_NSUB + lane] = 0;       // ready for the next query
+            if (heavy) {                                               // some of its records sit in the overflow list: the last arriver takes the bucket
+                if (lane == 0) {
+                    const int hp = atomicAdd(&ctl->heavy_cnt, 1);
+                    if (hp < INV_HEAVY_MAX) { ctl->heavy_bk[hp] = (int)bk; for (int u = 0; u < INV_NSUB; u++) ctl->heavy_n[hp][u] = min(c[u], scap); }
+                    else ctl->flags = 1;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < INV_NSUB; u++) {
+                    for (int i = lane; i < c[u]; i += 64) { w_key[n + i] = bkey[((size_t)bk * INV_NSUB + u) * scap + i]; w_val[n + i] = bval[((size_t)bk * INV_NSUB + u) * scap + i]; }
+                    n += c[u];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                inv_rank_sort(w_key, w_val, w_okey, w_oval, n, lane, 64);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                bool any;
+                const double acc = inv_ordered_sum(w_okey, w_oval, n, lane, &any);   // lane l owns entry 64 bk + l: its hits in ascending word order
+                const long long e = bk * 64 + lane;
+                const double v = (any && e < n_entries && (!keep || keep[e])) ? acc : INFINITY;
+                if (e < n_entries) acc_out[e] = v;
+                const double bm = inv_wave_min(v, lane);
+                if (lane == 0) bmin[bk] = bm;
+            }
+        }
+    }
+    // ---- arrival: this workgroup's accumulators, minima and heavy notes are out before its count is
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const int prev = __hip_atomic_fetch_add(&ctl->tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_cnt[2] = prev == (int)gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_cnt[2]) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (tid == 0) ctl->tick = 0;                                // (the next query's launch is ordered behind this one)
+    const int nh = min(__hip_atomic_load(&ctl->heavy_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), INV_HEAVY_MAX);
+    for (int hb = 0; hb < nh; hb++) inv_heavy_bucket(S, hb, scap, n_entries, keep, hsm, &s_cnt[3]);
+    if (nh) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __syncthreads(); }      // (this workgroup's own acc / bmin stores before its reads)
+    inv_select(S, nb, n_entries, k, hsm, s_cnt, seq);
 }
 
 // Scratch, pinned in / out blocks and the device slot table for `nslots` concurrent queries (sizes follow the current database).
@@ -730,6 +791,7 @@ static int inv_alloc_slots(bh_bow* bow, int nslots)
         bow->hq = nullptr; bow->hq_cap = 0;
         if (hipHostMalloc((void**)&bow->hq, need, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); bow->hq = nullptr; bow->inv_usable = 0; return BH_OK; }
         bow->hq_cap = need;
+        memset(bow->hq, 0, need);                               // (the result tags start at 0: no query carries that tag)
     }
     BH_HIP(ctx, hipMemsetAsync(bow->bcnt.p, 0, cb * nslots, st));
     std::vector<inv_slot> tab(nslots);
@@ -785,22 +847,32 @@ static int inv_build(bh_bow* bow)
     return BH_OK;
 }
 
-// The four launches of the inverted-file path for the first G slots (grid.y = slot), then one synchronisation.
-static int inv_launch(bh_bow* bow, int G, int max_nq, const uint8_t* keep, const inv_slot* dev_slot = nullptr)
+// The two launches of the inverted-file path for the first G slots (grid.y = slot), then one synchronisation.
+static int inv_launch(bh_bow* bow, int G, int max_nq, const uint8_t* keep, const inv_slot* dev_slot = nullptr, int nq1 = -1, int k1 = -1)
 {
+    // a single host query (nq1 >= 0) is tagged: 1, 2, ... (0 = untagged)
+    const int seq = (!dev_slot && G == 1 && nq1 >= 0 && !getenv("BH_BOW_SYNC")) ? (bow->q_seq = bow->q_seq == 0x7fffffff ? 1 : bow->q_seq + 1) : 0;
     bh_ctx* ctx = bow->ctx;
     hipStream_t st = ctx->stream;
     const size_t hlds = INV_HEAVY_LDS;
     const inv_slot* slots = dev_slot ? dev_slot : (const inv_slot*)bow->inv_slots.p;      // dev_slot: one device-resident query, nothing read back here
     bh_time_begin(ctx, BH_K_BOW_INV);
     hipLaunchKernelGGL(k_inv_gather, dim3((max_nq + 3) / 4, G), dim3(256), 0, st, slots, (const long long*)bow->inv_start.p, (const uint32_t*)bow->inv_entry.p,
-                       (const double*)bow->inv_val.p, bow->bcap);
-    hipLaunchKernelGGL(k_inv_reduce, dim3((unsigned)((bow->inv_nb + 3) / 4), G), dim3(256), 0, st, slots, bow->bcap, bow->n_entries, keep, bow->inv_nb);
-    hipLaunchKernelGGL(k_inv_heavy, dim3(INV_HEAVY_MAX, G), dim3(1024), hlds, st, slots, bow->bcap, bow->n_entries, keep);
-    hipLaunchKernelGGL(k_inv_select, dim3(1, G), dim3(1024), 0, st, slots, bow->inv_nb, bow->n_entries);
+                       (const double*)bow->inv_val.p, bow->bcap, nq1);
+    hipLaunchKernelGGL(k_inv_finish, dim3((unsigned)((bow->inv_nb + INV_FIN_BK - 1) / INV_FIN_BK), G), dim3(INV_FIN_T), hlds, st, slots, bow->bcap, bow->n_entries, keep,
+                       bow->inv_nb, k1, seq);
     bh_time_end(ctx);
     BH_HIP(ctx, hipGetLastError());
-    if (!dev_slot) BH_HIP(ctx, hipStreamSynchronize(st));
+    if (dev_slot) return BH_OK;
+    if (seq) {                                                 // bounded by time; a kernel fault never delivers the tag and the stream reports it below
+        const volatile int* tag = reinterpret_cast<const volatile int*>(bow->hq + INV_PIN_R) + INV_PIN_SEQ;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (long spin = 0; ; spin++) {
+            if (__atomic_load_n(const_cast<const int*>(tag), __ATOMIC_ACQUIRE) == seq) return BH_OK;
+            if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+    }
+    BH_HIP(ctx, hipStreamSynchronize(st));
     return BH_OK;
 }
 // results of a device-resident query: out of the slot's block into the caller's device arrays, if the inverted file could answer
@@ -864,7 +936,7 @@ static int inv_query(bh_bow* bow, const uint32_t* q_words, const double* q_vals,
         hipLaunchKernelGGL(k_bow_flag_set, dim3((n_subset + 255) / 256), dim3(256), 0, st, (const int*)d_sub, n_subset, bow->n_entries, flag);
         keep = flag;
     }
-    BH_TRY(inv_launch(bow, 1, nq, keep));
+    BH_TRY(inv_launch(bow, 1, nq, keep, nullptr, nq, max_results));
     *used = inv_read_slot(bow, 0, ids, scores, n_results);
     return BH_OK;
 }
@@ -1097,6 +1169,6 @@ extern "C" int bh_bow_query_l1_batch(bh_bow* bow, const uint32_t* q_words, const
 static int bow_set_func_attrs(bh_ctx* ctx)
 {
     BH_HIP(ctx, hipFuncSetAttribute((const void*)k_bow_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BOW_SCAN_LDS));
-    BH_HIP(ctx, hipFuncSetAttribute((const void*)k_inv_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INV_HEAVY_LDS));
+    BH_HIP(ctx, hipFuncSetAttribute((const void*)k_inv_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INV_HEAVY_LDS));
     return BH_OK;
 }

@@ -8,8 +8,8 @@ import json, subprocess, sys, os
 root, fpl = sys.argv[1], int(sys.argv[2])
 here = os.path.dirname(os.path.abspath(__file__))
 d = json.loads(subprocess.run([sys.executable, os.path.join(here, "pmc_summary.py"), root], capture_output=True, text=True, check=True).stdout)
-WIDE = {"k_gray_mask": 2, "k_gray_bits": 2, "k_pyr_down": 2, "k_pyr_down_bits": 2, "k_select": 2, "k_bow_scan": 2}      # >= 8 B per lane loads (12 B + 8 B, 12 B, 8 B records, 16 B)
-PER_LAUNCH = {"k_bow_scan", "k_bow_topk", "k_bow_topk_slices", "k_bow_pack", "k_inv_gather", "k_inv_reduce", "k_inv_heavy", "k_inv_select", "k_inv_count", "k_inv_fill", "k_inv_widen"}                # reported per launch (= per query), not per frame
+WIDE = {"k_gray_mask": 2, "k_gray_bits": 2, "k_gray_l1": 2, "k_pyr_down": 2, "k_pyr_down_bits": 2, "k_select": 2, "k_bow_scan": 2}      # >= 8 B per lane loads (12 B + 8 B, 12 B, 8 B records, 16 B)
+PER_LAUNCH = {"k_bow_scan", "k_bow_topk", "k_bow_topk_slices", "k_bow_pack", "k_inv_gather", "k_inv_finish", "k_inv_count", "k_inv_fill", "k_inv_widen"}                # reported per launch (= per query), not per frame
 out = {"_note": "HBM bytes per FRAME = (FETCH_SIZE x factor + WRITE_SIZE) KiB per launch / frames per launch; rocprofv3 --pmc, FETCH_SIZE and "
                 "WRITE_SIZE in separate passes, bench.py --frames 256 --pipelines 1 (launches of %d frames); k_pyr_down and k_blur are "
                 "summed over their launches per frame batch; k_bow_* entries are bytes per launch (one query of configs[3] on one GPU).  factor 2 = kernels with >= 8 B/lane loads (gfx950 FETCH_SIZE correction, "
@@ -23,7 +23,11 @@ for k, v in d.items():
     if base.startswith("k_ba") or "FETCH_SIZE" not in v:
         continue
     per_launch = (v["FETCH_SIZE"] * WIDE.get(base, 1) + v.get("WRITE_SIZE", 0.0)) * 1024.0
-    launches_per_batch = 7 if base in ("k_pyr_down", "k_pyr_down_bits") else 1
+    # the pyramid runs one launch per level transition (7 of them; 6 when k_gray_l1 makes level 1): counted from the dispatches
+    launches_per_batch = 1
+    if base in ("k_pyr_down", "k_pyr_down_bits"):
+        nf = d.get("k_fast", {}).get("dispatches", 0)
+        launches_per_batch = round(v.get("dispatches", 0) / nf) if nf else 7
     agg[base] = agg.get(base, 0.0) + per_launch * launches_per_batch / (1 if base in PER_LAUNCH else fpl)
 for k, v in sorted(agg.items()):
     out[k] = int(round(v))
