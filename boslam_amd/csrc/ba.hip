@@ -584,6 +584,7 @@ struct bh_ba {
     struct bcr_dev* bcr = nullptr;
     struct dbcr_dev* dsol = nullptr;   // distributed reduced-camera solve (sharded mode, long banded systems)
     long long ar_bytes = 0;            // of comm_bytes: plain all-reduces
+    int cam_parts = 1;                 // workgroups per free camera in the linearisation (k_ba_linearize: long edge lists of a dense local window are cut into parts)
     int schur_wave = 0;                // one wave per camera pair (many short edge lists) instead of a 256-thread workgroup
     int last_err_sel = 0;              // which err buffer holds "the last computeActiveErrors"
     // landmark-sharded multi-GPU mode (bh_ba_set_allreduce)
@@ -595,7 +596,12 @@ struct bh_ba {
 };
 
 // fan-in slots of a window (ba->fan): [l_chi nbp][l_max nbp][c_max Cf][u_sum nbp][e_chi ceil(E / 256)]
-static size_t ba_fan_doubles(size_t Pa, size_t Cf, size_t E) { const size_t nbp = (Pa * 8 + 255) / 256, ne = (E + 255) / 256; return 3 * nbp + Cf + ne + 8 + (nbp + Cf + ne) / 128 + 8; }
+#define BA_CAM_PARTS_MAX 8
+static size_t ba_fan_doubles(size_t Pa, size_t Cf, size_t E)
+{
+    const size_t nbp = (Pa * 8 + 255) / 256, ne = (E + 255) / 256;
+    return 3 * nbp + Cf + ne + 8 + (nbp + BA_CAM_PARTS_MAX * Cf + ne) / 128 + 8 + 27 * BA_CAM_PARTS_MAX * Cf + Cf / 2 + 2;      // .. + camera-part sums + camera arrival counters
+}
 
 // ---- k_ba_point: 8 lanes per active point; residual + Huber + Jacobians; Hll, bl, per-edge Hpl, per-edge error/chi
 #define BP_G 8
@@ -650,20 +656,26 @@ __device__ __forceinline__ void ba_point_body(int bid, const ba_cam* __restrict_
 }
 
 // ---- k_ba_cam: workgroup per free camera: Hpp (6x6) and bp (6) over the camera's edges
-__device__ __forceinline__ void ba_cam_body(int s, const ba_cam* __restrict__ cams, const double* __restrict__ pts,
+__device__ __forceinline__ bool ba_cam_body(int s, const ba_cam* __restrict__ cams, const double* __restrict__ pts,
                                                 const int* __restrict__ e_cam, const int* __restrict__ e_pt,
                                                 const double* __restrict__ e_meas, const int* __restrict__ c_start,
                                                 const int* __restrict__ c_edges, ba_K K, double delta,
                                                 double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ cdiag,
                                                 const int* __restrict__ c_pt = nullptr, const double* __restrict__ c_meas = nullptr,
-                                                double* __restrict__ md_out = nullptr /* thread 0: the camera's max |diag| */)
+                                                double* __restrict__ md_out = nullptr /* thread 0: the camera's max |diag| */,
+                                                int part = 0, int cp = 1, double* c_part = nullptr, int* c_cnt = nullptr)
 {
+    // Returns true (in every thread) in the workgroup that wrote the camera's blocks.  cp > 1 (a dense local window: 1 600 observations per
+    // keyframe at configs[2], 48 workgroups of six rounds each while the landmark workgroups finish in one): the camera's edge list is cut into
+    // cp contiguous parts, a workgroup each; a part leaves its 27 sums in c_part and counts itself in c_cnt[s], the part that arrives last adds the
+    // cp partial sums IN PART ORDER (the result does not depend on which one is last) and writes Hpp / bp / cdiag.
     __shared__ double s_red[27 * 4];
     const int tid = threadIdx.x;
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0;
-    const int u0 = c_start[s], u1 = c_start[s + 1];
+    int u0 = c_start[s], u1 = c_start[s + 1];
+    if (cp > 1) { const int per = (u1 - u0 + cp - 1) / cp, a = min(u1, u0 + part * per); u1 = min(u1, a + per); u0 = a; }
     // c_pt / c_meas (global-BA form): landmark slot and measurement of every c_edges entry in camera-major order, copied once per problem -
     // the loop then gathers the landmark only (the edge's camera, landmark slot and measurement were three more scattered lines per edge);
     // every edge of the list has this camera
@@ -685,6 +697,34 @@ __device__ __forceinline__ void ba_cam_body(int s, const ba_cam* __restrict__ ca
         for (int a = 0; a < 6; a++) acc[21 + a] -= r1 * (Jc[a] * er[0] + Jc[6 + a] * er[1]);
     }
     d_block_sum<27, 256>(acc, s_red);
+    if (cp > 1) {
+        __shared__ int s_last;
+        __shared__ double s_fin[27];
+        if (tid < 27) { double v = 0; for (int w = 0; w < 4; w++) v += s_red[w * 27 + tid]; fan_store(c_part + ((size_t)s * cp + part) * 27 + tid, v); }      // (= acc[tid]: the same sum in the same order)
+        if (tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // wave 0's 27 slot stores have left the CU
+            const int prev = __hip_atomic_fetch_add(c_cnt + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = prev == cp - 1 ? 1 : 0;
+            if (prev == cp - 1) __hip_atomic_store(c_cnt + s, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_last) return false;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (tid < 27) {
+            double v[BA_CAM_PARTS_MAX];
+#pragma unroll
+            for (int q = 0; q < BA_CAM_PARTS_MAX; q++) v[q] = q < cp ? fan_load(c_part + ((size_t)s * cp + q) * 27 + tid) : 0.0;
+            double t = v[0];
+#pragma unroll
+            for (int q = 1; q < BA_CAM_PARTS_MAX; q++) if (q < cp) t += v[q];
+            s_fin[tid] = t;
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 27; i++) acc[i] = s_fin[i];
+        }
+    }
     if (tid == 0) {
         double* H = Hpp + 36 * (size_t)s;
         int k = 0; double md = 0;
@@ -693,6 +733,7 @@ __device__ __forceinline__ void ba_cam_body(int s, const ba_cam* __restrict__ ca
         cdiag[s] = md;
         if (md_out) *md_out = md;
     }
+    return true;
 }
 
 // ---- k_ba_partial: first stage of the big sums (global-BA sizes): block b sums its contiguous slice of the edges / points
@@ -705,13 +746,20 @@ struct ba_fan {
     double *l_chi, *l_max, *c_max;      // linearisation: [nbp], [nbp], [Cf]
     double *u_sum, *e_chi;              // trial: [landmark workgroups of the update], [workgroups of the error kernel]
     int* grp;                           // arrival counters per group of 64 workgroups (zero between launches)
+    double* c_part;                     // [Cf][cp][27] sums of a camera's parts (cp > 1)
+    int* c_cnt;                         // [Cf] parts of a camera that have arrived (zero between launches)
+    int cp;                             // workgroups per free camera
 };
 static ba_fan ba_fan_of(const bh_ba* ba)
 {
     const size_t nbp = ((size_t)ba->Pa * BP_G + 255) / 256;
     double* f = (double*)ba->fan.p;
     ba_fan F; F.l_chi = f; F.l_max = f + nbp; F.c_max = f + 2 * nbp; F.u_sum = f + 2 * nbp + ba->Cf; F.e_chi = f + 3 * nbp + ba->Cf;
-    F.grp = (int*)(f + 3 * nbp + ba->Cf + ((size_t)ba->Ea + 255) / 256 + 1);
+    const size_t ne = ((size_t)ba->Ea + 255) / 256;
+    F.grp = (int*)(f + 3 * nbp + ba->Cf + ne + 1);
+    F.c_part = f + 3 * nbp + ba->Cf + ne + 8 + (nbp + BA_CAM_PARTS_MAX * (size_t)ba->Cf + ne) / 128 + 8;
+    F.c_cnt = (int*)(F.c_part + 27 * BA_CAM_PARTS_MAX * (size_t)ba->Cf);
+    F.cp = ba->cam_parts;
     return F;
 }
 __device__ __forceinline__ void ba_lin_fan_store(bool point_block, int slot, const double* mine, double md_cam, const ba_fan& F, double* s8)
@@ -724,7 +772,7 @@ __device__ __forceinline__ void ba_lin_fan_store(bool point_block, int slot, con
         if (lane == 0) s8[4 + wv] = m;
         __syncthreads();
         if (tid == 0) { fan_store(F.l_chi + slot, cs); fan_store(F.l_max + slot, fmax(fmax(s8[4], s8[5]), fmax(s8[6], s8[7]))); }
-    } else if (tid == 0) fan_store(F.c_max + slot, md_cam);
+    } else if (tid == 0 && slot >= 0) fan_store(F.c_max + slot, md_cam);      // (slot < 0: a camera part that was not the last to arrive)
 }
 // k_ba_prep's work from the slots: one wave
 // (phase 1, multi-GPU: this rank's chi and the maximum over ITS landmarks go to S->red for the all-reduce hook; k_ba_prep's phase 2 folds in the
@@ -755,11 +803,13 @@ __global__ __launch_bounds__(256) void k_ba_linearize(int nbp, const ba_cam* __r
     __shared__ double s_f[8];
     double mine[2] = { 0, 0 }, md_cam = 0;
     const bool pb = (int)blockIdx.x < nbp;
+    const int cp = F.cp > 1 ? F.cp : 1, c = (int)blockIdx.x - nbp, cs = cp > 1 ? c / cp : c;      // camera workgroups: camera cs, part c - cs * cp
+    bool fin = true;
     if (pb) ba_point_body(blockIdx.x, cams, pts, e_cam, e_meas, cslot, p_start, p_edges, Pa, K, delta, Hpl, Hll, bl, err, chi_e, pdiag, mine);
-    else ba_cam_body(blockIdx.x - nbp, cams, pts, e_cam, e_pt, e_meas, c_start, c_edges, K, delta, Hpp, bp, cdiag, c_pt, c_meas, &md_cam);
+    else fin = ba_cam_body(cs, cams, pts, e_cam, e_pt, e_meas, c_start, c_edges, K, delta, Hpp, bp, cdiag, c_pt, c_meas, &md_cam, c - cs * cp, cp, F.c_part, F.c_cnt);
     if (!F.l_chi) return;                                        // (BH_BA_FAN=0: the sums as separate launches, the A/B reference)
-    ba_lin_fan_store(pb, pb ? (int)blockIdx.x : (int)blockIdx.x - nbp, mine, md_cam, F, s_f);
-    if (fan_arrive(&S->tick[0], F.grp, (int)blockIdx.x, (int)gridDim.x)) ba_prep_fan(F, nbp, (int)gridDim.x - nbp, first, phase, S);
+    ba_lin_fan_store(pb, pb ? (int)blockIdx.x : (fin ? cs : -1), mine, md_cam, F, s_f);
+    if (fan_arrive(&S->tick[0], F.grp, (int)blockIdx.x, (int)gridDim.x)) ba_prep_fan(F, nbp, ((int)gridDim.x - nbp) / cp, first, phase, S);
 }
 
 #define BA_NPART 256
@@ -2904,9 +2954,12 @@ __global__ __launch_bounds__(256) void k_bb_linearize(const ba_view* __restrict_
     double mine[2] = { 0, 0 }, md_cam = 0;
     if (bx < nbp) ba_point_body(bx, V.cams[cur], V.pts[cur], V.e_cam, V.e_meas, V.cslot, V.p_start, V.p_edges, V.Pa, V.K, delta, V.Hpl, V.Hll, V.bl,
                                              V.err[0], V.chi_e[0], V.pdiag, mine);
-    else if (bx < nbp + V.Cf) ba_cam_body(bx - nbp, V.cams[cur], V.pts[cur], V.e_cam, V.e_pt, V.e_meas, V.c_start, V.c_edges, V.K, delta, V.Hpp, V.bp, V.cdiag, nullptr, nullptr, &md_cam);
-    else return;
-    ba_lin_fan_store(bx < nbp, bx < nbp ? bx : bx - nbp, mine, md_cam, V.fan, s_f);      // (read by k_bb_prep, the next launch)
+    const int cp = V.fan.cp > 1 ? V.fan.cp : 1, c = bx - nbp, cs = cp > 1 ? c / cp : c;
+    bool fin = true;
+    if (bx >= nbp + V.Cf * cp) return;
+    if (bx >= nbp) fin = ba_cam_body(cs, V.cams[cur], V.pts[cur], V.e_cam, V.e_pt, V.e_meas, V.c_start, V.c_edges, V.K, delta, V.Hpp, V.bp, V.cdiag, nullptr, nullptr, &md_cam,
+                                                     c - cs * cp, cp, V.fan.c_part, V.fan.c_cnt);
+    ba_lin_fan_store(bx < nbp, bx < nbp ? bx : (fin ? cs : -1), mine, md_cam, V.fan, s_f);      // (read by k_bb_prep, the next launch)
 }
 __global__ __launch_bounds__(1024) void k_bb_prep(const ba_view* __restrict__ views)
 {
@@ -4562,6 +4615,11 @@ static int ba_set_problem_rest(bh_ba* ba, int C, const double* R, const double* 
     BH_TRY(bh_reserve(ctx, &ba->dxp, sizeof(double) * ((size_t)rows_pad + 6))); BH_TRY(bh_reserve(ctx, &ba->dxl, sizeof(double) * 3 * ((size_t)Pa + 1)));
     BH_TRY(bh_reserve(ctx, &ba->part, sizeof(double) * 2 * BA_NPART));
     BH_TRY(bh_reserve(ctx, &ba->fan, sizeof(double) * ba_fan_doubles(Pa, Cf, E)));
+    {   // workgroups per free camera in the linearisation: a function of the problem's sizes alone (a window gives the same bits alone and in a batch)
+        const int per_cam = C > 0 ? E / C : 0;
+        ba->cam_parts = (Cf > 0 && Cf <= 64 && per_cam >= 512) ? std::min(BA_CAM_PARTS_MAX, (per_cam + 511) / 512 + 1) : 1;      // configs[2]: 1 600 per keyframe -> 5 (measured 1 / 4 / 7: 26.0 / 21.9 / 24.4 us)
+        if (const char* e = getenv("BH_BA_CAM_PARTS")) { const int v = atoi(e); if (v >= 1 && v <= BA_CAM_PARTS_MAX) ba->cam_parts = Cf > 0 ? v : 1; }      // A/B switch
+    }
     if (!small) {
         BH_HIP(ctx, hipMemsetAsync(ba->state.p, 0, sizeof(ba_state), ctx->stream));
         BH_HIP(ctx, hipMemsetAsync(ba->err[0].p, 0, sizeof(double) * 2 * (E + 1), ctx->stream));
@@ -4675,7 +4733,8 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
     ba_fan F = {}; if (use_fan) F = ba_fan_of(ba);
     if (use_fan) {
         BH_HIP(ctx, hipMemsetAsync(&state->tick[0], 0, sizeof(int) * 2, st));
-        BH_HIP(ctx, hipMemsetAsync(F.grp, 0, sizeof(int) * (((size_t)Pa * BP_G + 255) / 256 + Cf + ((size_t)Ea + 255) / 256 + 63) / 64 + 8, st));
+        BH_HIP(ctx, hipMemsetAsync(F.grp, 0, sizeof(int) * ((((size_t)Pa * BP_G + 255) / 256 + (size_t)BA_CAM_PARTS_MAX * Cf + ((size_t)Ea + 255) / 256 + 63) / 64 + 8), st));
+        if (F.cp > 1) BH_HIP(ctx, hipMemsetAsync(F.c_cnt, 0, sizeof(int) * Cf, st));
     }
     const int lead = ba->rank == 0 ? 1 : 0;              // the rank that contributes the replicated camera terms
     ba->comm_ms = 0; ba->comm_bytes = 0; ba->ar_bytes = 0;
@@ -4686,7 +4745,7 @@ extern "C" int bh_ba_optimize(bh_ba* ba, int iters, double huber_delta, int verb
         const ba_cam* cams = (const ba_cam*)ba->cams[ba->cur].p; const double* pts = (const double*)ba->pts[ba->cur].p;
         {
             const int nbp = (Pa * BP_G + 255) / 256;
-            BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_ba_linearize, dim3(nbp + Cf), dim3(256), st, nbp, cams, pts, e_cam, e_pt, e_meas, cslot, p_start, p_edges,
+            BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_ba_linearize, dim3(nbp + Cf * (F.cp > 1 ? F.cp : 1)), dim3(256), st, nbp, cams, pts, e_cam, e_pt, e_meas, cslot, p_start, p_edges,
                       c_start, c_edges, Pa, ba->K, huber_delta, Hpl, Hll, bl, (double*)ba->err[0].p, (double*)ba->chi_e[0].p, pdiag, Hpp, bp, cdiag,
                       ba->cam_major ? (const int*)ba->c_pt.p : (const int*)nullptr, ba->cam_major ? (const double*)ba->c_meas.p : (const double*)nullptr,
                       F, state, it == 0 ? 1 : 0, dist ? 1 : 0);
@@ -4882,7 +4941,8 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
         if (ba->schur_wave) g_s64 = std::max(g_s64, (ba->npairs + 7) / 8 * 8);
         hcur[w] = ba->cur;
         ba->log.clear(); ba->iters_done = 0;
-        g_lin = std::max(g_lin, (ba->Pa * BP_G + 255) / 256 + ba->Cf);
+        g_lin = std::max(g_lin, (ba->Pa * BP_G + 255) / 256 + ba->Cf * std::max(1, ba->cam_parts));
+        if (ba->cam_parts > 1) BH_HIP(ctx, hipMemsetAsync(V.fan.c_cnt, 0, sizeof(int) * ba->Cf, st));      // (a faulted launch could have left a count behind)
         g_pb = std::max(g_pb, (ba->Pa + 255) / 256);
         g_schur = std::max(g_schur, (ba->npairs + 7) / 8 * 8 + ba->Cf);
         g_upd = std::max(g_upd, (ba->Pa * BP_G + 255) / 256 + (ba->C + 255) / 256);

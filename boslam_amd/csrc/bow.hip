@@ -410,22 +410,22 @@ extern "C" int bh_bow_query_l1(bh_bow* bow, const uint32_t* q_words, const doubl
 //          what a list cannot hold goes to a global overflow list with the full entry id;
 //   k_inv_finish   every workgroup: a wave per bucket ranks the bucket's records by (entry, word rank) and adds them IN THAT ORDER - per
 //          entry the ascending word order of DBoW3's accumulation, so scores are bit-identical to the scan and to the oracle; buckets
-//          that overflowed are only noted.  The LAST workgroup to arrive (agent-scope counter) then takes the noted buckets - its 1024
-//          lanes rank a bucket's lists + its share of the overflow list through a (slot, rank) bitmap, the same ordered sums - and
+//          that overflowed are then taken by the whole workgroup - its 1024 lanes rank a bucket's lists + its share of the overflow
+//          list through a (slot, rank) bitmap, the same ordered sums.  The LAST workgroup to arrive (agent-scope counter)
 //          selects: a threshold from the 16 wave minima of the bucket minima (k <= 16 of them are k actual values, so at least k
 //          accumulators lie at or below it), the few accumulators at or below it collected and ordered by (value, id), results to
 //          pinned host memory.  (Rounds 3 - 4 ran these as three launches, k_inv_reduce / k_inv_heavy / k_inv_select.)
-// Anything that does not fit (overflow list, heavy-bucket table, a heavy bucket beyond 4096 records) raises a flag: the scan answers.
+// Anything that does not fit (overflow list, a heavy bucket beyond 4096 records, more than 1024 accumulators at the selection threshold)
+// raises a flag: the scan answers.
 #define INV_WORDS BOW_BITS
 #define INV_KMAX 16                                           // results the select kernel can deliver (k <= 16 wave minima)
 #define INV_NSUB 4                                            // lists per bucket
 #define INV_RANK_BITS 11                                      // query ranks < 2048 (BOW_QMAX = 1536)
 #define INV_OVF_CAP 65536                                     // records of the global overflow list
-#define INV_HEAVY_MAX 32                                      // buckets that may overflow in one query
 #define INV_HCAP 4096                                         // records a heavy bucket's workgroup can rank
 #define INV_SELCAP 1024                                       // accumulators at or below the threshold
 
-struct inv_ctl { int ovf_cnt, heavy_cnt, flags, tick; int heavy_bk[INV_HEAVY_MAX]; int heavy_n[INV_HEAVY_MAX][INV_NSUB]; };      // tick: workgroups of k_inv_finish that have reduced their buckets
+struct inv_ctl { int ovf_cnt, flags, tick, pad; };            // tick: workgroups of k_inv_finish that have summed their buckets
 // One query slot: its own scratch (bucket lists, overflow list, accumulators, control block) and its pinned in / out block
 //   [int nq][int k][pad 8] [u32 words[BOW_QMAX]] [f64 vals[BOW_QMAX]] [int n][int fallback][f64 scores[INV_KMAX]][int ids[INV_KMAX]].
 // bh_bow_query_l1 uses slot 0; bh_bow_query_l1_batch runs up to INV_QSLOTS queries per launch (blockIdx.y = slot).
@@ -552,17 +552,16 @@ __device__ __forceinline__ double inv_wave_min(double v, int lane)
 #define INV_FIN_BK (INV_FIN_T / 64)
 
 // one heavy bucket (its lists + its share of the overflow list) by the whole workgroup: O(n) sort by a (slot, rank) bitmap, ordered sums
-__device__ __forceinline__ void inv_heavy_bucket(const inv_slot& S, int hb, int scap, long long n_entries, const uint8_t* __restrict__ keep, uint32_t* hsm, int* s_n)
+__device__ __forceinline__ void inv_heavy_bucket(const inv_slot& S, long long bk, const int* cnt4, int scap, long long n_entries, const uint8_t* __restrict__ keep, uint32_t* hsm, int* s_n)
 {
     const uint32_t* __restrict__ bkey = S.bkey; const double* __restrict__ bval = S.bval; double* acc_out = S.acc; inv_ctl* ctl = S.ctl;
     const uint32_t* __restrict__ okey = S.okey; const double* __restrict__ oval = S.oval; double* bmin = S.bmin;
     uint32_t* s_key = hsm; uint32_t* s_okey = hsm + INV_HCAP;
     double* s_val = reinterpret_cast<double*>(hsm + 2 * INV_HCAP); double* s_oval = s_val + INV_HCAP;
     const int tid = threadIdx.x;
-    const long long bk = ctl->heavy_bk[hb];
     int n0 = 0;
     for (int u = 0; u < INV_NSUB; u++) {
-        const int cu = ctl->heavy_n[hb][u];
+        const int cu = cnt4[u];
         for (int i = tid; i < cu; i += INV_FIN_T) { s_key[n0 + i] = bkey[((size_t)bk * INV_NSUB + u) * scap + i]; s_val[n0 + i] = bval[((size_t)bk * INV_NSUB + u) * scap + i]; }
         n0 += cu;
     }
@@ -696,7 +695,7 @@ __device__ __forceinline__ void inv_select(const inv_slot& S, long long nb, long
     if (seq) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __syncthreads(); }      // the scores / ids of the other lanes before the tag
     if (tid == 0) {
         hi[0] = bad ? 0 : min(m, k); hi[1] = bad ? 1 : ctl->flags;
-        ctl->ovf_cnt = 0; ctl->heavy_cnt = 0; ctl->flags = 0;      // counters ready for the next query
+        ctl->ovf_cnt = 0; ctl->flags = 0;      // counters ready for the next query
         // a single host query polls for this tag (pinned, coherent memory) instead of waiting for the stream: the wake-up costs more than the kernels
         if (seq) __hip_atomic_store(&hi[INV_PIN_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -705,15 +704,19 @@ __device__ __forceinline__ void inv_select(const inv_slot& S, long long nb, long
 // k_inv_finish (round 5): everything behind the gather in ONE launch (was k_inv_reduce -> k_inv_heavy -> k_inv_select: three dependent
 // launches of 7 + 35 + 21 us for a relocalisation query, most of it launch, drain and first-load latency of one-workgroup kernels).
 //   every workgroup   a wave per bucket of 64 entries: rank its records by (entry, word rank), add them in that order, bucket minimum;
-//                     buckets whose lists overflowed are noted in ctl;
+//                     then the buckets of this workgroup whose lists overflowed (one for a relocalisation query, none for most others),
+//                     one after the other with all 1024 lanes: lists + the bucket's share of the overflow list, ranked through a
+//                     (slot, rank) bitmap, the same ordered sums;
 //   arrival           release fence, one agent-scope add on ctl->tick per workgroup;
-//   the last arriver  (acquire fence) takes the noted heavy buckets one after the other - there is one for a relocalisation query, none
-//                     for most others - and then selects the k best and writes the slot's result block.  No workgroup waits for another.
+//   the last arriver  (acquire fence) selects the k best and writes the slot's result block.  No workgroup waits for another.
 __global__ __launch_bounds__(INV_FIN_T) void k_inv_finish(const inv_slot* __restrict__ slots, int scap, long long n_entries, const uint8_t* __restrict__ keep,
                                                           long long nb, int k1, int seq)
 {
     extern __shared__ uint32_t hsm[];
     __shared__ int s_cnt[4];
+    __shared__ int s_hn, s_hb[INV_FIN_BK], s_hc[INV_FIN_BK][INV_NSUB];      // this workgroup's heavy buckets: wave index, list lengths
+    if (threadIdx.x == 0) s_hn = 0;
+    __syncthreads();
     const inv_slot S = slots[blockIdx.y];
     const int k = k1 >= 0 ? k1 : S.hdr[1];                      // (asked for now, used by the last arriver only)
     inv_ctl* ctl = S.ctl;
@@ -730,11 +733,10 @@ __global__ __launch_bounds__(INV_FIN_T) void k_inv_finish(const inv_slot* __rest
 #pragma unroll
             for (int u = 0; u < INV_NSUB; u++) { c[u] = bcnt[bk * INV_NSUB + u]; heavy = heavy || c[u] > scap; }
             if (lane < INV_NSUB) bcnt[bk * INV_NSUB + lane] = 0;       // ready for the next query
-            if (heavy) {                                               // some of its records sit in the overflow list: the last arriver takes the bucket
+            if (heavy) {                                               // some of its records sit in the overflow list: the whole workgroup takes the bucket below
                 if (lane == 0) {
-                    const int hp = atomicAdd(&ctl->heavy_cnt, 1);
-                    if (hp < INV_HEAVY_MAX) { ctl->heavy_bk[hp] = (int)bk; for (int u = 0; u < INV_NSUB; u++) ctl->heavy_n[hp][u] = min(c[u], scap); }
-                    else ctl->flags = 1;
+                    const int hp = atomicAdd(&s_hn, 1);
+                    s_hb[hp] = wv; for (int u = 0; u < INV_NSUB; u++) s_hc[hp][u] = min(c[u], scap);
                 }
             } else {
 #pragma unroll
@@ -755,8 +757,13 @@ __global__ __launch_bounds__(INV_FIN_T) void k_inv_finish(const inv_slot* __rest
             }
         }
     }
-    // ---- arrival: this workgroup's accumulators, minima and heavy notes are out before its count is
+    // ---- this workgroup's heavy buckets, one after the other, all 1024 lanes on each (the waves' staging areas are free now)
     __syncthreads();
+    {
+        const int nh = s_hn;
+        for (int hb = 0; hb < nh; hb++) inv_heavy_bucket(S, (long long)blockIdx.x * INV_FIN_BK + s_hb[hb], s_hc[hb], scap, n_entries, keep, hsm, &s_cnt[3]);
+    }
+    // ---- arrival: this workgroup's accumulators and minima are out before its count is
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const int prev = __hip_atomic_fetch_add(&ctl->tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -766,9 +773,6 @@ __global__ __launch_bounds__(INV_FIN_T) void k_inv_finish(const inv_slot* __rest
     if (!s_cnt[2]) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (tid == 0) ctl->tick = 0;                                // (the next query's launch is ordered behind this one)
-    const int nh = min(__hip_atomic_load(&ctl->heavy_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), INV_HEAVY_MAX);
-    for (int hb = 0; hb < nh; hb++) inv_heavy_bucket(S, hb, scap, n_entries, keep, hsm, &s_cnt[3]);
-    if (nh) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __syncthreads(); }      // (this workgroup's own acc / bmin stores before its reads)
     inv_select(S, nb, n_entries, k, hsm, s_cnt, seq);
 }
 

@@ -397,7 +397,8 @@ def test_control_sums_and_lookahead_switches_agree(ctx, monkeypatch):
     for pr, env in ((synth.ba_problem(n_kf=12, n_pts=500, seed=4), {}), (synth.ba_problem(n_kf=50, n_pts=10000, seed=7), {}),
                     (synth.ba_problem(n_kf=12, n_pts=500, seed=4), {"BH_BA_SELF_BATCH": "0"})):
         res = {}
-        for name, sw in (("default", {}), ("nolook", {"BH_BA_LOOKAHEAD": "0"}), ("nofan", {"BH_BA_FAN": "0", "BH_BA_SELF_BATCH": "0"})):
+        for name, sw in (("default", {}), ("nolook", {"BH_BA_LOOKAHEAD": "0"}), ("nofan", {"BH_BA_FAN": "0", "BH_BA_SELF_BATCH": "0"}),
+                         ("oneper", {"BH_BA_CAM_PARTS": "1"}), ("eightper", {"BH_BA_CAM_PARTS": "8"})):
             for k, v in {**env, **sw}.items():
                 monkeypatch.setenv(k, v)
             s = ba.LocalBA(ctx, pr["K"])
@@ -410,6 +411,9 @@ def test_control_sums_and_lookahead_switches_agree(ctx, monkeypatch):
         d0, (R0, t0), p0, l0 = res["default"]
         d1, (R1, t1), p1, l1 = res["nolook"]
         assert d1 == d0 and np.array_equal(R1, R0) and np.array_equal(t1, t0) and np.array_equal(p1, p0) and np.array_equal(l1, l0)
-        d2, (R2, t2), p2, l2 = res["nofan"]
-        assert d2 == d0 and np.array_equal(l2[:, 2:], l0[:, 2:])                       # trials per iteration, accept flags
-        assert np.allclose(l2[:, :2], l0[:, :2], rtol=1e-9) and np.abs(R2 - R0).max() < 1e-9 and np.abs(t2 - t0).max() < 1e-9 and np.abs(p2 - p0).max() < 1e-9
+        # another fixed summation order: BH_BA_FAN=0, and the camera blocks of the linearisation summed by one / eight workgroups per keyframe
+        # (BH_BA_CAM_PARTS; the default cuts the 1 600-observation lists of the 50-keyframe window into parts, the 12-keyframe window's not)
+        for name in ("nofan", "oneper", "eightper"):
+            d2, (R2, t2), p2, l2 = res[name]
+            assert d2 == d0 and np.array_equal(l2[:, 2:], l0[:, 2:]), name                # trials per iteration, accept flags
+            assert np.allclose(l2[:, :2], l0[:, :2], rtol=1e-9) and np.abs(R2 - R0).max() < 1e-9 and np.abs(t2 - t0).max() < 1e-9 and np.abs(p2 - p0).max() < 1e-9, name

@@ -118,6 +118,51 @@ def test_bow_inverted_file_follows_the_database_and_falls_back(ctx):
     d.close()
 
 
+def test_bow_several_heavy_buckets_are_taken_by_the_last_workgroup(ctx, monkeypatch):
+    """Round 5: k_inv_finish - every workgroup sums its light buckets, the workgroup that arrives last takes the buckets whose hit lists
+    overflowed, one after the other, and selects.  Three near-copies of the query in three different buckets of 64 entries (plus two in one
+    bucket) make three heavy buckets in one query; the inverted file must answer (scores bit-identical to the scan and to the oracle), also
+    with the stream-synchronising host path (BH_BOW_SYNC=1) instead of the polled result tag, and through the batched entry."""
+    rng = np.random.default_rng(18)
+    qw = np.sort(rng.choice(300000, size=1000, replace=False)).astype(np.uint32); qv = rng.random(1000); qv /= qv.sum()
+    rows = []
+    dup = {70: 900, 71: 700, 500: 950, 1500: 800}                             # entry -> words shared with the query (buckets 1, 1, 7, 23)
+    for e in range(70000):                                                     # (>= 65 536 entries: below that the selection has fewer than 16 wave minima and k = 10 goes to the scan)
+        other = np.unique(rng.integers(300000, 600000, size=120)).astype(np.uint32)
+        if e in dup:
+            w = np.sort(np.concatenate([rng.choice(qw, size=dup[e], replace=False), other[:60]])).astype(np.uint32)
+        else:
+            w = np.sort(np.concatenate([qw[rng.integers(0, 1000, size=rng.integers(0, 3))], other])).astype(np.uint32)
+            w = np.unique(w)
+        v = rng.random(len(w)); rows.append((w, v / v.sum()))
+    start = np.concatenate([[0], np.cumsum([len(r[0]) for r in rows])]).astype(np.int64)
+    words = np.concatenate([r[0] for r in rows]); vals = np.concatenate([r[1] for r in rows])
+    d = bow.BowDatabase(ctx)
+    d.set_db(start, words, vals)
+    oi, os_ = oracle.bow_query_l1(qw, qv, start, words, vals, 10)
+    assert set(oi[:4].tolist()) == set(dup)
+    d.set_mode("scan")
+    si, ss = d.query(qw, qv, 10)
+    d.set_mode("inverted")
+    for _ in range(4):                                                         # (the file is built once the database has been quiet for three queries)
+        ids, sc = d.query(qw, qv, 10)
+    ctx.timing(True)
+    ids, sc = d.query(qw, qv, 10)
+    kt = ctx.timing_read(); ctx.timing(False)
+    assert "k_bow_inverted" in kt and "k_bow_scan" not in kt, "the inverted file must answer this query itself"
+    assert np.array_equal(ids, oi) and np.array_equal(sc, os_) and np.array_equal(ids, si) and np.array_equal(sc, ss)
+    monkeypatch.setenv("BH_BOW_SYNC", "1")
+    ids2, sc2 = d.query(qw, qv, 10)
+    monkeypatch.delenv("BH_BOW_SYNC")
+    assert np.array_equal(ids2, oi) and np.array_equal(sc2, os_)
+    q3 = qw[::3].copy(); v3 = np.full(len(q3), 1.0 / len(q3))
+    got = d.query_batch([(qw, qv), (q3, v3), (qw, qv)], 7)
+    o3i, o3s = oracle.bow_query_l1(q3, v3, start, words, vals, 7)
+    assert np.array_equal(got[0][0], oi[:7]) and np.array_equal(got[0][1], os_[:7]) and np.array_equal(got[2][0], oi[:7])
+    assert np.array_equal(got[1][0], o3i) and np.array_equal(got[1][1], o3s)
+    d.close()
+
+
 @pytest.mark.parametrize("k,L,n", [(10, 3, 600), (10, 4, 1000), (4, 5, 37), (7, 2, 4096)])
 def test_vocabulary_transform_matches_oracle(ctx, k, L, n):
     voc = synth.vocabulary(k=k, L=L, seed=k * 10 + L)

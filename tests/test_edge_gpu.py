@@ -71,6 +71,55 @@ def test_depth_masks_take_the_bit_packed_pyramid(ctx, H, W):
     assert n.sum() > 0
 
 
+@pytest.mark.parametrize("H,W,scale,nlevels", [(480, 640, 1.2, 8), (123, 200, 1.2, 8), (250, 324, 1.3, 4), (96, 128, 1.25, 3), (301, 404, 1.07, 6)])
+def test_level0_and_level1_in_one_launch(ctx, monkeypatch, H, W, scale, nlevels):
+    """Round 5: k_gray_l1 makes the gray + mask-bit level 0 and level 1 of the pyramid in one launch (strips of level-1 rows, their level-0
+    rows kept in LDS) when the frame is BGR + depth with a width that is a multiple of 4.  Strip counts that do not divide the level, other
+    scale factors in the supported range (other strip heights), short pyramids: every level of the image and of the mask pyramid and everything downstream must
+    equal the oracle, and the two-launch form (BH_ORB_GRAY_L1=0) must give the same bytes."""
+    rng = np.random.default_rng(H + 3 * W)
+    bgr, _ = synth.render_batch(2)
+    crop = np.ascontiguousarray(bgr[:, 5:5 + H, 9:9 + W]) if H < 470 else np.ascontiguousarray(bgr[:, :H, :W])
+    depth = rng.integers(1, 5000, size=(2, H, W)).astype(np.uint16)
+    depth[0][rng.random((H, W)) < 0.2] = 0
+    for _ in range(10):
+        y, x, hh, ww = rng.integers(0, H - 8), rng.integers(0, W - 8), rng.integers(4, 50), rng.integers(4, 80)
+        depth[1, y:y + hh, x:x + ww] = 0
+    kw = dict(nfeatures=300, scaleFactor=scale, nlevels=nlevels)
+    params = frontend.make_params(**kw)
+    mask = (depth > 0).astype(np.uint8) * 255
+    out = {}
+    for form in ("fused", "two"):
+        if form == "two":
+            monkeypatch.setenv("BH_ORB_GRAY_L1", "0")
+        kps, desc, n = frontend.orb_detect_describe(ctx, crop, depth=depth, params=params)
+        lv = []
+        for f in range(2):
+            dev = frontend.orb_debug_fetch(ctx, f, H, W, params)
+            lv.append({name: [dev[name][int(dev["off"][l]):int(dev["off"][l]) + int(dev["pitch"][l]) * int(dev["h"][l])].reshape(int(dev["h"][l]), int(dev["pitch"][l]))[:, :int(dev["w"][l])].copy()
+                              for l in range(nlevels)] for name in ("pyr", "mask")})
+        out[form] = (kps.copy(), desc.copy(), n.copy(), lv)
+        if form == "two":
+            monkeypatch.delenv("BH_ORB_GRAY_L1")
+    kps, desc, n, lv = out["fused"]
+    k2, d2, n2, lv2 = out["two"]
+    assert np.array_equal(n, n2)
+    for f in range(2):
+        ok, od, rc, dbg = oracle.orb_detect_describe(crop[f], mask[f], oracle.orb_params(**kw), max_kp=4 * 300 + 256, debug=True)
+        for name in ("pyr", "mask"):
+            for l in range(nlevels):
+                w, h, ro = int(dbg["w"][l]), int(dbg["h"][l]), int(dbg["off"][l])
+                ref = dbg[name][ro:ro + w * h].reshape(h, w)
+                bad = np.argwhere(lv[f][name][l] != ref)
+                assert len(bad) == 0, (name, f, l, len(bad), bad[:3])
+                assert np.array_equal(lv2[f][name][l], ref), (name, f, l, "two-launch form")
+        assert rc == 0 and n[f] == len(ok), (f, n[f], len(ok))
+        assert np.array_equal(desc[f, :n[f]], od) and np.array_equal(d2[f, :n[f]], od)
+        for fld in ("x", "y", "angle", "response", "size"):
+            assert np.array_equal(kps[f, :n[f]][fld].view(np.uint32), ok[fld].view(np.uint32)), fld
+            assert np.array_equal(k2[f, :n[f]][fld].view(np.uint32), ok[fld].view(np.uint32)), fld
+
+
 @pytest.mark.parametrize("H,W", [(480, 640), (241, 322), (97, 129)])
 def test_matrix_core_pyramid_is_bit_identical(monkeypatch, H, W):
     """BH_ORB_PYR_MFMA=1 selects k_pyr_mfma (resize as two int8 matrix-core products, mask by run gathers + truth-table patches) instead of
