@@ -647,10 +647,13 @@ __device__ __forceinline__ void inv_select(const inv_slot& S, long long nb, long
     double* s_T = reinterpret_cast<double*>(s_bl + INV_SELCAP / 16);
     int& s_m = s_cnt[0]; int& s_nb = s_cnt[1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // buckets are dealt to the 16 waves round-robin (bucket b -> wave b % 16): a database of a few hundred buckets still gives every wave a
+    // minimum, so T is finite for k <= 16 (dealt in runs of 64, anything below 65 536 entries left waves empty and went to the scan)
+    const int tb = ((tid & 63) << 4) | wv;                     // this thread's first bucket; the others follow every 1024
     double mn = INFINITY, mine[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const long long b = tid + INV_FIN_T * u; mine[u] = b < nb ? bmin[b] : INFINITY; mn = fmin(mn, mine[u]); }
-    for (long long b = tid + 4 * INV_FIN_T; b < nb; b += INV_FIN_T) mn = fmin(mn, bmin[b]);
+    for (int u = 0; u < 4; u++) { const long long b = tb + INV_FIN_T * u; mine[u] = b < nb ? bmin[b] : INFINITY; mn = fmin(mn, mine[u]); }
+    for (long long b = tb + 4 * INV_FIN_T; b < nb; b += INV_FIN_T) mn = fmin(mn, bmin[b]);
     mn = inv_wave_min(mn, lane);
     if (lane == 0) s_wmin[wv] = mn;
     if (tid == 0) { s_m = 0; s_nb = 0; }
@@ -665,10 +668,10 @@ __device__ __forceinline__ void inv_select(const inv_slot& S, long long nb, long
     const double T = *s_T;                                     // +inf when fewer than k waves saw a hit: then every bucket with a hit is listed
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        const long long b = tid + INV_FIN_T * u;
+        const long long b = tb + INV_FIN_T * u;
         if (mine[u] <= T && mine[u] < INFINITY) { const int p = atomicAdd(&s_nb, 1); if (p < INV_SELCAP / 16) s_bl[p] = (int)b; }
     }
-    for (long long b = tid + 4 * INV_FIN_T; b < nb; b += INV_FIN_T) {
+    for (long long b = tb + 4 * INV_FIN_T; b < nb; b += INV_FIN_T) {
         const double v = bmin[b];
         if (v <= T && v < INFINITY) { const int p = atomicAdd(&s_nb, 1); if (p < INV_SELCAP / 16) s_bl[p] = (int)b; }
     }

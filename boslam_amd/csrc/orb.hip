@@ -1877,6 +1877,21 @@ static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
         for (int x = g.lv[l].w; x < align_up(g.lv[l].w, 4); x++) tab[g.lv[l].tabx_off + x] = tab[g.lv[l].tabx_off + g.lv[l].w - 1];
         lin_coeffs(g.lv[l - 1].h, g.lv[l].h, tab + g.lv[l].taby_off);
     }
+    // k_gray_l1: level-1 rows per strip = the most (in whole lane items) whose level-0 rows fit the staged GL_R0, checked against the row table
+    // itself (the resize ratio of a small level differs from scaleFactor by its rounding)
+    ctx->gl_sr = 0;
+    if (g.nlevels >= 2) {
+        const uint32_t* ty = tab + g.lv[1].taby_off; const int Dh = g.lv[1].h, Sh = g.lv[0].h;
+        for (int sr = (int)((GL_R0 - 2) / p->scaleFactor) / GL_PR * GL_PR; sr >= GL_PR && !ctx->gl_sr; sr -= GL_PR) {
+            int worst = 0;
+            for (int a = 0; a < Dh; a += sr) {
+                const int b = std::min(Dh, a + sr), ra = (int)(ty[a] >> 16);
+                const int rb = b == Dh ? Sh - 1 : std::min((int)(ty[b - 1] >> 16) + 1, Sh - 1);
+                worst = std::max(worst, rb - ra + 1);
+            }
+            if (worst <= GL_R0) ctx->gl_sr = sr;
+        }
+    }
     int rc = bh_reserve(ctx, &ctx->tab, sizeof(uint32_t) * tab_words);
     if (rc == BH_OK) {
         hipError_t e = hipMemcpyAsync(ctx->tab.p, tab, sizeof(uint32_t) * tab_words, hipMemcpyHostToDevice, ctx->stream);
@@ -2014,9 +2029,9 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
         {
             const int n = (g.lv[0].pitch >> 2) * g.lv[0].h;
             // level 0 + level 1 in one launch (k_gray_l1) when the reference call's case applies, a second level exists and the staged rows fit LDS
-            gl_sr = ((int)((GL_R0 - 2) / params->scaleFactor)) & ~1;
+            gl_sr = ctx->gl_sr;                                     // (ensure_geom: whole lane items whose level-0 rows fit the staged strip)
             const size_t gl_lds = (size_t)GL_R0 * (g.lv[0].pitch + 16) + (size_t)GL_R0 * (g.lv[0].mpitch + 1) * 4;
-            gl_fused = mbits && channels == 3 && (W & 3) == 0 && g.nlevels >= 2 && !ctx->pm_ok && gl_sr >= 2 && gl_lds <= 64 * 1024 && !getenv("BH_ORB_GRAY_GENERAL") &&
+            gl_fused = mbits && channels == 3 && (W & 3) == 0 && g.nlevels >= 2 && !ctx->pm_ok && gl_sr >= GL_PR && gl_lds <= 64 * 1024 && !getenv("BH_ORB_GRAY_GENERAL") &&
                        !(getenv("BH_ORB_GRAY_L1") && atoi(getenv("BH_ORB_GRAY_L1")) == 0);
             if (gl_fused) {
                 bh_time_begin(ctx, BH_K_GRAY);

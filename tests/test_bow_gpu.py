@@ -118,16 +118,17 @@ def test_bow_inverted_file_follows_the_database_and_falls_back(ctx):
     d.close()
 
 
-def test_bow_several_heavy_buckets_are_taken_by_the_last_workgroup(ctx, monkeypatch):
-    """Round 5: k_inv_finish - every workgroup sums its light buckets, the workgroup that arrives last takes the buckets whose hit lists
-    overflowed, one after the other, and selects.  Three near-copies of the query in three different buckets of 64 entries (plus two in one
+@pytest.mark.parametrize("n_entries", [20000, 70000])
+def test_bow_several_heavy_buckets_in_one_query(ctx, monkeypatch, n_entries):
+    """Round 5: k_inv_finish - every workgroup sums its light buckets, then takes its buckets whose hit lists overflowed; the workgroup that
+    arrives last selects (bucket minima dealt round-robin to its 16 waves, so a database of a few hundred buckets is answered too).  Three near-copies of the query in three different buckets of 64 entries (plus two in one
     bucket) make three heavy buckets in one query; the inverted file must answer (scores bit-identical to the scan and to the oracle), also
     with the stream-synchronising host path (BH_BOW_SYNC=1) instead of the polled result tag, and through the batched entry."""
     rng = np.random.default_rng(18)
     qw = np.sort(rng.choice(300000, size=1000, replace=False)).astype(np.uint32); qv = rng.random(1000); qv /= qv.sum()
     rows = []
     dup = {70: 900, 71: 700, 500: 950, 1500: 800}                             # entry -> words shared with the query (buckets 1, 1, 7, 23)
-    for e in range(70000):                                                     # (>= 65 536 entries: below that the selection has fewer than 16 wave minima and k = 10 goes to the scan)
+    for e in range(n_entries):
         other = np.unique(rng.integers(300000, 600000, size=120)).astype(np.uint32)
         if e in dup:
             w = np.sort(np.concatenate([rng.choice(qw, size=dup[e], replace=False), other[:60]])).astype(np.uint32)
