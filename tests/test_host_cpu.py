@@ -262,3 +262,21 @@ def test_exchange_bytes_of_the_segment_scheme_at_configs4():
     assert small["total"] > ba.exchange_bytes_per_trial(6 * 698, 6 * 12 + 5, 2, segments=False)["total"]      # the size of the 2-rank GPU test: the old scheme moves less
     assert ba.exchange_bytes_per_trial(6 * 100, 77, 2) is None
 
+
+
+def test_header_is_valid_c99_and_a_plain_c_consumer_builds(tmp_path):
+    """The boundary is a C ABI: include/boslam_hip.h must compile as strict C99 (what cgo / a JNI stub / a C host would include), and
+    tests/c_abi/consumer.c - detectAndCompute on two frames + a cross-check match, through dlopen, no Python - must build against it.
+    (tests/test_orb_gpu.py runs it on the GPU box and compares its output with the Python mirror.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tu = tmp_path / "hdr.c"
+    tu.write_text('#include "boslam_hip.h"\nint main(void) { bh_orb_params p; bh_kp k; (void)p; (void)k; return BH_OK; }\n')
+    flags = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include")]
+    r = subprocess.run(flags + ["-fsyntax-only", str(tu)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = tmp_path / "consumer"
+    r = subprocess.run(flags + ["-o", str(exe), os.path.join(root, "tests", "c_abi", "consumer.c"), "-ldl"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr

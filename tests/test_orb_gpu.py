@@ -185,3 +185,38 @@ def test_ragged_batches_do_not_depend_on_the_launch_mapping(ctx, B):
     torch.cuda.synchronize(); ctx.synchronize(); ctx.status()
     dn = fe.n_kp.cpu().numpy(); dd = fe.desc.cpu().numpy()
     assert np.array_equal(dn, n) and all(np.array_equal(dd[i, :n[i]], desc[i, :n[i]]) for i in range(B))
+
+
+def test_plain_c_consumer_of_the_abi_matches_the_python_mirror(ctx, tmp_path):
+    """tests/c_abi/consumer.c - a C99 program that dlopens the library and runs detectAndCompute on two frames + one cross-check match,
+    as a cgo / JNI / C host of the reference's call sites would - must print the counts and checksums the Python mirror produces."""
+    import os, subprocess
+    from boslam_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "consumer"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), "-o", str(exe),
+                        os.path.join(root, "tests", "c_abi", "consumer.c"), "-ldl"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    bgr, depth = synth.render_batch(2)
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    with open(tmp_path / "frames.bin", "wb") as f:
+        f.write(np.ascontiguousarray(bgr, dtype=np.uint8).tobytes()); f.write(depth.tobytes())
+    r = subprocess.run([str(exe), _lib.LIB_PATH, str(tmp_path / "frames.bin"), "480", "640"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    tok = r.stdout.split()
+    got = dict(n_kp=(int(tok[1]), int(tok[2])), n_match=int(tok[4]), kps=tok[6], desc=tok[8], match=tok[10])
+
+    def fnv(b, h):
+        for x in bytes(b):
+            h = ((h ^ x) * 1099511628211) & 0xffffffffffffffff
+        return h
+    params = frontend.make_params(nfeatures=1000)
+    kps, desc, n = frontend.orb_detect_describe(ctx, bgr, depth=depth, params=params, max_kp=1200)
+    hk = hd = hm = 1469598103934665603
+    for f in range(2):
+        hk = fnv(kps[f, :n[f]].tobytes(), hk); hd = fnv(desc[f, :n[f]].tobytes(), hd)
+    qi, ti, di, nm = frontend.match_pairs(ctx, desc[0:1], n[0:1], desc[1:2], n[1:2])
+    for a in (qi, ti, di):
+        hm = fnv(np.ascontiguousarray(a[0, :nm[0]], dtype=np.int32).tobytes(), hm)
+    assert got["n_kp"] == (int(n[0]), int(n[1])) and got["n_match"] == int(nm[0]) and got["n_match"] > 100
+    assert got["kps"] == "%016x" % hk and got["desc"] == "%016x" % hd and got["match"] == "%016x" % hm
