@@ -4617,7 +4617,7 @@ static int ba_set_problem_rest(bh_ba* ba, int C, const double* R, const double* 
     BH_TRY(bh_reserve(ctx, &ba->fan, sizeof(double) * ba_fan_doubles(Pa, Cf, E)));
     {   // workgroups per free camera in the linearisation: a function of the problem's sizes alone (a window gives the same bits alone and in a batch)
         const int per_cam = C > 0 ? E / C : 0;
-        ba->cam_parts = (Cf > 0 && Cf <= 64 && per_cam >= 512) ? std::min(BA_CAM_PARTS_MAX, (per_cam + 511) / 512 + 1) : 1;      // configs[2]: 1 600 per keyframe -> 5 (measured 1 / 4 / 7: 26.0 / 21.9 / 24.4 us)
+        ba->cam_parts = (Cf > 0 && Cf <= 64 && per_cam >= 512) ? std::min(BA_CAM_PARTS_MAX, (per_cam + 511) / 512) : 1;      // configs[2]: 1 600 per keyframe -> 4 (measured 1 / 4 / 7 parts: 26.0 / 21.9 / 24.4 us)
         if (const char* e = getenv("BH_BA_CAM_PARTS")) { const int v = atoi(e); if (v >= 1 && v <= BA_CAM_PARTS_MAX) ba->cam_parts = Cf > 0 ? v : 1; }      // A/B switch
     }
     if (!small) {
