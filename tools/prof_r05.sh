@@ -7,14 +7,14 @@
 #   ba_local ba_global ba_batch            kernel stats of the local, the global and the batched local BA
 #   ba_mfma_{local,global,batch}           SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES GRBM-free
 #   ba_fetch_{local,global,batch} ba_write_{...}   FETCH_SIZE / WRITE_SIZE (separate passes; x2 rule for wide loads in tools/ba_pmc.py)
-#   bow_fetch bow_write        FETCH_SIZE / WRITE_SIZE of the configs[3] BoW query
+#   bow bow_fetch bow_write    kernel stats and FETCH_SIZE / WRITE_SIZE of the configs[3] BoW query
 set -e
 KEEP=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 OUT=/tmp/prof_r05          # raw rocprofv3 output stays on the box (hundreds of MB); only the summaries are copied to gpurun_out
 mkdir -p $OUT $KEEP
 cd /tmp && export TMPDIR=/tmp
 PASSES="$@"
-[ -z "$PASSES" ] && PASSES="stats sq1 sq2 fetch write grbm ba_local ba_global ba_batch ba_mfma_local ba_mfma_global ba_mfma_batch ba_fetch_local ba_fetch_global ba_fetch_batch ba_write_local ba_write_global ba_write_batch bow_fetch bow_write"
+[ -z "$PASSES" ] && PASSES="stats sq1 sq2 fetch write grbm bow ba_local ba_global ba_batch ba_mfma_local ba_mfma_global ba_mfma_batch ba_fetch_local ba_fetch_global ba_fetch_batch ba_write_local ba_write_global ba_write_batch bow_fetch bow_write"
 B="python3 $GRAFT_REPO_ROOT/bench.py"
 FE="--frames 256 --steps 2 --warmup 1 --no-ba --no-global-ba --no-bow --no-inputs --cpu-sample 0 --pipelines 1"
 T=$GRAFT_REPO_ROOT/tools
@@ -44,6 +44,7 @@ for p in $PASSES; do
     ba_write_local)  pmc ba_write_local  WRITE_SIZE python3 $T/ba_only.py ;;
     ba_write_global) pmc ba_write_global WRITE_SIZE python3 $T/ba_global.py ;;
     ba_write_batch)  pmc ba_write_batch  WRITE_SIZE python3 $T/ba_batch.py 64 ;;
+    bow)       kst bow python3 $T/bow_only.py ;;
     bow_fetch) pmc bow_fetch FETCH_SIZE python3 $T/bow_only.py ;;
     bow_write) pmc bow_write WRITE_SIZE python3 $T/bow_only.py ;;
     *) echo "unknown pass $p" ;;
@@ -51,7 +52,7 @@ for p in $PASSES; do
 done
 # summaries -> gpurun_out
 cd $GRAFT_REPO_ROOT
-for d in stats ba_local ba_global ba_batch; do f=$(find $OUT/$d -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp $f $KEEP/${d}_kernel_stats.csv; done
+for d in stats bow ba_local ba_global ba_batch; do f=$(find $OUT/$d -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp $f $KEEP/${d}_kernel_stats.csv; done
 python3 tools/pmc_summary.py $OUT > $KEEP/pmc_summary.json 2> $KEEP/pmc_summary.err || echo "pmc_summary failed"
 python3 tools/pmc_traffic.py $OUT 128 > $KEEP/pmc_traffic.json 2> $KEEP/pmc_traffic.err || echo "pmc_traffic failed"
 python3 tools/ba_pmc.py $OUT > $KEEP/ba_pmc.json 2> $KEEP/ba_pmc.err || echo "ba_pmc failed"
