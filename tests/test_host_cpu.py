@@ -189,9 +189,10 @@ def test_two_rank_gloo_sharded_matching_equals_single_process(tmp_path):
 
 
 def test_committed_bench_line_meets_the_contract():
-    """profiles/r04_bench.json is the JSON line bench.py printed on the MI355X; check the measurement contract's fields."""
+    """profiles/r05_bench.json is the JSON line bench.py printed on the MI355X (python bench.py --gpus 1 --steps 20 --warmup 5, the driver's command); check the
+    measurement contract's fields."""
     import json
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench.json")).read().strip().splitlines()[-1])
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                  ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
                  ("cpu_baseline", dict)):
@@ -200,7 +201,9 @@ def test_committed_bench_line_meets_the_contract():
     assert "workload" in d["config"] and "configs[1]" in d["config"]["workload"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
-    assert r["traffic"] is None or r["traffic"] >= r["alg_bytes_per_launch"]          # PMC traffic cannot be below the compulsory bytes
+    # PMC traffic of the dominant kernel against ITS compulsory bytes: no multiple of them (wasted re-reads), and not far below them either - it
+    # can be a little below: the smallest pyramid levels a launch reads were written by the launch before it and are still in the L2s
+    assert r["traffic"] is None or 0.7 * r["kernel_bytes_per_launch"] <= r["traffic"] <= 1.5 * r["kernel_bytes_per_launch"]
     assert r["alg_bytes_per_launch"] == 1592000 * 125                                  # 1 592 000 B per frame x frames per launch
     assert abs(r["kernel_frac"] - r["kernel_achieved"] / r["peak"]) < 1e-4 and "byte_model" in r and "kernel_byte_model" in r
     c = d["cpu_baseline"]
@@ -224,6 +227,14 @@ def test_committed_bench_line_meets_the_contract():
     assert d["tracking"]["local_map_chain"]["tracked_frames"] > 900 and d["tracking"]["local_map_chain"]["candidates_per_frame"] > 2000
     assert d["bow_query"]["device_resident_query"]["equals_host_query"] is True and d["bow_query"]["interleaved_add_query"]["last_query_found_the_added_entry"] is True
     assert abs(d["value"] - 1000 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-3
+    # round 5: the counters come from summaries collected on the running build (not marked stale), the first tracking stage gates the second,
+    # the C entry point of the BoW query is timed beside the Python mirror
+    assert r["traffic"] is not None and "stale" not in sc and "stale" not in v
+    lm = d["tracking"]["local_map_chain"]
+    assert lm["tracked_frames"] + lm["skipped_after_stage1"] <= lm["frames"] and lm["skipped_after_stage1"] > 0
+    assert lm["tracked_frames"] <= d["tracking"]["device_resident_chain"]["tracked_pairs"] + 1       # (frame 0 has no predecessor in the first stage)
+    bq = d["bow_query"]
+    assert bq["c_abi_equals_mirror"] is True and bq["c_abi_ms_per_query"] <= bq["ms_per_query"] and bq["inverted_kernels_ms"] < bq["c_abi_ms_per_query"]
 
 
 def test_segment_plan_of_the_sharded_reduced_camera_solve():
