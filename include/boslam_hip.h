@@ -434,8 +434,9 @@ int  bh_bow_query_l1_subset(bh_bow* bow, const uint32_t* q_words, const double* 
 int  bh_bow_compare_l1(bh_bow* bow, int entry_i, int entry_j, int* n_common, double* score);
 /* How host-side queries are answered: 0 (default) = through the inverted file (word -> (entry, weight) rows, DBoW3's own structure,
  * built on the device after the database changed; ~1 MB touched per query of configs[3]) with the streaming scan as the fallback
- * (word ids >= 2^20, more than 2^21 database entries, max_results > 16, a query that overflows a bucket's hit list); 1 = always the
- * scan (400 MB streamed per query).
+ * (word ids >= 2^20, more than 2^21 database entries, max_results > 16, or a query whose hits exceed the staging: 65 536 overflow
+ * records, 4 096 records in one bucket of 64 entries, 1 024 accumulators at the selection threshold); 1 = always the scan (400 MB
+ * streamed per query).  A single host query returns when its pinned result block carries the query's tag (two launches; no stream wake-up).
  * Both give bit-identical ids and scores.  BH_MEM_DEVICE queries (bh_bow_query_l1 with device pointers; words strictly ascending is the
  * caller's promise there) take the inverted file too: its kernels run on the caller's query arrays, the results go straight into the
  * caller's device arrays, and the scan that is enqueued behind them returns at once when a device-side flag says the query has been
