@@ -2928,12 +2928,55 @@ __device__ __forceinline__ bool bb_where(int W, int& w, int& bid)
     return w < W;
 }
 
+// The control steps of a round (round 5: run by the LAST workgroup of the window's linearisation / error launch to arrive, as in bh_ba_optimize's own
+// kernels, instead of two more launches per round; every thread of that workgroup calls them).  seq = the round's tag for the pinned verdict slot.
+__device__ __forceinline__ void bb_report(ba_state* S, ba_state* hout, int seq)
+{
+    ba_state t = *S; t.pad = 0;
+    *hout = t;
+    __threadfence_system();
+    __atomic_store_n(&hout->pad, seq, __ATOMIC_RELEASE);
+}
+__device__ __forceinline__ void bb_prep_tail(const ba_view& V, int seq, bool report_fail)
+{
+    ba_state* S = V.state;
+    const int first = S->b_it == 0 ? 1 : 0;
+    ba_prep_fan(V.fan, (V.Pa * BP_G + 255) / 256, V.Cf, first, 0, S);
+    if (threadIdx.x == 0) {
+        S->b_last_err = 0;
+        if (first && !isfinite(S->max_diag)) {                   // non-finite Hessian at the initial estimate
+            S->b_done = 1; S->b_fail = 1;
+            if (report_fail) { S->b_fail = 2; bb_report(S, V.hstate + (seq & 1), seq); }      // (no error launch of this window will run: tell the host now)
+        }
+    }
+}
+__device__ __forceinline__ void bb_decide_tail(const ba_view& V, int seq)
+{
+    ba_state* S = V.state;
+    ba_decide_fan(V.fan, ba_err_blocks(V.Ea), (V.Pa * BP_G + 255) / 256, V.dxp, V.bp, V.n6, 0, 1, S, nullptr, 0);
+    if (threadIdx.x == 0) {                                      // the control flow of bh_ba_optimize's host loop
+        if (S->accepted) S->b_cur ^= 1;
+        S->b_last_err = 1;                                       // the trial's errors are the last computeActiveErrors
+        if (!S->again) {                                         // the iteration is over
+            if (S->b_verbose && !S->accepted) S->b_last_err = 0; // verbose branch of SparseOptimizer::optimize: errors at the restored estimate
+            S->b_it += 1; S->b_need_lin = 1;
+            if (S->terminate || S->b_it >= S->b_iters) S->b_done = 1;
+        } else S->b_need_lin = 0;
+        bb_report(S, V.hstate + (seq & 1), seq);                 // the verdict slot of this round's parity (the host is at most one round behind)
+    }
+}
+
 __global__ void k_bb_init(const ba_view* __restrict__ views, int W, int iters, int verbose)
 {
     const int w = blockIdx.x * 64 + threadIdx.x;
     if (w >= W) return;
     ba_state* S = views[w].state;
     S->tick[0] = 0; S->tick[1] = 0;
+    {   // arrival counters of the window's fan-in (the last arrivers leave them at zero; a buffer that grew starts with whatever it held)
+        const ba_view& V = views[w];
+        const int ng = ((V.Pa * BP_G + 255) / 256 + BA_CAM_PARTS_MAX * V.Cf + ba_err_blocks(V.Ea) + 63) / 64 + 8;
+        if (V.fan.grp) for (int i = 0; i < ng; i++) V.fan.grp[i] = 0;
+    }
     S->b_it = 0; S->b_iters = iters; S->b_need_lin = 1; S->b_done = (views[w].Ea == 0 || iters <= 0) ? 1 : 0; S->b_last_err = 0; S->b_verbose = verbose; S->b_fail = 0;
 }
 __global__ void k_bb_setcur(const ba_view* __restrict__ views, const int* __restrict__ cur, int W)
@@ -2942,13 +2985,13 @@ __global__ void k_bb_setcur(const ba_view* __restrict__ views, const int* __rest
     if (w < W) views[w].state->b_cur = cur[w];
 }
 
-__global__ __launch_bounds__(256) void k_bb_linearize(const ba_view* __restrict__ views, int W, double delta)
+__global__ __launch_bounds__(256) void k_bb_linearize(const ba_view* __restrict__ views, int W, double delta, int seq)
 {
     __shared__ double s_f[8];
     int w, bx;
     if (!bb_where(W, w, bx)) return;
     const ba_view& V = views[w];
-    const ba_state* S = V.state;
+    ba_state* S = V.state;
     if (S->b_done || !S->b_need_lin) return;
     const int nbp = (V.Pa * BP_G + 255) / 256, cur = S->b_cur;
     double mine[2] = { 0, 0 }, md_cam = 0;
@@ -2959,19 +3002,15 @@ __global__ __launch_bounds__(256) void k_bb_linearize(const ba_view* __restrict_
     if (bx >= nbp + V.Cf * cp) return;
     if (bx >= nbp) fin = ba_cam_body(cs, V.cams[cur], V.pts[cur], V.e_cam, V.e_pt, V.e_meas, V.c_start, V.c_edges, V.K, delta, V.Hpp, V.bp, V.cdiag, nullptr, nullptr, &md_cam,
                                                      c - cs * cp, cp, V.fan.c_part, V.fan.c_cnt);
-    ba_lin_fan_store(bx < nbp, bx < nbp ? bx : (fin ? cs : -1), mine, md_cam, V.fan, s_f);      // (read by k_bb_prep, the next launch)
+    ba_lin_fan_store(bx < nbp, bx < nbp ? bx : (fin ? cs : -1), mine, md_cam, V.fan, s_f);      // (read by the last arriver, or by k_bb_prep, the next launch)
+    if (seq > 0 && fan_arrive(&S->tick[0], V.fan.grp, bx, nbp + V.Cf * cp)) bb_prep_tail(V, seq, true);
 }
 __global__ __launch_bounds__(1024) void k_bb_prep(const ba_view* __restrict__ views)
 {
     const ba_view& V = views[blockIdx.y];
     ba_state* S = V.state;
     if (S->b_done || !S->b_need_lin) return;
-    const int first = S->b_it == 0 ? 1 : 0;
-    ba_prep_fan(V.fan, (V.Pa * BP_G + 255) / 256, V.Cf, first, 0, S);
-    if (threadIdx.x == 0) {
-        S->b_last_err = 0;
-        if (first && !isfinite(S->max_diag)) { S->b_done = 1; S->b_fail = 1; }          // non-finite Hessian at the initial estimate
-    }
+    bb_prep_tail(V, 0, false);                                   // (BH_BA_BB_TAIL=0: the control steps as launches of their own; k_bb_decide reports a failure)
 }
 __global__ __launch_bounds__(256) void k_bb_dinv(const ba_view* __restrict__ views, int W)
 {
@@ -3030,12 +3069,12 @@ __global__ __launch_bounds__(256) void k_bb_update(const ba_view* __restrict__ v
     const double t = fan_block_sum256(mine, s_f);
     if (threadIdx.x == 0) fan_store(V.fan.u_sum + bx, t);
 }
-__global__ __launch_bounds__(256) void k_bb_err(const ba_view* __restrict__ views, int W, double delta)
+__global__ __launch_bounds__(256) void k_bb_err(const ba_view* __restrict__ views, int W, double delta, int seq)
 {
     int w, bx;
     if (!bb_where(W, w, bx)) return;
     const ba_view& V = views[w];
-    const ba_state* S = V.state;
+    ba_state* S = V.state;
     if (S->b_done || bx >= ba_err_blocks(V.Ea)) return;
     const int cur = S->b_cur;
     __shared__ double s_f[4];
@@ -3043,6 +3082,7 @@ __global__ __launch_bounds__(256) void k_bb_err(const ba_view* __restrict__ view
     ba_err_body(bx, V.cams[cur ^ 1], V.pts[cur ^ 1], V.e_cam, V.e_pt, V.e_meas, V.Ea, delta, V.err[1], V.chi_e[1], &mine);
     const double t = fan_block_sum256(mine, s_f);
     if (threadIdx.x == 0) fan_store(V.fan.e_chi + bx, t);
+    if (seq > 0 && fan_arrive(&S->tick[1], V.fan.grp, bx, ba_err_blocks(V.Ea))) bb_decide_tail(V, seq);
 }
 __global__ __launch_bounds__(1024) void k_bb_decide(const ba_view* __restrict__ views, int seq)
 {
@@ -3059,20 +3099,7 @@ __global__ __launch_bounds__(1024) void k_bb_decide(const ba_view* __restrict__ 
         }
         return;
     }
-    ba_decide_fan(V.fan, ba_err_blocks(V.Ea), (V.Pa * BP_G + 255) / 256, V.dxp, V.bp, V.n6, 0, 1, S, nullptr, 0);
-    if (threadIdx.x == 0) {                                      // the control flow of bh_ba_optimize's host loop
-        if (S->accepted) S->b_cur ^= 1;
-        S->b_last_err = 1;                                       // the trial's errors are the last computeActiveErrors
-        if (!S->again) {                                         // the iteration is over
-            if (S->b_verbose && !S->accepted) S->b_last_err = 0; // verbose branch of SparseOptimizer::optimize: errors at the restored estimate
-            S->b_it += 1; S->b_need_lin = 1;
-            if (S->terminate || S->b_it >= S->b_iters) S->b_done = 1;
-        } else S->b_need_lin = 0;
-        ba_state t = *S; t.pad = 0;
-        *hout = t;
-        __threadfence_system();
-        __atomic_store_n(&hout->pad, seq, __ATOMIC_RELEASE);
-    }
+    bb_decide_tail(V, seq);
 }
 
 // multi-GPU: per-camera max |diag| of the all-reduced Hpp
@@ -4965,9 +4992,12 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
     // ahead (round r + 1 is in the queue while the verdicts of round r are polled; two pinned verdict slots per window, by round parity).  The
     // device never waits for the host's poll -> launch turnaround, which was ~25 us of an iteration (a tenth of a configs[2] window's, half of a
     // live window's); the one surplus round at the end finds every window done and returns at once.
+    // The control steps of a round run in the last workgroup of the window's linearisation / error launch to arrive (six launches per round; BH_BA_BB_TAIL=0:
+    // as launches of their own, eight per round - the A/B reference)
+    const bool tail_off = getenv("BH_BA_BB_TAIL") && atoi(getenv("BH_BA_BB_TAIL")) == 0;
     auto enqueue_round = [&](int seq) {
-        BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_bb_linearize, dim3(g_lin, W8), dim3(256), st, views, W, huber_delta);      // (windows that retry with a larger lambda skip these two)
-        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_prep, dim3(1, W), dim3(1024), st, views);
+        BH_LAUNCH(ctx, BH_K_BA_LINEARIZE, k_bb_linearize, dim3(g_lin, W8), dim3(256), st, views, W, huber_delta, tail_off ? 0 : seq);      // (windows that retry with a larger lambda skip it)
+        if (tail_off) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_prep, dim3(1, W), dim3(1024), st, views);
         BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_dinv, dim3(g_pb + 8, W8), dim3(256), st, views, W);
         BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_schur, dim3(g_schur, W8), dim3(256), st, views, W);
         if (g_s64) BH_LAUNCH(ctx, BH_K_BA_SCHUR, k_bb_schur64, dim3(g_s64, W8), dim3(64), st, views, W);
@@ -4975,8 +5005,8 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
         hipLaunchKernelGGL(k_bb_chol, dim3(W), dim3(1024), sizeof(double) * CD_LDS_DOUBLES, st, views);
         bh_time_end(ctx);
         BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_bb_update, dim3(g_upd, W8), dim3(256), st, views, W);
-        BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_bb_err, dim3(g_eb, W8), dim3(256), st, views, W, huber_delta);
-        BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_decide, dim3(1, W), dim3(1024), st, views, seq);
+        BH_LAUNCH(ctx, BH_K_BA_UPDATE, k_bb_err, dim3(g_eb, W8), dim3(256), st, views, W, huber_delta, tail_off ? 0 : seq);
+        if (tail_off) BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bb_decide, dim3(1, W), dim3(1024), st, views, seq);
     };
     const bool look_off = getenv("BH_BA_LOOKAHEAD") && atoi(getenv("BH_BA_LOOKAHEAD")) == 0;      // A/B switch: enqueue a round only after the last one's verdicts
     int seq_cur = 0;
