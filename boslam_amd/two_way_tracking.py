@@ -4,10 +4,10 @@ on the tracking state); the state machine of the script is then replayed frame b
 a frame batched into one launch.
 
 Line references are to experiments/pnp_two_way_tracking.py.  Reference quirks kept on purpose:
-  * camera_state[1] starts as zeros(3) (:98-99) and tvec is (3, 1), so the accumulated translation broadcasts to 3x3 (:74);
+  * camera_state[1] starts as zeros(3) (:98-99) and tvec is (3, 1), so the accumulated translation broadcasts to 3x3 (:75);
   * the current frame's keypoint cloud is moved to the "global" frame with the fused (R, t) and the matched inliers are
     overwritten with the previous frame's points (:91, camera.py:32-43) - the next frame's PnP input depends on it;
-  * a failed frame leaves prev_frame_ob untouched (`continue`, :39,44,63) and the next frame re-initialises.
+  * a failed frame leaves prev_frame_ob untouched (`continue`, :40,47,66) and the next frame re-initialises.
 `backend` supplies detect/match/pnp so that the same replay runs on the GPU library and, in tests, on the CPU oracle."""
 import numpy as np
 
@@ -23,7 +23,7 @@ def replay(desc, n, xy, cloud, match_fn, pnp2_fn, rodrigues_fn):
                num_union=np.zeros(F, np.int32), R=np.zeros((F, 3, 3)), t=np.zeros((F, 3)), cam_R=np.zeros((F, 3, 3)),
                cam_t_norm=np.zeros(F), norm_tvec=np.zeros(F), point_diff=np.zeros(F))
     for f in range(F):
-        if state == 1:                                                                  # :35
+        if state == 1:                                                                  # :37
             log["state"][f] = 1
             qi, ti, d = match_fn(prev, f)                                               # :42
             good = d < 20                                                               # :43
@@ -32,21 +32,21 @@ def replay(desc, n, xy, cloud, match_fn, pnp2_fn, rodrigues_fn):
                 continue
             ip, ic = qi[good], ti[good]
             log["num_matches"][f] = len(ip)
-            a = np.ascontiguousarray(cloud[prev][ip]); b = np.ascontiguousarray(xy[f, ic].astype(np.float64))        # :50-51
-            a1 = np.ascontiguousarray(xy[prev, ip].astype(np.float64)); b1 = np.ascontiguousarray(cloud[f][ic])      # :53-54
-            (ok_ab, r_ab, t_ab, in_ab), (ok_ba, r_ba, t_ba, in_ba) = pnp2_fn(a, b, b1, a1)                           # :56-60
-            if not ok_ab or not ok_ba:                                                  # :62
+            a = np.ascontiguousarray(cloud[prev][ip]); b = np.ascontiguousarray(xy[f, ic].astype(np.float64))        # :51-52
+            a1 = np.ascontiguousarray(xy[prev, ip].astype(np.float64)); b1 = np.ascontiguousarray(cloud[f][ic])      # :54-55
+            (ok_ab, r_ab, t_ab, in_ab), (ok_ba, r_ba, t_ba, in_ba) = pnp2_fn(a, b, b1, a1)                           # :57-61
+            if not ok_ab or not ok_ba:                                                  # :63
                 state = 0; log["state"][f] = -2
                 continue
-            R_ab = rodrigues_fn(r_ab); R_ba = rodrigues_fn(r_ba)                        # :67-68
-            R = (R_ab + np.linalg.inv(R_ba)) / 2.0                                      # :70
-            t = (np.reshape(t_ab, (3, 1)) - np.reshape(t_ba, (3, 1))) / 2.0             # :71
-            cam = (cam[0] @ R, cam[1] + t)                                              # :74
-            inl = np.union1d(np.ravel(in_ab), np.ravel(in_ba)).astype(np.int64)         # :76
+            R_ab = rodrigues_fn(r_ab); R_ba = rodrigues_fn(r_ba)                        # :68-69
+            R = (R_ab + np.linalg.inv(R_ba)) / 2.0                                      # :71
+            t = (np.reshape(t_ab, (3, 1)) - np.reshape(t_ba, (3, 1))) / 2.0             # :72
+            cam = (cam[0] @ R, cam[1] + t)                                              # :75
+            inl = np.union1d(np.ravel(in_ab), np.ravel(in_ba)).astype(np.int64)         # :77
             log["num_inliers"][f] = len(np.ravel(in_ab)); log["num_union"][f] = len(inl)
             log["norm_tvec"][f] = np.linalg.norm(t)
-            prev_cloud = cloud[prev][ip[inl]]                                           # :86
-            new_inds = ic[inl]                                                          # :88
+            prev_cloud = cloud[prev][ip[inl]]                                           # :87
+            new_inds = ic[inl]                                                          # :89
             cloud[f] = cloud[f] @ R + t[:, 0]                                           # :91 -> camera.py:35
             log["point_diff"][f] = np.average(np.linalg.norm(cloud[f][new_inds] - prev_cloud, axis=1))               # camera.py:40
             cloud[f][new_inds] = prev_cloud                                             # camera.py:43

@@ -536,3 +536,38 @@ def test_p3p_small_against_numpy_roots_and_generated_poses():
     img2 = img.copy(); img2[3] += 60.0
     assert oracle.solve_pnp_ransac(X, img2, K4)[0] is False
     assert oracle.solve_pnp_ransac(X[:3], img[:3], K4)[0] is False
+
+
+def test_config1_golden_log_equals_an_independent_restatement_of_the_script():
+    """the golden log of configs[0] was generated THROUGH the product's boslam_amd.two_way_tracking.replay, which
+    the GPU test replays too - a slip in the script's fusion lines would cancel.  oracle/two_way_script.py restates
+    experiments/pnp_two_way_tracking.py:31-105 on its own (while / continue, frame objects with transform2global, zip(*...) index
+    extraction, a Python set union) and shares no code with the product: its log over the oracle's back ends must equal the golden
+    fixture - states, match / inlier counts, fused R and t bit for bit, the 3-D point difference to rounding of its mean."""
+    from oracle import two_way_script
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config1_golden.npz"))
+    from boslam_amd import synth
+    nfr = 100                                                          # all 100 frames of the fixture (a few seconds)
+    bgr, depth = synth.render_batch(nfr, traj="config1")
+    kps, desc, nk, rc = oracle.orb_batch(bgr, depth, oracle.orb_params(nfeatures=600), 768)
+    assert np.all(np.asarray(rc) == 0) and np.array_equal(nk, g["n_kp"][:nfr])
+    K4 = np.array([synth.FX, synth.FY, synth.CX, synth.CY])
+    frames = []
+    for f in range(nfr):
+        xy = oracle.kp_to_int(kps[f, :nk[f]])
+        frames.append((desc[f, :nk[f]], xy, oracle.backproject(depth[f], xy, synth.FX, synth.FY, synth.CX, synth.CY)))
+    recs = two_way_script.run_script(frames, oracle.match_crosscheck, lambda o, i: oracle.solve_pnp_ransac(o, i, K4), oracle.rodrigues)
+    assert len(recs) == nfr
+    tracked = 0
+    for f, r in enumerate(recs):
+        assert r["state"] == g["state"][f], (f, r["state"], g["state"][f])
+        if r["state"] != 1:
+            continue
+        tracked += 1
+        assert r["log"]["num_matches"] == g["num_matches"][f] and r["log"]["num_inliers"] == g["num_inliers"][f] and r["num_union"] == g["num_union"][f]
+        assert np.array_equal(r["rvec"], g["R"][f]) and np.array_equal(r["tvec"], g["t"][f]), f
+        assert r["log"]["norm_tvec"] == g["norm_tvec"][f]
+        assert abs(r["log"]["3d_point_diff"] - g["point_diff"][f]) <= 1e-12 * max(1.0, abs(g["point_diff"][f]))
+        assert np.array_equal(r["camera_state"][0], g["cam_R"][f])
+        assert np.linalg.norm(np.ravel(r["camera_state"][1])) == g["cam_t_norm"][f]
+    assert tracked >= nfr - 2
