@@ -4325,6 +4325,27 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
     char* hp = (char*)ctx->pin; char* dp = (char*)ctx->st_a.p; char* ds = (char*)ctx->st_d.p;
     bld_view* hv = (bld_view*)hp;
     bool all_piecewise = true;
+    // The VALUES of a window - landmarks, measurements, camera blocks: two thirds of what goes up - are read by the last launch only (the workgroups
+    // behind the pairs of k_bld_join_merge).  When every window is a big one (tier 2: configs[2], alone or batched) they are packed and sent AFTER the
+    // structure kernels are enqueued, so the host's packing and the transfer run under those kernels instead of in front of them
+    // (BH_BA_BUILD_VALUES_FIRST=1: the former order).
+    const bool values_later = n_t1 == 0 && !(getenv("BH_BA_BUILD_VALUES_FIRST") && atoi(getenv("BH_BA_BUILD_VALUES_FIRST")) == 1);
+    auto put_values = [&](int w) -> int {
+        const ba_prob& q = pr[w]; const lay& l = L[w];
+        const bool piecewise = l.tier == 2;
+        auto put = [&](size_t off, const void* src, size_t bytes) -> int {
+            memcpy(hp + off, src, bytes);
+            if (piecewise) BH_HIP(ctx, hipMemcpyAsync(dp + off, hp + off, bytes, hipMemcpyHostToDevice, st));
+            return BH_OK;
+        };
+        BH_TRY(put(l.ms, q.meas, sizeof(double) * 2 * (size_t)q.E));
+        BH_TRY(put(l.pt, q.points, sizeof(double) * 3 * (size_t)q.P));
+        ba_cam* hc = (ba_cam*)(hp + l.cm);
+        memset(hc, 0, sizeof(ba_cam) * (size_t)q.C);
+        for (int i = 0; i < q.C; i++) { h_quat_from_R(q.R + 9 * (size_t)i, hc[i].q); for (int k = 0; k < 3; k++) hc[i].t[k] = q.t[3 * (size_t)i + k]; }
+        if (piecewise) BH_HIP(ctx, hipMemcpyAsync(dp + l.cm, hp + l.cm, sizeof(ba_cam) * (size_t)q.C, hipMemcpyHostToDevice, st));
+        return BH_OK;
+    };
     for (int w = 0; w < W; w++) {
         bld_view V = {};
         V.info = (int*)ds;                                                         // (a window that is not staged: C = 0 makes both kernels leave at once)
@@ -4355,12 +4376,8 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
                 return BH_OK;
             };
             BH_TRY(put(l.ep, q.edge_pose, sizeof(int) * (size_t)q.E)); BH_TRY(put(l.pp, q.edge_point, sizeof(int) * (size_t)q.E));
-            BH_TRY(put(l.fx, q.fixed, (size_t)q.C)); BH_TRY(put(l.pt, q.points, sizeof(double) * 3 * (size_t)q.P));
-            BH_TRY(put(l.ms, q.meas, sizeof(double) * 2 * (size_t)q.E));
-            ba_cam* hc = (ba_cam*)(hp + l.cm);
-            memset(hc, 0, sizeof(ba_cam) * (size_t)q.C);
-            for (int i = 0; i < q.C; i++) { h_quat_from_R(q.R + 9 * (size_t)i, hc[i].q); for (int k = 0; k < 3; k++) hc[i].t[k] = q.t[3 * (size_t)i + k]; }
-            if (piecewise) BH_HIP(ctx, hipMemcpyAsync(dp + l.cm, hp + l.cm, sizeof(ba_cam) * (size_t)q.C, hipMemcpyHostToDevice, st));
+            BH_TRY(put(l.fx, q.fixed, (size_t)q.C));
+            if (!values_later) BH_TRY(put_values(w));
             all_piecewise &= piecewise;
         }
         hv[w] = V;
@@ -4388,6 +4405,8 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
         BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_chist, gW, dim3(256), st, dv);
         BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_cplace, gW, dim3(256), st, dv);
     }
+    if (values_later)
+        for (int w = 0; w < W; w++) if (taken[w]) BH_TRY(put_values(w));
     BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bld_join_merge, dim3((unsigned)(max_pairs + max_blocks), W), dim3(256), st, (const bld_view*)dp, max_pairs);
     char* hb0 = hp + up;
     BH_HIP(ctx, hipMemcpyAsync(hb0, ds, back, hipMemcpyDeviceToHost, st));

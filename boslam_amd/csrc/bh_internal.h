@@ -73,6 +73,7 @@ struct bh_ctx {
     bh_pm_level pm[BH_MAX_LEVELS] = {};
     int         pm_ok = 0;           // every level's windows fit the kernel's tile (else k_pyr_down_bits)
     int         gl_sr = 0;           // k_gray_l1: level-1 rows per strip for the current geometry (0: level 0 and level 1 as two launches)
+    int         pp_sr[BH_MAX_LEVELS] = {};      // k_pyr_pair: rows of level l + 1 per strip when levels l, l + 1 are made by one launch (0: not as a pair)
     int         last_pipe = 0;
     bh_buf      st_img, st_mask, st_depth, st_kps, st_desc, st_nkp;     // host-mode staging
     bh_buf      st_a, st_b, st_c, st_d, st_e, st_f, st_g, st_h;         // generic staging (match / BA)

@@ -504,6 +504,108 @@ __global__ __launch_bounds__(256) void k_gray_l1(const uint8_t* __restrict__ img
     }
 }
 
+// ------------------------------------------------------------------------------------------------ levels l and l + 1 in one launch
+// k_pyr_pair (round 5): what k_gray_l1 does for levels 0 / 1, for any later pair.  The six launches of levels 2 .. 7 are the front end's
+// shortest kernels (6 - 20 us each, 48 per 1 000 frames) and each re-reads the level the one before has just written; here a workgroup
+// takes a strip of `sr` rows of level l + 1,
+//   1. resizes the <= GL_R0 rows of level l they read from level l - 1 in HBM (pyr_xsetup / pyr_load / pyr_row, two rows per lane item:
+//      the statements of k_pyr_down_bits, hence the same bytes), writes them to HBM (rows two strips share are written twice, identically)
+//      and keeps them with their mask words in LDS;
+//   2. resizes level l + 1 from LDS exactly as k_gray_l1's second phase does.
+// Three launches instead of six for an 8-level pyramid behind k_gray_l1, and levels 2 / 4 / 6 are not read back.  Measured at configs[1]:
+// 0.674 -> 0.668 ms of kernel time per 1 000 frames, the step unchanged (317.9 / 317.8 against 316.0 / 317.1 k frames/s in an A / B / A / B run):
+// what the six launches cost is their vector instructions and the latency of each workgroup's own load -> compute -> store chain, not the
+// launch boundaries - so it runs on request only (BH_ORB_PYR_PAIR=1), tested like k_pyr_mfma.
+__global__ __launch_bounds__(256) void k_pyr_pair(uint8_t* __restrict__ pyr, bh_orb_geom g, int level, int sr, const uint32_t* __restrict__ tab,
+                                                  uint32_t* __restrict__ mbits, uint32_t* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t gl_sm[];
+    const bh_level_geom Z = g.lv[level - 1], S = g.lv[level], D = g.lv[level + 1];
+    uint8_t* const sg = gl_sm;                                             // [GL_R0][S.pitch + 16] rows of level l
+    const int gp = S.pitch + 16;
+    uint32_t* const sm = reinterpret_cast<uint32_t*>(gl_sm + (size_t)GL_R0 * gp);      // [GL_R0][S.mpitch + 1] their mask words
+    const int mp = S.mpitch + 1;
+    const int tid = threadIdx.x;
+    const int y1a = blockIdx.x * sr, y1b = min(D.h, y1a + sr);
+    uint8_t* __restrict__ fp = pyr + (size_t)blockIdx.y * g.pyr_stride;
+    uint32_t* __restrict__ fm = mbits + (size_t)blockIdx.y * g.mstride;
+    const int ra = (int)(tab[D.taby_off + y1a] >> 16);
+    int rb = min((int)(tab[D.taby_off + y1b - 1] >> 16) + 1, S.h - 1);
+    if (blockIdx.x == gridDim.x - 1) rb = S.h - 1;                          // (the last strip finishes level l whatever the last source row is)
+    const int nr = rb - ra + 1;
+    if (nr > GL_R0) { if (tid == 0) atomicOr(status, BH_ST_CAND_OVERFLOW); return; }      // cannot happen: the host sizes sr from the row table
+    // ---- level l rows ra .. rb from level l - 1 -> HBM and LDS
+    {
+        const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(fp + Z.off, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_ms = __builtin_amdgcn_make_buffer_rsrc(fm + Z.moff, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(fp + S.off, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(fm + S.moff, 0, 0x7fffffff, 0x00020000);
+        const int groups = S.pitch >> 2, nblk = (nr + PD_R - 1) / PD_R;    // groups: a multiple of 16, the 16 lanes of a DPP row share their rows
+        for (int idx = tid; idx < nblk * groups; idx += 256) {
+            const int yb = pyr_div_groups(idx, groups);
+            const int x = (idx - __mul24(yb, groups)) << 2, y0 = ra + yb * PD_R;
+            pyr_xs X;
+            pyr_xsetup(X, S, tab, x);
+            pyr_ld L[PD_R]; uint32_t yc[PD_R];
+#pragma unroll
+            for (int k = 0; k < PD_R; k++) {
+                const uint32_t ty = tab[S.taby_off + min(y0 + k, S.h - 1)];
+                const int r0 = (int)(ty >> 16), r1 = min(r0 + 1, Z.h - 1);
+                yc[k] = ty & 0xffffu;
+                pyr_load(L[k], rs_src, rs_ms, Z, X, r0, r1);
+            }
+            uint32_t o4[PD_R], nbw[PD_R];
+#pragma unroll
+            for (int k = 0; k < PD_R; k++) pyr_row(L[k], X, yc[k], tid, &o4[k], &nbw[k]);
+            const int od = (int)(__umul24((uint32_t)y0, (uint32_t)S.pitch) + (uint32_t)x), om = (int)((__umul24((uint32_t)y0, (uint32_t)S.mpitch) + (uint32_t)(x >> 5)) << 2);
+#pragma unroll
+            for (int k = 0; k < PD_R; k++) {
+                if (y0 + k <= rb) {
+                    const int r = y0 + k - ra;
+                    __builtin_amdgcn_raw_buffer_store_b32(o4[k], rs_dst, od, k * S.pitch, 0);
+                    *reinterpret_cast<uint32_t*>(sg + __umul24((uint32_t)r, (uint32_t)gp) + (uint32_t)x) = o4[k];
+                    if ((tid & 7) == 7) {
+                        __builtin_amdgcn_raw_buffer_store_b32(nbw[k], rs_md, om, k * S.mpitch * 4, 0);
+                        sm[__umul24((uint32_t)r, (uint32_t)mp) + (uint32_t)(x >> 5)] = nbw[k];
+                    }
+                }
+            }
+        }
+    }
+    for (int i = tid; i < nr * 6; i += 256) {                              // the words behind a row's last column group / mask word: zero (only padding columns meet them)
+        const int r = i / 6, k = i - r * 6;
+        if (k < 4) *reinterpret_cast<uint32_t*>(sg + __umul24((uint32_t)r, (uint32_t)gp) + (uint32_t)S.pitch + 4u * k) = 0u;
+        else sm[__umul24((uint32_t)r, (uint32_t)mp) + (uint32_t)(S.pitch >> 5) + (uint32_t)(k - 4)] = 0u;
+    }
+    __syncthreads();
+    // ---- level l + 1 rows y1a .. y1b - 1 from the LDS rows (the second phase of k_gray_l1)
+    uint8_t* __restrict__ dst = fp + D.off;
+    uint32_t* __restrict__ md = fm + D.moff;
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(md, 0, 0x7fffffff, 0x00020000);
+    const int g1 = D.pitch >> 2, nblk = (y1b - y1a + GL_PR - 1) / GL_PR;
+    for (int idx = tid; idx < nblk * g1; idx += 256) {
+        const int yb = pyr_div_groups(idx, g1);
+        const int x = (idx - __mul24(yb, g1)) << 2, y0 = y1a + GL_PR * yb;
+        pyr_xs X;
+        pyr_xsetup(X, D, tab, x);
+        const int od = (int)(__umul24((uint32_t)y0, (uint32_t)D.pitch) + (uint32_t)x), om = (int)((__umul24((uint32_t)y0, (uint32_t)D.mpitch) + (uint32_t)(x >> 5)) << 2);
+#pragma unroll
+        for (int k = 0; k < GL_PR; k++) {
+            const uint32_t ty = tab[D.taby_off + min(y0 + k, D.h - 1)];
+            const int r0 = (int)(ty >> 16), r1 = min(r0 + 1, S.h - 1);
+            pyr_ld L;
+            pyr_load_lds(L, sg, sm, gp, mp, X, min(r0, rb) - ra, min(r1, rb) - ra);
+            uint32_t o4, nbw;
+            pyr_row(L, X, ty & 0xffffu, tid, &o4, &nbw);
+            if (y0 + k < y1b) {
+                __builtin_amdgcn_raw_buffer_store_b32(o4, rs_dst, od, k * D.pitch, 0);
+                if ((tid & 7) == 7) __builtin_amdgcn_raw_buffer_store_b32(nbw, rs_md, om, k * D.mpitch * 4, 0);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ pyramid level l from l-1 on the matrix cores
 // The resize is a separable linear map with at most two taps per output and axis, i.e. two products with banded matrices, and the
 // arithmetic of INTER_LINEAR_EXACT (8.8 horizontal, 16.16 vertical, one rounding at the end) is exact in int32 in any order.  The
@@ -1892,6 +1994,25 @@ static int ensure_geom(bh_ctx* ctx, const bh_orb_params* p, int H, int W)
             if (worst <= GL_R0) ctx->gl_sr = sr;
         }
     }
+    // k_pyr_pair: the same for levels l, l + 1 from level l - 1; besides the staged rows the strips must cover every row of level l
+    // (they do for any scale factor below 2: a strip ends one row below its last source row, the next starts at most there)
+    for (int l = 0; l < BH_MAX_LEVELS; l++) ctx->pp_sr[l] = 0;
+    for (int l = 1; l + 1 < g.nlevels; l++) {
+        const uint32_t* ty = tab + g.lv[l + 1].taby_off; const int Dh = g.lv[l + 1].h, Sh = g.lv[l].h;
+        const size_t lds = (size_t)GL_R0 * (g.lv[l].pitch + 16) + (size_t)GL_R0 * (g.lv[l].mpitch + 1) * 4;
+        if (lds > 64 * 1024) continue;
+        for (int sr = (int)((GL_R0 - 2) / p->scaleFactor) / GL_PR * GL_PR; sr >= GL_PR && !ctx->pp_sr[l]; sr -= GL_PR) {
+            int worst = 0, next = 0; bool covered = true;
+            for (int a = 0; a < Dh; a += sr) {
+                const int b = std::min(Dh, a + sr), ra = (int)(ty[a] >> 16);
+                const int rb = b == Dh ? Sh - 1 : std::min((int)(ty[b - 1] >> 16) + 1, Sh - 1);
+                worst = std::max(worst, rb - ra + 1);
+                covered = covered && ra <= next;
+                next = rb + 1;
+            }
+            if (worst <= GL_R0 && covered && next == Sh) ctx->pp_sr[l] = sr;
+        }
+    }
     int rc = bh_reserve(ctx, &ctx->tab, sizeof(uint32_t) * tab_words);
     if (rc == BH_OK) {
         hipError_t e = hipMemcpyAsync(ctx->tab.p, tab, sizeof(uint32_t) * tab_words, hipMemcpyHostToDevice, ctx->stream);
@@ -2045,8 +2166,17 @@ extern "C" int bh_orb_detect_describe(bh_ctx* ctx, const uint8_t* img, int chann
                 BH_LAUNCH(ctx, BH_K_GRAY, k_gray_mask, dim3((n + 255) / 256, nb), dim3(256), st, d_img, channels, d_mask, d_depth,
                           pyr, mpyr, W, H, g.lv[0].pitch, g.pyr_stride, mbits, g.lv[0].mpitch, g.mstride);
         }
+        // (on request: bit-identical, 0.674 -> 0.668 ms of kernel time and an unchanged step at configs[1] - the six short launches were not what the pyramid costs)
+        const bool pairs_on = mbits && !ctx->pm_ok && getenv("BH_ORB_PYR_PAIR") && atoi(getenv("BH_ORB_PYR_PAIR")) == 1;
         for (int l = gl_fused ? 2 : 1; l < g.nlevels; l++) {
-            if (mbits && ctx->pm_ok) {
+            if (pairs_on && l + 1 < g.nlevels && ctx->pp_sr[l] >= GL_PR) {      // levels l and l + 1 in one launch
+                const int sr = ctx->pp_sr[l];
+                const size_t lds = (size_t)GL_R0 * (g.lv[l].pitch + 16) + (size_t)GL_R0 * (g.lv[l].mpitch + 1) * 4;
+                bh_time_begin(ctx, BH_K_PYR);
+                hipLaunchKernelGGL(k_pyr_pair, dim3((g.lv[l + 1].h + sr - 1) / sr, nb), dim3(256), lds, st, pyr, g, l, sr, (const uint32_t*)ctx->tab.p, mbits, (uint32_t*)ctx->status.p);
+                bh_time_end(ctx);
+                l++;
+            } else if (mbits && ctx->pm_ok) {
                 BH_LAUNCH(ctx, BH_K_PYR, k_pyr_mfma, dim3(ctx->pm[l].tiles_x, ctx->pm[l].tiles_y + (g.lv[l].h + PM_MH - 1) / PM_MH, nb), dim3(256), st, pyr, g, l, (const uint32_t*)ctx->tab.p,
                           (const uint32_t*)ctx->rtab.p, ctx->pm[l], mbits);
             } else if (mbits) {

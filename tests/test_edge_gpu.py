@@ -76,7 +76,9 @@ def test_level0_and_level1_in_one_launch(ctx, monkeypatch, H, W, scale, nlevels)
     """Round 5: k_gray_l1 makes the gray + mask-bit level 0 and level 1 of the pyramid in one launch (strips of level-1 rows, their level-0
     rows kept in LDS) when the frame is BGR + depth with a width that is a multiple of 4.  Strip counts that do not divide the level, other
     scale factors in the supported range (other strip heights), short pyramids: every level of the image and of the mask pyramid and everything downstream must
-    equal the oracle, and the two-launch form (BH_ORB_GRAY_L1=0) must give the same bytes."""
+    equal the oracle, and the two-launch form (BH_ORB_GRAY_L1=0) must give the same bytes.  BH_ORB_PYR_PAIR=1 makes the later levels in pairs the
+    same way (k_pyr_pair: levels 2 + 3, 4 + 5, 6 + 7 behind k_gray_l1 - form "pairs"; 1 + 2, 3 + 4, ... in the two-launch form - form "two"; an odd
+    level out by k_pyr_down_bits): same bytes again."""
     rng = np.random.default_rng(H + 3 * W)
     bgr, _ = synth.render_batch(2)
     crop = np.ascontiguousarray(bgr[:, 5:5 + H, 9:9 + W]) if H < 470 else np.ascontiguousarray(bgr[:, :H, :W])
@@ -89,7 +91,9 @@ def test_level0_and_level1_in_one_launch(ctx, monkeypatch, H, W, scale, nlevels)
     params = frontend.make_params(**kw)
     mask = (depth > 0).astype(np.uint8) * 255
     out = {}
-    for form in ("fused", "two"):
+    for form in ("fused", "two", "pairs"):
+        if form in ("two", "pairs"):
+            monkeypatch.setenv("BH_ORB_PYR_PAIR", "1")             # "two": levels 1 + 2, 3 + 4, ... in pairs; "pairs": 2 + 3, 4 + 5, ... behind k_gray_l1
         if form == "two":
             monkeypatch.setenv("BH_ORB_GRAY_L1", "0")
         kps, desc, n = frontend.orb_detect_describe(ctx, crop, depth=depth, params=params)
@@ -101,9 +105,13 @@ def test_level0_and_level1_in_one_launch(ctx, monkeypatch, H, W, scale, nlevels)
         out[form] = (kps.copy(), desc.copy(), n.copy(), lv)
         if form == "two":
             monkeypatch.delenv("BH_ORB_GRAY_L1")
+        if form in ("two", "pairs"):
+            monkeypatch.delenv("BH_ORB_PYR_PAIR")
     kps, desc, n, lv = out["fused"]
     k2, d2, n2, lv2 = out["two"]
-    assert np.array_equal(n, n2)
+    k3, d3, n3, lv3 = out["pairs"]
+    assert np.array_equal(n, n2) and np.array_equal(n, n3)
+    assert np.array_equal(d3, desc) and np.array_equal(k3.view(np.uint8), kps.view(np.uint8))
     for f in range(2):
         ok, od, rc, dbg = oracle.orb_detect_describe(crop[f], mask[f], oracle.orb_params(**kw), max_kp=4 * 300 + 256, debug=True)
         for name in ("pyr", "mask"):
@@ -113,6 +121,7 @@ def test_level0_and_level1_in_one_launch(ctx, monkeypatch, H, W, scale, nlevels)
                 bad = np.argwhere(lv[f][name][l] != ref)
                 assert len(bad) == 0, (name, f, l, len(bad), bad[:3])
                 assert np.array_equal(lv2[f][name][l], ref), (name, f, l, "two-launch form")
+                assert np.array_equal(lv3[f][name][l], ref), (name, f, l, "levels in pairs")
         assert rc == 0 and n[f] == len(ok), (f, n[f], len(ok))
         assert np.array_equal(desc[f, :n[f]], od) and np.array_equal(d2[f, :n[f]], od)
         for fld in ("x", "y", "angle", "response", "size"):
