@@ -4330,12 +4330,17 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
     // structure kernels are enqueued, so the host's packing and the transfer run under those kernels instead of in front of them
     // (BH_BA_BUILD_VALUES_FIRST=1: the former order).
     const bool values_later = n_t1 == 0 && !(getenv("BH_BA_BUILD_VALUES_FIRST") && atoi(getenv("BH_BA_BUILD_VALUES_FIRST")) == 1);
+    // ... and on a stream of their own (the first auxiliary stream of the context, forked behind whatever the context's stream holds - the staging
+    // buffer may still be in use there - and joined in front of the last launch): in stream order the transfer would wait for the structure kernels
+    // instead of running beside them.
+    hipStream_t vst = (values_later && ctx->aux_stream[0] && ctx->ev_fork && ctx->ev_join[0]) ? ctx->aux_stream[0] : st;
+    if (vst != st) { BH_HIP(ctx, hipEventRecord(ctx->ev_fork, st)); BH_HIP(ctx, hipStreamWaitEvent(vst, ctx->ev_fork, 0)); }
     auto put_values = [&](int w) -> int {
         const ba_prob& q = pr[w]; const lay& l = L[w];
         const bool piecewise = l.tier == 2;
         auto put = [&](size_t off, const void* src, size_t bytes) -> int {
             memcpy(hp + off, src, bytes);
-            if (piecewise) BH_HIP(ctx, hipMemcpyAsync(dp + off, hp + off, bytes, hipMemcpyHostToDevice, st));
+            if (piecewise) BH_HIP(ctx, hipMemcpyAsync(dp + off, hp + off, bytes, hipMemcpyHostToDevice, vst));
             return BH_OK;
         };
         BH_TRY(put(l.ms, q.meas, sizeof(double) * 2 * (size_t)q.E));
@@ -4343,7 +4348,7 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
         ba_cam* hc = (ba_cam*)(hp + l.cm);
         memset(hc, 0, sizeof(ba_cam) * (size_t)q.C);
         for (int i = 0; i < q.C; i++) { h_quat_from_R(q.R + 9 * (size_t)i, hc[i].q); for (int k = 0; k < 3; k++) hc[i].t[k] = q.t[3 * (size_t)i + k]; }
-        if (piecewise) BH_HIP(ctx, hipMemcpyAsync(dp + l.cm, hp + l.cm, sizeof(ba_cam) * (size_t)q.C, hipMemcpyHostToDevice, st));
+        if (piecewise) BH_HIP(ctx, hipMemcpyAsync(dp + l.cm, hp + l.cm, sizeof(ba_cam) * (size_t)q.C, hipMemcpyHostToDevice, vst));
         return BH_OK;
     };
     for (int w = 0; w < W; w++) {
@@ -4405,8 +4410,10 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
         BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_chist, gW, dim3(256), st, dv);
         BH_LAUNCH(ctx, BH_K_BA_OTHER, k_b2_cplace, gW, dim3(256), st, dv);
     }
-    if (values_later)
+    if (values_later) {
         for (int w = 0; w < W; w++) if (taken[w]) BH_TRY(put_values(w));
+        if (vst != st) { BH_HIP(ctx, hipEventRecord(ctx->ev_join[0], vst)); BH_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[0], 0)); }
+    }
     BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bld_join_merge, dim3((unsigned)(max_pairs + max_blocks), W), dim3(256), st, (const bld_view*)dp, max_pairs);
     char* hb0 = hp + up;
     BH_HIP(ctx, hipMemcpyAsync(hb0, ds, back, hipMemcpyDeviceToHost, st));
@@ -4923,6 +4930,8 @@ struct bh_ba_batch {
     std::vector<bh_ba*> win;
     bh_buf views, curs;
     ba_state* hstates = nullptr;      // pinned, TWO per window (round parity): k_bb_decide's verdicts - the host runs one round ahead of them
+    ba_view* hviews = nullptr;        // pinned staging of the view table and the windows' state selectors (behind hstates in the same allocation): they go up
+    int* hcurs = nullptr;             // without a synchronisation (as host vectors they had to be waited for before going out of scope: a host round trip per call)
     int seq = 0;
 };
 
@@ -4935,11 +4944,13 @@ extern "C" int bh_ba_batch_create(bh_ctx* ctx, int W, bh_ba* const* windows, bh_
     (void)hipFuncSetAttribute((const void*)k_bb_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CD_LDS_DOUBLES));
     bh_ba_batch* b = new bh_ba_batch();
     b->ctx = ctx; b->win.assign(windows, windows + W);
-    if (hipHostMalloc((void**)&b->hstates, sizeof(ba_state) * 2 * W, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+    const size_t hs_bytes = (sizeof(ba_state) * 2 * W + 255) & ~(size_t)255, hv_bytes = (sizeof(ba_view) * W + 255) & ~(size_t)255;
+    if (hipHostMalloc((void**)&b->hstates, hs_bytes + hv_bytes + sizeof(int) * W, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
         (void)hipGetLastError(); delete b;
         return bh_set_err(ctx, BH_ERR_HIP, "bh_ba_batch_create: pinned allocation failed");
     }
-    memset(b->hstates, 0, sizeof(ba_state) * 2 * W);
+    memset(b->hstates, 0, hs_bytes + hv_bytes + sizeof(int) * W);
+    b->hviews = (ba_view*)((char*)b->hstates + hs_bytes); b->hcurs = (int*)((char*)b->hstates + hs_bytes + hv_bytes);
     *out = b;
     return BH_OK;
 }
@@ -4961,8 +4972,8 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
     const int W = (int)b->win.size(), W8 = W == 1 ? 1 : (W + 7) & ~7;      // grids are (blocks, windows rounded up to 8): see bb_where
     BH_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    std::vector<ba_view> hv(W);
-    std::vector<int> hcur(W);
+    // (the pinned staging is free: the previous call returned after reading its last verdicts, which the device wrote behind these copies)
+    ba_view* const hv = b->hviews; int* const hcur = b->hcurs;
     int g_lin = 1, g_pb = 1, g_schur = 1, g_upd = 1, g_eb = 1, g_s64 = 0;
     for (int w = 0; w < W; w++) {
         bh_ba* ba = b->win[w];
@@ -4996,9 +5007,8 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
         if (iters_done) iters_done[w] = 0;
     }
     BH_TRY(bh_reserve(ctx, &b->views, sizeof(ba_view) * W)); BH_TRY(bh_reserve(ctx, &b->curs, sizeof(int) * W));
-    BH_HIP(ctx, hipMemcpyAsync(b->views.p, hv.data(), sizeof(ba_view) * W, hipMemcpyHostToDevice, st));
-    BH_HIP(ctx, hipMemcpyAsync(b->curs.p, hcur.data(), sizeof(int) * W, hipMemcpyHostToDevice, st));
-    BH_HIP(ctx, hipStreamSynchronize(st));                     // hv / hcur go out of scope below
+    BH_HIP(ctx, hipMemcpyAsync(b->views.p, hv, sizeof(ba_view) * W, hipMemcpyHostToDevice, st));
+    BH_HIP(ctx, hipMemcpyAsync(b->curs.p, hcur, sizeof(int) * W, hipMemcpyHostToDevice, st));
     const ba_view* views = (const ba_view*)b->views.p;
     hipLaunchKernelGGL(k_bb_init, dim3((W + 63) / 64), dim3(64), 0, st, views, W, iters, verbose_errors ? 1 : 0);
     hipLaunchKernelGGL(k_bb_setcur, dim3((W + 63) / 64), dim3(64), 0, st, views, (const int*)b->curs.p, W);
@@ -5031,6 +5041,7 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
     int seq_cur = 0;
     if (active > 0) { seq_cur = ++b->seq; enqueue_round(seq_cur); }
     std::vector<int> it_known(W, 0);                           // iterations a window had completed at the last verdict the host has read
+    bool polled = false;
     for (int round = 0; active > 0 && round < iters * 10 + 2; round++) {
         int seq_next = 0;
         // no look-ahead behind a round that ends the run if its trials are accepted (every live window is in its last iteration): the surplus
@@ -5062,6 +5073,7 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
                     return bh_set_err(ctx, BH_ERR_HIP, "bh_ba_batch_optimize: no verdict from window %d", w);
                 }
             }
+            polled = true;
             ba_state hs; memcpy(&hs, hp, sizeof(hs));
             bh_ba* ba = b->win[w];
             if (hs.b_fail) { done[w] = 1; active--; rc = bh_set_err(ctx, BH_ERR_NUMERIC, "bh_ba_batch_optimize: non-finite Hessian at the initial estimate of window %d", w); continue; }
@@ -5079,6 +5091,7 @@ extern "C" int bh_ba_batch_optimize(bh_ba_batch* b, int iters, double huber_delt
         else if (active > 0) { seq_cur = ++b->seq; enqueue_round(seq_cur); }
     }
     for (int w = 0; w < W; w++) b->win[w]->verbose_last = verbose_errors;
+    if (!polled) BH_HIP(ctx, hipStreamSynchronize(st));        // no verdict was read (nothing to optimise): the pinned view staging must not be rewritten under its copy
     return rc;
 }
 
