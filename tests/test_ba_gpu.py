@@ -392,13 +392,16 @@ def test_set_problems_mixed_windows_and_errors(ctx):
 def test_control_sums_and_lookahead_switches_agree(ctx, monkeypatch):
     """Round 5: the sums of the Levenberg control ride in the producing kernels (fan-in: per-workgroup slots, the last arriver adds them up) and
     the host enqueues a round before it has seen the last one's verdicts.  Both have an A/B switch: BH_BA_LOOKAHEAD=0 must not change a bit;
-    BH_BA_BB_TAIL=0 (a batched window's control steps as launches of their own instead of in the last workgroup to arrive) neither;
+    BH_BA_BB_TAIL=0 (a batched window's control steps as launches of their own instead of in the last workgroup to arrive) neither, nor
+    BH_BA_BUILD_VALUES_FIRST=1 (the problem build of the 50-keyframe window sends landmarks / measurements / camera blocks on the context's stream in front
+    of the structure kernels instead of on the auxiliary stream beside them);
     BH_BA_FAN=0 (the sums as separate launches, another fixed summation order) must give the same Levenberg decisions and the same states to
     rounding - on a local window (host loop), and on the banded solver path."""
     for pr, env in ((synth.ba_problem(n_kf=12, n_pts=500, seed=4), {}), (synth.ba_problem(n_kf=50, n_pts=10000, seed=7), {}),
                     (synth.ba_problem(n_kf=12, n_pts=500, seed=4), {"BH_BA_SELF_BATCH": "0"})):
         res = {}
-        for name, sw in (("default", {}), ("nolook", {"BH_BA_LOOKAHEAD": "0"}), ("notail", {"BH_BA_BB_TAIL": "0"}), ("nofan", {"BH_BA_FAN": "0", "BH_BA_SELF_BATCH": "0"}),
+        for name, sw in (("default", {}), ("nolook", {"BH_BA_LOOKAHEAD": "0"}), ("notail", {"BH_BA_BB_TAIL": "0"}), ("valuesfirst", {"BH_BA_BUILD_VALUES_FIRST": "1"}),
+                         ("nofan", {"BH_BA_FAN": "0", "BH_BA_SELF_BATCH": "0"}),
                          ("oneper", {"BH_BA_CAM_PARTS": "1"}), ("eightper", {"BH_BA_CAM_PARTS": "8"})):
             for k, v in {**env, **sw}.items():
                 monkeypatch.setenv(k, v)
@@ -410,7 +413,7 @@ def test_control_sums_and_lookahead_switches_agree(ctx, monkeypatch):
             for k in {**env, **sw}:
                 monkeypatch.delenv(k)
         d0, (R0, t0), p0, l0 = res["default"]
-        for name in ("nolook", "notail"):                     # who enqueues when, and which workgroup adds the slots up, must not change a bit
+        for name in ("nolook", "notail", "valuesfirst"):      # who enqueues when, which workgroup adds the slots up, and on which stream a big window's values go up, must not change a bit
             d1, (R1, t1), p1, l1 = res[name]
             assert d1 == d0 and np.array_equal(R1, R0) and np.array_equal(t1, t0) and np.array_equal(p1, p0) and np.array_equal(l1, l0), name
         # another fixed summation order: BH_BA_FAN=0, and the camera blocks of the linearisation summed by one / eight workgroups per keyframe
