@@ -4335,6 +4335,8 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
     // instead of running beside them.
     hipStream_t vst = (values_later && ctx->aux_stream[0] && ctx->ev_fork && ctx->ev_join[0]) ? ctx->aux_stream[0] : st;
     if (vst != st) { BH_HIP(ctx, hipEventRecord(ctx->ev_fork, st)); BH_HIP(ctx, hipStreamWaitEvent(vst, ctx->ev_fork, 0)); }
+    // (an error return between the fork and the join must not leave a transfer from the pinned block in flight on the auxiliary stream: the next call packs into that block)
+    struct vjoin_guard { hipStream_t v; bool armed; ~vjoin_guard() { if (armed) (void)hipStreamSynchronize(v); } } vguard{ vst, vst != st };
     auto put_values = [&](int w) -> int {
         const ba_prob& q = pr[w]; const lay& l = L[w];
         const bool piecewise = l.tier == 2;
@@ -4412,7 +4414,7 @@ static int ba_small_many(bh_ctx* ctx, int W, bh_ba* const* bas, const ba_prob* p
     }
     if (values_later) {
         for (int w = 0; w < W; w++) if (taken[w]) BH_TRY(put_values(w));
-        if (vst != st) { BH_HIP(ctx, hipEventRecord(ctx->ev_join[0], vst)); BH_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[0], 0)); }
+        if (vst != st) { BH_HIP(ctx, hipEventRecord(ctx->ev_join[0], vst)); BH_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[0], 0)); vguard.armed = false; }
     }
     BH_LAUNCH(ctx, BH_K_BA_OTHER, k_bld_join_merge, dim3((unsigned)(max_pairs + max_blocks), W), dim3(256), st, (const bld_view*)dp, max_pairs);
     char* hb0 = hp + up;
