@@ -446,6 +446,18 @@ def run_rank(args):
                     o2 = lt.step(himg[rep & 1], hdep[rep & 1])
                     lat2.append(time.perf_counter() - t0)
                 lt.close()
+                lt = frontend.LiveTracker(ctx, 480, 640, params, K5, torch_device=dev, use_graph=True)      # ... and each frame's launches replayed as one HIP graph
+                lat3, o3 = [], None
+                for rep in range(24):
+                    t0 = time.perf_counter()
+                    o3 = lt.step(himg[rep & 1], hdep[rep & 1])
+                    lat3.append(time.perf_counter() - t0)
+                lt.close()
+                r["live_single_frame_graph"] = {"ms_per_frame": round(float(np.median(lat3[6:])) * 1e3, 3), "frames_per_s": round(1.0 / float(np.median(lat3[6:])), 1),
+                                                "status_last": o3["status"], "n_inlier_last": o3["n_inlier"],
+                                                "equals_enqueued": bool(o3["status"] == o2["status"] and o3["n_inlier"] == o2["n_inlier"] and np.array_equal(o3["R"], o2["R"])),
+                                                "stages": "the loop of live_single_frame_device_state with use_graph=True: staging copies + every launch of the frame + the verdict "
+                                                          "copy captured once per slot parity (torch.cuda.CUDAGraph on the stream the library has adopted) and replayed"}
                 r["live_single_frame_device_state"] = {"ms_per_frame": round(float(np.median(lat2[4:])) * 1e3, 3), "frames_per_s": round(1.0 / float(np.median(lat2[4:])), 1),
                                                        "status_last": o2["status"], "n_inlier_last": o2["n_inlier"],
                                                        "stages": "frontend.LiveTracker: one pinned H2D of the frame, ORB + back-projection + bh_track_refkf against the previous "

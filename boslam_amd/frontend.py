@@ -264,9 +264,12 @@ class LiveTracker:
     ORB + back-projection + the tracking step against the PREVIOUS frame's descriptors / cloud (kept on the device, two slots) run on
     the context's stream, and only the verdict comes back: (status, R, t, n_match, n_inlier).  Nothing else crosses PCIe."""
 
-    def __init__(self, ctx, H, W, params, K, max_kp=None, torch_device="cuda:0"):
+    def __init__(self, ctx, H, W, params, K, max_kp=None, torch_device="cuda:0", use_graph=False):
+        """use_graph: from the third frame on a step replays a captured HIP graph (one per slot parity: staging copies, the ~15 launches of ORB,
+        back-projection and the tracking step, the verdict copy) instead of enqueuing them one by one - the per-frame path is launch-bound."""
         import torch
         self.torch = torch
+        self.use_graph, self.graphs, self.steps = bool(use_graph), [None, None], 0
         self.ctx, self.H, self.W, self.params = ctx, H, W, params
         self.K = np.ascontiguousarray(K, dtype=np.float64)
         self.max_kp = m = max_kp or default_max_kp(params)
@@ -288,22 +291,19 @@ class LiveTracker:
         if self.stream is not None:
             self.ctx.synchronize(); self.ctx.set_stream(None); self.stream = None
 
-    def step(self, bgr, depth):
-        """bgr u8[H][W][3], depth u16[H][W] numpy arrays -> dict(status, R, t, n_match, n_inlier) or None for the first frame."""
+    def _enqueue(self, k, p, with_prev):
+        """One frame's work on self.stream: staging copies, ORB into slot k, back-projection, the tracking step against slot p, the verdict copy."""
         from . import tracking
         torch, L, c, m = self.torch, _lib.lib(), self.ctx, self.max_kp
-        self.h_bgr[0].numpy()[...] = bgr; self.h_depth[0].numpy()[...] = depth
         with torch.cuda.stream(self.stream):
             self.d_bgr.copy_(self.h_bgr, non_blocking=True); self.d_depth.copy_(self.h_depth, non_blocking=True)
-        k, p = self.slot, self.slot ^ 1
         c.check(L.bh_orb_detect_describe(c.h, _lib.ptr(self.d_bgr), 3, None, _lib.ptr(self.d_depth), 1, self.H, self.W, C.byref(self.params), m,
                                          C.c_void_p(self.kps.data_ptr() + 24 * m * k), C.c_void_p(self.desc.data_ptr() + 32 * m * k),
                                          C.c_void_p(self.n_kp.data_ptr() + 4 * k), BH_MEM_DEVICE))
         c.check(L.bh_kp_backproject(c.h, C.c_void_p(self.kps.data_ptr() + 24 * m * k), C.c_void_p(self.n_kp.data_ptr() + 4 * k), _lib.ptr(self.d_depth), 1,
                                     self.H, self.W, m, float(self.K[0]), float(self.K[1]), float(self.K[2]), float(self.K[3]),
                                     C.c_void_p(self.kp_xy.data_ptr() + 16 * m * k), C.c_void_p(self.cloud.data_ptr() + 24 * m * k), BH_MEM_DEVICE))
-        res = None
-        if self.have_prev:
+        if with_prev:
             v = self.verdict.data_ptr()
             out = dict(qidx=self.qidx.data_ptr(), tidx=self.tidx.data_ptr(), dist=self.dist.data_ptr(), n_match=v + 4, R=v + 16, t=v + 88,
                        inlier=self.inlier.data_ptr(), n_inlier=v + 8, status=v)
@@ -311,6 +311,26 @@ class LiveTracker:
                                         self.desc.data_ptr() + 32 * m * p, self.n_kp.data_ptr() + 4 * p, self.cloud.data_ptr() + 24 * m * p, m, 1, self.K, out, m)
             with torch.cuda.stream(self.stream):
                 self.h_verdict.copy_(self.verdict, non_blocking=True)
+
+    def step(self, bgr, depth):
+        """bgr u8[H][W][3], depth u16[H][W] numpy arrays -> dict(status, R, t, n_match, n_inlier) or None for the first frame."""
+        torch, c = self.torch, self.ctx
+        self.h_bgr[0].numpy()[...] = bgr; self.h_depth[0].numpy()[...] = depth
+        k, p = self.slot, self.slot ^ 1
+        res = None
+        if self.use_graph and self.have_prev and self.steps >= 2:
+            # every buffer, launch shape and argument of a frame with this slot parity is the same as two frames ago (the library's workspaces have
+            # reached their sizes: nothing allocates, nothing synchronises in the BH_MEM_DEVICE entry points) - capture once, then replay
+            if self.graphs[k] is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
+                    self._enqueue(k, p, True)
+                self.graphs[k] = g
+            with torch.cuda.stream(self.stream):
+                self.graphs[k].replay()
+        else:
+            self._enqueue(k, p, self.have_prev)
+        self.steps += 1
         # every call ends synchronised - also the first one, which has no verdict to wait for: the next step() overwrites the single
         # pinned staging pair (h_bgr / h_depth), and this frame's host-to-device copy must have left it by then
         c.synchronize()

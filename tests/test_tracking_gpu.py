@@ -104,6 +104,33 @@ def test_live_tracker_equals_the_host_staged_calls(ctx):
         lt.close()
 
 
+def test_live_tracker_graph_replay_equals_the_enqueued_steps(ctx):
+    """frontend.LiveTracker(use_graph=True): from the third frame on a step replays a captured HIP graph (staging copies, the launches of ORB,
+    back-projection and the tracking step, the verdict copy; one graph per slot parity) instead of enqueuing them.  Same frames through both forms:
+    every verdict and pose bit for bit - and the frames differ from step to step, so a graph that had captured data instead of work would show."""
+    torch = pytest.importorskip("torch")
+    from boslam_amd import frontend
+    bgr, depth = synth.render_batch(9)
+    params = frontend.make_params(nfeatures=600)
+    K = np.array([synth.FX, synth.FY, synth.CX, synth.CY, 0.06])
+    order = [0, 1, 2, 3, 2, 5, 6, 7, 8, 4]                       # not monotone: a replay must read the frame that was staged for it
+    res = {}
+    for form in (False, True):
+        lt = frontend.LiveTracker(ctx, bgr.shape[1], bgr.shape[2], params, K, use_graph=form)
+        try:
+            res[form] = [lt.step(bgr[i], depth[i]) for i in order]
+            assert (lt.graphs[0] is not None and lt.graphs[1] is not None) == form
+        finally:
+            lt.close()
+    assert res[False][0] is None and res[True][0] is None
+    n_ok = 0
+    for a, b in zip(res[False][1:], res[True][1:]):
+        assert a["status"] == b["status"] and a["n_match"] == b["n_match"] and a["n_inlier"] == b["n_inlier"]
+        assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"])
+        n_ok += a["status"] == 0
+    assert n_ok >= 6
+
+
 def _oracle_local_map(p, b, d_max=30, min_matches=15, min_inliers=15, see=None):
     """slam/tracking.py:91-136 as the composition of the parts' oracles: gate -> stacked feats / pts3d -> match `<=` -> CamOnlyBA -> verdict."""
     M = int(p["M"][b]); R, t = p["R"][b], p["t"][b]
