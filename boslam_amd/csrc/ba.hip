@@ -1404,8 +1404,9 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
 // L2 once per panel and spends most of a panel in one wave's triangular solves; here the strictly lower tiles (16x16, MFMA
 // accumulator layout) live in the registers of one 1024-thread workgroup, the diagonal tiles in LDS, and every O(n^3) and O(n^2)
 // step is a matrix-core instruction.  Wave 0 is the panel wave (no tiles: its registers hold the 16x16 factor and its inverse);
-// waves 1..15 own the tiles, at most 11 each: tile t of the column-major enumeration of the strict lower triangle belongs to wave
-// 1 + t mod 15 and never moves; the diagonal tiles are updated in LDS by the panel wave while the tile waves update theirs.
+// waves 1..15 own the tiles, at most 11 each: the tiles of the column-major enumeration of the strict lower triangle are dealt to the waves once
+// (round-robin, the three waves on the panel wave's SIMD fewer: see the tile-id set-up below) and never move; the diagonal tiles are updated in LDS
+// by the tile waves that own them.
 //   per block column J:  [2] wave 0 factors diagonal tile J (row per lane, v_readlane broadcasts), inverts the 16x16 triangle
 //        (column per lane) and finishes y_J = Linv y_J;  [3] the tile waves turn their tiles of column J into
 //        L(i,J) = T(i,J) Linv' with 4 MFMAs (operands via LDS), publish them and take L(i,J) y_J out of y_i;  [4] they update
@@ -1591,9 +1592,20 @@ __device__ __forceinline__ void ba_chol_dense_body(const double* __restrict__ A_
         ba_d4 Tl[CD_NTW];
 #pragma unroll
         for (int k = 0; k < 12; k++) {
+#ifndef CD_EVEN_TILES
+            // Round 5: waves 4, 8, 12 share SIMD 0 with the panel wave (waves go round the four SIMDs), and the panel wave's f64 multiply-add chains - the factorisation
+            // of a diagonal tile - wait behind their f64 MFMAs, which hold the SIMD's f64 pipe for 32 cycles each: they take 7 tiles, the other twelve 11 (rounds 0 .. 6
+            // deal a tile to all fifteen tile waves, rounds 7 .. 10 to the twelve others).  The panel wave's factor loop: 1.63 -> 0.94 us per tile, the solve 127 -> 122.6 us
+            // (tools/chol_clocks.py); the same tiles with the same arithmetic, so the same bits.  -DCD_EVEN_TILES: tile t to wave 1 + t mod 15 as before.
+            const bool simd0 = (wv & 3) == 0;
+            const int t = k < 7 ? (wv - 1) + 15 * k : 105 + 12 * (k - 7) + (wv - 1 - (wv >> 2));
+            int j = 0, rem = t;
+            const bool have = k < CD_NTW && t < T && !(simd0 && k >= 7);
+#else
             const int t = (wv - 1) + 15 * k;
             int j = 0, rem = t;
             const bool have = k < CD_NTW && t < T;
+#endif
             if (have) { while (rem >= NT - 1 - j) { rem -= NT - 1 - j; j++; } }
             const int i = j + 1 + rem;
             tq[k >> 1] |= (uint32_t)(have ? (i | (j << 8)) : 0xffff) << (16 * (k & 1));
